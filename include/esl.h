@@ -1,0 +1,205 @@
+/*
+ * esl.h — C-ABI of the MI355X-native EllipsoidSLAM hot-path backend.
+ *
+ * Drop-in boundary (SURVEY.md §8 b).  The reference has no FFI; its boundary is the public
+ * surface of three C++ classes that `Tracking` instantiates directly.  Each entry point
+ * below names the reference member it replaces:
+ *
+ *   esl_optimize*        <- EllipsoidSLAM::Optimizer::GlobalObjectGraphOptimization
+ *                           (reference include/core/Optimizer.h:20-23, src/core/Optimizer.cpp:83-317)
+ *                           + g2o::SparseOptimizer::optimize / OptimizationAlgorithmLevenberg::solve
+ *                           (Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-419,
+ *                            core/optimization_algorithm_levenberg.cpp:61-164)
+ *   esl_lm_*  (step API) <- the pieces of the above that exchange scalars between shards:
+ *                           computeActiveErrors/activeRobustChi2 (sparse_optimizer.cpp:61-114),
+ *                           BlockSolver::buildSystem/setLambda/solve (core/block_solver.hpp:354-604),
+ *                           computeLambdaInit/computeScale (optimization_algorithm_levenberg.cpp:166-189)
+ *   esl_fit_frame        <- EllipsoidSLAM::EllipsoidExtractor::EstimateLocalEllipsoid
+ *                           (reference src/pca/EllipsoidExtractor.h:57-58, .cpp:292-493)
+ *   esl_init_quadric     <- EllipsoidSLAM::Initializer::initializeQuadric
+ *                           (reference include/core/Initializer.h:47-50, src/core/Initializer.cpp:24-56)
+ *
+ * Conventions (identical to the reference's own vectors):
+ *   SE3 7-vector      = x y z qx qy qz qw        (g2o::SE3Quat::toVector, types/se3quat.h:144-155)
+ *   ellipsoid 10-vec  = x y z qx qy qz qw a b c  (g2o::ellipsoid::toVector, src/core/Ellipsoid.cpp:152-157)
+ *   camera states are Tcw (world -> camera), ellipsoid poses are object -> world.
+ * All arrays are caller-allocated, plain pointers and sizes; no exceptions cross this boundary;
+ * every function returns an esl_status.  A context is bound to one HIP device and one stream and
+ * is re-entrant per context (not thread-safe within one context).
+ *
+ * There is NO CPU fallback behind these symbols: without a usable HIP device the compute entry
+ * points return ESL_ERR_NO_DEVICE.
+ */
+#ifndef ESL_H_
+#define ESL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESL_ABI_VERSION 1
+#define ESL_MAX_TRACE 32
+
+typedef enum {
+  ESL_OK = 0,
+  ESL_ERR_NO_DEVICE = 1,   /* no HIP device / HIP runtime error on create */
+  ESL_ERR_INVALID = 2,     /* bad argument (null pointer, negative size, index out of range) */
+  ESL_ERR_HIP = 3,         /* HIP runtime call failed; see esl_last_error() */
+  ESL_ERR_STATE = 4,       /* call sequence error (e.g. step API before esl_lm_begin) */
+  ESL_ERR_ALLOC = 5
+} esl_status;
+
+typedef struct esl_ctx esl_ctx;
+
+/* ---- graph description (SoA, host pointers) ------------------------------------------------
+ * Mirrors what Optimizer.cpp:127-279 assembles into g2o objects. */
+typedef struct {
+  double fx, fy, cx, cy;          /* Kalib (EdgeSE3EllipsoidProj::setKalib, BasicEllipsoidEdges.cpp:114) */
+  int32_t n_cams;                 /* VertexSE3Expmap count  (Optimizer.cpp:127-139) */
+  int32_t n_objs;                 /* VertexEllipsoid count  (Optimizer.cpp:175-180) */
+  const uint8_t* cam_fixed;       /* n_cams flags; NULL = all fixed (mapping mode, Optimizer.cpp:126,135) */
+
+  /* EdgeSE3EllipsoidProj (Optimizer.cpp:201-245): information = weight * I4 */
+  int32_t n_bbox;
+  const int32_t* bbox_cam;
+  const int32_t* bbox_obj;
+  const double* bbox_meas;        /* n_bbox x 4 : x1 y1 x2 y2; entries < 5 are ignored (BasicEllipsoidEdges.cpp:109) */
+  const double* bbox_weight;      /* n_bbox     : Observation::rate */
+
+  /* EdgeSE3Ellipsoid9DOF (Optimizer.cpp:249-279): information = weight * I9
+   * (the caller passes weight = Optimizer.Edges.3DEllipsoid.Scale * prob) */
+  int32_t n_e3d;
+  const int32_t* e3d_cam;
+  const int32_t* e3d_obj;
+  const double* e3d_meas;         /* n_e3d x 10 : local (camera-frame) ellipsoid */
+  const double* e3d_weight;       /* n_e3d */
+
+  /* EdgeEllipsoidGravityPlanePrior (Optimizer.cpp:183-196): information = grav_weight
+   * (the caller passes GravityPrior.Scale^2) */
+  int32_t n_grav;
+  const int32_t* grav_obj;
+  double grav_normal[4];          /* ground plane param; only [0..2] enter the residual */
+  double grav_weight;
+
+  /* EdgeSE3Expmap odometry (Optimizer.cpp:142-158; SLAM mode only): information = diag(odom_info) */
+  int32_t n_odom;
+  const int32_t* odom_i;          /* vertex 0 */
+  const int32_t* odom_j;          /* vertex 1 */
+  const double* odom_meas;        /* n_odom x 7 */
+  const double* odom_info;        /* n_odom x 6 ; NULL = identity */
+} esl_graph;
+
+typedef enum {
+  ESL_JAC_NUMERIC = 0,   /* central differences, delta = numeric_delta (g2o base_binary_edge.hpp:147-197) */
+  ESL_JAC_ANALYTIC = 1   /* closed-form Jacobians of the same residuals */
+} esl_jacobian_mode;
+
+typedef enum {
+  ESL_SOLVER_AUTO = 0,        /* all cameras fixed: batched 9x9 blocks; else Schur on ellipsoids + dense Cholesky */
+  ESL_SOLVER_DENSE_FULL = 1   /* one dense factorisation of the whole free system (what g2o LinearSolverDense does) */
+} esl_linear_solver;
+
+typedef struct {
+  int32_t max_iters;        /* 10  (Optimizer.cpp:291) */
+  int32_t max_trials;       /* 10  (optimization_algorithm_levenberg.cpp:49) */
+  double tau;               /* 1e-5 (optimization_algorithm_levenberg.cpp:45) */
+  int32_t jacobian_mode;    /* esl_jacobian_mode */
+  double numeric_delta;     /* 1e-9 */
+  int32_t linear_solver;    /* esl_linear_solver */
+  int32_t drop_nan_bbox;    /* 1: pre-evaluate bbox edges and drop those with NaN chi2 (Optimizer.cpp:234-243) */
+} esl_lm_params;
+
+typedef struct {
+  int32_t iterations;       /* outer iterations run (SparseOptimizer::optimize return value) */
+  int32_t total_trials;     /* sum of inner LM trials */
+  int32_t n_bbox_valid;
+  int32_t n_bbox_dropped;
+  int32_t stop_reason;      /* 0 max_iters, 1 Terminate(trials==max or rho==0), 2 Terminate(nBad>=3), 3 nothing to optimise */
+  double chi2_initial;
+  double chi2_final;
+  double lambda_final;
+  int32_t trace_len;
+  double trace_chi2[ESL_MAX_TRACE];     /* chi2 after each outer iteration */
+  double trace_lambda[ESL_MAX_TRACE];   /* lambda after each outer iteration */
+  int32_t trace_trials[ESL_MAX_TRACE];  /* inner trials of each outer iteration */
+} esl_lm_report;
+
+/* Partial sums one shard contributes; summed (chi2, scale) or max-ed (max_diag) across shards. */
+typedef struct {
+  double chi2;
+  double max_diag;
+  double scale;      /* sum_j x_j (lambda x_j + b_j) */
+  int32_t solve_ok;  /* 1 if every local factorisation had positive pivots (AND across shards) */
+  int32_t pad;
+} esl_lm_partials;
+
+/* ---- context ---------------------------------------------------------------------------------*/
+int esl_abi_version(void);
+const char* esl_last_error(void);
+int esl_device_count(void);
+int esl_ctx_create(int device_id, esl_ctx** out);
+int esl_ctx_destroy(esl_ctx* ctx);
+int esl_ctx_synchronize(esl_ctx* ctx);
+void esl_lm_params_default(esl_lm_params* p);
+
+/* ---- one-shot optimiser (host buffers in, host buffers out) ------------------------------------*/
+int esl_optimize(esl_ctx* ctx, const esl_graph* g, double* cams_io /* n_cams x 7 */,
+                 double* objs_io /* n_objs x 10 */, const esl_lm_params* p, esl_lm_report* out);
+
+/* ---- resident / step API (graph + states stay in HBM; used by bench and by the sharded driver) --*/
+int esl_graph_upload(esl_ctx* ctx, const esl_graph* g);
+int esl_states_upload(esl_ctx* ctx, const double* cams, const double* objs);
+int esl_states_download(esl_ctx* ctx, double* cams, double* objs);
+int esl_optimize_resident(esl_ctx* ctx, const esl_lm_params* p, esl_lm_report* out);
+
+int esl_lm_begin(esl_ctx* ctx, const esl_lm_params* p, int32_t* n_valid, int32_t* n_dropped);
+/* residuals at current states -> chi2 ; then H,b -> max_diag */
+int esl_lm_linearize(esl_ctx* ctx, esl_lm_partials* out);
+/* SLAM mode only: pointer/size of this shard's partial reduced camera system [S | b_s] in HBM
+ * (device pointer, n x (n+1) doubles, column-major); the caller may sum it across shards in place. */
+int esl_lm_reduced_system(esl_ctx* ctx, double lambda, void** dev_ptr, int64_t* n);
+/* backup states, solve (H + lambda I) x = b, apply x, recompute chi2; states stay updated */
+int esl_lm_try_step(esl_ctx* ctx, double lambda, esl_lm_partials* out);
+/* accept != 0: discard backup; accept == 0: restore states from backup */
+int esl_lm_commit(esl_ctx* ctx, int accept);
+
+/* host-only helper: balanced partition of ellipsoids (with all their edges) over n_parts shards.
+ * part_of_obj receives n_objs entries.  (SURVEY.md §8 e) */
+int esl_partition_objects(const esl_graph* g, int32_t n_parts, int32_t* part_of_obj);
+
+/* ---- single-frame fit -----------------------------------------------------------------------*/
+typedef struct {
+  int32_t stride;               /* 3  (PointCloudFilter.cpp:31-32) */
+  double depth_scale;           /* 5000 (TUM3.yaml Camera.scale) */
+  double depth_min, depth_max;  /* 0.1, 6 (PointCloudFilter.cpp:38; Config.cpp:29) */
+  double voxel_leaf;            /* 0.01 (EllipsoidExtractor.cpp:98) */
+  double plane_dist;            /* 0.05 (EllipsoidExtractor.cpp:570) */
+  double cluster_tolerance;     /* 0.02 (TUM3.yaml:8) */
+  int32_t min_cluster_size;     /* 100  (TUM3.yaml:9) */
+  double center_dis;            /* 0.5  (TUM3.yaml:10) */
+  int32_t symmetry_open;        /* 1 */
+  double symmetry_grid;         /* 0.1 (TUM3.yaml:23) */
+  double symmetry_sigma;        /* 0.1 (TUM3.yaml:26) */
+  int32_t symmetry_lm_iters;    /* 5 in the reference; 0 = score the 9 hypotheses only */
+} esl_fit_params;
+
+void esl_fit_params_default(esl_fit_params* p);
+
+int esl_fit_frame(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t height,
+                  const double* bboxes /* B x 4 */, const int32_t* labels /* B */, int32_t n_boxes,
+                  const double Twc[7], const double intr[5] /* fx fy cx cy scale */,
+                  const double ground[4], const esl_fit_params* p,
+                  double* ellipsoids_out /* B x 10, camera frame */, double* prob_out /* B */,
+                  int32_t* status_out /* B, mirrors miSystemState 0..4 */);
+
+/* ---- SVD quadric initialisation -----------------------------------------------------------------*/
+int esl_init_quadric(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const double* bboxes /* n x 4 */,
+                     int32_t n, const double K[4], int32_t rows, int32_t cols, int32_t faithful,
+                     double ellipsoid_out[10], double qstar_out[16], int32_t* ok);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESL_H_ */

@@ -1,0 +1,77 @@
+/*
+ * esl_oracle.h — CPU restatement (plain C, fp64, single thread) of the reference hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (object-oriented-slam_amd/, the C-ABI
+ * library) may include, link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the reported CPU baseline.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: the reference ships no tests, golden vectors or fixtures for
+ * this path and cannot be compiled here (every translation unit needs Eigen, which is absent, plus
+ * OpenCV/PCL for the fit path).  The restatement is pinned instead by (i) analytic known-answer
+ * tests (tests/test_oracle_kat.py), (ii) an independent numpy restatement
+ * (oracle/np_oracle.py) that must agree with it, and (iii) golden vectors generated from both
+ * (tests/golden/).  Each function cites the reference file:line it follows.
+ */
+#ifndef ESL_ORACLE_H_
+#define ESL_ORACLE_H_
+
+#include "../include/esl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* linear-solver choice of the oracle LM */
+#define ESL_ORACLE_DENSE 0  /* faithful: dense pivoted LDLT of the whole free system (linear_solver_dense.h:65-113) */
+#define ESL_ORACLE_BLOCK 1  /* "CPU, improved over reference": per-ellipsoid 9x9 (mapping) / Schur + dense (SLAM) */
+
+/* --- SE3 / ellipsoid primitives (g2o types/se3quat.h, src/core/Ellipsoid.cpp) ------------------*/
+void esl_oracle_se3_exp(const double upd[6], double out[7]);
+void esl_oracle_se3_log(const double T[7], double out[6]);
+void esl_oracle_se3_mul(const double A[7], const double B[7], double out[7]);
+void esl_oracle_se3_inv(const double A[7], double out[7]);
+void esl_oracle_cam_oplus(const double cam[7], const double upd[6], double out[7]);
+void esl_oracle_obj_oplus(const double obj[10], const double upd[9], double out[10]);
+void esl_oracle_obj_to_minimal(const double obj[10], double out[9]);
+void esl_oracle_obj_from_minimal(const double v[9], double out[10]);
+void esl_oracle_quadric(const double obj[10], double Q[16]);
+void esl_oracle_project_bbox(const double cam[7], const double obj[10], const double K[4], double out[4]);
+
+/* --- residuals (src/core/BasicEllipsoidEdges.cpp, types_six_dof_expmap.h) ---------------------*/
+void esl_oracle_res_bbox(const double cam[7], const double obj[10], const double K[4],
+                         const double meas[4], double r[4]);
+void esl_oracle_res_e3d(const double cam[7], const double obj[10], const double meas[10], double r[9]);
+void esl_oracle_res_grav(const double obj[10], const double normal[4], double r[1]);
+void esl_oracle_res_odom(const double cam_i[7], const double cam_j[7], const double meas[7], double r[6]);
+
+/* --- numeric Jacobians, row-major D x dim (g2o core/base_binary_edge.hpp:131-205) ---------------*/
+void esl_oracle_jac_bbox(const double cam[7], const double obj[10], const double K[4], const double meas[4],
+                         double delta, double Jc[4 * 6], double Jo[4 * 9]);
+void esl_oracle_jac_e3d(const double cam[7], const double obj[10], const double meas[10], double delta,
+                        double Jc[9 * 6], double Jo[9 * 9]);
+void esl_oracle_jac_grav(const double obj[10], const double normal[4], double delta, double Jo[9]);
+void esl_oracle_jac_odom(const double cam_i[7], const double cam_j[7], const double meas[7], double delta,
+                         double Ji[6 * 6], double Jj[6 * 6]);
+
+/* --- dense pivoted LDLT (Eigen::LDLT as used by linear_solver_dense.h:107-111) -----------------*/
+/* A is n x n row-major symmetric (overwritten), b -> x; returns 1 iff isPositive(). */
+int esl_oracle_ldlt_solve(double* A, int n, const double* b, double* x);
+
+/* --- the optimiser (src/core/Optimizer.cpp:83-317 + g2o LM) --------------------------------------*/
+int esl_oracle_optimize(const esl_graph* g, double* cams_io, double* objs_io, const esl_lm_params* p,
+                        int solver, esl_lm_report* out);
+
+/* one linearisation: dense H (n x n row-major) and b of the free system in g2o's variable order.
+ * free_index receives, for every vertex (cams then objs), the first row in H or -1.
+ * Returns n (call with H == NULL to query n). */
+int esl_oracle_build_system(const esl_graph* g, const double* cams, const double* objs, double delta,
+                            int drop_nan_bbox, double* H, double* b, int32_t* free_index, double* chi2);
+
+/* timing helper for bench.py's cpu_baseline: seconds spent in linearise / solve / error evaluation
+ * of the last esl_oracle_optimize call */
+void esl_oracle_last_timing(double t[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
