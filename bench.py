@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py — LM iterations/s of the quadric graph optimisation on MI355X (BASELINE.json metric).
+
+One "step" = one Optimizer::GlobalObjectGraphOptimization-equivalent call (up to 10 LM iterations,
+reference Optimizer.cpp:291) over one device-resident synthetic graph of the BASELINE.json
+configs[3] shape (10k cams / 2k ellipsoids / ~200k bbox edges, SURVEY.md §8 d), restarted from the
+same initial estimate every step (device-side state restore, no PCIe in the timed region).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode mapping|slam] [--config C4|C3]
+
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU (RCCL).  The path
+shards by ellipsoid (SURVEY.md §8 e): every rank owns one graph-sized shard (weak scaling), the only
+exchange in mapping mode is the all-reduce of the LM scalars (chi2, max diag, scale, ok) per trial.
+value = LM iterations x shards / max-over-ranks wall time.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6    # SURVEY.md §8 d (vendor sheet): FP64 matrix
+
+
+def algorithmic_bytes_linearize(g, slam):
+    """SURVEY.md §8 d: per bbox edge 48 B read (+432 B H_co written in SLAM mode), per 3-D edge 96 B
+    (+432 B), per camera 56 B read (+216 B written in SLAM mode), per ellipsoid 80 B read + 432 B written."""
+    nb, n3 = len(g.bbox_cam), len(g.e3d_cam)
+    b = nb * 48 + n3 * 96 + g.n_cams * 56 + g.n_objs * (80 + 432)
+    if slam:
+        b += (nb + n3) * 432 + g.n_cams * 216
+    return b
+
+
+def cpu_baseline(pkg, g, c, o, params, budget_s=25.0):
+    """The CPU restatement (oracle/, single thread) timed on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    # sample: the first n_s ellipsoids with all their edges, sized so the run takes ~10-30 s
+    n_s = min(g.n_objs, 400)
+    sub = g.subset_objects(np.arange(n_s))
+    t0 = time.perf_counter()
+    _, _, rep = po.optimize(sub, c, o[:n_s], params, solver=po.ORACLE_BLOCK)
+    dt = time.perf_counter() - t0
+    tm = po.last_timing()
+    its = max(rep["iterations"], 1)
+    per_iter_sample = dt / its
+    scale = g.n_objs / n_s                       # linear in edges for the block ("improved") solver
+    block_it_s = 1.0 / (per_iter_sample * scale)
+    # faithful dense LDLT (linear_solver_dense.h:65-113): time one n=9*64 dense solve, extrapolate n^3
+    n_d = min(g.n_objs, 64)
+    subd = g.subset_objects(np.arange(n_d))
+    pd = pkg.default_lm_params(max_iters=1, numeric_delta=params.numeric_delta)
+    po.optimize(subd, c, o[:n_d], pd, solver=po.ORACLE_DENSE)
+    td = po.last_timing()
+    dense_solve_full = td["solve_s"] * (g.n_objs / n_d) ** 3
+    return {
+        "value": block_it_s, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+        "sample": (f"oracle/esl_oracle.c (CPU restatement, numeric Jacobians, per-ellipsoid LDLT = 'improved over "
+                   f"reference' solver), first {n_s} of {g.n_objs} ellipsoids with all their edges, {its} LM iterations in "
+                   f"{dt:.1f} s, scaled linearly by {scale:.1f}x"),
+        "split_s": tm,
+        "faithful_dense_ldlt": {
+            "note": ("reference's LinearSolverDense factorises the whole 9N x 9N system every trial; measured on "
+                     f"N={n_d} and extrapolated by (N/{n_d})^3"),
+            "solve_s_per_trial_extrapolated": dense_solve_full,
+            "iterations_per_s_extrapolated": 1.0 / (per_iter_sample * scale + dense_solve_full),
+        },
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="mapping", choices=["mapping", "slam"])
+    ap.add_argument("--config", default="C4")
+    ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    pkg = importlib.import_module("object-oriented-slam_amd")
+    slam = a.mode == "slam"
+    # every rank owns one graph-sized shard (same camera trajectory, its own ellipsoids: different seed)
+    g, c, o, _ = pkg.synth.make_config(a.config, seed=rank, slam=slam)
+    params = pkg.default_lm_params(jacobian_mode=1 if a.jacobian == "analytic" else 0)
+    ctx = pkg.Context(local_rank)
+    ctx.upload_graph(g)
+    ctx.upload_states(c, o)
+    ctx.snapshot_states()
+
+    if world > 1:
+        par = importlib.import_module("object-oriented-slam_amd.parallel")
+        runner = par.ShardedLM(ctx, dist, device=torch.device("cuda", local_rank))
+
+    def one_step():
+        ctx.restore_states()
+        if world > 1:
+            return runner.optimize(params)
+        return ctx.optimize_resident(params)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        one_step()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    iters = trials = 0
+    rep = None
+    for _ in range(a.steps):
+        rep = one_step()
+        iters += rep["iterations"]
+        trials += rep["total_trials"]
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        lin = prof.get("linearize", dict(count=0, total_ms=0.0))
+        dom_name = "linearize"
+        dom = lin
+        if slam and "cholesky_solve" in prof and prof["cholesky_solve"]["total_ms"] > lin["total_ms"]:
+            dom_name, dom = "cholesky_solve", prof["cholesky_solve"]
+        avg_ms = dom["total_ms"] / max(dom["count"], 1)
+        if dom_name == "linearize":
+            abytes = algorithmic_bytes_linearize(g, slam)
+            achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roof = {"kernel": "k_map_linearize" if not slam else "slam_linearize", "bound": "hbm",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms,
+                    "launches": dom["count"]}
+        else:
+            n = 6 * int((~g.cam_fixed.astype(bool)).sum())
+            flops = n ** 3 / 3.0 + 2.0 * n * n
+            achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roof = {"kernel": "dense_cholesky_f64", "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None,
+                    "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": dom["count"]}
+        out = {
+            "metric": "LM iterations/sec (cams+ellipsoids)",
+            "value": world * iters / dt,
+            "unit": "LM iterations/s (one graph-sized shard per GPU, summed over GPUs)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.config} synthetic graph per GPU: {g.n_cams} cams, {g.n_objs} ellipsoids, "
+                                   f"{len(g.bbox_cam)} bbox + {len(g.e3d_cam)} 3-D + {len(g.grav_obj)} gravity"
+                                   f"{' + %d odometry' % len(g.odom_i) if slam else ''} edges; "
+                                   f"{'SLAM mode (free cameras, Schur)' if slam else 'mapping mode (cameras fixed, as shipped)'}; "
+                                   f"{a.jacobian} Jacobians; optimize(10) per step",
+                       "lm_iterations_per_step": iters / a.steps, "lm_trials_per_step": trials / a.steps,
+                       "parallelism": f"ellipsoid-sharded x{world}"},
+            "kernel_ms": prof,
+            "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, g, c, o, pkg.default_lm_params())
+            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

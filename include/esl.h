@@ -153,6 +153,19 @@ int esl_graph_upload(esl_ctx* ctx, const esl_graph* g);
 int esl_states_upload(esl_ctx* ctx, const double* cams, const double* objs);
 int esl_states_download(esl_ctx* ctx, double* cams, double* objs);
 int esl_optimize_resident(esl_ctx* ctx, const esl_lm_params* p, esl_lm_report* out);
+/* device-side copy of the current states (snapshot) and back (restore): lets a caller re-run the
+ * optimiser from the same initial estimate without touching PCIe (the reference re-optimises the
+ * whole graph every frame, Optimizer.cpp:127,166,250). */
+int esl_states_snapshot(esl_ctx* ctx);
+int esl_states_restore(esl_ctx* ctx);
+
+/* per-kernel timing with HIP events recorded on the context's own stream.
+ * kernel ids: 0 linearise, 1 LM trial (solve + retract + chi2), 2 reduced-system build (Schur),
+ *             3 dense Cholesky + solves, 4 reductions / misc.
+ * esl_profile_get drains the events: count[k] launches, total_ms[k] summed durations. */
+#define ESL_PROF_KINDS 8
+int esl_profile_enable(esl_ctx* ctx, int enable);
+int esl_profile_get(esl_ctx* ctx, int64_t count[ESL_PROF_KINDS], double total_ms[ESL_PROF_KINDS]);
 
 int esl_lm_begin(esl_ctx* ctx, const esl_lm_params* p, int32_t* n_valid, int32_t* n_dropped);
 /* residuals at current states -> chi2 ; then H,b -> max_diag */
@@ -164,6 +177,13 @@ int esl_lm_reduced_system(esl_ctx* ctx, double lambda, void** dev_ptr, int64_t* 
 int esl_lm_try_step(esl_ctx* ctx, double lambda, esl_lm_partials* out);
 /* accept != 0: discard backup; accept == 0: restore states from backup */
 int esl_lm_commit(esl_ctx* ctx, int accept);
+
+/* inspection (tests, debugging): copy one device array of the current linearisation to the host.
+ * which: 0 Hoo (n_objs x 45 packed upper 9x9), 1 bo (n_objs x 9), 2 xo (n_objs x 9, last trial),
+ *        3 Hcc (n_free_cams x 36), 4 bc (n_free_cams x 6), 5 xc (n_free_cams x 6, last trial),
+ *        6 reduced system [S | b_s] (n x (n+1), column-major), 7 trial ellipsoids (n_objs x 10),
+ *        8 trial cameras (n_cams x 7).  count = number of doubles the caller's buffer holds. */
+int esl_lm_download(esl_ctx* ctx, int32_t which, double* dst, int64_t count);
 
 /* host-only helper: balanced partition of ellipsoids (with all their edges) over n_parts shards.
  * part_of_obj receives n_objs entries.  (SURVEY.md §8 e) */

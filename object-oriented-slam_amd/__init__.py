@@ -5,6 +5,8 @@ include/esl.h); this package is the thin host-side mirror of the reference's cla
 The directory name carries a hyphen, so import it with
     importlib.import_module("object-oriented-slam_amd")
 """
-from . import abi  # noqa: F401
+from . import abi, lib, synth  # noqa: F401
+from .abi import Graph, default_lm_params  # noqa: F401
+from .lib import Context, EslError  # noqa: F401
 
-__all__ = ["abi"]
+__all__ = ["abi", "lib", "synth", "Graph", "default_lm_params", "Context", "EslError"]

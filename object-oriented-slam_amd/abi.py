@@ -1,8 +1,8 @@
 """ctypes mirror of include/esl.h (the C-ABI of the MI355X backend).
 
-Only plain-old-data layouts live here; both the product binding (lib.py) and the test-only oracle
-binding (oracle/pyoracle.py) build their argument structs from these classes so that the HIP path
-and the CPU restatement are always called with byte-identical inputs.
+Only plain-old-data layouts live here.  The product binding (lib.py) builds its argument structs
+from these classes; the test-only CPU checker reuses the same layouts so that both sides of a
+parity test are always called with byte-identical inputs.
 """
 import ctypes as C
 

@@ -1,0 +1,637 @@
+// esl_capi.hip — C-ABI of libesl_hip.so (include/esl.h): context, graph upload, LM driver.
+//
+// Host-side control mirrors OptimizationAlgorithmLevenberg::solve
+// (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164) and
+// SparseOptimizer::optimize (core/sparse_optimizer.cpp:354-419); all arithmetic on states, residuals,
+// Jacobians and normal equations runs in the HIP kernels of esl_kernels_*.hpp.  There is no CPU
+// fallback: without a HIP device every compute entry point fails with ESL_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "esl_ctx.hpp"
+#include "esl_kernels_map.hpp"
+#include "esl_slam.hpp"
+
+namespace esl {
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+}  // namespace esl
+
+using namespace esl;
+
+namespace esl {
+ProfScope::ProfScope(esl_ctx* ctx, int kind) : c(ctx), slot(-1) {
+  if (!c->prof_on) return;
+  if (c->prof_used + 2 > c->prof_ev.size()) {
+    if (c->prof_ev.size() >= 16384) { prof_drain(c); }
+    else {
+      for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->prof_ev.push_back(e); }
+      c->prof_kind.resize(c->prof_ev.size() / 2);
+    }
+  }
+  slot = (int)c->prof_used;
+  c->prof_kind[slot / 2] = kind;
+  c->prof_used += 2;
+  (void)hipEventRecord(c->prof_ev[slot], c->stream);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(c->prof_ev[slot + 1], c->stream);
+}
+int prof_drain(esl_ctx* c) {
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return ESL_ERR_HIP;
+  for (size_t s = 0; s + 1 < c->prof_used; s += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->prof_ev[s], c->prof_ev[s + 1]) == hipSuccess) {
+      const int k = c->prof_kind[s / 2];
+      c->prof_count[k]++;
+      c->prof_ms[k] += ms;
+    }
+  }
+  c->prof_used = 0;
+  return ESL_OK;
+}
+}  // namespace esl
+
+template <class T>
+static int dev_upload(T** dst, const T* src, size_t n, hipStream_t st) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  ESL_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) ESL_HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+  return ESL_OK;
+}
+template <class T>
+static int dev_alloc(T** dst, size_t n) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  ESL_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  return ESL_OK;
+}
+template <class T>
+static void dev_free(T** p) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+extern "C" {
+
+int esl_abi_version(void) { return ESL_ABI_VERSION; }
+const char* esl_last_error(void) { return g_err.c_str(); }
+
+int esl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void esl_lm_params_default(esl_lm_params* p) {
+  p->max_iters = 10;
+  p->max_trials = 10;
+  p->tau = 1e-5;
+  p->jacobian_mode = ESL_JAC_NUMERIC;
+  p->numeric_delta = 1e-9;
+  p->linear_solver = ESL_SOLVER_AUTO;
+  p->drop_nan_bbox = 1;
+}
+
+int esl_ctx_create(int device_id, esl_ctx** out) {
+  if (!out) return ESL_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device visible: libesl_hip has no CPU fallback");
+    return ESL_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= n) { set_error("device id out of range"); return ESL_ERR_INVALID; }
+  ESL_HIP_TRY(hipSetDevice(device_id));
+  esl_ctx* c = new esl_ctx();
+  c->device = device_id;
+  ESL_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  ESL_HIP_TRY(hipHostMalloc((void**)&c->host_part, 16 * sizeof(double), hipHostMallocDefault));
+  ESL_HIP_TRY(hipMalloc((void**)&c->dev_part, 16 * sizeof(double)));
+  ESL_HIP_TRY(hipMalloc((void**)&c->chol_info, 4 * sizeof(int)));
+  *out = c;
+  return ESL_OK;
+}
+
+static void free_graph(esl_ctx* c) {
+  DevGraph& g = c->g;
+  dev_free(&g.bb_start); dev_free(&g.e3_start); dev_free(&g.gr_cnt);
+  dev_free(&g.bb_cam); dev_free(&g.bb_obj); dev_free(&g.bb_meas); dev_free(&g.bb_w); dev_free(&g.bb_valid);
+  dev_free(&g.e3_cam); dev_free(&g.e3_obj); dev_free(&g.e3_meas); dev_free(&g.e3_w);
+  dev_free(&g.od_i); dev_free(&g.od_j); dev_free(&g.od_meas); dev_free(&g.od_info);
+  dev_free(&g.cam_fixed); dev_free(&g.cam_slot);
+  dev_free(&g.cbb_start); dev_free(&g.cbb_edge); dev_free(&g.ce3_start); dev_free(&g.ce3_edge);
+  dev_free(&g.cod_start); dev_free(&g.cod_edge);
+  dev_free(&c->cams); dev_free(&c->cams_trial); dev_free(&c->objs); dev_free(&c->objs_trial);
+  dev_free(&c->Hoo); dev_free(&c->bo); dev_free(&c->xo); dev_free(&c->obj_part);
+  dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
+  dev_free(&c->Abb); dev_free(&c->Ae3); dev_free(&c->Aod); dev_free(&c->Dinv); dev_free(&c->Yb); dev_free(&c->Ye3);
+  dev_free(&c->S); dev_free(&c->cam_part); dev_free(&c->od_part);
+  dev_free(&c->cams_snap); dev_free(&c->objs_snap);
+  c->S_n = 0;
+  c->graph_loaded = false;
+  c->states_loaded = false;
+  c->lm.begun = false;
+}
+
+int esl_ctx_destroy(esl_ctx* c) {
+  if (!c) return ESL_OK;
+  (void)hipSetDevice(c->device);
+  free_graph(c);
+  for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+  if (c->host_part) (void)hipHostFree(c->host_part);
+  dev_free(&c->dev_part);
+  dev_free(&c->chol_info);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return ESL_OK;
+}
+
+int esl_ctx_synchronize(esl_ctx* c) {
+  if (!c) return ESL_ERR_INVALID;
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graph upload: validate, sort edges by ellipsoid (stable), build CSR
+// ---------------------------------------------------------------------------------------------------
+static int validate_graph(const esl_graph* g) {
+  if (!g || g->n_cams < 0 || g->n_objs < 0 || g->n_bbox < 0 || g->n_e3d < 0 || g->n_grav < 0 || g->n_odom < 0) {
+    set_error("esl_graph: null or negative size");
+    return ESL_ERR_INVALID;
+  }
+  if ((g->n_bbox && (!g->bbox_cam || !g->bbox_obj || !g->bbox_meas || !g->bbox_weight)) ||
+      (g->n_e3d && (!g->e3d_cam || !g->e3d_obj || !g->e3d_meas || !g->e3d_weight)) ||
+      (g->n_grav && !g->grav_obj) || (g->n_odom && (!g->odom_i || !g->odom_j || !g->odom_meas))) {
+    set_error("esl_graph: null edge array with non-zero count");
+    return ESL_ERR_INVALID;
+  }
+  for (int i = 0; i < g->n_bbox; ++i)
+    if (g->bbox_cam[i] < 0 || g->bbox_cam[i] >= g->n_cams || g->bbox_obj[i] < 0 || g->bbox_obj[i] >= g->n_objs) {
+      set_error("esl_graph: bbox edge index out of range");
+      return ESL_ERR_INVALID;
+    }
+  for (int i = 0; i < g->n_e3d; ++i)
+    if (g->e3d_cam[i] < 0 || g->e3d_cam[i] >= g->n_cams || g->e3d_obj[i] < 0 || g->e3d_obj[i] >= g->n_objs) {
+      set_error("esl_graph: 3-D edge index out of range");
+      return ESL_ERR_INVALID;
+    }
+  for (int i = 0; i < g->n_grav; ++i)
+    if (g->grav_obj[i] < 0 || g->grav_obj[i] >= g->n_objs) { set_error("esl_graph: gravity edge index out of range"); return ESL_ERR_INVALID; }
+  for (int i = 0; i < g->n_odom; ++i)
+    if (g->odom_i[i] < 0 || g->odom_i[i] >= g->n_cams || g->odom_j[i] < 0 || g->odom_j[i] >= g->n_cams) {
+      set_error("esl_graph: odometry edge index out of range");
+      return ESL_ERR_INVALID;
+    }
+  return ESL_OK;
+}
+
+static void csr_by_key(const int32_t* key, int n, int n_keys, std::vector<int>& start, std::vector<int>& perm) {
+  start.assign((size_t)n_keys + 1, 0);
+  for (int i = 0; i < n; ++i) start[(size_t)key[i] + 1]++;
+  for (int k = 0; k < n_keys; ++k) start[(size_t)k + 1] += start[k];
+  perm.resize((size_t)n);
+  std::vector<int> pos(start.begin(), start.end() - 1);
+  for (int i = 0; i < n; ++i) perm[(size_t)pos[key[i]]++] = i;
+}
+
+int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
+  if (!c) return ESL_ERR_INVALID;
+  int rc = validate_graph(g);
+  if (rc) return rc;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  free_graph(c);
+  DevGraph& d = c->g;
+  hipStream_t st = c->stream;
+  d.n_cams = g->n_cams; d.n_objs = g->n_objs; d.n_bbox = g->n_bbox; d.n_e3d = g->n_e3d; d.n_odom = g->n_odom;
+  d.K[0] = g->fx; d.K[1] = g->fy; d.K[2] = g->cx; d.K[3] = g->cy;
+  d.grav_n[0] = g->grav_normal[0]; d.grav_n[1] = g->grav_normal[1]; d.grav_n[2] = g->grav_normal[2];
+  d.grav_w = g->grav_weight;
+  {  // rotate_ellipsoid's yaw table (src/core/Ellipsoid.cpp:78, 100): yaw = k*pi/2, k = -1,0,1,2
+    const double ang[4] = {-1, 0, 1, 2};
+    for (int k = 0; k < 4; ++k) { const double yaw = ang[k] * M_PI / 2.0; d.yt.s[k] = std::sin(yaw * 0.5); d.yt.c[k] = std::cos(yaw * 0.5); }
+  }
+  const int N = g->n_objs, F = g->n_cams;
+  std::vector<int> start, perm;
+  // bbox
+  csr_by_key(g->bbox_obj, g->n_bbox, N, start, perm);
+  {
+    std::vector<int> cam(g->n_bbox), obj(g->n_bbox);
+    std::vector<double> meas((size_t)g->n_bbox * 4), w(g->n_bbox);
+    std::vector<unsigned char> valid((size_t)g->n_bbox, 1);
+    for (int k = 0; k < g->n_bbox; ++k) {
+      const int i = perm[k];
+      cam[k] = g->bbox_cam[i]; obj[k] = g->bbox_obj[i]; w[k] = g->bbox_weight[i];
+      for (int j = 0; j < 4; ++j) meas[(size_t)k * 4 + j] = g->bbox_meas[(size_t)i * 4 + j];
+    }
+    if ((rc = dev_upload(&d.bb_start, start.data(), start.size(), st))) return rc;
+    if ((rc = dev_upload(&d.bb_cam, cam.data(), cam.size(), st))) return rc;
+    if ((rc = dev_upload(&d.bb_obj, obj.data(), obj.size(), st))) return rc;
+    if ((rc = dev_upload(&d.bb_meas, meas.data(), meas.size(), st))) return rc;
+    if ((rc = dev_upload(&d.bb_w, w.data(), w.size(), st))) return rc;
+    if ((rc = dev_upload(&d.bb_valid, valid.data(), valid.size(), st))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(st));
+    // camera-side CSR over the SORTED bbox edges
+    std::vector<int> cs, cp;
+    csr_by_key(cam.data(), g->n_bbox, F, cs, cp);
+    if ((rc = dev_upload(&d.cbb_start, cs.data(), cs.size(), st))) return rc;
+    if ((rc = dev_upload(&d.cbb_edge, cp.data(), cp.size(), st))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(st));
+  }
+  // 3-D edges
+  csr_by_key(g->e3d_obj, g->n_e3d, N, start, perm);
+  {
+    std::vector<int> cam(g->n_e3d), obj(g->n_e3d);
+    std::vector<double> meas((size_t)g->n_e3d * 10), w(g->n_e3d);
+    for (int k = 0; k < g->n_e3d; ++k) {
+      const int i = perm[k];
+      cam[k] = g->e3d_cam[i]; obj[k] = g->e3d_obj[i]; w[k] = g->e3d_weight[i];
+      for (int j = 0; j < 10; ++j) meas[(size_t)k * 10 + j] = g->e3d_meas[(size_t)i * 10 + j];
+    }
+    if ((rc = dev_upload(&d.e3_start, start.data(), start.size(), st))) return rc;
+    if ((rc = dev_upload(&d.e3_cam, cam.data(), cam.size(), st))) return rc;
+    if ((rc = dev_upload(&d.e3_obj, obj.data(), obj.size(), st))) return rc;
+    if ((rc = dev_upload(&d.e3_meas, meas.data(), meas.size(), st))) return rc;
+    if ((rc = dev_upload(&d.e3_w, w.data(), w.size(), st))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int> cs, cp;
+    csr_by_key(cam.data(), g->n_e3d, F, cs, cp);
+    if ((rc = dev_upload(&d.ce3_start, cs.data(), cs.size(), st))) return rc;
+    if ((rc = dev_upload(&d.ce3_edge, cp.data(), cp.size(), st))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(st));
+  }
+  // gravity
+  {
+    std::vector<int> cnt((size_t)N, 0);
+    for (int i = 0; i < g->n_grav; ++i) cnt[g->grav_obj[i]]++;
+    for (int o = 0; o < N; ++o)
+      if (cnt[o] > 64) { set_error("more than 64 gravity edges on one ellipsoid"); return ESL_ERR_INVALID; }
+    if ((rc = dev_upload(&d.gr_cnt, cnt.data(), cnt.size(), st))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(st));
+  }
+  // cameras + odometry
+  {
+    std::vector<unsigned char> fixed((size_t)F, 1);
+    std::vector<int> slot((size_t)F, -1);
+    int nf = 0;
+    if (g->cam_fixed)
+      for (int i = 0; i < F; ++i) fixed[i] = g->cam_fixed[i] ? 1 : 0;
+    // a free camera only enters the system if it has an active edge (sparse_optimizer.cpp:236-257)
+    std::vector<unsigned char> touched((size_t)F, 0);
+    for (int i = 0; i < g->n_bbox; ++i) touched[g->bbox_cam[i]] = 1;
+    for (int i = 0; i < g->n_e3d; ++i) touched[g->e3d_cam[i]] = 1;
+    for (int i = 0; i < g->n_odom; ++i)
+      if (!(fixed[g->odom_i[i]] && fixed[g->odom_j[i]])) { touched[g->odom_i[i]] = 1; touched[g->odom_j[i]] = 1; }
+    for (int i = 0; i < F; ++i)
+      if (!fixed[i] && touched[i]) slot[i] = nf++;
+    d.n_free_cams = nf;
+    if ((rc = dev_upload(&d.cam_fixed, fixed.data(), fixed.size(), st))) return rc;
+    if ((rc = dev_upload(&d.cam_slot, slot.data(), slot.size(), st))) return rc;
+    std::vector<double> info((size_t)g->n_odom * 6, 1.0);
+    if (g->odom_info) std::copy(g->odom_info, g->odom_info + (size_t)g->n_odom * 6, info.begin());
+    if ((rc = dev_upload(&d.od_i, g->odom_i, (size_t)g->n_odom, st))) return rc;
+    if ((rc = dev_upload(&d.od_j, g->odom_j, (size_t)g->n_odom, st))) return rc;
+    if ((rc = dev_upload(&d.od_meas, g->odom_meas, (size_t)g->n_odom * 7, st))) return rc;
+    if ((rc = dev_upload(&d.od_info, info.data(), info.size(), st))) return rc;
+    // camera-side CSR over odometry edges: entry = edge*2 + side
+    std::vector<int> key((size_t)g->n_odom * 2), cs, cp;
+    for (int i = 0; i < g->n_odom; ++i) { key[(size_t)2 * i] = g->odom_i[i]; key[(size_t)2 * i + 1] = g->odom_j[i]; }
+    csr_by_key(key.data(), g->n_odom * 2, F, cs, cp);
+    if ((rc = dev_upload(&d.cod_start, cs.data(), cs.size(), st))) return rc;
+    if ((rc = dev_upload(&d.cod_edge, cp.data(), cp.size(), st))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(st));
+  }
+  // states + mapping-mode system
+  if ((rc = dev_alloc(&c->cams, (size_t)F * 7))) return rc;
+  if ((rc = dev_alloc(&c->cams_trial, (size_t)F * 7))) return rc;
+  if ((rc = dev_alloc(&c->objs, (size_t)N * 10))) return rc;
+  if ((rc = dev_alloc(&c->objs_trial, (size_t)N * 10))) return rc;
+  if ((rc = dev_alloc(&c->Hoo, (size_t)N * 45))) return rc;
+  if ((rc = dev_alloc(&c->bo, (size_t)N * 9))) return rc;
+  if ((rc = dev_alloc(&c->xo, (size_t)N * 9))) return rc;
+  if ((rc = dev_alloc(&c->obj_part, (size_t)N * 4))) return rc;
+  ESL_HIP_TRY(hipMemsetAsync(c->obj_part, 0, std::max<size_t>(N, 1) * 4 * sizeof(double), st));
+  if (d.n_free_cams > 0) {
+    if ((rc = slam_alloc(c))) return rc;
+  }
+  ESL_HIP_TRY(hipStreamSynchronize(st));
+  c->graph_loaded = true;
+  return ESL_OK;
+}
+
+int esl_states_upload(esl_ctx* c, const double* cams, const double* objs) {
+  if (!c || !c->graph_loaded) { set_error("esl_states_upload: no graph loaded"); return ESL_ERR_STATE; }
+  if ((c->g.n_cams && !cams) || (c->g.n_objs && !objs)) return ESL_ERR_INVALID;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  if (c->g.n_cams) ESL_HIP_TRY(hipMemcpyAsync(c->cams, cams, (size_t)c->g.n_cams * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (c->g.n_objs) ESL_HIP_TRY(hipMemcpyAsync(c->objs, objs, (size_t)c->g.n_objs * 10 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  c->states_loaded = true;
+  c->lm.begun = false;
+  return ESL_OK;
+}
+
+int esl_states_download(esl_ctx* c, double* cams, double* objs) {
+  if (!c || !c->states_loaded) { set_error("esl_states_download: no states"); return ESL_ERR_STATE; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  if (cams && c->g.n_cams) ESL_HIP_TRY(hipMemcpyAsync(cams, c->cams, (size_t)c->g.n_cams * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (objs && c->g.n_objs) ESL_HIP_TRY(hipMemcpyAsync(objs, c->objs, (size_t)c->g.n_objs * 10 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// step API
+// ---------------------------------------------------------------------------------------------------
+static int read_parts(esl_ctx* c, double out[4]) {
+  ESL_HIP_TRY(hipMemcpyAsync(c->host_part, c->dev_part, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 4; ++i) out[i] = c->host_part[i];
+  return ESL_OK;
+}
+
+int esl_lm_begin(esl_ctx* c, const esl_lm_params* p, int32_t* n_valid, int32_t* n_dropped) {
+  if (!c || !p) return ESL_ERR_INVALID;
+  if (!c->graph_loaded || !c->states_loaded) { set_error("esl_lm_begin: upload graph and states first"); return ESL_ERR_STATE; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  c->lm.p = *p;
+  c->lm.slam = c->g.n_free_cams > 0;
+  c->lm.have_trial = false;
+  int dropped = 0;
+  if (c->g.n_bbox) {
+    if (p->drop_nan_bbox) {
+      int* cnt = c->chol_info + 2;
+      ESL_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(k_bbox_validate, dim3((c->g.n_bbox + 255) / 256), dim3(256), 0, c->stream, c->g, c->cams, c->objs, cnt);
+      ESL_HIP_TRY(hipGetLastError());
+      ESL_HIP_TRY(hipMemcpyAsync(&dropped, cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+      ESL_HIP_TRY(hipMemsetAsync(c->g.bb_valid, 1, (size_t)c->g.n_bbox, c->stream));
+    }
+  }
+  if (n_valid) *n_valid = c->g.n_bbox - dropped;
+  if (n_dropped) *n_dropped = dropped;
+  c->lm.begun = true;
+  return ESL_OK;
+}
+
+int esl_lm_linearize(esl_ctx* c, esl_lm_partials* out) {
+  if (!c || !out) return ESL_ERR_INVALID;
+  if (!c->lm.begun) { set_error("esl_lm_linearize before esl_lm_begin"); return ESL_ERR_STATE; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  const DevGraph& g = c->g;
+  const int N = g.n_objs;
+  if (c->lm.slam) {
+    int rc = slam_linearize(c);
+    if (rc) return rc;
+  } else if (N > 0) {
+    const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    {
+    ProfScope ps(c, 0);
+    if (c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC)
+      hipLaunchKernelGGL(k_map_linearize<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, c->cams, c->objs,
+                         c->lm.p.numeric_delta, c->Hoo, c->bo, c->obj_part);
+    else
+      hipLaunchKernelGGL(k_map_linearize<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, c->cams, c->objs,
+                         c->lm.p.numeric_delta, c->Hoo, c->bo, c->obj_part);
+    }
+    ESL_HIP_TRY(hipGetLastError());
+    ProfScope ps2(c, 4);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, N, c->dev_part, 0);
+    ESL_HIP_TRY(hipGetLastError());
+  } else {
+    ESL_HIP_TRY(hipMemsetAsync(c->dev_part, 0, 4 * sizeof(double), c->stream));
+  }
+  double v[4];
+  int rc = read_parts(c, v);
+  if (rc) return rc;
+  out->chi2 = v[0]; out->max_diag = v[1]; out->scale = 0; out->solve_ok = 1; out->pad = 0;
+  return ESL_OK;
+}
+
+int esl_lm_try_step(esl_ctx* c, double lambda, esl_lm_partials* out) {
+  if (!c || !out) return ESL_ERR_INVALID;
+  if (!c->lm.begun) { set_error("esl_lm_try_step before esl_lm_begin"); return ESL_ERR_STATE; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  const DevGraph& g = c->g;
+  const int N = g.n_objs;
+  if (c->lm.slam) {
+    int rc = slam_try_step(c, lambda);
+    if (rc) return rc;
+  } else if (N > 0) {
+    const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    {
+      ProfScope ps(c, 1);
+      hipLaunchKernelGGL(k_map_try_step, grid, block, 0, c->stream, g, c->cams, c->objs, lambda, c->Hoo, c->bo, c->xo,
+                         c->objs_trial, c->obj_part);
+    }
+    ESL_HIP_TRY(hipGetLastError());
+    ProfScope ps2(c, 4);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, N, c->dev_part, 0);
+    ESL_HIP_TRY(hipGetLastError());
+  } else {
+    ESL_HIP_TRY(hipMemsetAsync(c->dev_part, 0, 4 * sizeof(double), c->stream));
+  }
+  double v[4];
+  int rc = read_parts(c, v);
+  if (rc) return rc;
+  out->chi2 = v[0]; out->max_diag = 0; out->scale = v[2]; out->solve_ok = (N == 0 || v[3] > 0.5) ? 1 : 0; out->pad = 0;
+  c->lm.lambda_used = lambda;
+  c->lm.have_trial = true;
+  return ESL_OK;
+}
+
+int esl_lm_commit(esl_ctx* c, int accept) {
+  if (!c) return ESL_ERR_INVALID;
+  if (!c->lm.begun || !c->lm.have_trial) { set_error("esl_lm_commit without a trial step"); return ESL_ERR_STATE; }
+  if (accept) {  // discardTop: the trial states become the estimate
+    std::swap(c->objs, c->objs_trial);
+    if (c->lm.slam) std::swap(c->cams, c->cams_trial);
+  }
+  c->lm.have_trial = false;
+  return ESL_OK;
+}
+
+int esl_lm_reduced_system(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n) {
+  if (!c || !dev_ptr || !n) return ESL_ERR_INVALID;
+  if (!c->lm.begun) return ESL_ERR_STATE;
+  if (!c->lm.slam) { *dev_ptr = nullptr; *n = 0; return ESL_OK; }
+  return slam_build_reduced(c, lambda, dev_ptr, n);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the LM loop (optimization_algorithm_levenberg.cpp:61-164 + sparse_optimizer.cpp:354-419)
+// ---------------------------------------------------------------------------------------------------
+int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
+  if (!c || !p || !out) return ESL_ERR_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  int32_t nv = 0, nd = 0;
+  int rc = esl_lm_begin(c, p, &nv, &nd);
+  if (rc) return rc;
+  out->n_bbox_valid = nv;
+  out->n_bbox_dropped = nd;
+  const DevGraph& g = c->g;
+  const bool any_edge = (nv > 0) || g.n_e3d > 0 || (g.n_odom > 0 && g.n_free_cams > 0);
+  bool any_grav = false;
+  if (!any_edge) {  // gravity edges alone also make a graph
+    std::vector<int> cnt((size_t)std::max(g.n_objs, 1));
+    if (g.n_objs) ESL_HIP_TRY(hipMemcpy(cnt.data(), g.gr_cnt, (size_t)g.n_objs * sizeof(int), hipMemcpyDeviceToHost));
+    for (int o = 0; o < g.n_objs; ++o) any_grav = any_grav || cnt[o] > 0;
+  }
+  if (!any_edge && !any_grav) { out->stop_reason = 3; return ESL_OK; }
+
+  double lambda = -1, ni = 2;
+  int nBad = 0, it = 0, total_trials = 0;
+  bool ok_outer = true;
+  double currentChi = 0;
+  for (it = 0; it < p->max_iters && ok_outer; ++it) {
+    esl_lm_partials lin;
+    if ((rc = esl_lm_linearize(c, &lin))) return rc;
+    currentChi = lin.chi2;
+    const double iniChi = currentChi;
+    if (it == 0) {
+      out->chi2_initial = currentChi;
+      lambda = p->tau * lin.max_diag;  // computeLambdaInit
+      ni = 2;
+      nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      esl_lm_partials tr;
+      if ((rc = esl_lm_try_step(c, lambda, &tr))) return rc;
+      double tempChi = tr.solve_ok ? tr.chi2 : DBL_MAX;
+      rho = (currentChi - tempChi) / (tr.scale + 1e-3);
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        if ((rc = esl_lm_commit(c, 1))) return rc;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        if ((rc = esl_lm_commit(c, 0))) return rc;
+      }
+      qmax++;
+    } while (rho < 0 && qmax < p->max_trials);
+    total_trials += qmax;
+    if (it < ESL_MAX_TRACE) {
+      out->trace_chi2[it] = currentChi; out->trace_lambda[it] = lambda; out->trace_trials[it] = qmax;
+      out->trace_len = it + 1;
+    }
+    if (qmax == p->max_trials || rho == 0) { ok_outer = false; out->stop_reason = 1; }
+    else {
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      if (nBad >= 3) { ok_outer = false; out->stop_reason = 2; }
+    }
+  }
+  out->iterations = it;
+  out->total_trials = total_trials;
+  out->chi2_final = currentChi;
+  out->lambda_final = lambda;
+  return ESL_OK;
+}
+
+int esl_optimize(esl_ctx* c, const esl_graph* g, double* cams_io, double* objs_io, const esl_lm_params* p,
+                 esl_lm_report* out) {
+  if (!c || !g || !p || !out) return ESL_ERR_INVALID;
+  int rc;
+  if ((rc = esl_graph_upload(c, g))) return rc;
+  if ((rc = esl_states_upload(c, cams_io, objs_io))) return rc;
+  if ((rc = esl_optimize_resident(c, p, out))) return rc;
+  return esl_states_download(c, cams_io, objs_io);
+}
+
+int esl_states_snapshot(esl_ctx* c) {
+  if (!c || !c->states_loaded) { set_error("esl_states_snapshot: no states"); return ESL_ERR_STATE; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  const size_t nc = (size_t)c->g.n_cams * 7, no = (size_t)c->g.n_objs * 10;
+  if (!c->cams_snap) ESL_HIP_TRY(hipMalloc((void**)&c->cams_snap, std::max<size_t>(nc, 1) * sizeof(double)));
+  if (!c->objs_snap) ESL_HIP_TRY(hipMalloc((void**)&c->objs_snap, std::max<size_t>(no, 1) * sizeof(double)));
+  if (nc) ESL_HIP_TRY(hipMemcpyAsync(c->cams_snap, c->cams, nc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (no) ESL_HIP_TRY(hipMemcpyAsync(c->objs_snap, c->objs, no * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return ESL_OK;
+}
+
+int esl_states_restore(esl_ctx* c) {
+  if (!c || !c->cams_snap || !c->objs_snap) { set_error("esl_states_restore: no snapshot"); return ESL_ERR_STATE; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  const size_t nc = (size_t)c->g.n_cams * 7, no = (size_t)c->g.n_objs * 10;
+  if (nc) ESL_HIP_TRY(hipMemcpyAsync(c->cams, c->cams_snap, nc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (no) ESL_HIP_TRY(hipMemcpyAsync(c->objs, c->objs_snap, no * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  c->lm.begun = false;
+  return ESL_OK;
+}
+
+int esl_profile_enable(esl_ctx* c, int enable) {
+  if (!c) return ESL_ERR_INVALID;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  if (c->prof_on) prof_drain(c);
+  c->prof_on = enable != 0;
+  for (int k = 0; k < ESL_PROF_KINDS; ++k) { c->prof_count[k] = 0; c->prof_ms[k] = 0; }
+  return ESL_OK;
+}
+
+int esl_profile_get(esl_ctx* c, int64_t count[ESL_PROF_KINDS], double total_ms[ESL_PROF_KINDS]) {
+  if (!c || !count || !total_ms) return ESL_ERR_INVALID;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  int rc = prof_drain(c);
+  if (rc) return rc;
+  for (int k = 0; k < ESL_PROF_KINDS; ++k) { count[k] = c->prof_count[k]; total_ms[k] = c->prof_ms[k]; }
+  return ESL_OK;
+}
+
+int esl_lm_download(esl_ctx* c, int32_t which, double* dst, int64_t count) {
+  if (!c || !dst || count < 0) return ESL_ERR_INVALID;
+  if (!c->graph_loaded) { set_error("esl_lm_download: no graph"); return ESL_ERR_STATE; }
+  const DevGraph& g = c->g;
+  const double* src = nullptr;
+  int64_t n = 0;
+  switch (which) {
+    case 0: src = c->Hoo; n = (int64_t)g.n_objs * 45; break;
+    case 1: src = c->bo; n = (int64_t)g.n_objs * 9; break;
+    case 2: src = c->xo; n = (int64_t)g.n_objs * 9; break;
+    case 3: src = c->Hcc; n = (int64_t)g.n_free_cams * 36; break;
+    case 4: src = c->bc; n = (int64_t)g.n_free_cams * 6; break;
+    case 5: src = c->xc; n = (int64_t)g.n_free_cams * 6; break;
+    case 6: src = c->S; n = c->S_n * (c->S_n + 1); break;
+    case 7: src = c->objs_trial; n = (int64_t)g.n_objs * 10; break;
+    case 8: src = c->cams_trial; n = (int64_t)g.n_cams * 7; break;
+    default: set_error("esl_lm_download: unknown array"); return ESL_ERR_INVALID;
+  }
+  if (!src || count < n) { set_error("esl_lm_download: array not available or buffer too small"); return ESL_ERR_INVALID; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  if (n) ESL_HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+
+// host-only: balanced partition of ellipsoids by edge count (greedy longest-processing-time)
+int esl_partition_objects(const esl_graph* g, int32_t n_parts, int32_t* part_of_obj) {
+  if (!g || n_parts <= 0 || (!part_of_obj && g->n_objs > 0)) return ESL_ERR_INVALID;
+  int rc = validate_graph(g);
+  if (rc) return rc;
+  const int N = g->n_objs;
+  std::vector<int64_t> load((size_t)N, 1);
+  for (int i = 0; i < g->n_bbox; ++i) load[g->bbox_obj[i]] += 4;
+  for (int i = 0; i < g->n_e3d; ++i) load[g->e3d_obj[i]] += 9;
+  std::vector<int> order((size_t)N);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
+  std::vector<int64_t> tot((size_t)n_parts, 0);
+  for (int k = 0; k < N; ++k) {
+    int best = 0;
+    for (int q = 1; q < n_parts; ++q)
+      if (tot[q] < tot[best]) best = q;
+    part_of_obj[order[k]] = best;
+    tot[best] += load[order[k]];
+  }
+  return ESL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// esl_ctx.hpp — context / device-resident graph shared by the translation units of libesl_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/esl.h"
+#include "esl_math.hpp"
+
+namespace esl {
+
+void set_error(const std::string& s);
+#define ESL_HIP_TRY(expr)                                                                         \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      esl::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+      return ESL_ERR_HIP;                                                                         \
+    }                                                                                             \
+  } while (0)
+
+// Device-resident graph: edges sorted by ellipsoid (CSR), camera-side CSR for the SLAM-mode gather.
+struct DevGraph {
+  int n_cams = 0, n_objs = 0;
+  int n_bbox = 0, n_e3d = 0, n_odom = 0;
+  double K[4];
+  double grav_n[3];
+  double grav_w = 0;
+  YawTable yt;
+  // per ellipsoid
+  int* bb_start = nullptr;   // n_objs + 1
+  int* e3_start = nullptr;   // n_objs + 1
+  int* gr_cnt = nullptr;     // n_objs : number of gravity-prior edges on this ellipsoid
+  // bbox edges, sorted by ellipsoid (stable)
+  int* bb_cam = nullptr; int* bb_obj = nullptr;
+  double* bb_meas = nullptr; double* bb_w = nullptr;
+  unsigned char* bb_valid = nullptr;
+  // 3-D edges, sorted by ellipsoid (stable)
+  int* e3_cam = nullptr; int* e3_obj = nullptr;
+  double* e3_meas = nullptr; double* e3_w = nullptr;
+  // odometry
+  int* od_i = nullptr; int* od_j = nullptr; double* od_meas = nullptr; double* od_info = nullptr;
+  // cameras
+  unsigned char* cam_fixed = nullptr;  // n_cams
+  int* cam_slot = nullptr;             // n_cams: index among free cameras or -1
+  int n_free_cams = 0;
+  // camera-side CSR over (bbox, e3d) edges for H_cc / b_c gathers (SLAM mode)
+  int* cbb_start = nullptr; int* cbb_edge = nullptr;
+  int* ce3_start = nullptr; int* ce3_edge = nullptr;
+  int* cod_start = nullptr; int* cod_edge = nullptr;  // odometry edges touching each camera (edge*2 + side)
+};
+
+struct LmState {
+  bool begun = false;
+  esl_lm_params p;
+  bool slam = false;          // any free camera
+  double lambda_used = 0;
+  bool have_trial = false;
+};
+
+}  // namespace esl
+
+struct esl_ctx;
+namespace esl {
+// RAII event bracket around a group of launches of one kernel class
+struct ProfScope {
+  esl_ctx* c; int slot;
+  ProfScope(esl_ctx* ctx, int kind);
+  ~ProfScope();
+};
+int prof_drain(esl_ctx* c);
+}  // namespace esl
+
+struct esl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  esl::DevGraph g;
+  bool graph_loaded = false;
+  bool states_loaded = false;
+  // states: current and trial (pointer swap on accept)
+  double* cams = nullptr; double* cams_trial = nullptr;   // n_cams x 7
+  double* objs = nullptr; double* objs_trial = nullptr;   // n_objs x 10
+  // mapping-mode system
+  double* Hoo = nullptr;      // n_objs x 45 packed upper
+  double* bo = nullptr;       // n_objs x 9
+  double* xo = nullptr;       // n_objs x 9
+  double* obj_part = nullptr; // n_objs x 4 : chi2, maxdiag, scale, ok
+  // SLAM-mode system
+  double* Hcc = nullptr;      // n_free_cams x 36 diagonal blocks
+  double* bc = nullptr;       // n_free_cams x 6
+  double* xc = nullptr;       // n_free_cams x 6 (solution of the reduced system)
+  double* Wbb = nullptr;      // n_bbox x 54  (H_co blocks, 6x9 row-major)
+  double* We3 = nullptr;      // n_e3d x 54
+  double* Abb = nullptr;      // n_bbox x 27 (per-edge camera contributions: 21 packed + 6)
+  double* Ae3 = nullptr;      // n_e3d x 27
+  double* Aod = nullptr;      // n_odom x (2*27 + 36): per-edge Hii, bi, Hjj, bj packed, Hij full
+  double* Dinv = nullptr;     // n_objs x 81
+  double* Yb = nullptr;       // n_bbox x 54 : W D^-1
+  double* Ye3 = nullptr;      // n_e3d x 54
+  double* S = nullptr;        // n x (n+1) column-major reduced system [S | b_s], n = 6 n_free_cams
+  int64_t S_n = 0;
+  double* cam_part = nullptr; // n_cams x 4
+  double* od_part = nullptr;  // n_odom : chi2 per odometry edge
+  int* chol_info = nullptr;
+  // reductions
+  double* host_part = nullptr;  // pinned: 8 doubles
+  double* dev_part = nullptr;
+  esl::LmState lm;
+  double* cams_snap = nullptr; double* objs_snap = nullptr;
+  // profiling (HIP events on this stream)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;   // pairs
+  std::vector<int> prof_kind;
+  size_t prof_used = 0;
+  int64_t prof_count[ESL_PROF_KINDS] = {0};
+  double prof_ms[ESL_PROF_KINDS] = {0};
+  size_t cap_cams = 0, cap_objs = 0;
+};

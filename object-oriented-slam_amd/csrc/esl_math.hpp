@@ -1,0 +1,646 @@
+// esl_math.hpp — fp64 device arithmetic of the EllipsoidSLAM hot path for gfx950.
+//
+// Everything here is per-lane scalar fp64 (the path is small-matrix algebra per edge; MFMA is
+// reserved for the dense reduced-camera solve).  Functions name the reference routine whose
+// result they reproduce (paths relative to the reference tree):
+//   SE3 exp/log/product        Thirdparty/g2o/g2o/types/se3quat.h:110-134, 229-322
+//   ellipsoid retraction       src/core/Ellipsoid.cpp:38-47
+//   bbox of projected quadric  src/core/Ellipsoid.cpp:209-307 — evaluated here with the closed-form
+//                              tangent lines of the dual conic C* = P Q* P^T (no 3x3 inverse, no atan2):
+//                              x = (C02 -/+ sqrt(C02^2 - C00 C22)) / C22, y likewise with index 1
+//   9-DoF log error, 4 yaws    src/core/Ellipsoid.cpp:63-117
+//   gravity prior              src/core/BasicEllipsoidEdges.cpp:129-152
+//   odometry                   Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:90-99
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define ESL_HD __host__ __device__ __forceinline__
+
+namespace esl {
+
+struct Quat { double x, y, z, w; };
+struct SE3 { Quat r; double t[3]; };
+struct Ell { SE3 pose; double s[3]; };
+struct Mat3 { double m[9]; };  // row-major
+
+ESL_HD Quat q_mul(const Quat& a, const Quat& b) {
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+ESL_HD Quat q_conj(const Quat& a) { return Quat{-a.x, -a.y, -a.z, a.w}; }
+
+ESL_HD void q_rot(const Quat& q, const double v[3], double out[3]) {
+  double ux = q.y * v[2] - q.z * v[1], uy = q.z * v[0] - q.x * v[2], uz = q.x * v[1] - q.y * v[0];
+  ux += ux; uy += uy; uz += uz;
+  out[0] = v[0] + q.w * ux + (q.y * uz - q.z * uy);
+  out[1] = v[1] + q.w * uy + (q.z * ux - q.x * uz);
+  out[2] = v[2] + q.w * uz + (q.x * uy - q.y * ux);
+}
+
+ESL_HD Mat3 q_to_R(const Quat& q) {
+  Mat3 R;
+  double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz;       R.m[2] = txz + twy;
+  R.m[3] = txy + twz;       R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
+  R.m[6] = txz - twy;       R.m[7] = tyz + twx;       R.m[8] = 1 - (txx + tyy);
+  return R;
+}
+
+// rotation matrix -> quaternion; branch on the largest diagonal combination
+ESL_HD Quat q_from_R(const Mat3& Rm) {
+  const double* R = Rm.m;
+  Quat q;
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (R[7] - R[5]) * t; q.y = (R[2] - R[6]) * t; q.z = (R[3] - R[1]) * t;
+  } else if (R[0] >= R[4] && R[0] >= R[8]) {
+    t = sqrt(R[0] - R[4] - R[8] + 1.0);
+    q.x = 0.5 * t; t = 0.5 / t;
+    q.w = (R[7] - R[5]) * t; q.y = (R[3] + R[1]) * t; q.z = (R[6] + R[2]) * t;
+  } else if (R[4] >= R[8]) {
+    t = sqrt(R[4] - R[8] - R[0] + 1.0);
+    q.y = 0.5 * t; t = 0.5 / t;
+    q.w = (R[2] - R[6]) * t; q.z = (R[7] + R[5]) * t; q.x = (R[1] + R[3]) * t;
+  } else {
+    t = sqrt(R[8] - R[0] - R[4] + 1.0);
+    q.z = 0.5 * t; t = 0.5 / t;
+    q.w = (R[3] - R[1]) * t; q.x = (R[2] + R[6]) * t; q.y = (R[5] + R[7]) * t;
+  }
+  return q;
+}
+
+// SE3Quat::normalizeRotation: w >= 0, unit norm
+ESL_HD Quat q_normalize_pos(Quat q) {
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+  return q;
+}
+
+ESL_HD SE3 se3_load(const double* v) {
+  SE3 T;
+  T.t[0] = v[0]; T.t[1] = v[1]; T.t[2] = v[2];
+  T.r.x = v[3]; T.r.y = v[4]; T.r.z = v[5]; T.r.w = v[6];
+  return T;
+}
+ESL_HD void se3_store(const SE3& T, double* v) {
+  v[0] = T.t[0]; v[1] = T.t[1]; v[2] = T.t[2];
+  v[3] = T.r.x; v[4] = T.r.y; v[5] = T.r.z; v[6] = T.r.w;
+}
+ESL_HD Ell ell_load(const double* v) {
+  Ell e;
+  e.pose = se3_load(v);
+  e.s[0] = v[7]; e.s[1] = v[8]; e.s[2] = v[9];
+  return e;
+}
+ESL_HD void ell_store(const Ell& e, double* v) {
+  se3_store(e.pose, v);
+  v[7] = e.s[0]; v[8] = e.s[1]; v[9] = e.s[2];
+}
+
+ESL_HD SE3 se3_mul(const SE3& A, const SE3& B) {
+  SE3 R;
+  double rt[3];
+  q_rot(A.r, B.t, rt);
+  R.t[0] = A.t[0] + rt[0]; R.t[1] = A.t[1] + rt[1]; R.t[2] = A.t[2] + rt[2];
+  R.r = q_normalize_pos(q_mul(A.r, B.r));
+  return R;
+}
+ESL_HD SE3 se3_inv(const SE3& A) {
+  SE3 R;
+  R.r = q_conj(A.r);
+  double nt[3] = {-A.t[0], -A.t[1], -A.t[2]};
+  q_rot(R.r, nt, R.t);
+  return R;
+}
+
+ESL_HD Mat3 skew(const double v[3]) {
+  Mat3 m;
+  m.m[0] = 0;     m.m[1] = -v[2]; m.m[2] = v[1];
+  m.m[3] = v[2];  m.m[4] = 0;     m.m[5] = -v[0];
+  m.m[6] = -v[1]; m.m[7] = v[0];  m.m[8] = 0;
+  return m;
+}
+ESL_HD Mat3 m3_mul(const Mat3& a, const Mat3& b) {
+  Mat3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      c.m[i * 3 + j] = a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j] + a.m[i * 3 + 2] * b.m[6 + j];
+  return c;
+}
+ESL_HD void m3_vec(const Mat3& a, const double v[3], double o[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = a.m[i * 3] * v[0] + a.m[i * 3 + 1] * v[1] + a.m[i * 3 + 2] * v[2];
+}
+
+// SE3Quat::exp including g2o's small-angle branch (R = I + W + W^2, V = R)
+ESL_HD SE3 se3_exp(const double u[6]) {
+  const double w[3] = {u[0], u[1], u[2]}, ups[3] = {u[3], u[4], u[5]};
+  const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const Mat3 Om = skew(w);
+  const Mat3 Om2 = m3_mul(Om, Om);
+  double a, b, c, bv;
+  if (theta < 0.00001) { a = 1.0; b = 1.0; bv = 1.0; c = 1.0; }
+  else {
+    const double st = sin(theta), ct = cos(theta);
+    a = st / theta; b = (1 - ct) / (theta * theta); bv = b; c = (theta - st) / (theta * theta * theta);
+  }
+  Mat3 R, V;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+    R.m[i] = id + a * Om.m[i] + b * Om2.m[i];
+    V.m[i] = (theta < 0.00001) ? R.m[i] : (id + bv * Om.m[i] + c * Om2.m[i]);
+  }
+  SE3 T;
+  T.r = q_normalize_pos(q_from_R(R));
+  m3_vec(V, ups, T.t);
+  return T;
+}
+
+// SE3Quat::log
+ESL_HD void se3_log(const SE3& T, double out[6]) {
+  const Mat3 R = q_to_R(T.r);
+  const double d = 0.5 * (R.m[0] + R.m[4] + R.m[8] - 1);
+  const double dR[3] = {R.m[7] - R.m[5], R.m[2] - R.m[6], R.m[3] - R.m[1]};
+  double f, c;
+  if (d > 0.99999) { f = 0.5; c = 1. / 12.; }
+  else {
+    const double theta = acos(d);
+    f = theta / (2 * sqrt(1 - d * d));
+    c = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+  }
+  const double w[3] = {f * dR[0], f * dR[1], f * dR[2]};
+  const Mat3 Om = skew(w);
+  const Mat3 Om2 = m3_mul(Om, Om);
+  Mat3 Vinv;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+    Vinv.m[i] = id - 0.5 * Om.m[i] + c * Om2.m[i];
+  }
+  double ups[3];
+  m3_vec(Vinv, T.t, ups);
+  out[0] = w[0]; out[1] = w[1]; out[2] = w[2];
+  out[3] = ups[0]; out[4] = ups[1]; out[5] = ups[2];
+}
+
+ESL_HD Ell ell_oplus(const Ell& e, const double u[9]) {  // ellipsoid::exp_update
+  Ell r;
+  r.pose = se3_mul(e.pose, se3_exp(u));
+  r.s[0] = e.s[0] + u[6]; r.s[1] = e.s[1] + u[7]; r.s[2] = e.s[2] + u[8];
+  return r;
+}
+ESL_HD SE3 cam_oplus(const SE3& T, const double u[6]) { return se3_mul(se3_exp(u), T); }  // VertexSE3Expmap::oplusImpl
+
+// ------------------------------------------------------------------------------------------------
+// bbox edge.  M = K [Rcw|tcw] T_wo  (3x4, columns m0 m1 m2 m3);  C* = sum_k s_k^2 m_k m_k^T - m3 m3^T
+// ------------------------------------------------------------------------------------------------
+struct BoxGeom {
+  double m[4][3];   // columns of M
+  double n[4][3];   // columns of N = [Rco | tco] (camera-frame object pose), needed for camera Jacobians
+  double C00, C01, C02, C11, C12, C22;
+};
+
+ESL_HD void box_geom(const SE3& Tcw, const Ell& e, const double K[4], BoxGeom& g) {
+  const Mat3 Rc = q_to_R(Tcw.r);
+  const Mat3 Ro = q_to_R(e.pose.r);
+  const Mat3 Rco = m3_mul(Rc, Ro);
+  double tco[3];
+  m3_vec(Rc, e.pose.t, tco);
+  tco[0] += Tcw.t[0]; tco[1] += Tcw.t[1]; tco[2] += Tcw.t[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { g.n[k][0] = Rco.m[k]; g.n[k][1] = Rco.m[3 + k]; g.n[k][2] = Rco.m[6 + k]; }
+  g.n[3][0] = tco[0]; g.n[3][1] = tco[1]; g.n[3][2] = tco[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    g.m[k][0] = K[0] * g.n[k][0] + K[2] * g.n[k][2];
+    g.m[k][1] = K[1] * g.n[k][1] + K[3] * g.n[k][2];
+    g.m[k][2] = g.n[k][2];
+  }
+  const double d0 = e.s[0] * e.s[0], d1 = e.s[1] * e.s[1], d2 = e.s[2] * e.s[2];
+#define ESL_CIJ(i, j) (d0 * g.m[0][i] * g.m[0][j] + d1 * g.m[1][i] * g.m[1][j] + d2 * g.m[2][i] * g.m[2][j] - g.m[3][i] * g.m[3][j])
+  g.C00 = ESL_CIJ(0, 0); g.C01 = ESL_CIJ(0, 1); g.C02 = ESL_CIJ(0, 2);
+  g.C11 = ESL_CIJ(1, 1); g.C12 = ESL_CIJ(1, 2); g.C22 = ESL_CIJ(2, 2);
+#undef ESL_CIJ
+}
+
+// bbox (x1,y1,x2,y2) from the dual conic; NaN when the outline is not a real ellipse (C22 >= 0:
+// the ellipsoid meets the camera's principal plane / camera inside) — the cases where the
+// reference's A^2 / B^2 go negative (Ellipsoid.cpp:240-243).
+ESL_HD void box_from_conic(const BoxGeom& g, double bb[4], double sq[2]) {
+  const double du = g.C02 * g.C02 - g.C00 * g.C22;
+  const double dv = g.C12 * g.C12 - g.C11 * g.C22;
+  if (!(g.C22 < 0) || !(du >= 0) || !(dv >= 0)) {
+    const double qnan = __builtin_nan("");
+    bb[0] = bb[1] = bb[2] = bb[3] = qnan; sq[0] = sq[1] = qnan;
+    return;
+  }
+  const double su = sqrt(du), sv = sqrt(dv);
+  const double inv = 1.0 / g.C22;
+  bb[0] = (g.C02 + su) * inv; bb[2] = (g.C02 - su) * inv;   // C22 < 0: "+" root is the smaller one
+  bb[1] = (g.C12 + sv) * inv; bb[3] = (g.C12 - sv) * inv;
+  sq[0] = su; sq[1] = sv;
+}
+
+ESL_HD void res_bbox(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4]) {
+  BoxGeom g;
+  box_geom(Tcw, e, K, g);
+  double bb[4], sq[2];
+  box_from_conic(g, bb, sq);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (meas[i] >= 5) ? bb[i] - meas[i] : 0.0;
+}
+
+// derivative of the 4 bbox coordinates given (dC00, dC02, dC22, dC11, dC12)
+ESL_HD void box_dcoords(const BoxGeom& g, const double bb[4], const double sq[2], double dC00, double dC02,
+                        double dC22, double dC11, double dC12, double out[4]) {
+  const double inv = 1.0 / g.C22;
+  const double ddu = (2 * g.C02 * dC02 - dC00 * g.C22 - g.C00 * dC22) / (2 * sq[0]);
+  const double ddv = (2 * g.C12 * dC12 - dC11 * g.C22 - g.C11 * dC22) / (2 * sq[1]);
+  out[0] = (dC02 + ddu - bb[0] * dC22) * inv;
+  out[2] = (dC02 - ddu - bb[2] * dC22) * inv;
+  out[1] = (dC12 + ddv - bb[1] * dC22) * inv;
+  out[3] = (dC12 - ddv - bb[3] * dC22) * inv;
+}
+
+// Analytic Jacobians of the bbox residual.  Jo: 4x9 row-major wrt the ellipsoid retraction
+// (pose * exp([w,v]), s + ds); Jc: 4x6 wrt the camera retraction exp([w,v]) * Tcw (may be null).
+ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4],
+                     double* Jo, double* Jc) {
+  BoxGeom g;
+  box_geom(Tcw, e, K, g);
+  double bb[4], sq[2];
+  box_from_conic(g, bb, sq);
+  bool mask[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { mask[i] = meas[i] >= 5; r[i] = mask[i] ? bb[i] - meas[i] : 0.0; }
+  const double d[3] = {e.s[0] * e.s[0], e.s[1] * e.s[1], e.s[2] * e.s[2]};
+  double col[4];
+  // symmetric outer-sum helper: entries (0,0),(0,2),(2,2),(1,1),(1,2) of a b^T + b a^T
+#define ESL_SYM5(a, b, f, o00, o02, o22, o11, o12)                                    \
+  o00 = (f) * 2 * a[0] * b[0]; o02 = (f) * (a[0] * b[2] + a[2] * b[0]); o22 = (f) * 2 * a[2] * b[2]; \
+  o11 = (f) * 2 * a[1] * b[1]; o12 = (f) * (a[1] * b[2] + a[2] * b[1]);
+  if (Jo) {
+    double c00, c02, c22, c11, c12;
+    // rotations: dC/dwx = (d1-d2)(m1 m2^T + m2 m1^T), dwy = (d2-d0)(m0 m2^T+..), dwz = (d0-d1)(m0 m1^T+..)
+    ESL_SYM5(g.m[1], g.m[2], (d[1] - d[2]), c00, c02, c22, c11, c12)
+    box_dcoords(g, bb, sq, c00, c02, c22, c11, c12, col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Jo[i * 9 + 0] = mask[i] ? col[i] : 0.0;
+    ESL_SYM5(g.m[0], g.m[2], (d[2] - d[0]), c00, c02, c22, c11, c12)
+    box_dcoords(g, bb, sq, c00, c02, c22, c11, c12, col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Jo[i * 9 + 1] = mask[i] ? col[i] : 0.0;
+    ESL_SYM5(g.m[0], g.m[1], (d[0] - d[1]), c00, c02, c22, c11, c12)
+    box_dcoords(g, bb, sq, c00, c02, c22, c11, c12, col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Jo[i * 9 + 2] = mask[i] ? col[i] : 0.0;
+    // translations: dC/dv_j = -(m_j m3^T + m3 m_j^T)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ESL_SYM5(g.m[j], g.m[3], -1.0, c00, c02, c22, c11, c12)
+      box_dcoords(g, bb, sq, c00, c02, c22, c11, c12, col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Jo[i * 9 + 3 + j] = mask[i] ? col[i] : 0.0;
+    }
+    // scales: dC/ds_k = 2 s_k m_k m_k^T
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double f = 2 * e.s[k];
+      c00 = f * g.m[k][0] * g.m[k][0]; c02 = f * g.m[k][0] * g.m[k][2]; c22 = f * g.m[k][2] * g.m[k][2];
+      c11 = f * g.m[k][1] * g.m[k][1]; c12 = f * g.m[k][1] * g.m[k][2];
+      box_dcoords(g, bb, sq, c00, c02, c22, c11, c12, col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Jo[i * 9 + 6 + k] = mask[i] ? col[i] : 0.0;
+    }
+  }
+  if (Jc) {
+    // B = N D M^T (3x3): B[a][b] = sum_k d_k n_k[a] m_k[b] - n3[a] m3[b]
+    double B[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        B[a][b] = d[0] * g.n[0][a] * g.m[0][b] + d[1] * g.n[1][a] * g.m[1][b] + d[2] * g.n[2][a] * g.m[2][b] - g.n[3][a] * g.m[3][b];
+    // dC = X + X^T, X = K [e_j]x B.  rows of [e_j]x B: (e_j x B_col) per column
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double Y[3][3];  // [e_j]x B
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) { Y[j][b] = 0; Y[j1][b] = -B[j2][b]; Y[j2][b] = B[j1][b]; }
+      double X[3][3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        X[0][b] = K[0] * Y[0][b] + K[2] * Y[2][b];
+        X[1][b] = K[1] * Y[1][b] + K[3] * Y[2][b];
+        X[2][b] = Y[2][b];
+      }
+      box_dcoords(g, bb, sq, 2 * X[0][0], X[0][2] + X[2][0], 2 * X[2][2], 2 * X[1][1], X[1][2] + X[2][1], col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Jc[i * 6 + j] = mask[i] ? col[i] : 0.0;
+    }
+    // translation of the camera: dM = K e_j e4^T -> X = -(K e_j) m3^T
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double ke[3] = {0, 0, 0};
+      if (j == 0) { ke[0] = K[0]; }
+      else if (j == 1) { ke[1] = K[1]; }
+      else { ke[0] = K[2]; ke[1] = K[3]; ke[2] = 1.0; }
+      double c00, c02, c22, c11, c12;
+      ESL_SYM5(ke, g.m[3], -1.0, c00, c02, c22, c11, c12)
+      box_dcoords(g, bb, sq, c00, c02, c22, c11, c12, col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Jc[i * 6 + 3 + j] = mask[i] ? col[i] : 0.0;
+    }
+  }
+#undef ESL_SYM5
+}
+
+// ------------------------------------------------------------------------------------------------
+// 9-DoF 3-D edge
+// ------------------------------------------------------------------------------------------------
+struct YawTable { double s[4], c[4]; };  // sin/cos of k*pi/4 for k = -1,0,1,2, computed once on the host
+
+// residual and the chosen hypothesis' relative pose E = T_k^-1 T_est
+ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9],
+                    SE3* E_out = nullptr) {
+  const SE3 Twc = se3_inv(Tcw);
+  const SE3 mw = se3_mul(Twc, meas.pose);
+  double best = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    SE3 rot;
+    rot.r = q_normalize_pos(Quat{0, 0, yt.s[k], yt.c[k]});
+    rot.t[0] = rot.t[1] = rot.t[2] = 0;
+    const SE3 Tk = se3_mul(mw, rot);
+    const SE3 E = se3_mul(se3_inv(Tk), est.pose);
+    double e[9];
+    se3_log(E, e);
+    const bool swap = (k == 0 || k == 2);  // yaw = -90 or +90 degrees: a/b swapped
+    e[6] = est.s[0] - (swap ? meas.s[1] : meas.s[0]);
+    e[7] = est.s[1] - (swap ? meas.s[0] : meas.s[1]);
+    e[8] = est.s[2] - meas.s[2];
+    double n2 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) n2 += e[i] * e[i];
+    const double nn = sqrt(n2);
+    if (k == 0 || nn < best) {
+      best = nn;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) r[i] = e[i];
+      if (E_out) *E_out = E;
+    }
+  }
+}
+
+// d log(E exp(delta)) / d delta at 0 (6x6, row-major; rows/cols ordered [omega, upsilon])
+ESL_HD void dlog_right(const SE3& E, double J[36]) {
+  const Mat3 R = q_to_R(E.r);
+  const double d = 0.5 * (R.m[0] + R.m[4] + R.m[8] - 1);
+  const double dRv[3] = {R.m[7] - R.m[5], R.m[2] - R.m[6], R.m[3] - R.m[1]};
+  double f, fp, c, cp, theta;
+  const bool small = d > 0.99999;
+  if (small) { f = 0.5; fp = 0.0; c = 1. / 12.; cp = 0.0; theta = 0.0; }
+  else {
+    theta = acos(d);
+    const double st = sqrt(1 - d * d), ct = d;
+    f = theta / (2 * st);
+    // f(d) = theta/(2 sin theta), d theta/dd = -1/sin theta
+    fp = -(st - theta * ct) / (2 * st * st * st);
+    const double th2 = theta * theta;
+    const double tn = tan(theta / 2);
+    c = (1 - theta / (2 * tn)) / th2;
+    // dc/dtheta
+    const double g = theta / (2 * tn);
+    const double gp = 1 / (2 * tn) - theta / (4 * tn * tn) * (1 + tn * tn);
+    cp = (-gp) / th2 - 2 * (1 - g) / (th2 * theta);
+  }
+  const double w[3] = {f * dRv[0], f * dRv[1], f * dRv[2]};
+  const Mat3 Om = skew(w);
+  const Mat3 Om2 = m3_mul(Om, Om);
+  Mat3 Vinv;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Vinv.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) - 0.5 * Om.m[i] + c * Om2.m[i];
+  // rotation directions: dR = R [e_j]x
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    // columns of R [e_j]x : col j = 0, col j1 = R col j2, col j2 = -R col j1   ([e_j]x e_j1 = e_j2, [e_j]x e_j2 = -e_j1)
+    Mat3 dRm;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { dRm.m[a * 3 + j] = 0; dRm.m[a * 3 + j1] = R.m[a * 3 + j2]; dRm.m[a * 3 + j2] = -R.m[a * 3 + j1]; }
+    const double dd = 0.5 * (dRm.m[0] + dRm.m[4] + dRm.m[8]);
+    const double ddR[3] = {dRm.m[7] - dRm.m[5], dRm.m[2] - dRm.m[6], dRm.m[3] - dRm.m[1]};
+    double dw[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dw[a] = fp * dd * dRv[a] + f * ddR[a];
+    // d upsilon = dVinv * t ; dVinv = -0.5 dOm + cp dtheta Om2 + c (dOm Om + Om dOm)
+    const Mat3 dOm = skew(dw);
+    const Mat3 A1 = m3_mul(dOm, Om), A2 = m3_mul(Om, dOm);
+    const double dtheta = small ? 0.0 : (w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2]) / theta;
+    Mat3 dV;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dV.m[i] = -0.5 * dOm.m[i] + cp * dtheta * Om2.m[i] + c * (A1.m[i] + A2.m[i]);
+    double du[3];
+    m3_vec(dV, E.t, du);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { J[a * 6 + j] = dw[a]; J[(3 + a) * 6 + j] = du[a]; }
+  }
+  // translation directions: dt = R e_j -> d upsilon = Vinv R e_j ; d omega = 0
+  const Mat3 VR = m3_mul(Vinv, R);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { J[a * 6 + 3 + j] = 0.0; J[(3 + a) * 6 + 3 + j] = VR.m[a * 3 + j]; }
+}
+
+// Ad(T) for twists ordered [omega, upsilon]  (SE3Quat::adj, se3quat.h:324-333)
+ESL_HD void se3_adj(const SE3& T, double A[36]) {
+  const Mat3 R = q_to_R(T.r);
+  const Mat3 tR = m3_mul(skew(T.t), R);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      A[a * 6 + b] = R.m[a * 3 + b];
+      A[a * 6 + 3 + b] = 0.0;
+      A[(3 + a) * 6 + b] = tR.m[a * 3 + b];
+      A[(3 + a) * 6 + 3 + b] = R.m[a * 3 + b];
+    }
+}
+
+// Analytic Jacobians of the 3-D edge.  Jo 9x9, Jc 9x6 (may be null).
+ESL_HD void jac_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9],
+                    double* Jo, double* Jc) {
+  SE3 E;
+  res_e3d(Tcw, est, meas, yt, r, &E);
+  double Jp[36];
+  dlog_right(E, Jp);
+  if (Jo) {
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int b = 0; b < 9; ++b) Jo[a * 9 + b] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) Jo[a * 9 + b] = Jp[a * 6 + b];
+    Jo[6 * 9 + 6] = 1.0; Jo[7 * 9 + 7] = 1.0; Jo[8 * 9 + 8] = 1.0;
+  }
+  if (Jc) {
+    // exp(d) Tcw  ==  right perturbation of E by Ad((Tcw T_est)^-1) d
+    const SE3 Tco = se3_mul(Tcw, est.pose);
+    double Ad[36];
+    se3_adj(se3_inv(Tco), Ad);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += Jp[a * 6 + k] * Ad[k * 6 + b];
+        Jc[a * 6 + b] = s;
+      }
+#pragma unroll
+    for (int a = 6; a < 9; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) Jc[a * 6 + b] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gravity prior
+// ------------------------------------------------------------------------------------------------
+ESL_HD double res_grav(const Ell& e, const double nrm[3]) {
+  const Mat3 R = q_to_R(e.pose.r);
+  const double z[3] = {R.m[2], R.m[5], R.m[8]};
+  const double dot = z[0] * nrm[0] + z[1] * nrm[1] + z[2] * nrm[2];
+  const double zn = sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+  const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+  double c = dot / zn / nn;
+  if (c > 1) c = c - 0.0001;
+  else if (c < -1) c = c + 0.0001;
+  return acos(c);
+}
+ESL_HD double jac_grav(const Ell& e, const double nrm[3], double Jo[9]) {
+  const Mat3 R = q_to_R(e.pose.r);
+  const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+  const double n[3] = {nrm[0] / nn, nrm[1] / nn, nrm[2] / nn};
+  const double zn = sqrt(R.m[2] * R.m[2] + R.m[5] * R.m[5] + R.m[8] * R.m[8]);
+  double c = (R.m[2] * n[0] + R.m[5] * n[1] + R.m[8] * n[2]) / zn;
+  const double c0 = (R.m[0] * n[0] + R.m[3] * n[1] + R.m[6] * n[2]) / zn;  // x-axis . n
+  const double c1 = (R.m[1] * n[0] + R.m[4] * n[1] + R.m[7] * n[2]) / zn;  // y-axis . n
+  if (c > 1) c = c - 0.0001;
+  else if (c < -1) c = c + 0.0001;
+  const double s2 = 1 - c * c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Jo[i] = 0.0;
+  if (s2 > 1e-24) {
+    const double is = 1.0 / sqrt(s2);
+    // z' = z + wy * x_axis - wx * y_axis  ->  dc/dwx = -c1, dc/dwy = c0 ; d acos = -dc / sin
+    Jo[0] = c1 * is;
+    Jo[1] = -c0 * is;
+  }
+  return acos(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// odometry  r = log(Z Ti Tj^-1)
+// ------------------------------------------------------------------------------------------------
+ESL_HD void res_odom(const SE3& Ti, const SE3& Tj, const SE3& Z, double r[6], SE3* E_out = nullptr) {
+  const SE3 E = se3_mul(se3_mul(Z, Ti), se3_inv(Tj));
+  se3_log(E, r);
+  if (E_out) *E_out = E;
+}
+ESL_HD void jac_odom(const SE3& Ti, const SE3& Tj, const SE3& Z, double r[6], double* Ji, double* Jj) {
+  SE3 E;
+  res_odom(Ti, Tj, Z, r, &E);
+  double Jp[36];
+  dlog_right(E, Jp);
+  if (Jj) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Jj[i] = -Jp[i];
+  }
+  if (Ji) {
+    double Ad[36];
+    se3_adj(se3_mul(Tj, se3_inv(Ti)), Ad);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += Jp[a * 6 + k] * Ad[k * 6 + b];
+        Ji[a * 6 + b] = s;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small SPD solve: (H + lambda I) x = b for one 9x9 (or dxd) block, Cholesky-free LDL^T without
+// pivoting; returns false on a non-positive pivot.  H is the packed upper triangle, row-major.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+ESL_HD bool ldlt_solve_packed(const double* Hp, double lambda, const double* b, double* x) {
+  double L[D * D];
+  // unpack
+  int p = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) { const double v = Hp[p++]; L[i * D + j] = v; L[j * D + i] = v; }
+#pragma unroll
+  for (int i = 0; i < D; ++i) L[i * D + i] += lambda;
+  bool ok = true;
+  double dinv[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    double dk = L[k * D + k];
+#pragma unroll
+    for (int j = 0; j < k; ++j) dk -= L[k * D + j] * L[k * D + j] * L[j * D + j];
+    L[k * D + k] = dk;
+    if (!(dk > 0)) ok = false;
+    dinv[k] = 1.0 / dk;
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) {
+      double v = L[i * D + k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) v -= L[i * D + j] * L[k * D + j] * L[j * D + j];
+      L[i * D + k] = v * dinv[k];
+    }
+  }
+  double y[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s -= L[i * D + j] * y[j];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) y[i] *= dinv[i];
+#pragma unroll
+  for (int i = D - 1; i >= 0; --i) {
+    double s = y[i];
+#pragma unroll
+    for (int j = i + 1; j < D; ++j) s -= L[j * D + i] * x[j];
+    x[i] = s;
+  }
+  return ok;
+}
+
+}  // namespace esl

@@ -1,0 +1,177 @@
+"""ctypes binding of csrc/libesl_hip.so (the C-ABI of include/esl.h).
+
+The library is the product: if it is missing or no HIP device is usable, everything here raises —
+there is no CPU fallback (the CPU restatement under oracle/ is test infrastructure and is never
+imported from this package).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libesl_hip.so")
+_lib = None
+
+EXPORTS = [
+    "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
+    "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
+    "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame",
+    "esl_init_quadric",
+]
+
+
+class EslError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", _CSRC])
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EslError(f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.esl_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise EslError(f"libesl_hip.so does not export {name}")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().esl_last_error().decode(errors="replace")
+        raise EslError(f"{what} failed with esl_status {rc}: {msg}")
+
+
+def device_count():
+    return int(load().esl_device_count())
+
+
+_dp = C.POINTER(C.c_double)
+
+
+class Context:
+    """One HIP device + stream + device-resident graph/states (esl_ctx)."""
+
+    def __init__(self, device=0):
+        L = load()
+        self._h = C.c_void_p()
+        _check(L.esl_ctx_create(C.c_int(device), C.byref(self._h)), "esl_ctx_create")
+        self._graph = None
+
+    def close(self):
+        if self._h:
+            load().esl_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- one shot -----------------------------------------------------------------------------
+    def optimize(self, graph, cams, objs, params=None):
+        p = params if params is not None else abi.default_lm_params()
+        g = graph.c_struct()
+        cams = np.array(cams, dtype=np.float64, order="C").reshape(-1, 7).copy()
+        objs = np.array(objs, dtype=np.float64, order="C").reshape(-1, 10).copy()
+        rep = abi.EslLmReport()
+        _check(load().esl_optimize(self._h, C.byref(g), cams.ctypes.data_as(_dp), objs.ctypes.data_as(_dp),
+                                   C.byref(p), C.byref(rep)), "esl_optimize")
+        return cams, objs, rep.as_dict()
+
+    # ---- resident / step API --------------------------------------------------------------------
+    def upload_graph(self, graph):
+        self._graph = graph
+        g = graph.c_struct()
+        _check(load().esl_graph_upload(self._h, C.byref(g)), "esl_graph_upload")
+
+    def upload_states(self, cams, objs):
+        cams = np.ascontiguousarray(cams, dtype=np.float64)
+        objs = np.ascontiguousarray(objs, dtype=np.float64)
+        _check(load().esl_states_upload(self._h, cams.ctypes.data_as(_dp), objs.ctypes.data_as(_dp)), "esl_states_upload")
+
+    def download_states(self):
+        cams = np.zeros((self._graph.n_cams, 7))
+        objs = np.zeros((self._graph.n_objs, 10))
+        _check(load().esl_states_download(self._h, cams.ctypes.data_as(_dp), objs.ctypes.data_as(_dp)), "esl_states_download")
+        return cams, objs
+
+    def optimize_resident(self, params=None):
+        p = params if params is not None else abi.default_lm_params()
+        rep = abi.EslLmReport()
+        _check(load().esl_optimize_resident(self._h, C.byref(p), C.byref(rep)), "esl_optimize_resident")
+        return rep.as_dict()
+
+    def lm_begin(self, params=None):
+        p = params if params is not None else abi.default_lm_params()
+        nv, nd = C.c_int32(0), C.c_int32(0)
+        _check(load().esl_lm_begin(self._h, C.byref(p), C.byref(nv), C.byref(nd)), "esl_lm_begin")
+        return nv.value, nd.value
+
+    def lm_linearize(self):
+        out = abi.EslLmPartials()
+        _check(load().esl_lm_linearize(self._h, C.byref(out)), "esl_lm_linearize")
+        return out
+
+    def lm_try_step(self, lam):
+        out = abi.EslLmPartials()
+        _check(load().esl_lm_try_step(self._h, C.c_double(lam), C.byref(out)), "esl_lm_try_step")
+        return out
+
+    def lm_commit(self, accept):
+        _check(load().esl_lm_commit(self._h, C.c_int(1 if accept else 0)), "esl_lm_commit")
+
+    def lm_reduced_system(self, lam):
+        ptr, n = C.c_void_p(), C.c_int64(0)
+        _check(load().esl_lm_reduced_system(self._h, C.c_double(lam), C.byref(ptr), C.byref(n)), "esl_lm_reduced_system")
+        return ptr.value, n.value
+
+    def lm_download(self, which, count):
+        out = np.zeros(int(count))
+        _check(load().esl_lm_download(self._h, C.c_int32(which), out.ctypes.data_as(_dp), C.c_int64(int(count))),
+               "esl_lm_download")
+        return out
+
+    def snapshot_states(self):
+        _check(load().esl_states_snapshot(self._h), "esl_states_snapshot")
+
+    def restore_states(self):
+        _check(load().esl_states_restore(self._h), "esl_states_restore")
+
+    def profile_enable(self, on=True):
+        _check(load().esl_profile_enable(self._h, C.c_int(1 if on else 0)), "esl_profile_enable")
+
+    def profile_get(self):
+        cnt = (C.c_int64 * 8)()
+        ms = (C.c_double * 8)()
+        _check(load().esl_profile_get(self._h, cnt, ms), "esl_profile_get")
+        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "k6", "k7"]
+        return {n: dict(count=int(cnt[i]), total_ms=float(ms[i])) for i, n in enumerate(names) if cnt[i]}
+
+    def synchronize(self):
+        _check(load().esl_ctx_synchronize(self._h), "esl_ctx_synchronize")
+
+
+def partition_objects(graph, n_parts):
+    """Host-only balanced partition of ellipsoids over shards (works without a GPU)."""
+    g = graph.c_struct()
+    out = np.zeros(graph.n_objs, dtype=np.int32)
+    _check(load().esl_partition_objects(C.byref(g), C.c_int32(n_parts), out.ctypes.data_as(C.POINTER(C.c_int32))),
+           "esl_partition_objects")
+    return out

@@ -129,15 +129,20 @@ def make_graph(n_cams=500, n_objs=50, n_bbox_target=5000, seed=0, slam=False, fr
     Rcw = np.swapaxes(Rwc, -1, -2)
     tcw = -(Rcw @ pos[..., None])[..., 0]
     cams_true = np.concatenate([tcw, _R_to_quat(Rcw)], 1)
-    # --- visibility: bbox fully inside image minus 10 px border, object in front
-    ci, oi = np.meshgrid(np.arange(F), np.arange(N), indexing='ij')
-    ci, oi = ci.ravel(), oi.ravel()
-    bb, z, c22 = project_bboxes(cams_true, objs_true, K, ci, oi)
+    # --- visibility: bbox fully inside image minus 10 px border, object in front (chunked over cameras)
     border = 10
-    vis = (np.isfinite(bb).all(1) & (z > 0.3) & (c22 < 0) & (bb[:, 0] > border) & (bb[:, 1] > border)
-           & (bb[:, 2] < IMG_W - border) & (bb[:, 3] < IMG_H - border) & (bb[:, 2] - bb[:, 0] > 8)
-           & (bb[:, 3] - bb[:, 1] > 8))
-    ci, oi, bb = ci[vis], oi[vis], bb[vis]
+    ci_l, oi_l, bb_l = [], [], []
+    chunk = max(1, 2_000_000 // max(N, 1))
+    for c0 in range(0, F, chunk):
+        cc, oo = np.meshgrid(np.arange(c0, min(F, c0 + chunk)), np.arange(N), indexing='ij')
+        cc, oo = cc.ravel(), oo.ravel()
+        bb, z, c22 = project_bboxes(cams_true, objs_true, K, cc, oo)
+        with np.errstate(invalid='ignore'):
+            vis = (np.isfinite(bb).all(1) & (z > 0.3) & (c22 < 0) & (bb[:, 0] > border) & (bb[:, 1] > border)
+                   & (bb[:, 2] < IMG_W - border) & (bb[:, 3] < IMG_H - border) & (bb[:, 2] - bb[:, 0] > 8)
+                   & (bb[:, 3] - bb[:, 1] > 8))
+        ci_l.append(cc[vis]); oi_l.append(oo[vis]); bb_l.append(bb[vis])
+    ci, oi, bb = np.concatenate(ci_l), np.concatenate(oi_l), np.concatenate(bb_l)
     if len(ci) > n_bbox_target:
         sel = np.sort(rng.choice(len(ci), size=n_bbox_target, replace=False))
         ci, oi, bb = ci[sel], oi[sel], bb[sel]

@@ -141,6 +141,11 @@ def project_bbox(Tcw, To, s, K):
     Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
     P = Km @ Tcw[:3, :]
     C = P @ quadric(To, s) @ P.T
+    if not C[2, 2] < 0:
+        # the outline is a real ellipse iff the ellipsoid does not meet the camera's principal plane
+        # (pi^T Q* pi < 0 for pi = P^T e3); otherwise the reference's A^2/B^2 go negative -> NaN
+        # (Ellipsoid.cpp:240-246)
+        return np.full(4, np.nan)
     with np.errstate(invalid="ignore"):
         du = np.sqrt(C[0, 2] ** 2 - C[0, 0] * C[2, 2])
         dv = np.sqrt(C[1, 2] ** 2 - C[1, 1] * C[2, 2])
