@@ -170,9 +170,11 @@ int esl_profile_get(esl_ctx* ctx, int64_t count[ESL_PROF_KINDS], double total_ms
 int esl_lm_begin(esl_ctx* ctx, const esl_lm_params* p, int32_t* n_valid, int32_t* n_dropped);
 /* residuals at current states -> chi2 ; then H,b -> max_diag */
 int esl_lm_linearize(esl_ctx* ctx, esl_lm_partials* out);
-/* SLAM mode only: pointer/size of this shard's partial reduced camera system [S | b_s] in HBM
- * (device pointer, n x (n+1) doubles, column-major); the caller may sum it across shards in place. */
-int esl_lm_reduced_system(esl_ctx* ctx, double lambda, void** dev_ptr, int64_t* n);
+/* SLAM mode only: build this shard's reduced camera system for `lambda` and return its device pointer.
+ * Layout: (n+1) x n doubles, column-major with leading dimension lda; rows 0..n-1 hold the LOWER
+ * triangle of S = Hcc + lambda I - sum_o W_o (Hoo + lambda I)^-1 W_o^T, row n holds b_s^T.
+ * A multi-GPU caller may sum the lda*n doubles across shards in place (SURVEY.md §8 e). */
+int esl_lm_reduced_system(esl_ctx* ctx, double lambda, void** dev_ptr, int64_t* n, int64_t* lda);
 /* backup states, solve (H + lambda I) x = b, apply x, recompute chi2; states stay updated */
 int esl_lm_try_step(esl_ctx* ctx, double lambda, esl_lm_partials* out);
 /* accept != 0: discard backup; accept == 0: restore states from backup */
@@ -181,7 +183,7 @@ int esl_lm_commit(esl_ctx* ctx, int accept);
 /* inspection (tests, debugging): copy one device array of the current linearisation to the host.
  * which: 0 Hoo (n_objs x 45 packed upper 9x9), 1 bo (n_objs x 9), 2 xo (n_objs x 9, last trial),
  *        3 Hcc (n_free_cams x 36), 4 bc (n_free_cams x 6), 5 xc (n_free_cams x 6, last trial),
- *        6 reduced system [S | b_s] (n x (n+1), column-major), 7 trial ellipsoids (n_objs x 10),
+ *        6 reduced system ((n+1) x n column-major, lda = round_up(n+1,16): lda*n doubles), 7 trial ellipsoids (n_objs x 10),
  *        8 trial cameras (n_cams x 7).  count = number of doubles the caller's buffer holds. */
 int esl_lm_download(esl_ctx* ctx, int32_t which, double* dst, int64_t count);
 

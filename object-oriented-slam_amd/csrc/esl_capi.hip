@@ -123,6 +123,8 @@ static void free_graph(esl_ctx* c) {
   dev_free(&g.cam_fixed); dev_free(&g.cam_slot);
   dev_free(&g.cbb_start); dev_free(&g.cbb_edge); dev_free(&g.ce3_start); dev_free(&g.ce3_edge);
   dev_free(&g.cod_start); dev_free(&g.cod_edge);
+  dev_free(&g.ue_start); dev_free(&g.ue_id); dev_free(&g.ue_slot);
+  dev_free(&c->Linv_ws); dev_free(&c->z_ws);
   dev_free(&c->cams); dev_free(&c->cams_trial); dev_free(&c->objs); dev_free(&c->objs_trial);
   dev_free(&c->Hoo); dev_free(&c->bo); dev_free(&c->xo); dev_free(&c->obj_part);
   dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
@@ -226,6 +228,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
       cam[k] = g->bbox_cam[i]; obj[k] = g->bbox_obj[i]; w[k] = g->bbox_weight[i];
       for (int j = 0; j < 4; ++j) meas[(size_t)k * 4 + j] = g->bbox_meas[(size_t)i * 4 + j];
     }
+    c->h_bb_cam = cam; c->h_bb_obj = obj;
     if ((rc = dev_upload(&d.bb_start, start.data(), start.size(), st))) return rc;
     if ((rc = dev_upload(&d.bb_cam, cam.data(), cam.size(), st))) return rc;
     if ((rc = dev_upload(&d.bb_obj, obj.data(), obj.size(), st))) return rc;
@@ -250,6 +253,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
       cam[k] = g->e3d_cam[i]; obj[k] = g->e3d_obj[i]; w[k] = g->e3d_weight[i];
       for (int j = 0; j < 10; ++j) meas[(size_t)k * 10 + j] = g->e3d_meas[(size_t)i * 10 + j];
     }
+    c->h_e3_cam = cam; c->h_e3_obj = obj;
     if ((rc = dev_upload(&d.e3_start, start.data(), start.size(), st))) return rc;
     if ((rc = dev_upload(&d.e3_cam, cam.data(), cam.size(), st))) return rc;
     if ((rc = dev_upload(&d.e3_obj, obj.data(), obj.size(), st))) return rc;
@@ -287,6 +291,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     for (int i = 0; i < F; ++i)
       if (!fixed[i] && touched[i]) slot[i] = nf++;
     d.n_free_cams = nf;
+    c->h_cam_slot = slot;
     if ((rc = dev_upload(&d.cam_fixed, fixed.data(), fixed.size(), st))) return rc;
     if ((rc = dev_upload(&d.cam_slot, slot.data(), slot.size(), st))) return rc;
     std::vector<double> info((size_t)g->n_odom * 6, 1.0);
@@ -455,11 +460,16 @@ int esl_lm_commit(esl_ctx* c, int accept) {
   return ESL_OK;
 }
 
-int esl_lm_reduced_system(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n) {
-  if (!c || !dev_ptr || !n) return ESL_ERR_INVALID;
+int esl_lm_reduced_system(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n, int64_t* lda) {
+  if (!c || !dev_ptr || !n || !lda) return ESL_ERR_INVALID;
   if (!c->lm.begun) return ESL_ERR_STATE;
-  if (!c->lm.slam) { *dev_ptr = nullptr; *n = 0; return ESL_OK; }
-  return slam_build_reduced(c, lambda, dev_ptr, n);
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  if (!c->lm.slam) { *dev_ptr = nullptr; *n = 0; *lda = 0; return ESL_OK; }
+  *lda = c->S_lda;
+  int rc = slam_build_reduced(c, lambda, dev_ptr, n);
+  if (rc) return rc;
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -599,7 +609,7 @@ int esl_lm_download(esl_ctx* c, int32_t which, double* dst, int64_t count) {
     case 3: src = c->Hcc; n = (int64_t)g.n_free_cams * 36; break;
     case 4: src = c->bc; n = (int64_t)g.n_free_cams * 6; break;
     case 5: src = c->xc; n = (int64_t)g.n_free_cams * 6; break;
-    case 6: src = c->S; n = c->S_n * (c->S_n + 1); break;
+    case 6: src = c->S; n = c->S_lda * c->S_n; break;
     case 7: src = c->objs_trial; n = (int64_t)g.n_objs * 10; break;
     case 8: src = c->cams_trial; n = (int64_t)g.n_cams * 7; break;
     default: set_error("esl_lm_download: unknown array"); return ESL_ERR_INVALID;

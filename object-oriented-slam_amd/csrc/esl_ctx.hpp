@@ -50,6 +50,9 @@ struct DevGraph {
   int* cbb_start = nullptr; int* cbb_edge = nullptr;
   int* ce3_start = nullptr; int* ce3_edge = nullptr;
   int* cod_start = nullptr; int* cod_edge = nullptr;  // odometry edges touching each camera (edge*2 + side)
+  // per ellipsoid: unified list of edges whose camera is free (u = bbox index, or n_bbox + 3-D index)
+  int* ue_start = nullptr; int* ue_id = nullptr; int* ue_slot = nullptr;
+  int n_ue = 0;
 };
 
 struct LmState {
@@ -117,4 +120,9 @@ struct esl_ctx {
   int64_t prof_count[ESL_PROF_KINDS] = {0};
   double prof_ms[ESL_PROF_KINDS] = {0};
   size_t cap_cams = 0, cap_objs = 0;
+  // host copies kept from upload (edge -> camera after sorting by ellipsoid)
+  std::vector<int> h_bb_cam, h_bb_obj, h_e3_cam, h_e3_obj, h_cam_slot;
+  double* Linv_ws = nullptr;  // ceil(n/NB) x NB x NB
+  double* z_ws = nullptr;
+  int64_t S_lda = 0;
 };

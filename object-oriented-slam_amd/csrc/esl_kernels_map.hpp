@@ -56,7 +56,7 @@ __device__ __forceinline__ void numeric_jac_obj(const Ell& e, double delta, int 
 }
 
 // ---- NaN pre-check of bbox edges (Optimizer.cpp:234-243) ------------------------------------------
-__global__ void k_bbox_validate(DevGraph g, const double* __restrict__ cams, const double* __restrict__ objs,
+static __global__ void k_bbox_validate(DevGraph g, const double* __restrict__ cams, const double* __restrict__ objs,
                                 int* __restrict__ n_dropped) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.n_bbox) return;
@@ -74,7 +74,7 @@ __global__ void k_bbox_validate(DevGraph g, const double* __restrict__ cams, con
 // ---- linearise: one wave per ellipsoid ------------------------------------------------------------
 // out: Hoo[o*45..] packed upper, bo[o*9..], part[o*4+0] = chi2, part[o*4+1] = max |H_kk|
 template <int JAC>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_map_linearize(
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_map_linearize(
     DevGraph g, const double* __restrict__ cams, const double* __restrict__ objs, double delta,
     double* __restrict__ Hoo, double* __restrict__ bo, double* __restrict__ part) {
   const int lane = threadIdx.x & 63;
@@ -183,7 +183,7 @@ __device__ __forceinline__ double obj_chi2(const DevGraph& g, const double* __re
 
 // ---- LM trial: solve 9x9, retract, re-evaluate chi2; one wave per ellipsoid ---------------------------
 // part[o*4+0] = chi2(new), part[o*4+2] = sum x (lambda x + b), part[o*4+3] = pivots positive ? 1 : 0
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void k_map_try_step(
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_map_try_step(
     DevGraph g, const double* __restrict__ cams, const double* __restrict__ objs, double lambda,
     const double* __restrict__ Hoo, const double* __restrict__ bo, double* __restrict__ xo,
     double* __restrict__ objs_trial, double* __restrict__ part) {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_map_try_step(
 }
 
 // ---- deterministic reduction of the per-vertex partials: out = {sum chi2, max maxdiag, sum scale, min ok}
-__global__ __launch_bounds__(256) void k_reduce_parts(const double* __restrict__ part, int n, double* __restrict__ out,
+static __global__ __launch_bounds__(256) void k_reduce_parts(const double* __restrict__ part, int n, double* __restrict__ out,
                                                       int accumulate) {
   __shared__ double s0[256], s1[256], s2[256], s3[256];
   double a = 0, b = 0, c = 0, d = 1;

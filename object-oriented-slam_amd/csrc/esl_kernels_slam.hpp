@@ -1,0 +1,488 @@
+// esl_kernels_slam.hpp — SLAM-mode kernels: free SE3 cameras + 9-DoF ellipsoids.
+//
+// This is the `bSLAM_mode = true` branch of the reference (src/core/Optimizer.cpp:126-158: camera 0
+// fixed, odometry EdgeSE3Expmap between consecutive frames) solved the way g2o's BlockSolver does
+// when the ellipsoids are marginalised (Thirdparty/g2o/g2o/core/block_solver.hpp:367-486):
+//     S   = Hcc + lambda I - sum_o  W_o (Hoo + lambda I)^-1 W_o^T
+//     b_s = b_c            - sum_o  W_o (Hoo + lambda I)^-1 b_o
+//     x_c = S^-1 b_s ;  x_o = (Hoo + lambda I)^-1 (b_o - W_o^T x_c)
+// which is the same solution as the dense LDLT of the whole system the shipped solver would compute.
+//
+// Work split:
+//   k_slam_linearize   one wave per ellipsoid (edges sorted by ellipsoid => coalesced): residuals,
+//                      Jacobians wrt ellipsoid AND camera, Hoo/b_o in registers + wave reduction,
+//                      per-edge W = Jc^T W Jo (6x9) and camera terms A = Jc^T W Jc, g = -Jc^T W r to HBM (SoA)
+//   k_slam_odom        one lane per odometry edge
+//   k_slam_cam_gather  one lane per free camera: Hcc, b_c from its edges (camera-side CSR; deterministic)
+//   k_slam_prepare     one wave per ellipsoid: Dinv = (Hoo+lambda I)^-1, Y_e = W_e Dinv, b_s -= Y_e b_o
+//   k_slam_schur       one workgroup per ellipsoid: S[c1,c2] -= Y_e1 W_e2^T over the ellipsoid's edge pairs
+//   dense Cholesky     esl_chol.hpp (FP64 MFMA)
+//   k_slam_backsub     one wave per ellipsoid: x_o, retraction, trial states
+//   k_slam_cam_update  one lane per camera: retraction exp(x_c) * Tcw
+//   chi2 of the trial  k_slam_chi2_obj (wave per ellipsoid) + k_slam_chi2_odom
+#pragma once
+#include "esl_kernels_map.hpp"
+
+namespace esl {
+
+// numeric central-difference Jacobian wrt a camera (g2o base_binary_edge.hpp:147-170)
+template <class F>
+__device__ __forceinline__ void numeric_jac_cam(const SE3& T, double delta, int D, double* J, F&& eval) {
+  const double scalar = 1.0 / (2 * delta);
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    double u[6] = {0, 0, 0, 0, 0, 0};
+    double rp[9], rm[9];
+    u[d] = delta;
+    eval(cam_oplus(T, u), rp);
+    u[d] = -delta;
+    eval(cam_oplus(T, u), rm);
+    for (int k = 0; k < D; ++k) J[k * 6 + d] = scalar * (rp[k] - rm[k]);
+  }
+}
+
+// per-edge camera-side products, written SoA (index k * EU + u)
+template <int D>
+__device__ __forceinline__ void store_cam_terms(const double* Jc, const double* Jo, const double* r, double w,
+                                                double* __restrict__ W, double* __restrict__ A, long EU, long u) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += Jc[k * 6 + a] * w * Jo[k * 9 + b];
+      W[(long)(a * 9 + b) * EU + u] = s;
+    }
+  int p = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = a; c < 6; ++c) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += Jc[k * 6 + a] * w * Jc[k * 6 + c];
+      A[(long)(p++) * EU + u] = s;
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s += Jc[k * 6 + a] * (w * r[k]);
+    A[(long)(21 + a) * EU + u] = -s;
+  }
+}
+
+template <int JAC>
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_linearize(
+    DevGraph g, const double* __restrict__ cams, const double* __restrict__ objs, double delta,
+    double* __restrict__ Hoo, double* __restrict__ bo, double* __restrict__ part, double* __restrict__ W,
+    double* __restrict__ A) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (o >= g.n_objs) return;
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  const Ell e = ell_load(objs + 10 * o);
+  double acc[54];
+#pragma unroll
+  for (int i = 0; i < 54; ++i) acc[i] = 0.0;
+  double chi = 0.0;
+  for (int i = g.bb_start[o] + lane; i < g.bb_start[o + 1]; i += 64) {
+    if (!g.bb_valid[i]) continue;
+    const int ci = g.bb_cam[i];
+    const SE3 T = se3_load(cams + 7 * ci);
+    const bool cam_free = g.cam_slot[ci] >= 0;
+    double meas[4] = {g.bb_meas[4 * i], g.bb_meas[4 * i + 1], g.bb_meas[4 * i + 2], g.bb_meas[4 * i + 3]};
+    const double w = g.bb_w[i];
+    double r[4], Jo[36], Jc[24];
+    if (JAC == ESL_JAC_ANALYTIC) {
+      jac_bbox(T, e, g.K, meas, r, Jo, cam_free ? Jc : nullptr);
+    } else {
+      res_bbox(T, e, g.K, meas, r);
+      numeric_jac_obj(e, delta, 4, Jo, [&](const Ell& ep, double* out) { res_bbox(T, ep, g.K, meas, out); });
+      if (cam_free) numeric_jac_cam(T, delta, 4, Jc, [&](const SE3& Tp, double* out) { res_bbox(Tp, e, g.K, meas, out); });
+    }
+    chi += w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    accum_obj<4>(Jo, r, w, acc);
+    if (cam_free) store_cam_terms<4>(Jc, Jo, r, w, W, A, EU, (long)i);
+  }
+  for (int i = g.e3_start[o] + lane; i < g.e3_start[o + 1]; i += 64) {
+    const int ci = g.e3_cam[i];
+    const SE3 T = se3_load(cams + 7 * ci);
+    const bool cam_free = g.cam_slot[ci] >= 0;
+    const Ell m = ell_load(g.e3_meas + 10 * i);
+    const double w = g.e3_w[i];
+    double r[9], Jo[81], Jc[54];
+    if (JAC == ESL_JAC_ANALYTIC) {
+      jac_e3d(T, e, m, g.yt, r, Jo, cam_free ? Jc : nullptr);
+    } else {
+      res_e3d(T, e, m, g.yt, r);
+      numeric_jac_obj(e, delta, 9, Jo, [&](const Ell& ep, double* out) { res_e3d(T, ep, m, g.yt, out); });
+      if (cam_free) numeric_jac_cam(T, delta, 9, Jc, [&](const SE3& Tp, double* out) { res_e3d(Tp, e, m, g.yt, out); });
+    }
+    double c = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c += r[k] * r[k];
+    chi += w * c;
+    accum_obj<9>(Jo, r, w, acc);
+    if (cam_free) store_cam_terms<9>(Jc, Jo, r, w, W, A, EU, (long)g.n_bbox + i);
+  }
+  if (lane < g.gr_cnt[o]) {
+    double J[9], r[1];
+    if (JAC == ESL_JAC_ANALYTIC) {
+      r[0] = jac_grav(e, g.grav_n, J);
+    } else {
+      r[0] = res_grav(e, g.grav_n);
+      numeric_jac_obj(e, delta, 1, J, [&](const Ell& ep, double* out) { out[0] = res_grav(ep, g.grav_n); });
+    }
+    chi += g.grav_w * r[0] * r[0];
+    accum_obj<1>(J, r, g.grav_w, acc);
+  }
+#pragma unroll
+  for (int i = 0; i < 54; ++i) acc[i] = wave_sum(acc[i]);
+  chi = wave_sum(chi);
+  if (lane == 0) {
+    double md = 0;
+    int p = 0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) { md = fmax(md, fabs(acc[p])); p += 9 - a; }
+#pragma unroll
+    for (int i = 0; i < 45; ++i) Hoo[(size_t)o * 45 + i] = acc[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bo[(size_t)o * 9 + i] = acc[45 + i];
+    part[o * 4 + 0] = chi;
+    part[o * 4 + 1] = md;
+    part[o * 4 + 2] = 0;
+    part[o * 4 + 3] = 1;
+  }
+}
+
+// odometry edges: Aod[e*90 ..] = Hii(21) bi(6) Hjj(21) bj(6) Hij(36, row-major i x j); od_part[e] = chi2
+template <int JAC>
+static __global__ void k_slam_odom(DevGraph g, const double* __restrict__ cams, double delta, double* __restrict__ Aod,
+                            double* __restrict__ od_chi) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.n_odom) return;
+  const int vi = g.od_i[e], vj = g.od_j[e];
+  const bool fi = g.cam_slot[vi] >= 0, fj = g.cam_slot[vj] >= 0;
+  double* out = Aod + (size_t)e * 90;
+  if (!fi && !fj) {  // inactive edge (all vertices fixed)
+    od_chi[e] = 0;
+    for (int k = 0; k < 90; ++k) out[k] = 0;
+    return;
+  }
+  const SE3 Ti = se3_load(cams + 7 * vi), Tj = se3_load(cams + 7 * vj), Z = se3_load(g.od_meas + 7 * e);
+  double r[6], Ji[36], Jj[36];
+  if (JAC == ESL_JAC_ANALYTIC) {
+    jac_odom(Ti, Tj, Z, r, Ji, Jj);
+  } else {
+    res_odom(Ti, Tj, Z, r);
+    numeric_jac_cam(Ti, delta, 6, Ji, [&](const SE3& Tp, double* o6) { res_odom(Tp, Tj, Z, o6); });
+    numeric_jac_cam(Tj, delta, 6, Jj, [&](const SE3& Tp, double* o6) { res_odom(Ti, Tp, Z, o6); });
+  }
+  double w[6], chi = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { w[k] = g.od_info[6 * e + k]; chi += r[k] * w[k] * r[k]; }
+  od_chi[e] = chi;
+  int p = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int c = a; c < 6; ++c) {
+      double s = 0, t = 0;
+      for (int k = 0; k < 6; ++k) { s += Ji[k * 6 + a] * w[k] * Ji[k * 6 + c]; t += Jj[k * 6 + a] * w[k] * Jj[k * 6 + c]; }
+      out[p] = fi ? s : 0.0;
+      out[27 + p] = fj ? t : 0.0;
+      ++p;
+    }
+  for (int a = 0; a < 6; ++a) {
+    double s = 0, t = 0;
+    for (int k = 0; k < 6; ++k) { s += Ji[k * 6 + a] * w[k] * r[k]; t += Jj[k * 6 + a] * w[k] * r[k]; }
+    out[21 + a] = fi ? -s : 0.0;
+    out[48 + a] = fj ? -t : 0.0;
+  }
+  for (int a = 0; a < 6; ++a)
+    for (int c = 0; c < 6; ++c) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += Ji[k * 6 + a] * w[k] * Jj[k * 6 + c];
+      out[54 + a * 6 + c] = (fi && fj) ? s : 0.0;
+    }
+}
+
+// one lane per camera: Hcc (36 full, row-major), bc (6); cam_part = {0, max diag, 0, 1}
+static __global__ void k_slam_cam_gather(DevGraph g, const double* __restrict__ A, const double* __restrict__ Aod,
+                                  double* __restrict__ Hcc, double* __restrict__ bc, double* __restrict__ cam_part) {
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cidx >= g.n_cams) return;
+  const int slot = g.cam_slot[cidx];
+  cam_part[cidx * 4 + 0] = 0; cam_part[cidx * 4 + 1] = 0; cam_part[cidx * 4 + 2] = 0; cam_part[cidx * 4 + 3] = 1;
+  if (slot < 0) return;
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0;
+  for (int q = g.cbb_start[cidx]; q < g.cbb_start[cidx + 1]; ++q) {
+    const int e = g.cbb_edge[q];
+    if (!g.bb_valid[e]) continue;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] += A[(long)k * EU + e];
+  }
+  for (int q = g.ce3_start[cidx]; q < g.ce3_start[cidx + 1]; ++q) {
+    const long u = (long)g.n_bbox + g.ce3_edge[q];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] += A[(long)k * EU + u];
+  }
+  for (int q = g.cod_start[cidx]; q < g.cod_start[cidx + 1]; ++q) {
+    const int es = g.cod_edge[q];
+    const double* src = Aod + (size_t)(es >> 1) * 90 + ((es & 1) ? 27 : 0);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] += src[k];
+  }
+  double md = 0;
+  int p = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = a; c < 6; ++c) {
+      const double v = acc[p++];
+      Hcc[(size_t)slot * 36 + a * 6 + c] = v;
+      Hcc[(size_t)slot * 36 + c * 6 + a] = v;
+      if (a == c) md = fmax(md, fabs(v));
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) bc[(size_t)slot * 6 + a] = acc[21 + a];
+  cam_part[cidx * 4 + 1] = md;
+}
+
+// S <- 0 is done by memset; this adds the camera blocks: diagonal Hcc + lambda I, b_c into row n,
+// odometry off-diagonal blocks into the LOWER triangle.
+static __global__ void k_slam_S_init(DevGraph g, const double* __restrict__ Hcc, const double* __restrict__ bc,
+                              const double* __restrict__ Aod, double lambda, double* __restrict__ S, long lda, long n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = g.n_free_cams;
+  if (t < nf) {
+    for (int a = 0; a < 6; ++a) {
+      for (int c = 0; c < 6; ++c)
+        S[(long)(6 * t + a) + (long)(6 * t + c) * lda] = Hcc[(size_t)t * 36 + a * 6 + c] + ((a == c) ? lambda : 0.0);
+      S[n + (long)(6 * t + a) * lda] = bc[(size_t)t * 6 + a];
+    }
+  } else if (t < nf + g.n_odom) {
+    const int e = t - nf;
+    const int si = g.cam_slot[g.od_i[e]], sj = g.cam_slot[g.od_j[e]];
+    if (si < 0 || sj < 0) return;
+    const double* Hij = Aod + (size_t)e * 90 + 54;  // 6x6 row-major: rows = vertex i, cols = vertex j
+    for (int a = 0; a < 6; ++a)
+      for (int c = 0; c < 6; ++c) {
+        const double v = Hij[a * 6 + c];
+        // block (si, sj) of H; store into the lower triangle
+        if (si > sj) atomicAdd(&S[(long)(6 * si + a) + (long)(6 * sj + c) * lda], v);
+        else atomicAdd(&S[(long)(6 * sj + c) + (long)(6 * si + a) * lda], v);
+      }
+  }
+}
+
+// one wave per ellipsoid: Dinv = (Hoo + lambda I)^-1 (lanes 0..8 each solve one unit vector),
+// then Y_e = W_e Dinv for its free-camera edges and b_s[cam] -= Y_e b_o.  part[o*4+3] = pivots ok.
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
+    DevGraph g, double lambda, const double* __restrict__ Hoo, const double* __restrict__ bo,
+    const double* __restrict__ W, double* __restrict__ Y, double* __restrict__ Dinv, double* __restrict__ S, long lda,
+    long n, double* __restrict__ part) {
+  __shared__ double sD[kWavesPerBlock][81];
+  __shared__ double sb[kWavesPerBlock][9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int o = blockIdx.x * kWavesPerBlock + wv;
+  if (o >= g.n_objs) return;
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  int ok = 1;
+  if (lane < 9) {
+    double e[9], x[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e[i] = (i == lane) ? 1.0 : 0.0;
+    ok = ldlt_solve_packed<9>(Hoo + (size_t)o * 45, lambda, e, x) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { sD[wv][i * 9 + lane] = x[i]; Dinv[(size_t)o * 81 + i * 9 + lane] = x[i]; }
+    sb[wv][lane] = bo[(size_t)o * 9 + lane];
+  }
+  ok = __all(ok);
+  if (lane == 0) part[o * 4 + 3] = (double)ok;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int q = g.ue_start[o] + lane; q < g.ue_start[o + 1]; q += 64) {
+    const long u = g.ue_id[q];
+    const int slot = g.ue_slot[q];
+    if (u < g.n_bbox && !g.bb_valid[u]) continue;
+    double t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double wrow[9];
+#pragma unroll
+      for (int b = 0; b < 9; ++b) wrow[b] = W[(long)(a * 9 + b) * EU + u];
+#pragma unroll
+      for (int b = 0; b < 9; ++b) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s += wrow[k] * sD[wv][k * 9 + b];
+        Y[(long)(a * 9 + b) * EU + u] = s;
+        t[a] += s * sb[wv][b];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) atomicAdd(&S[n + (long)(6 * slot + a) * lda], -t[a]);
+  }
+}
+
+// one workgroup per ellipsoid: all ordered pairs (p, q) of its free-camera edges with slot_p >= slot_q:
+// S[block(slot_p, slot_q)] -= Y_p W_q^T   (lower triangle; same-camera pairs hit the diagonal block twice,
+// once as (p,q) and once as (q,p), which is exactly the symmetric sum).
+static __global__ __launch_bounds__(256) void k_slam_schur(DevGraph g, const double* __restrict__ W,
+                                                    const double* __restrict__ Y, double* __restrict__ S, long lda) {
+  const int o = blockIdx.x;
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  const int q0 = g.ue_start[o], m = g.ue_start[o + 1] - q0;
+  const long npairs = (long)m * m;
+  for (long idx = (long)blockIdx.y * blockDim.x + threadIdx.x; idx < npairs; idx += (long)gridDim.y * blockDim.x) {
+    const int p = (int)(idx / m), q = (int)(idx % m);
+    const int sp = g.ue_slot[q0 + p], sq = g.ue_slot[q0 + q];
+    if (sp < sq) continue;
+    const long up = g.ue_id[q0 + p], uq = g.ue_id[q0 + q];
+    if ((up < g.n_bbox && !g.bb_valid[up]) || (uq < g.n_bbox && !g.bb_valid[uq])) continue;
+    double yp[54];
+#pragma unroll
+    for (int k = 0; k < 54; ++k) yp[k] = Y[(long)k * EU + up];
+    double out[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) out[k] = 0;
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      double wq[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) wq[c] = W[(long)(c * 9 + b) * EU + uq];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out[a * 6 + c] += yp[a * 9 + b] * wq[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) atomicAdd(&S[(long)(6 * sp + a) + (long)(6 * sq + c) * lda], -out[a * 6 + c]);
+  }
+}
+
+// one wave per ellipsoid: x_o = Dinv (b_o - sum_e W_e^T x_c[cam_e]); trial ellipsoid; scale partial
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_backsub(
+    DevGraph g, double lambda, const double* __restrict__ objs, const double* __restrict__ bo,
+    const double* __restrict__ W, const double* __restrict__ Dinv, const double* __restrict__ xc,
+    double* __restrict__ xo, double* __restrict__ objs_trial, double* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (o >= g.n_objs) return;
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  const Ell e = ell_load(objs + 10 * o);
+  const bool active = (g.bb_start[o + 1] > g.bb_start[o]) || (g.e3_start[o + 1] > g.e3_start[o]) || g.gr_cnt[o] > 0;
+  if (!active) {
+    if (lane == 0) { ell_store(e, objs_trial + 10 * o); part[o * 4 + 2] = 0; }
+    return;
+  }
+  double t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = g.ue_start[o] + lane; q < g.ue_start[o + 1]; q += 64) {
+    const long u = g.ue_id[q];
+    if (u < g.n_bbox && !g.bb_valid[u]) continue;
+    const int slot = g.ue_slot[q];
+    double x6[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) x6[a] = xc[(size_t)slot * 6 + a];
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      double s = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) s += W[(long)(a * 9 + b) * EU + u] * x6[a];
+      t[b] += s;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 9; ++b) t[b] = wave_sum(t[b]);
+#pragma unroll
+  for (int b = 0; b < 9; ++b) t[b] = __shfl(t[b], 0, 64);
+  double x[9], bb[9];
+  double scale = 0;
+#pragma unroll
+  for (int b = 0; b < 9; ++b) bb[b] = bo[(size_t)o * 9 + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s += Dinv[(size_t)o * 81 + i * 9 + k] * (bb[k] - t[k]);
+    x[i] = s;
+    scale += s * (lambda * s + bb[i]);
+  }
+  const Ell en = ell_oplus(e, x);
+  if (lane == 0) {
+    ell_store(en, objs_trial + 10 * o);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) xo[(size_t)o * 9 + i] = x[i];
+    part[o * 4 + 2] = scale;
+  }
+}
+
+// one lane per camera: trial camera = exp(x_c) * Tcw for free cameras; scale partial
+static __global__ void k_slam_cam_update(DevGraph g, double lambda, const double* __restrict__ cams,
+                                  const double* __restrict__ xc, const double* __restrict__ bc,
+                                  double* __restrict__ cams_trial, double* __restrict__ cam_part) {
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cidx >= g.n_cams) return;
+  const SE3 T = se3_load(cams + 7 * cidx);
+  const int slot = g.cam_slot[cidx];
+  double scale = 0;
+  if (slot < 0) {
+    se3_store(T, cams_trial + 7 * cidx);
+  } else {
+    double u[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { u[a] = xc[(size_t)slot * 6 + a]; scale += u[a] * (lambda * u[a] + bc[(size_t)slot * 6 + a]); }
+    se3_store(cam_oplus(T, u), cams_trial + 7 * cidx);
+  }
+  cam_part[cidx * 4 + 0] = 0; cam_part[cidx * 4 + 1] = 0; cam_part[cidx * 4 + 2] = scale; cam_part[cidx * 4 + 3] = 1;
+}
+
+// chi2 of the trial states: ellipsoid-attached edges (wave per ellipsoid) ...
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_chi2_obj(DevGraph g, const double* __restrict__ cams,
+                                                                        const double* __restrict__ objs,
+                                                                        double* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (o >= g.n_objs) return;
+  const Ell e = ell_load(objs + 10 * o);
+  const double chi = obj_chi2(g, cams, e, o, lane);
+  if (lane == 0) part[o * 4 + 0] = chi;
+}
+// ... and odometry edges
+static __global__ void k_slam_chi2_odom(DevGraph g, const double* __restrict__ cams, double* __restrict__ od_chi) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.n_odom) return;
+  const int vi = g.od_i[e], vj = g.od_j[e];
+  if (g.cam_slot[vi] < 0 && g.cam_slot[vj] < 0) { od_chi[e] = 0; return; }
+  double r[6];
+  res_odom(se3_load(cams + 7 * vi), se3_load(cams + 7 * vj), se3_load(g.od_meas + 7 * e), r);
+  double chi = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) chi += r[k] * g.od_info[6 * e + k] * r[k];
+  od_chi[e] = chi;
+}
+
+// deterministic sum of a plain array into out[0] (accumulate)
+static __global__ __launch_bounds__(256) void k_sum_into(const double* __restrict__ v, int n, double* __restrict__ out) {
+  __shared__ double s[256];
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += s[0];
+}
+
+// xc <- solution vector x (n doubles) : plain copy kernel not needed (same layout: slot*6 + a)
+
+}  // namespace esl

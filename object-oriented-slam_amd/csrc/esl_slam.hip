@@ -1,8 +1,179 @@
-// esl_slam.hip — placeholder until the Schur path lands (next milestone)
+// esl_slam.hip — host orchestration of SLAM mode (free cameras): linearise, Schur complement onto the
+// cameras, dense FP64-MFMA Cholesky of the reduced camera system, back-substitution, trial states.
+// See esl_kernels_slam.hpp for the maths and the reference citations.
 #include "esl_slam.hpp"
+
+#include <algorithm>
+
+#include "esl_chol.hpp"
+#include "esl_kernels_slam.hpp"
+
 namespace esl {
-int slam_alloc(esl_ctx*) { return ESL_OK; }
-int slam_linearize(esl_ctx*) { set_error("SLAM mode not built yet"); return ESL_ERR_STATE; }
-int slam_build_reduced(esl_ctx*, double, void**, int64_t*) { set_error("SLAM mode not built yet"); return ESL_ERR_STATE; }
-int slam_try_step(esl_ctx*, double) { set_error("SLAM mode not built yet"); return ESL_ERR_STATE; }
+
+template <class T>
+static int up(T** dst, const T* src, size_t n, hipStream_t st) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  ESL_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) ESL_HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+  return ESL_OK;
+}
+template <class T>
+static int al(T** dst, size_t n) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  ESL_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  return ESL_OK;
+}
+
+int slam_alloc(esl_ctx* c) {
+  DevGraph& g = c->g;
+  const int N = g.n_objs, F = g.n_cams, nf = g.n_free_cams;
+  int rc;
+  // unified per-ellipsoid list of edges whose camera is free
+  std::vector<int> start((size_t)N + 1, 0), id, slot;
+  {
+    std::vector<std::vector<std::pair<int, int>>> per((size_t)N);
+    for (int i = 0; i < g.n_bbox; ++i) {
+      const int s = c->h_cam_slot[c->h_bb_cam[i]];
+      if (s >= 0) per[c->h_bb_obj[i]].push_back({i, s});
+    }
+    for (int i = 0; i < g.n_e3d; ++i) {
+      const int s = c->h_cam_slot[c->h_e3_cam[i]];
+      if (s >= 0) per[c->h_e3_obj[i]].push_back({g.n_bbox + i, s});
+    }
+    for (int o = 0; o < N; ++o) {
+      start[(size_t)o + 1] = start[o] + (int)per[o].size();
+      for (auto& pr : per[o]) { id.push_back(pr.first); slot.push_back(pr.second); }
+    }
+  }
+  g.n_ue = (int)id.size();
+  if ((rc = up(&g.ue_start, start.data(), start.size(), c->stream))) return rc;
+  if ((rc = up(&g.ue_id, id.data(), id.size(), c->stream))) return rc;
+  if ((rc = up(&g.ue_slot, slot.data(), slot.size(), c->stream))) return rc;
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t EU = (size_t)g.n_bbox + g.n_e3d;
+  if ((rc = al(&c->Hcc, (size_t)nf * 36))) return rc;
+  if ((rc = al(&c->bc, (size_t)nf * 6))) return rc;
+  if ((rc = al(&c->Wbb, EU * 54))) return rc;   // unified W  [54][EU]
+  if ((rc = al(&c->Abb, EU * 27))) return rc;   // unified A  [27][EU]
+  if ((rc = al(&c->Yb, EU * 54))) return rc;    // unified Y  [54][EU]
+  if ((rc = al(&c->Aod, (size_t)g.n_odom * 90))) return rc;
+  if ((rc = al(&c->Dinv, (size_t)N * 81))) return rc;
+  if ((rc = al(&c->cam_part, (size_t)F * 4))) return rc;
+  if ((rc = al(&c->od_part, (size_t)g.n_odom))) return rc;
+  const int64_t n = 6 * (int64_t)nf;
+  c->S_n = n;
+  c->S_lda = ((n + 1 + 15) / 16) * 16;
+  if ((rc = al(&c->S, (size_t)c->S_lda * (size_t)n))) return rc;
+  if ((rc = al(&c->xc, (size_t)n))) return rc;
+  const size_t np = (size_t)((n + kNB - 1) / kNB);
+  if ((rc = al(&c->Linv_ws, np * kNB * kNB))) return rc;
+  if ((rc = al(&c->z_ws, (size_t)kNB))) return rc;
+  // W / A of edges that are never written (fixed camera) must not hold NaN garbage where they are summed
+  ESL_HIP_TRY(hipMemsetAsync(c->Abb, 0, std::max<size_t>(EU, 1) * 27 * sizeof(double), c->stream));
+  ESL_HIP_TRY(hipMemsetAsync(c->Wbb, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+
+static int reduce_all(esl_ctx* c) {
+  const DevGraph& g = c->g;
+  hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, g.n_objs, c->dev_part, 0);
+  hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->cam_part, g.n_cams, c->dev_part, 1);
+  if (g.n_odom) hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(256), 0, c->stream, c->od_part, g.n_odom, c->dev_part);
+  ESL_HIP_TRY(hipGetLastError());
+  return ESL_OK;
+}
+
+int slam_linearize(esl_ctx* c) {
+  const DevGraph& g = c->g;
+  const int N = g.n_objs, F = g.n_cams;
+  const bool an = c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC;
+  const double delta = c->lm.p.numeric_delta;
+  {
+    ProfScope ps(c, 0);
+    if (N > 0) {
+      const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+      if (an)
+        hipLaunchKernelGGL(k_slam_linearize<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, c->cams, c->objs, delta, c->Hoo,
+                           c->bo, c->obj_part, c->Wbb, c->Abb);
+      else
+        hipLaunchKernelGGL(k_slam_linearize<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, c->cams, c->objs, delta, c->Hoo,
+                           c->bo, c->obj_part, c->Wbb, c->Abb);
+    }
+    if (g.n_odom) {
+      const dim3 grid((g.n_odom + 127) / 128), block(128);
+      if (an) hipLaunchKernelGGL(k_slam_odom<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, c->cams, delta, c->Aod, c->od_part);
+      else hipLaunchKernelGGL(k_slam_odom<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, c->cams, delta, c->Aod, c->od_part);
+    }
+    hipLaunchKernelGGL(k_slam_cam_gather, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, c->Abb, c->Aod, c->Hcc, c->bc,
+                       c->cam_part);
+  }
+  ESL_HIP_TRY(hipGetLastError());
+  ProfScope ps2(c, 4);
+  return reduce_all(c);
+}
+
+int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out) {
+  const DevGraph& g = c->g;
+  const int N = g.n_objs;
+  const long n = (long)c->S_n, lda = (long)c->S_lda;
+  {
+    ProfScope ps(c, 2);
+    ESL_HIP_TRY(hipMemsetAsync(c->S, 0, (size_t)lda * (size_t)n * sizeof(double), c->stream));
+    const int tot = g.n_free_cams + g.n_odom;
+    hipLaunchKernelGGL(k_slam_S_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, g, c->Hcc, c->bc, c->Aod, lambda, c->S,
+                       lda, n);
+    if (N > 0) {
+      const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+      hipLaunchKernelGGL(k_slam_prepare, grid, block, 0, c->stream, g, lambda, c->Hoo, c->bo, c->Wbb, c->Yb, c->Dinv, c->S, lda,
+                         n, c->obj_part);
+      hipLaunchKernelGGL(k_slam_schur, dim3(N, 8), dim3(256), 0, c->stream, g, c->Wbb, c->Yb, c->S, lda);
+    }
+  }
+  ESL_HIP_TRY(hipGetLastError());
+  if (dev_ptr) *dev_ptr = c->S;
+  if (n_out) *n_out = n;
+  c->lm.lambda_used = lambda;
+  return ESL_OK;
+}
+
+int slam_try_step(esl_ctx* c, double lambda) {
+  const DevGraph& g = c->g;
+  const int N = g.n_objs, F = g.n_cams;
+  int rc = slam_build_reduced(c, lambda, nullptr, nullptr);
+  if (rc) return rc;
+  {
+    ProfScope ps(c, 3);
+    ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
+    ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream));
+  }
+  {
+    ProfScope ps(c, 1);
+    const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    if (N > 0)
+      hipLaunchKernelGGL(k_slam_backsub, grid, block, 0, c->stream, g, lambda, c->objs, c->bo, c->Wbb, c->Dinv, c->xc, c->xo,
+                         c->objs_trial, c->obj_part);
+    hipLaunchKernelGGL(k_slam_cam_update, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, lambda, c->cams, c->xc, c->bc,
+                       c->cams_trial, c->cam_part);
+    if (N > 0) hipLaunchKernelGGL(k_slam_chi2_obj, grid, block, 0, c->stream, g, c->cams_trial, c->objs_trial, c->obj_part);
+    if (g.n_odom)
+      hipLaunchKernelGGL(k_slam_chi2_odom, dim3((g.n_odom + 127) / 128), dim3(128), 0, c->stream, g, c->cams_trial, c->od_part);
+  }
+  ESL_HIP_TRY(hipGetLastError());
+  {
+    ProfScope ps2(c, 4);
+    if ((rc = reduce_all(c))) return rc;
+  }
+  // fold the Cholesky pivot check into the "ok" partial
+  int info = 0;
+  ESL_HIP_TRY(hipMemcpyAsync(&info, c->chol_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (info) {
+    const double zero = 0.0;
+    ESL_HIP_TRY(hipMemcpyAsync(c->dev_part + 3, &zero, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return ESL_OK;
+}
+
 }  // namespace esl

@@ -138,9 +138,10 @@ class Context:
         _check(load().esl_lm_commit(self._h, C.c_int(1 if accept else 0)), "esl_lm_commit")
 
     def lm_reduced_system(self, lam):
-        ptr, n = C.c_void_p(), C.c_int64(0)
-        _check(load().esl_lm_reduced_system(self._h, C.c_double(lam), C.byref(ptr), C.byref(n)), "esl_lm_reduced_system")
-        return ptr.value, n.value
+        ptr, n, lda = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        _check(load().esl_lm_reduced_system(self._h, C.c_double(lam), C.byref(ptr), C.byref(n), C.byref(lda)),
+               "esl_lm_reduced_system")
+        return ptr.value, n.value, lda.value
 
     def lm_download(self, which, count):
         out = np.zeros(int(count))

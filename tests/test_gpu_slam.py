@@ -1,0 +1,98 @@
+"""SLAM mode (free cameras, odometry, Schur + dense FP64-MFMA Cholesky) against the CPU restatement.
+
+The reference ships this branch switched off (bSLAM_mode = false, Optimizer.cpp:126); parity is
+"what g2o would do with that graph": the oracle's dense LDLT of the whole system (ORACLE_DENSE)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def lower_to_full(S, n, lda):
+    M = S.reshape(n, lda).T  # column-major (lda x n) -> M[row, col]
+    L = M[:n, :n]
+    full = np.tril(L) + np.tril(L, -1).T
+    return full, M[n, :n].copy()
+
+
+def cam_err(a, b):
+    from oracle import np_oracle as npo
+    e = 0.0
+    for x, y in zip(a, b):
+        d = npo.se3_log(npo.T_inv(npo.T_from7(x)) @ npo.T_from7(y))
+        e = max(e, np.linalg.norm(d))
+    return e
+
+
+@pytest.mark.parametrize("jac,delta,tol", [(0, 1e-6, 5e-6), (1, 1e-6, 5e-6)])
+def test_slam_linearisation_matches_oracle(pkg, po, ctx, jac, delta, tol):
+    g, c, o, _ = pkg.synth.make_graph(30, 6, 200, seed=3, slam=True)
+    H, b, fidx, chi = po.build_system(g, c, o, delta=1e-6)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ctx.lm_begin(pkg.default_lm_params(jacobian_mode=jac, numeric_delta=delta))
+    part = ctx.lm_linearize()
+    assert part.chi2 == pytest.approx(chi, rel=1e-9)
+    nf = int((~g.cam_fixed.astype(bool)).sum())
+    Hcc = ctx.lm_download(3, nf * 36).reshape(nf, 6, 6)
+    bc = ctx.lm_download(4, nf * 6).reshape(nf, 6)
+    free = [i for i in range(g.n_cams) if not g.cam_fixed[i]]
+    for s, ci in enumerate(free):
+        i = fidx[ci]
+        assert i == 6 * s
+        np.testing.assert_allclose(Hcc[s], H[i:i + 6, i:i + 6], atol=tol * np.abs(H[i:i + 6, i:i + 6]).max())
+        np.testing.assert_allclose(bc[s], b[i:i + 6], atol=tol * max(np.abs(b[i:i + 6]).max(), 1.0))
+    assert part.max_diag == pytest.approx(np.abs(np.diag(H)).max(), rel=1e-5)
+    # reduced system vs a numpy Schur complement of the oracle's dense H
+    lam = 1e-5 * part.max_diag
+    ptr, n, lda = ctx.lm_reduced_system(lam)
+    assert n == 6 * nf
+    S, bs = lower_to_full(ctx.lm_download(6, lda * n), n, lda)
+    Hl = H + lam * np.eye(len(b))
+    Hpp, Hpl, Hll = Hl[:n, :n], Hl[:n, n:], Hl[n:, n:]
+    S_ref = Hpp - Hpl @ np.linalg.solve(Hll, Hpl.T)
+    bs_ref = b[:n] - Hpl @ np.linalg.solve(Hll, b[n:])
+    np.testing.assert_allclose(S, S_ref, atol=tol * np.abs(S_ref).max())
+    np.testing.assert_allclose(bs, bs_ref, atol=tol * np.abs(bs_ref).max())
+
+
+@pytest.mark.parametrize("n_cams", [12, 40, 100])
+def test_dense_cholesky_solves_reduced_system(pkg, ctx, n_cams):
+    """x_c from the MFMA Cholesky equals numpy's solve of the same S, b_s (1, 2 and 5 panels of 128)."""
+    g, c, o, _ = pkg.synth.make_graph(n_cams, 8, 40 * n_cams // 4, seed=4, slam=True)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ctx.lm_begin(pkg.default_lm_params(jacobian_mode=1))
+    part = ctx.lm_linearize()
+    lam = 1e-5 * part.max_diag
+    ptr, n, lda = ctx.lm_reduced_system(lam)
+    S, bs = lower_to_full(ctx.lm_download(6, lda * n), n, lda)
+    out = ctx.lm_try_step(lam)
+    assert out.solve_ok == 1
+    xc = ctx.lm_download(5, n)
+    ref = np.linalg.solve(S, bs)
+    np.testing.assert_allclose(xc, ref, atol=1e-9 * np.abs(ref).max() + 1e-12, rtol=1e-7)
+    ctx.lm_commit(False)
+
+
+@pytest.mark.parametrize("jac", [0, 1])
+def test_slam_lm_matches_faithful_dense_oracle(pkg, po, ctx, jac):
+    g, c, o, _ = pkg.synth.make_graph(30, 6, 200, seed=3, slam=True)
+    p = pkg.default_lm_params(numeric_delta=1e-6)
+    co, oo, ro = po.optimize(g, c, o, p, solver=0)  # dense LDLT of the whole system, like LinearSolverDense
+    cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6))
+    n = min(len(rg["trace_chi2"]), len(ro["trace_chi2"]))
+    np.testing.assert_allclose(rg["trace_chi2"][:n], ro["trace_chi2"][:n], rtol=1e-4)
+    assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-4)
+    assert np.array_equal(cg[0], c[0])  # camera 0 is fixed (Optimizer.cpp:138)
+    assert cam_err(cg, co) < 1e-4
+    np.testing.assert_allclose(og[:, :3], oo[:, :3], atol=1e-4 * np.abs(oo[:, :3]).max())
+    np.testing.assert_allclose(og[:, 7:], oo[:, 7:], rtol=1e-3)
+
+
+def test_c3_slam_runs_and_reduces_chi2(pkg, po, ctx):
+    """BASELINE.json configs[2] in SLAM mode: n = 6*499 = 2994 reduced system, 24 panels."""
+    g, c, o, _ = pkg.synth.make_config("C3", seed=0, slam=True)
+    cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1))
+    assert rg["chi2_final"] < 0.2 * rg["chi2_initial"]
+    co, oo, ro = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=1e-6), solver=1)
+    assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-3)
+    assert cam_err(cg, co) < 1e-3
