@@ -11,9 +11,4 @@ int esl_fit_frame(esl_ctx*, const uint16_t*, int32_t, int32_t, const double*, co
   esl::set_error("esl_fit_frame: not built yet");
   return ESL_ERR_STATE;
 }
-int esl_init_quadric(esl_ctx*, const double*, const double*, int32_t, const double*, int32_t, int32_t, int32_t, double*,
-                     double*, int32_t*) {
-  esl::set_error("esl_init_quadric: not built yet");
-  return ESL_ERR_STATE;
-}
 }

@@ -165,6 +165,17 @@ class Context:
         names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "k6", "k7"]
         return {n: dict(count=int(cnt[i]), total_ms=float(ms[i])) for i, n in enumerate(names) if cnt[i]}
 
+    def init_quadric(self, poses_Twc, bboxes, K, rows=480, cols=640, faithful=1):
+        """Initializer::initializeQuadric: returns (ellipsoid 10-vector, Q* 4x4, ok)."""
+        poses = np.ascontiguousarray(poses_Twc, dtype=np.float64).reshape(-1, 7)
+        boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
+        Kd = np.ascontiguousarray(K, dtype=np.float64)
+        e = np.zeros(10); Q = np.zeros(16); ok = C.c_int32(0)
+        _check(load().esl_init_quadric(self._h, poses.ctypes.data_as(_dp), boxes.ctypes.data_as(_dp), C.c_int32(len(poses)),
+                                       Kd.ctypes.data_as(_dp), C.c_int32(rows), C.c_int32(cols), C.c_int32(faithful),
+                                       e.ctypes.data_as(_dp), Q.ctypes.data_as(_dp), C.byref(ok)), "esl_init_quadric")
+        return e, Q.reshape(4, 4), bool(ok.value)
+
     def synchronize(self):
         _check(load().esl_ctx_synchronize(self._h), "esl_ctx_synchronize")
 

@@ -67,6 +67,10 @@ int esl_oracle_optimize(const esl_graph* g, double* cams_io, double* objs_io, co
 int esl_oracle_build_system(const esl_graph* g, const double* cams, const double* objs, double delta,
                             int drop_nan_bbox, double* H, double* b, int32_t* free_index, double* chi2);
 
+/* --- Initializer::initializeQuadric (src/core/Initializer.cpp:24-248) -------------------------------*/
+int esl_oracle_init_quadric(const double* poses_Twc, const double* bboxes, int n, const double K[4], int rows, int cols,
+                            int faithful, double ell_out[10], double qstar_out[16], int* ok);
+
 /* timing helper for bench.py's cpu_baseline: seconds spent in linearise / solve / error evaluation
  * of the last esl_oracle_optimize call */
 void esl_oracle_last_timing(double t[3]);

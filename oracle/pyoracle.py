@@ -146,6 +146,18 @@ def build_system(graph, cams, objs, delta=1e-9, drop_nan=1):
     return H, b, fidx, chi2.value
 
 
+def init_quadric(poses_Twc, bboxes, K, rows=480, cols=640, faithful=1):
+    poses = np.ascontiguousarray(poses_Twc, dtype=np.float64).reshape(-1, 7)
+    boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
+    Kd = np.ascontiguousarray(K, dtype=np.float64)
+    e = np.zeros(10); Q = np.zeros(16); ok = C.c_int(0)
+    dp = C.POINTER(C.c_double)
+    lib().esl_oracle_init_quadric(poses.ctypes.data_as(dp), boxes.ctypes.data_as(dp), C.c_int(len(poses)),
+                                  Kd.ctypes.data_as(dp), C.c_int(rows), C.c_int(cols), C.c_int(faithful),
+                                  e.ctypes.data_as(dp), Q.ctypes.data_as(dp), C.byref(ok))
+    return e, Q.reshape(4, 4), bool(ok.value)
+
+
 def last_timing():
     t = (C.c_double * 3)()
     lib().esl_oracle_last_timing(t)
