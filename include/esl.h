@@ -216,6 +216,14 @@ int esl_fit_frame(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t he
                   double* ellipsoids_out /* B x 10, camera frame */, double* prob_out /* B */,
                   int32_t* status_out /* B, mirrors miSystemState 0..4 */);
 
+/* same, plus per-box stage counters for tests/profiling (16 doubles per box: [0] in-range samples, [1] voxels at
+ * voxel_leaf, [2] after the supporting-plane filter, [3] clusters >= min_cluster_size, [4] chosen cluster size,
+ * [5] voxels at symmetry_grid, [6..14] probability of the 9 symmetry hypotheses); debug_out may be NULL */
+int esl_fit_frame_debug(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes,
+                        const int32_t* labels, int32_t n_boxes, const double Twc[7], const double intr[5],
+                        const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
+                        int32_t* status_out, double* debug_out);
+
 /* ---- SVD quadric initialisation -----------------------------------------------------------------*/
 int esl_init_quadric(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const double* bboxes /* n x 4 */,
                      int32_t n, const double K[4], int32_t rows, int32_t cols, int32_t faithful,

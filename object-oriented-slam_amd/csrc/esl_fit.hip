@@ -1,14 +1,844 @@
-// esl_fit.hip — single-frame fit + quadric initialisation entry points (kernels land in a later milestone)
+// esl_fit.hip — esl_fit_frame: the single-frame ellipsoid fit, ONE WORKGROUP PER BOUNDING BOX, one launch
+// per frame for all boxes (the boxes of a frame are independent: no collective, replicas only).
+//
+// Replaces EllipsoidSLAM::EllipsoidExtractor::EstimateLocalEllipsoid (reference
+// src/pca/EllipsoidExtractor.cpp:292-493) with its helpers: getPointCloudInRect
+// (src/symmetry/PointCloudFilter.cpp:21-56), DownSamplePointCloudOnly (:249-261, PCL VoxelGrid),
+// transformPointCloud (src/core/Geometry.cpp:44-66), ApplySupportingPlaneFilter (:562-578), GetCenter
+// (:583-643), ApplyEuclideanFilter (:646-737, PCL EuclideanClusterExtraction), ProcessPCA (:170-196),
+// AdjustChirality / AlignZAxisToGravity / calibRotMatAccordingToGroundPlane (:760-788, 207-267),
+// Symmetry::estimateSymmetry (src/symmetry/Symmetry.cpp:88-128) with SymmetrySolver::GetPointCloudProb
+// (src/symmetry/SymmetrySolver.cpp:49-138) and the 1-edge g2o LM (:217-333), ProcessPCANormalized (:495-531).
+//
+// PCL's unpinned pieces are replaced by deterministic, order-independent equivalents (same definitions as
+// the CPU checker): voxel grid = hash table keyed by floorf(p/leaf) with EXACT fixed-point (2^-30 m)
+// integer atomics for the centroids; Euclidean clusters = connected components by lock-free union-find
+// over a 2 cm cell hash; 1-NN = brute force over the <= few hundred 10 cm voxels.
+//
+// Stages run back to back inside the workgroup (1024 threads = 16 waves on one CU), separated by
+// agent-scope fence + barrier; reductions are wave shuffles + one LDS hop.  The 9 symmetry hypotheses
+// each get their own wavefront (lanes over mirrored points).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "esl_ctx.hpp"
+
+namespace esl {
+
+constexpr int kFitThreads = 1024;
+constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kKeyOff = 1 << 20;
+#define ESL_FIX 1073741824.0  // 2^30
+
+struct FitArgs {
+  const uint16_t* depth; int w, h;
+  const double* bboxes; const int* labels; int n_boxes;
+  double Twc[7], intr[5], ground[4];
+  esl_fit_params p;
+  // workspace (per box strides)
+  long cap, H;
+  unsigned long long* hk; long long* hsx; long long* hsy; long long* hsz; unsigned int* hcnt;
+  float* pwx; float* pwy; float* pwz; unsigned long long* pkey;
+  unsigned long long* ck; int* chead; int* nxt; int* parent;
+  int* csize; unsigned long long* cminkey; unsigned long long* cmind;
+  double* po; float* pof;
+  double* out_ell; double* out_prob; int* out_status; double* out_dbg;
+};
+
+__device__ __forceinline__ unsigned long long hash64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
+__device__ __forceinline__ void stage_sync() { __threadfence(); __syncthreads(); }
+
+// block-wide sum, result to every thread (wave shuffle + LDS)
+__device__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0;
+  for (int i = 0; i < kFitThreads / 64; ++i) s += red[i];
+  return s;
+}
+__device__ double block_max(double v, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = red[0];
+  for (int i = 1; i < kFitThreads / 64; ++i) s = fmax(s, red[i]);
+  return s;
+}
+
+__device__ __forceinline__ unsigned long long vox_key(float x, float y, float z, float inv) {
+  const int ix = (int)floorf(x * inv), iy = (int)floorf(y * inv), iz = (int)floorf(z * inv);
+  return ((unsigned long long)(iz + kKeyOff) << 42) | ((unsigned long long)(iy + kKeyOff) << 21) | (unsigned long long)(ix + kKeyOff);
+}
+__device__ __forceinline__ void vox_insert(const FitArgs& a, long base, unsigned long long key, float x, float y, float z) {
+  unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&a.hk[base + slot], kEmpty, key);
+    if (prev == kEmpty || prev == key) break;
+    slot = (slot + 1) & (unsigned long long)(a.H - 1);
+  }
+  atomicAdd((unsigned long long*)&a.hsx[base + slot], (unsigned long long)llrint((double)x * ESL_FIX));
+  atomicAdd((unsigned long long*)&a.hsy[base + slot], (unsigned long long)llrint((double)y * ESL_FIX));
+  atomicAdd((unsigned long long*)&a.hsz[base + slot], (unsigned long long)llrint((double)z * ESL_FIX));
+  atomicAdd(&a.hcnt[base + slot], 1u);
+}
+
+__device__ __forceinline__ unsigned long long cell_key(float x, float y, float z, double tol, int dx, int dy, int dz) {
+  const long long cx = (long long)floor((double)x / tol) + dx, cy = (long long)floor((double)y / tol) + dy,
+                  cz = (long long)floor((double)z / tol) + dz;
+  return ((unsigned long long)(cz + kKeyOff) << 42) | ((unsigned long long)(cy + kKeyOff) << 21) | (unsigned long long)(cx + kKeyOff);
+}
+__device__ __forceinline__ int uf_find(int* parent, int i) {
+  for (;;) {
+    const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == i) return i;
+    i = p;
+  }
+}
+
+// ---- tiny host/device linear algebra used by lane 0 -------------------------------------------------------
+__device__ void jacobi3(const double* Ain, double* w, double* V) {
+  double A[9];
+  for (int i = 0; i < 9; ++i) A[i] = Ain[i];
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        const double c = 1 / sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < 3; ++k) { const double x = A[k * 3 + p], y = A[k * 3 + q]; A[k * 3 + p] = c * x - s * y; A[k * 3 + q] = s * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = A[p * 3 + k], y = A[q * 3 + k]; A[p * 3 + k] = c * x - s * y; A[q * 3 + k] = s * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = V[k * 3 + p], y = V[k * 3 + q]; V[k * 3 + p] = c * x - s * y; V[k * 3 + q] = s * x + c * y; }
+      }
+  }
+  for (int i = 0; i < 3; ++i) w[i] = A[i * 4];
+  for (int i = 0; i < 3; ++i) {
+    int m = i;
+    for (int j = i + 1; j < 3; ++j)
+      if (w[j] < w[m]) m = j;
+    if (m != i) {
+      const double t = w[i]; w[i] = w[m]; w[m] = t;
+      for (int k = 0; k < 3; ++k) { const double u = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + m]; V[k * 3 + m] = u; }
+    }
+  }
+  for (int j = 0; j < 3; ++j) {
+    int m = 0;
+    for (int k = 1; k < 3; ++k)
+      if (fabs(V[k * 3 + j]) > fabs(V[m * 3 + j])) m = k;
+    if (V[m * 3 + j] < 0)
+      for (int k = 0; k < 3; ++k) V[k * 3 + j] = -V[k * 3 + j];
+  }
+}
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void xform(const Mat3& R, const double* t, const double* p, double* o) {
+  o[0] = R.m[0] * p[0] + R.m[1] * p[1] + R.m[2] * p[2] + t[0];
+  o[1] = R.m[3] * p[0] + R.m[4] * p[1] + R.m[5] * p[2] + t[1];
+  o[2] = R.m[6] * p[0] + R.m[7] * p[1] + R.m[8] * p[2] + t[2];
+}
+
+// ---- g2o::plane (include/core/Plane.h:46-129) --------------------------------------------------------------
+struct PlaneT { double p[4]; double dual; };
+__device__ void plane_oplus3(PlaneT& pl, double az, double el, double dd) {
+  const double s = sin(el), c = cos(el);
+  const double n[3] = {c * cos(az), c * sin(az), s};
+  const double paz = atan2(pl.p[1], pl.p[0]), pel = atan2(pl.p[2], sqrt(pl.p[0] * pl.p[0] + pl.p[1] * pl.p[1]));
+  const double ca = cos(paz), sa = sin(paz), cb = cos(-pel), sb = sin(-pel);
+  const double R[9] = {ca * cb, -sa, ca * sb, sa * cb, ca, sa * sb, -sb, 0, cb};
+  const double d = -pl.p[3] + dd;
+  double q[3];
+  for (int i = 0; i < 3; ++i) q[i] = R[i * 3] * n[0] + R[i * 3 + 1] * n[1] + R[i * 3 + 2] * n[2];
+  pl.p[0] = q[0]; pl.p[1] = q[1]; pl.p[2] = q[2]; pl.p[3] = -d;
+  const double nn = sqrt(pl.p[0] * pl.p[0] + pl.p[1] * pl.p[1] + pl.p[2] * pl.p[2]);
+  for (int i = 0; i < 4; ++i) pl.p[i] *= (1. / nn);
+}
+__device__ __forceinline__ void plane_update(PlaneT& pl, const double* u, bool dual) {
+  plane_oplus3(pl, u[0], 0.0, u[1]);
+  if (dual) pl.dual += u[2];
+}
+__device__ __forceinline__ void plane_another(const PlaneT& pl, double* out) {
+  const double az = atan2(pl.p[1], pl.p[0]);
+  out[0] = sin(az); out[1] = -cos(az); out[2] = 0; out[3] = -pl.dual;
+}
+__device__ __forceinline__ void mirror_point(const double* p, const double* pl, double* r) {
+  const double nn = sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+  const double n[3] = {pl[0] / nn, pl[1] / nn, pl[2] / nn};
+  const double sv = pl[0] * p[0] + pl[1] * p[1] + pl[2] * p[2] + pl[3];
+  const double dis = fabs(sv) / nn;
+  const double symbol = sv > 0 ? -1 : 1;
+  r[0] = p[0] + 2 * symbol * dis * n[0]; r[1] = p[1] + 2 * symbol * dis * n[1]; r[2] = p[2] + 2 * symbol * dis * n[2];
+}
+
+struct SymCtx {
+  const uint16_t* depth; int w, h;
+  int bb[4];
+  double K[4], scale, sigma;
+  double P[12], camc[3];
+  const double* po; const float* pof; int n;
+};
+
+// edge error (= -mean ln P) of one plane hypothesis, evaluated by ONE WAVE (lanes over mirrored points)
+__device__ double sym_error_wave(const SymCtx& c, const PlaneT& pl, bool dual) {
+  const int lane = threadIdx.x & 63;
+  double p2[4];
+  if (dual) plane_another(pl, p2);
+  const int ns = dual ? 2 * c.n : c.n;
+  double ln_total = 0;
+  double invalid = 0;
+  for (int i = lane; i < ns; i += 64) {
+    const double* src = c.po + 3 * (long)(i < c.n ? i : i - c.n);
+    double p[3];
+    mirror_point(src, (i < c.n) ? pl.p : p2, p);
+    double uh[3];
+    for (int r = 0; r < 3; ++r) uh[r] = c.P[r * 4] * p[0] + c.P[r * 4 + 1] * p[1] + c.P[r * 4 + 2] * p[2] + c.P[r * 4 + 3];
+    const double u = uh[0] / uh[2], v = uh[1] / uh[2];
+    bool use_nn = true;
+    const bool finite_pt = isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]);
+    if (isfinite(u) && isfinite(v) && fabs(u) < 1e9 && fabs(v) < 1e9) {
+      const int x = (int)u, y = (int)v;
+      if (c.bb[0] < x && x < c.bb[2] && c.bb[1] < y && y < c.bb[3] && x >= 0 && y >= 0 && x < c.w && y < c.h) {
+        const uint16_t d = c.depth[(size_t)y * c.w + x];
+        const double realz = (double)d * sqrt((x - c.K[2]) * (x - c.K[2]) + c.K[0] * c.K[0] + (y - c.K[3]) * (y - c.K[3])) / c.K[0];
+        const uint16_t dp = (uint16_t)realz;
+        if (dp == 0) use_nn = false;
+        else {
+          const double depth = dp / c.scale;
+          const double dx = c.camc[0] - p[0], dy = c.camc[1] - p[1], dz = c.camc[2] - p[2];
+          if (sqrt(dx * dx + dy * dy + dz * dz) > depth) use_nn = false;
+        }
+      }
+    }
+    double dis = 0;
+    if (use_nn) {
+      if (!finite_pt) invalid += 1;
+      else {
+        double best = 1e300;
+        for (int j = 0; j < c.n; ++j) {
+          const double dx = p[0] - (double)c.pof[3 * j], dy = p[1] - (double)c.pof[3 * j + 1], dz = p[2] - (double)c.pof[3 * j + 2];
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          if (d2 < best) best = d2;
+        }
+        dis = sqrt(best);
+      }
+    }
+    const double si = 1.0 / c.sigma;
+    ln_total += -0.5 * si * si * dis * dis;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { ln_total += __shfl_xor(ln_total, off, 64); invalid += __shfl_xor(invalid, off, 64); }
+  const double valid = (double)ns - invalid;
+  const double aver = valid > 0 ? ln_total / valid : -INFINITY;
+  return -aver;
+}
+
+// Eigen-style pivoted LDLT for n <= 3 (what g2o's LinearSolverDense runs on the 2x2 / 3x3 system)
+__device__ bool ldlt_small(double* A, int n, const double* b, double* x) {
+  int tr[3];
+  int sign = 0;
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    double bv = fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i) { const double v = fabs(A[i * n + i]); if (v > bv) { bv = v; big = i; } }
+    tr[k] = big;
+    if (k != big) {
+      const int s = n - big - 1;
+      for (int j = 0; j < k; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[big * n + j]; A[big * n + j] = t; }
+      for (int i = 0; i < s; ++i) { const double t = A[(big + 1 + i) * n + k]; A[(big + 1 + i) * n + k] = A[(big + 1 + i) * n + big]; A[(big + 1 + i) * n + big] = t; }
+      for (int i = k + 1; i < big; ++i) { const double t = A[i * n + k]; A[i * n + k] = A[big * n + i]; A[big * n + i] = t; }
+      const double t = A[k * n + k]; A[k * n + k] = A[big * n + big]; A[big * n + big] = t;
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      double temp[3], s = 0;
+      for (int j = 0; j < k; ++j) { temp[j] = A[j * n + j] * A[k * n + j]; s += A[k * n + j] * temp[j]; }
+      A[k * n + k] -= s;
+      for (int i = 0; i < rs; ++i) { double t = 0; for (int j = 0; j < k; ++j) t += A[(k + 1 + i) * n + j] * temp[j]; A[(k + 1 + i) * n + k] -= t; }
+    }
+    const double akk = A[k * n + k];
+    const bool valid = fabs(akk) > 0;
+    if (k == 0 && !valid) { sign = 0; for (int j = 0; j < n; ++j) tr[j] = j; break; }
+    if (rs > 0 && valid) for (int i = 0; i < rs; ++i) A[(k + 1 + i) * n + k] /= akk;
+    if (sign == 1) { if (akk < 0) sign = 2; }
+    else if (sign == -1) { if (akk > 0) sign = 2; }
+    else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+  }
+  const bool positive = (sign == 1 || sign == 0);
+  if (positive) {
+    for (int i = 0; i < n; ++i) x[i] = b[i];
+    for (int i = 0; i < n; ++i) if (tr[i] != i) { const double t = x[i]; x[i] = x[tr[i]]; x[tr[i]] = t; }
+    for (int i = 0; i < n; ++i) { double s = x[i]; for (int j = 0; j < i; ++j) s -= A[i * n + j] * x[j]; x[i] = s; }
+    for (int i = 0; i < n; ++i) { const double d = A[i * n + i]; x[i] = (fabs(d) > 2.2250738585072014e-308) ? x[i] / d : 0.0; }
+    for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int j = i + 1; j < n; ++j) s -= A[j * n + i] * x[j]; x[i] = s; }
+    for (int i = n - 1; i >= 0; --i) if (tr[i] != i) { const double t = x[i]; x[i] = x[tr[i]]; x[tr[i]] = t; }
+  }
+  return positive;
+}
+
+// the 1-edge LM of SymmetrySolver::OptimizeSymmetry(Dual)Plane, run redundantly by all lanes of one wave
+__device__ double sym_optimize_wave(const SymCtx& c, PlaneT& pl, bool dual, int iters) {
+  const int dim = dual ? 3 : 2;
+  const double delta = 1e-9;
+  double lambda = 0, ni = 2;
+  int nbad = 0;
+  double e_last = sym_error_wave(c, pl, dual);
+  for (int it = 0; it < iters; ++it) {
+    const double e0 = sym_error_wave(c, pl, dual);
+    e_last = e0;
+    double cur = e0 * e0;
+    const double ini = cur;
+    double J[3] = {0, 0, 0}, H[9], b[3];
+    for (int d = 0; d < dim; ++d) {
+      double u[3] = {0, 0, 0};
+      PlaneT pp = pl, pm = pl;
+      u[d] = delta; plane_update(pp, u, dual);
+      u[d] = -delta; plane_update(pm, u, dual);
+      J[d] = (1.0 / (2 * delta)) * (sym_error_wave(c, pp, dual) - sym_error_wave(c, pm, dual));
+    }
+    for (int a = 0; a < dim; ++a) { b[a] = J[a] * (-(1.0 * e0)); for (int k = 0; k < dim; ++k) H[a * dim + k] = J[a] * 1.0 * J[k]; }
+    if (it == 0) {
+      double md = 0;
+      for (int a = 0; a < dim; ++a) md = fmax(md, fabs(H[a * dim + a]));
+      lambda = 1e-5 * md; ni = 2; nbad = 0;
+    }
+    double rho = 0;
+    int q = 0;
+    do {
+      const PlaneT bak = pl;
+      double M[9], x[3] = {0, 0, 0};
+      for (int a = 0; a < dim * dim; ++a) M[a] = H[a];
+      for (int a = 0; a < dim; ++a) M[a * dim + a] += lambda;
+      const bool ok = ldlt_small(M, dim, b, x);
+      plane_update(pl, x, dual);
+      const double et = sym_error_wave(c, pl, dual);
+      e_last = et;
+      const double tmp = ok ? et * et : 1.7976931348623157e308;
+      double scale = 0;
+      for (int a = 0; a < dim; ++a) scale += x[a] * (lambda * x[a] + b[a]);
+      rho = (cur - tmp) / (scale + 1e-3);
+      if (rho > 0 && isfinite(tmp)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+        lambda *= (1. / 3. > alpha ? 1. / 3. : alpha);
+        ni = 2; cur = tmp;
+      } else { lambda *= ni; ni *= 2; pl = bak; }
+      q++;
+    } while (rho < 0 && q < 10);
+    if (q == 10 || rho == 0) break;
+    if ((ini - cur) * 1e3 < ini) nbad++; else nbad = 0;
+    if (nbad >= 3) break;
+  }
+  return e_last;
+}
+
+__device__ __forceinline__ int symmetry_type(int label) {  // EllipsoidExtractor::LoadSymmetryPrior (:52-79)
+  switch (label) {
+    case 58: return 0;
+    case 59: case 62: case 57: case 66: case 63: case 64: case 41: return 1;
+    case 28: return 2;
+    default: return -1;
+  }
+}
+
+struct FitShared {
+  double red[kFitThreads / 64];
+  int M, n0, n1, ncl, chosen, maxsize, only, status, ns0, npo, cnt;
+  unsigned long long minkey;
+  double center[3], cen[3], cov[6];
+  double Two[7], Tow[7];
+  double Row[9];
+  double prob[9];
+  PlaneT planes[9];
+  double best_plane[5];
+  double Rmo[9], Tmo[3];
+  SymCtx sc;
+};
+
+static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
+  __shared__ FitShared S;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long base = (long)b * a.H, pbase = (long)b * a.cap;
+  const double* bbox = a.bboxes + 4 * b;
+  const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
+  if (tid == 0) { S.M = 0; S.n0 = 0; S.n1 = 0; S.ncl = 0; S.chosen = -1; S.maxsize = 0; S.only = -1; S.status = 0; S.ns0 = 0; S.npo = 0; S.cnt = 0; S.minkey = kEmpty; }
+  __syncthreads();
+  // 1 + 2. scan the box, voxel-hash at voxel_leaf
+  const int x1 = (int)bbox[0], y1 = (int)bbox[1], x2 = (int)bbox[2], y2 = (int)bbox[3];
+  const int st = a.p.stride;
+  const int nsx = x2 > x1 ? (x2 - x1 + st - 1) / st : 0, nsy = y2 > y1 ? (y2 - y1 + st - 1) / st : 0;
+  {
+    const float inv = 1.0f / (float)a.p.voxel_leaf;
+    int mine = 0;
+    for (long idx = tid; idx < (long)nsx * nsy; idx += kFitThreads) {
+      const int x = x1 + (int)(idx % nsx) * st, y = y1 + (int)(idx / nsx) * st;
+      if (x < 0 || y < 0 || x >= a.w || y >= a.h) continue;
+      const uint16_t d = a.depth[(size_t)y * a.w + x];
+      const double z = d / scale;
+      if (z <= a.p.depth_min || z > a.p.depth_max) continue;
+      const float px = (float)((x - cx) * z / fx), py = (float)((y - cy) * z / fy), pz = (float)z;
+      vox_insert(a, base, vox_key(px, py, pz, inv), px, py, pz);
+      ++mine;
+    }
+    if (mine) atomicAdd(&S.n0, mine);
+  }
+  stage_sync();
+  // 3 + 4. centroids -> world -> supporting-plane filter
+  const SE3 Twc = se3_load(a.Twc);
+  const Mat3 Rwc = q_to_R(Twc.r);
+  const double gn = sqrt(a.ground[0] * a.ground[0] + a.ground[1] * a.ground[1] + a.ground[2] * a.ground[2]);
+  for (long s = tid; s < a.H; s += kFitThreads) {
+    const unsigned int cnt = __hip_atomic_load(&a.hcnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!cnt) continue;
+    atomicAdd(&S.n1, 1);
+    const double c = (double)cnt;
+    const double p[3] = {(double)(float)((double)a.hsx[base + s] / c / ESL_FIX), (double)(float)((double)a.hsy[base + s] / c / ESL_FIX),
+                         (double)(float)((double)a.hsz[base + s] / c / ESL_FIX)};
+    double q[3];
+    xform(Rwc, Twc.t, p, q);
+    const double dis = (a.ground[0] * q[0] + a.ground[1] * q[1] + a.ground[2] * q[2] + a.ground[3]) / gn;
+    if (dis > a.p.plane_dist) {
+      const int i = atomicAdd(&S.M, 1);
+      a.pwx[pbase + i] = (float)q[0]; a.pwy[pbase + i] = (float)q[1]; a.pwz[pbase + i] = (float)q[2];
+      a.pkey[pbase + i] = a.hk[base + s];
+    }
+  }
+  __syncthreads();
+  const int M = S.M;
+  if (M < 1) { if (tid == 0) { a.out_status[b] = 4; a.out_dbg[16 * b] = S.n0; a.out_dbg[16 * b + 1] = S.n1; } return; }
+  // 5. GetCenter: 10 x 10 samples around the box centre (first two waves)
+  {
+    double sx = 0, sy = 0, sz = 0, cn = 0;
+    if (tid < 100) {
+      const int x = (int)((bbox[0] + bbox[2]) / 2.0), y = (int)((bbox[1] + bbox[3]) / 2.0);
+      const int xd = (int)(fabs(bbox[0] - bbox[2]) / 4.0 / 10), yd = (int)(fabs(bbox[1] - bbox[3]) / 4.0 / 10);
+      const int x_ = x + (tid / 10 - 5) * xd, y_ = y + (tid % 10 - 5) * yd;
+      if (x_ >= 0 && y_ >= 0 && x_ < a.w && y_ < a.h) {
+        const uint16_t d = a.depth[(size_t)y_ * a.w + x_];
+        const float pz = (float)(d / scale);
+        if (!(pz <= 0.1 || pz > a.p.depth_max)) {
+          sx = (float)((x_ - cx) * pz / fx); sy = (float)((y_ - cy) * pz / fy); sz = pz; cn = 1;
+        }
+      }
+    }
+    sx = block_sum(sx, S.red); sy = block_sum(sy, S.red); sz = block_sum(sz, S.red); cn = block_sum(cn, S.red);
+    if (cn < 2) { if (tid == 0) a.out_status[b] = 1; return; }
+    if (tid == 0) { const double c[3] = {sx / cn, sy / cn, sz / cn}; xform(Rwc, Twc.t, c, S.center); }
+  }
+  // 6. Euclidean clustering: cell hash + lock-free union-find
+  const double tol = a.p.cluster_tolerance, tol2 = tol * tol;
+  for (long s = tid; s < a.H; s += kFitThreads) { a.ck[base + s] = kEmpty; a.chead[base + s] = -1; }
+  for (int i = tid; i < M; i += kFitThreads) { a.parent[pbase + i] = i; a.csize[pbase + i] = 0; a.cminkey[pbase + i] = kEmpty; a.cmind[pbase + i] = kEmpty; }
+  stage_sync();
+  for (int i = tid; i < M; i += kFitThreads) {
+    const unsigned long long key = cell_key(a.pwx[pbase + i], a.pwy[pbase + i], a.pwz[pbase + i], tol, 0, 0, 0);
+    unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
+    for (;;) {
+      const unsigned long long prev = atomicCAS(&a.ck[base + slot], kEmpty, key);
+      if (prev == kEmpty || prev == key) break;
+      slot = (slot + 1) & (unsigned long long)(a.H - 1);
+    }
+    a.nxt[pbase + i] = atomicExch(&a.chead[base + slot], i);
+  }
+  stage_sync();
+  for (int i = tid; i < M; i += kFitThreads) {
+    const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const unsigned long long key = cell_key(xi, yi, zi, tol, dx, dy, dz);
+          unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
+          int head = -1;
+          for (;;) {
+            const unsigned long long k = __hip_atomic_load(&a.ck[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == key) { head = __hip_atomic_load(&a.chead[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (k == kEmpty) break;
+            slot = (slot + 1) & (unsigned long long)(a.H - 1);
+          }
+          for (int j = head; j >= 0; j = a.nxt[pbase + j]) {
+            if (j <= i) continue;
+            const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
+            if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
+              int ra = i, rb = j;
+              for (;;) {
+                ra = uf_find(a.parent + pbase, ra); rb = uf_find(a.parent + pbase, rb);
+                if (ra == rb) break;
+                if (ra < rb) { const int t = ra; ra = rb; rb = t; }
+                if (atomicCAS(&a.parent[pbase + ra], ra, rb) == ra) break;
+              }
+            }
+          }
+        }
+  }
+  stage_sync();
+  for (int i = tid; i < M; i += kFitThreads) {
+    const int r = uf_find(a.parent + pbase, i);
+    a.nxt[pbase + i] = r;  // root of every point (the list links are no longer needed)
+    atomicAdd(&a.csize[pbase + r], 1);
+    atomicMin(&a.cminkey[pbase + r], a.pkey[pbase + i]);
+    const double dx = S.center[0] - a.pwx[pbase + i], dy = S.center[1] - a.pwy[pbase + i], dz = S.center[2] - a.pwz[pbase + i];
+    const double d = sqrt(dx * dx + dy * dy + dz * dz);
+    atomicMin(&a.cmind[pbase + r], (unsigned long long)__double_as_longlong(d));
+  }
+  stage_sync();
+  // choose the cluster: the only one, else the largest (ties: smaller voxel key) within center_dis of the centre
+  for (int r = tid; r < M; r += kFitThreads) {
+    const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sz >= a.p.min_cluster_size) {
+      atomicAdd(&S.ncl, 1);
+      atomicMax(&S.only, r);
+      const double md = __longlong_as_double((long long)__hip_atomic_load(&a.cmind[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (md < a.p.center_dis) atomicMax(&S.maxsize, sz);
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < M; r += kFitThreads) {
+    const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sz >= a.p.min_cluster_size && sz == S.maxsize) {
+      const double md = __longlong_as_double((long long)__hip_atomic_load(&a.cmind[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (md < a.p.center_dis) atomicMin(&S.minkey, __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < M; r += kFitThreads) {
+    const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sz >= a.p.min_cluster_size && sz == S.maxsize && S.maxsize > 0 &&
+        __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S.minkey) S.chosen = r;
+  }
+  __syncthreads();
+  if (tid == 0 && S.ncl == 1) S.chosen = S.only;
+  __syncthreads();
+  const int chosen = S.chosen;
+  if (chosen < 0) {
+    if (tid == 0) { a.out_status[b] = 2; a.out_dbg[16 * b] = S.n0; a.out_dbg[16 * b + 1] = S.n1; a.out_dbg[16 * b + 2] = M; a.out_dbg[16 * b + 3] = S.ncl; }
+    return;
+  }
+  const int nc = a.csize[pbase + chosen];
+  // 7. PCA of the chosen cluster (two passes like PCL: centroid, then normalised covariance)
+  {
+    double sx = 0, sy = 0, sz = 0;
+    for (int i = tid; i < M; i += kFitThreads)
+      if (a.nxt[pbase + i] == chosen) { sx += a.pwx[pbase + i]; sy += a.pwy[pbase + i]; sz += a.pwz[pbase + i]; }
+    sx = block_sum(sx, S.red); sy = block_sum(sy, S.red); sz = block_sum(sz, S.red);
+    const double cen[3] = {sx / nc, sy / nc, sz / nc};
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < M; i += kFitThreads)
+      if (a.nxt[pbase + i] == chosen) {
+        const double d0 = a.pwx[pbase + i] - cen[0], d1 = a.pwy[pbase + i] - cen[1], d2 = a.pwz[pbase + i] - cen[2];
+        cv[0] += d0 * d0; cv[1] += d0 * d1; cv[2] += d0 * d2; cv[3] += d1 * d1; cv[4] += d1 * d2; cv[5] += d2 * d2;
+      }
+    for (int k = 0; k < 6; ++k) cv[k] = block_sum(cv[k], S.red);
+    if (tid == 0) {
+      const double cov[9] = {cv[0] / nc, cv[1] / nc, cv[2] / nc, cv[1] / nc, cv[3] / nc, cv[4] / nc, cv[2] / nc, cv[4] / nc, cv[5] / nc};
+      double ev[3], rot[9];
+      jacobi3(cov, ev, rot);
+      {  // AdjustChirality
+        const double c0[3] = {rot[0], rot[3], rot[6]}, c1[3] = {rot[1], rot[4], rot[7]};
+        double c2[3];
+        cross3(c0, c1, c2);
+        rot[2] = c2[0]; rot[5] = c2[1]; rot[8] = c2[2];
+      }
+      const double nh[3] = {a.ground[0] / gn, a.ground[1] / gn, a.ground[2] / gn};
+      {  // AlignZAxisToGravity
+        double maxc = 0; int maxid = -1; bool pos = true;
+        for (int i = 0; i < 3; ++i) {
+          const double c = rot[i] * nh[0] + rot[3 + i] * nh[1] + rot[6 + i] * nh[2];
+          if (fabs(c) > maxc) { maxc = fabs(c); pos = c > 0; maxid = i; }
+        }
+        if (maxid < 0) maxid = 2;
+        double z[3], x[3], y[3];
+        for (int r = 0; r < 3; ++r) { z[r] = pos ? rot[r * 3 + maxid] : -rot[r * 3 + maxid]; x[r] = rot[r * 3 + (maxid + 1) % 3]; }
+        cross3(z, x, y);
+        for (int r = 0; r < 3; ++r) { rot[r * 3] = x[r]; rot[r * 3 + 1] = y[r]; rot[r * 3 + 2] = z[r]; }
+      }
+      {  // calibRotMatAccordingToGroundPlane
+        const double z[3] = {rot[2], rot[5], rot[8]}, nrm[3] = {a.ground[0], a.ground[1], a.ground[2]};
+        double ax[3];
+        cross3(z, nrm, ax);
+        const double an2 = ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2];
+        if (an2 > 0) { const double an = sqrt(an2); ax[0] /= an; ax[1] /= an; ax[2] /= an; }
+        const double zn = sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+        const double ct = (nrm[0] * z[0] + nrm[1] * z[1] + nrm[2] * z[2]) / gn / zn;
+        const double th = acos(ct), s = sin(th), c = cos(th);
+        const double sa[3] = {s * ax[0], s * ax[1], s * ax[2]}, c1[3] = {(1 - c) * ax[0], (1 - c) * ax[1], (1 - c) * ax[2]};
+        double Ra[9], t;
+        t = c1[0] * ax[1]; Ra[1] = t - sa[2]; Ra[3] = t + sa[2];
+        t = c1[0] * ax[2]; Ra[2] = t + sa[1]; Ra[6] = t - sa[1];
+        t = c1[1] * ax[2]; Ra[5] = t - sa[0]; Ra[7] = t + sa[0];
+        Ra[0] = c1[0] * ax[0] + c; Ra[4] = c1[1] * ax[1] + c; Ra[8] = c1[2] * ax[2] + c;
+        double out[9];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) out[i * 3 + j] = Ra[i * 3] * rot[j] + Ra[i * 3 + 1] * rot[3 + j] + Ra[i * 3 + 2] * rot[6 + j];
+        for (int i = 0; i < 9; ++i) rot[i] = out[i];
+      }
+      const double xn = sqrt(rot[0] * rot[0] + rot[3] * rot[3] + rot[6] * rot[6]);
+      const double x[3] = {rot[0] / xn, rot[3] / xn, rot[6] / xn};
+      double y[3];
+      cross3(nh, x, y);
+      Mat3 Rwo;
+      Rwo.m[0] = x[0]; Rwo.m[1] = y[0]; Rwo.m[2] = nh[0];
+      Rwo.m[3] = x[1]; Rwo.m[4] = y[1]; Rwo.m[5] = nh[1];
+      Rwo.m[6] = x[2]; Rwo.m[7] = y[2]; Rwo.m[8] = nh[2];
+      SE3 Two;
+      Two.r = q_from_R(Rwo);
+      Two.t[0] = cen[0]; Two.t[1] = cen[1]; Two.t[2] = cen[2];
+      const SE3 Tow = se3_inv(Two);
+      se3_store(Two, S.Two); se3_store(Tow, S.Tow);
+      const Mat3 Row = q_to_R(Tow.r);
+      for (int i = 0; i < 9; ++i) S.Row[i] = Row.m[i];
+    }
+  }
+  // 8. voxel grid at symmetry_grid over the cluster, then into the object frame
+  for (long s = tid; s < a.H; s += kFitThreads) { a.hk[base + s] = kEmpty; a.hsx[base + s] = 0; a.hsy[base + s] = 0; a.hsz[base + s] = 0; a.hcnt[base + s] = 0; }
+  stage_sync();
+  {
+    const float inv = 1.0f / (float)a.p.symmetry_grid;
+    for (int i = tid; i < M; i += kFitThreads)
+      if (a.nxt[pbase + i] == chosen) {
+        const float px = a.pwx[pbase + i], py = a.pwy[pbase + i], pz = a.pwz[pbase + i];
+        vox_insert(a, base, vox_key(px, py, pz, inv), px, py, pz);
+      }
+  }
+  stage_sync();
+  double* po = a.po + 12 * pbase;   // up to 4 * cap points
+  float* pof = a.pof + 3 * pbase;
+  for (long s = tid; s < a.H; s += kFitThreads) {
+    const unsigned int cnt = __hip_atomic_load(&a.hcnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!cnt) continue;
+    const double c = (double)cnt;
+    const double p[3] = {(double)(float)((double)a.hsx[base + s] / c / ESL_FIX), (double)(float)((double)a.hsy[base + s] / c / ESL_FIX),
+                         (double)(float)((double)a.hsz[base + s] / c / ESL_FIX)};
+    const int i = atomicAdd(&S.ns0, 1);
+    double q[3];
+    q[0] = S.Row[0] * p[0] + S.Row[1] * p[1] + S.Row[2] * p[2] + S.Tow[0];
+    q[1] = S.Row[3] * p[0] + S.Row[4] * p[1] + S.Row[5] * p[2] + S.Tow[1];
+    q[2] = S.Row[6] * p[0] + S.Row[7] * p[1] + S.Row[8] * p[2] + S.Tow[2];
+    po[3 * i] = q[0]; po[3 * i + 1] = q[1]; po[3 * i + 2] = q[2];
+    pof[3 * i] = (float)q[0]; pof[3 * i + 1] = (float)q[1]; pof[3 * i + 2] = (float)q[2];
+  }
+  stage_sync();
+  const int ns0 = S.ns0;
+  int npo = ns0;
+  double prob_sym = 1.0;
+  // 9. symmetry: 9 hypotheses, one wavefront each
+  const int stype = symmetry_type(a.labels ? a.labels[b] : -1);
+  const bool run_sym = a.p.symmetry_open && stype > 0 && ns0 > 0;
+  if (run_sym) {
+    if (tid == 0) {
+      SymCtx& c = S.sc;
+      c.depth = a.depth; c.w = a.w; c.h = a.h;
+      for (int k = 0; k < 4; ++k) c.bb[k] = (int)bbox[k];
+      c.K[0] = fx; c.K[1] = fy; c.K[2] = cx; c.K[3] = cy; c.scale = scale; c.sigma = a.p.symmetry_sigma;
+      const SE3 Toc = se3_mul(se3_load(S.Tow), se3_load(a.Twc));
+      const SE3 Tco = se3_inv(Toc);
+      const Mat3 Rco = q_to_R(Tco.r);
+      for (int cc = 0; cc < 4; ++cc) {
+        const double c0 = cc < 3 ? Rco.m[cc] : Tco.t[0], c1 = cc < 3 ? Rco.m[3 + cc] : Tco.t[1], c2 = cc < 3 ? Rco.m[6 + cc] : Tco.t[2];
+        c.P[cc] = fx * c0 + cx * c2; c.P[4 + cc] = fy * c1 + cy * c2; c.P[8 + cc] = c2;
+      }
+      c.camc[0] = Toc.t[0]; c.camc[1] = Toc.t[1]; c.camc[2] = Toc.t[2];
+      c.po = po; c.pof = pof; c.n = ns0;
+    }
+    __syncthreads();
+    const int wv = tid >> 6;
+    if (wv < 9) {
+      PlaneT pl;
+      const int i = wv / 3, m = wv % 3;
+      const double dis = -0.2 + 0.2 * i, ang = -(M_PI / 180.0 * 5) + (M_PI / 180.0 * 5) * m;
+      pl.p[0] = sin(ang); pl.p[1] = -cos(ang); pl.p[2] = 0; pl.p[3] = -dis; pl.dual = 0;
+      const double e = sym_optimize_wave(S.sc, pl, stype == 2, a.p.symmetry_lm_iters);
+      if ((tid & 63) == 0) { S.prob[wv] = exp(-e); S.planes[wv] = pl; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int best = 0;
+      for (int k = 1; k < 9; ++k) if (S.prob[k] > S.prob[best]) best = k;
+      for (int k = 0; k < 4; ++k) S.best_plane[k] = S.planes[best].p[k];
+      S.best_plane[4] = S.planes[best].dual;
+    }
+    __syncthreads();
+    prob_sym = S.prob[0];
+    for (int k = 1; k < 9; ++k) prob_sym = fmax(prob_sym, S.prob[k]);
+    // complete the cloud with the mirrored points
+    PlaneT best;
+    for (int k = 0; k < 4; ++k) best.p[k] = S.best_plane[k];
+    best.dual = S.best_plane[4];
+    double p2[4];
+    plane_another(best, p2);
+    for (int i = tid; i < ns0; i += kFitThreads) {
+      double m1[3];
+      mirror_point(po + 3 * i, best.p, m1);
+      po[3 * (ns0 + i)] = m1[0]; po[3 * (ns0 + i) + 1] = m1[1]; po[3 * (ns0 + i) + 2] = m1[2];
+      if (stype == 2) {
+        double m2[3], m3[3];
+        mirror_point(po + 3 * i, p2, m2);
+        mirror_point(m1, p2, m3);
+        po[3 * (2 * ns0 + i)] = m2[0]; po[3 * (2 * ns0 + i) + 1] = m2[1]; po[3 * (2 * ns0 + i) + 2] = m2[2];
+        po[3 * (3 * ns0 + i)] = m3[0]; po[3 * (3 * ns0 + i) + 1] = m3[1]; po[3 * (3 * ns0 + i) + 2] = m3[2];
+      }
+    }
+    npo = (stype == 2) ? 4 * ns0 : 2 * ns0;
+    stage_sync();
+    double sx = 0, sy = 0, sz = 0;
+    for (int i = tid; i < npo; i += kFitThreads) { sx += po[3 * i]; sy += po[3 * i + 1]; sz += po[3 * i + 2]; }
+    sx = block_sum(sx, S.red); sy = block_sum(sy, S.red); sz = block_sum(sz, S.red);
+    if (tid == 0) {
+      const double cc[3] = {sx / (double)npo, sy / (double)npo, sz / (double)npo};
+      const double nn = sqrt(best.p[0] * best.p[0] + best.p[1] * best.p[1] + best.p[2] * best.p[2]);
+      const double x[3] = {best.p[0] / nn, best.p[1] / nn, best.p[2] / nn}, z[3] = {0, 0, 1};
+      double y[3];
+      cross3(z, x, y);
+      Mat3 Rom;
+      Rom.m[0] = x[0]; Rom.m[1] = y[0]; Rom.m[2] = z[0];
+      Rom.m[3] = x[1]; Rom.m[4] = y[1]; Rom.m[5] = z[1];
+      Rom.m[6] = x[2]; Rom.m[7] = y[2]; Rom.m[8] = z[2];
+      SE3 Tom;
+      Tom.r = q_from_R(Rom);
+      Tom.t[0] = cc[0]; Tom.t[1] = cc[1]; Tom.t[2] = cc[2];
+      const SE3 Tmo = se3_inv(Tom);
+      const Mat3 Rmo = q_to_R(Tmo.r);
+      for (int i = 0; i < 9; ++i) S.Rmo[i] = Rmo.m[i];
+      S.Tmo[0] = Tmo.t[0]; S.Tmo[1] = Tmo.t[1]; S.Tmo[2] = Tmo.t[2];
+      const SE3 Twm = se3_mul(se3_load(S.Two), Tom);
+      se3_store(Twm, S.Two);
+    }
+    __syncthreads();
+  }
+  // 10. extents in the (re-centred) object frame, ellipsoid, back to the camera frame
+  double mx = 0, my = 0, mz = 0;
+  for (int i = tid; i < npo; i += kFitThreads) {
+    double p[3] = {po[3 * i], po[3 * i + 1], po[3 * i + 2]};
+    if (run_sym) {
+      const double q0 = S.Rmo[0] * p[0] + S.Rmo[1] * p[1] + S.Rmo[2] * p[2] + S.Tmo[0];
+      const double q1 = S.Rmo[3] * p[0] + S.Rmo[4] * p[1] + S.Rmo[5] * p[2] + S.Tmo[1];
+      const double q2 = S.Rmo[6] * p[0] + S.Rmo[7] * p[1] + S.Rmo[8] * p[2] + S.Tmo[2];
+      p[0] = q0; p[1] = q1; p[2] = q2;
+    }
+    mx = fmax(mx, fabs(p[0])); my = fmax(my, fabs(p[1])); mz = fmax(mz, fabs(p[2]));
+  }
+  mx = block_max(mx, S.red); my = block_max(my, S.red); mz = block_max(mz, S.red);
+  if (tid == 0) {
+    SE3 I;
+    I.r = Quat{0, 0, 0, 1}; I.t[0] = I.t[1] = I.t[2] = 0;
+    const SE3 g = se3_mul(se3_load(S.Two), I);
+    const SE3 l = se3_mul(se3_inv(se3_load(a.Twc)), g);
+    double* o = a.out_ell + 10 * b;
+    se3_store(l, o);
+    o[7] = mx; o[8] = my; o[9] = mz;
+    a.out_prob[b] = prob_sym;
+    a.out_status[b] = 0;
+    double* dbg = a.out_dbg + 16 * b;
+    dbg[0] = S.n0; dbg[1] = S.n1; dbg[2] = M; dbg[3] = S.ncl; dbg[4] = nc; dbg[5] = ns0;
+    for (int k = 0; k < 9; ++k) dbg[6 + k] = run_sym ? S.prob[k] : 0.0;
+  }
+}
+
+}  // namespace esl
+
+using namespace esl;
+
 extern "C" {
+
 void esl_fit_params_default(esl_fit_params* p) {
   p->stride = 3; p->depth_scale = 5000; p->depth_min = 0.1; p->depth_max = 6.0; p->voxel_leaf = 0.01;
   p->plane_dist = 0.05; p->cluster_tolerance = 0.02; p->min_cluster_size = 100; p->center_dis = 0.5;
   p->symmetry_open = 1; p->symmetry_grid = 0.1; p->symmetry_sigma = 0.1; p->symmetry_lm_iters = 5;
 }
-int esl_fit_frame(esl_ctx*, const uint16_t*, int32_t, int32_t, const double*, const int32_t*, int32_t, const double*,
-                  const double*, const double*, const esl_fit_params*, double*, double*, int32_t*) {
-  esl::set_error("esl_fit_frame: not built yet");
-  return ESL_ERR_STATE;
+
+int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes,
+                        const int32_t* labels, int32_t n_boxes, const double Twc[7], const double intr[5],
+                        const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
+                        int32_t* status_out, double* debug_out) {
+  if (!c || !depth || !bboxes || !Twc || !intr || !ground || !p || !ellipsoids_out || !prob_out || !status_out || width <= 0 ||
+      height <= 0 || n_boxes < 0) {
+    set_error("esl_fit_frame: bad argument");
+    return ESL_ERR_INVALID;
+  }
+  if (p->stride < 1 || p->voxel_leaf <= 0 || p->cluster_tolerance <= 0 || p->symmetry_grid <= 0) {
+    set_error("esl_fit_frame: bad parameters");
+    return ESL_ERR_INVALID;
+  }
+  if (n_boxes == 0) return ESL_OK;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  FitArgs a{};
+  a.w = width; a.h = height; a.n_boxes = n_boxes; a.p = *p;
+  for (int i = 0; i < 7; ++i) a.Twc[i] = Twc[i];
+  for (int i = 0; i < 5; ++i) a.intr[i] = intr[i];
+  for (int i = 0; i < 4; ++i) a.ground[i] = ground[i];
+  long cap = 64;
+  for (int b = 0; b < n_boxes; ++b) {
+    const long w = (long)(bboxes[4 * b + 2] - bboxes[4 * b]) / p->stride + 2, h = (long)(bboxes[4 * b + 3] - bboxes[4 * b + 1]) / p->stride + 2;
+    if (w > 0 && h > 0) cap = std::max(cap, w * h);
+  }
+  long H = 1024;
+  while (H < 2 * cap) H <<= 1;
+  a.cap = cap; a.H = H;
+  // one slab for everything
+  const size_t B = (size_t)n_boxes;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_depth = take((size_t)width * height * 2), o_bb = take(B * 32), o_lab = take(B * 4);
+  const size_t o_hk = take(B * H * 8), o_hsx = take(B * H * 8), o_hsy = take(B * H * 8), o_hsz = take(B * H * 8), o_hcnt = take(B * H * 4);
+  const size_t o_pwx = take(B * cap * 4), o_pwy = take(B * cap * 4), o_pwz = take(B * cap * 4), o_pkey = take(B * cap * 8);
+  const size_t o_ck = take(B * H * 8), o_chead = take(B * H * 4), o_nxt = take(B * cap * 4), o_par = take(B * cap * 4);
+  const size_t o_cs = take(B * cap * 4), o_cmk = take(B * cap * 8), o_cmd = take(B * cap * 8);
+  const size_t o_po = take(B * cap * 12 * 8), o_pof = take(B * cap * 3 * 4);
+  const size_t o_ell = take(B * 80), o_prob = take(B * 8), o_st = take(B * 4), o_dbg = take(B * 128);
+  char* slab = nullptr;
+  ESL_HIP_TRY(hipMalloc((void**)&slab, off));
+  a.depth = (const uint16_t*)(slab + o_depth); a.bboxes = (const double*)(slab + o_bb); a.labels = (const int*)(slab + o_lab);
+  a.hk = (unsigned long long*)(slab + o_hk); a.hsx = (long long*)(slab + o_hsx); a.hsy = (long long*)(slab + o_hsy);
+  a.hsz = (long long*)(slab + o_hsz); a.hcnt = (unsigned int*)(slab + o_hcnt);
+  a.pwx = (float*)(slab + o_pwx); a.pwy = (float*)(slab + o_pwy); a.pwz = (float*)(slab + o_pwz); a.pkey = (unsigned long long*)(slab + o_pkey);
+  a.ck = (unsigned long long*)(slab + o_ck); a.chead = (int*)(slab + o_chead); a.nxt = (int*)(slab + o_nxt); a.parent = (int*)(slab + o_par);
+  a.csize = (int*)(slab + o_cs); a.cminkey = (unsigned long long*)(slab + o_cmk); a.cmind = (unsigned long long*)(slab + o_cmd);
+  a.po = (double*)(slab + o_po); a.pof = (float*)(slab + o_pof);
+  a.out_ell = (double*)(slab + o_ell); a.out_prob = (double*)(slab + o_prob); a.out_status = (int*)(slab + o_st); a.out_dbg = (double*)(slab + o_dbg);
+  hipStream_t st = c->stream;
+  std::vector<int32_t> lab((size_t)n_boxes, -1);
+  if (labels) for (int b = 0; b < n_boxes; ++b) lab[b] = labels[b];
+  int rc = ESL_OK;
+  auto fail = [&](hipError_t e, const char* what) { set_error(std::string(what) + ": " + hipGetErrorString(e)); rc = ESL_ERR_HIP; };
+  hipError_t e;
+  if ((e = hipMemcpyAsync(slab + o_depth, depth, (size_t)width * height * 2, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e, "upload depth");
+  if (!rc && (e = hipMemcpyAsync(slab + o_bb, bboxes, B * 32, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e, "upload boxes");
+  if (!rc && (e = hipMemcpyAsync(slab + o_lab, lab.data(), B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e, "upload labels");
+  if (!rc && (e = hipMemsetAsync(slab + o_hk, 0xFF, B * H * 8, st)) != hipSuccess) fail(e, "clear hash");
+  if (!rc && (e = hipMemsetAsync(slab + o_hsx, 0, (o_pwx - o_hsx), st)) != hipSuccess) fail(e, "clear sums");
+  if (!rc && (e = hipMemsetAsync(slab + o_ell, 0, off - o_ell, st)) != hipSuccess) fail(e, "clear outputs");
+  if (!rc) {
+    ProfScope ps(c, 5);
+    hipLaunchKernelGGL(k_fit_frame, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) fail(e, "k_fit_frame");
+  }
+  std::vector<double> dbg(B * 16);
+  if (!rc && (e = hipMemcpyAsync(ellipsoids_out, slab + o_ell, B * 80, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
+  if (!rc && (e = hipMemcpyAsync(prob_out, slab + o_prob, B * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
+  if (!rc && (e = hipMemcpyAsync(status_out, slab + o_st, B * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
+  if (!rc && (e = hipMemcpyAsync(dbg.data(), slab + o_dbg, B * 128, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
+  if ((e = hipStreamSynchronize(st)) != hipSuccess && !rc) fail(e, "sync");
+  (void)hipFree(slab);
+  if (!rc && debug_out) std::copy(dbg.begin(), dbg.end(), debug_out);
+  return rc;
 }
+
+int esl_fit_frame(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
+                  int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4], const esl_fit_params* p,
+                  double* ellipsoids_out, double* prob_out, int32_t* status_out) {
+  return esl_fit_frame_debug(c, depth, width, height, bboxes, labels, n_boxes, Twc, intr, ground, p, ellipsoids_out, prob_out,
+                             status_out, nullptr);
 }
+
+}  // extern "C"

@@ -20,7 +20,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug",
     "esl_init_quadric",
 ]
 
@@ -176,8 +176,38 @@ class Context:
                                        e.ctypes.data_as(_dp), Q.ctypes.data_as(_dp), C.byref(ok)), "esl_init_quadric")
         return e, Q.reshape(4, 4), bool(ok.value)
 
+    def fit_frame(self, depth, bboxes, labels, Twc, intr, ground, params=None):
+        """EllipsoidExtractor::EstimateLocalEllipsoid for every box of one frame.
+        Returns (ellipsoids (B,10) in the camera frame, prob (B,), status (B,), debug (B,16))."""
+        p = params if params is not None else default_fit_params()
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        h, w = depth.shape
+        boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
+        B = len(boxes)
+        lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float64); intr = np.ascontiguousarray(intr, dtype=np.float64)
+        ground = np.ascontiguousarray(ground, dtype=np.float64)
+        ell = np.zeros((B, 10)); prob = np.zeros(B); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 16))
+        _check(load().esl_fit_frame_debug(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                                          boxes.ctypes.data_as(_dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(B),
+                                          Twc.ctypes.data_as(_dp), intr.ctypes.data_as(_dp), ground.ctypes.data_as(_dp),
+                                          C.byref(p), ell.ctypes.data_as(_dp), prob.ctypes.data_as(_dp),
+                                          st.ctypes.data_as(C.POINTER(C.c_int32)), dbg.ctypes.data_as(_dp)), "esl_fit_frame")
+        return ell, prob, st, dbg
+
     def synchronize(self):
         _check(load().esl_ctx_synchronize(self._h), "esl_ctx_synchronize")
+
+
+def default_fit_params(**kw):
+    """Reference settings (Example/param/TUM3.yaml, PointCloudFilter.cpp:31-38, EllipsoidExtractor.cpp:98,570)."""
+    p = abi.EslFitParams()
+    load().esl_fit_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
 
 
 def partition_objects(graph, n_parts):

@@ -211,3 +211,58 @@ CONFIGS = {
 def make_config(name, seed=0, slam=False, **kw):
     F, N, E = CONFIGS[name]
     return make_graph(F, N, E, seed=seed, slam=slam, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthetic RGB-D frames for the single-frame fit (BASELINE.json configs[1] and configs[4] shapes)
+# ---------------------------------------------------------------------------------------------------
+def make_depth_scene(width=640, height=480, n_objs=3, seed=0, scale=5000.0, cam_height=1.3, spread=1.2,
+                     size=(0.15, 0.45), noise_mm=1.0):
+    """Ray-cast ellipsoids standing on the ground plane z = 0 into a 16-bit depth image.
+    Returns dict(depth (h,w) u16, bboxes (B,4), labels (B,), Twc (7,), intr (5,), ground (4,), objs (B,10))."""
+    rng = np.random.default_rng(seed)
+    sx = width / 640.0
+    fx, fy, cx, cy = TUM3_K[0] * sx, TUM3_K[1] * sx, TUM3_K[2] * sx, TUM3_K[3] * sx
+    # camera at (-2.6, 0, cam_height) looking at the origin region, x right / y down / z forward
+    pos = np.array([-2.6, 0.0, cam_height])
+    fwd = np.array([0.0, 0.0, 0.3]) - pos; fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    Rwc = np.stack([right, down, fwd], -1)
+    Twc = np.concatenate([pos, _R_to_quat(Rwc[None])[0]])
+    # objects: ellipsoids on the ground, spread across the view
+    B = n_objs
+    s = rng.uniform(size[0], size[1], size=(B, 3))
+    ys = np.linspace(-spread, spread, B) if B > 1 else np.zeros(1)
+    ctr = np.stack([rng.uniform(-0.3, 0.6, B), ys + 0.05 * rng.standard_normal(B), s[:, 2]], 1)
+    yaw = rng.uniform(-0.6, 0.6, B)
+    qo = _euler_zyx_to_quat(np.zeros(B), np.zeros(B), yaw)
+    objs = np.concatenate([ctr, qo, s], 1)
+    # rays
+    u, v = np.meshgrid(np.arange(width), np.arange(height))
+    dirs_c = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u, dtype=float)], -1)  # camera frame, z = 1
+    dirs_w = dirs_c @ Rwc.T
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t = -pos[2] / dirs_w[..., 2]           # ground plane z_w = 0 (t = camera-frame depth since dirs_c.z = 1)
+    zc = np.where((t > 0) & np.isfinite(t), t, np.inf)
+    for k in range(B):
+        Ro = _quat_to_R(qo[k][None])[0]
+        o = (pos - ctr[k]) @ Ro / s[k]
+        d = (dirs_w @ Ro) / s[k]
+        A = (d * d).sum(-1); Bq = 2 * (d * o).sum(-1); Cq = (o * o).sum() - 1
+        disc = Bq * Bq - 4 * A * Cq
+        with np.errstate(invalid='ignore'):
+            tt = (-Bq - np.sqrt(disc)) / (2 * A)
+        hit = (disc > 0) & (tt > 0)
+        zc = np.where(hit & (tt < zc), tt, zc)
+    zc = zc + (noise_mm * 1e-3) * rng.standard_normal(zc.shape)
+    depth = np.where(np.isfinite(zc) & (zc < 13.0), np.clip(np.rint(zc * scale), 0, 65535), 0).astype(np.uint16)
+    # boxes from the exact projected outline, padded by 4 px, clipped to the image
+    Tcw_R = Rwc.T; Tcw_t = -Rwc.T @ pos
+    cams7 = np.concatenate([Tcw_t, _R_to_quat(Tcw_R[None])[0]])[None]
+    bb, _, _ = project_bboxes(cams7, objs, (fx, fy, cx, cy), np.zeros(B, int), np.arange(B))
+    bb = bb + np.array([-4, -4, 4, 4.0])
+    bb[:, [0, 2]] = np.clip(bb[:, [0, 2]], 1, width - 2); bb[:, [1, 3]] = np.clip(bb[:, [1, 3]], 1, height - 2)
+    labels = np.array([[28, 41, 0, 58][k % 4] for k in range(B)], dtype=np.int32)  # dual / single symmetry / none / none
+    return dict(depth=depth, bboxes=bb, labels=labels, Twc=Twc, intr=np.array([fx, fy, cx, cy, scale]),
+                ground=np.array([0.0, 0.0, 1.0, 0.0]), objs=objs)

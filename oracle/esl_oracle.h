@@ -71,6 +71,14 @@ int esl_oracle_build_system(const esl_graph* g, const double* cams, const double
 int esl_oracle_init_quadric(const double* poses_Twc, const double* bboxes, int n, const double K[4], int rows, int cols,
                             int faithful, double ell_out[10], double qstar_out[16], int* ok);
 
+/* --- EllipsoidExtractor::EstimateLocalEllipsoid (src/pca/EllipsoidExtractor.cpp:292-493) --------------------
+ * debug_out (optional, 16 doubles per box): [0] in-range samples, [1] 1 cm voxels, [2] after plane filter,
+ * [3] clusters >= MinClusterSize, [4] chosen cluster size, [5] GridSize voxels, [6..14] prob of the 9 hypotheses */
+int esl_oracle_fit_frame(const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
+                         int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4],
+                         const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
+                         double* debug_out);
+
 /* timing helper for bench.py's cpu_baseline: seconds spent in linearise / solve / error evaluation
  * of the last esl_oracle_optimize call */
 void esl_oracle_last_timing(double t[3]);

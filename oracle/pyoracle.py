@@ -158,6 +158,37 @@ def init_quadric(poses_Twc, bboxes, K, rows=480, cols=640, faithful=1):
     return e, Q.reshape(4, 4), bool(ok.value)
 
 
+def default_fit_params(**kw):
+    p = _abi.EslFitParams(stride=3, depth_scale=5000.0, depth_min=0.1, depth_max=6.0, voxel_leaf=0.01, plane_dist=0.05,
+                          cluster_tolerance=0.02, min_cluster_size=100, center_dis=0.5, symmetry_open=1,
+                          symmetry_grid=0.1, symmetry_sigma=0.1, symmetry_lm_iters=5)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def fit_frame(depth, bboxes, labels, Twc, intr, ground, params=None):
+    """Returns (ellipsoids (B,10) camera frame, prob (B,), status (B,), debug (B,16))."""
+    p = params if params is not None else default_fit_params()
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    h, w = depth.shape
+    boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
+    B = len(boxes)
+    lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+    Twc = np.ascontiguousarray(Twc, dtype=np.float64); intr = np.ascontiguousarray(intr, dtype=np.float64)
+    ground = np.ascontiguousarray(ground, dtype=np.float64)
+    ell = np.zeros((B, 10)); prob = np.zeros(B); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 16))
+    dp = C.POINTER(C.c_double)
+    lib().esl_oracle_fit_frame(depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                               boxes.ctypes.data_as(dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(B),
+                               Twc.ctypes.data_as(dp), intr.ctypes.data_as(dp), ground.ctypes.data_as(dp), C.byref(p),
+                               ell.ctypes.data_as(dp), prob.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                               dbg.ctypes.data_as(dp))
+    return ell, prob, st, dbg
+
+
 def last_timing():
     t = (C.c_double * 3)()
     lib().esl_oracle_last_timing(t)
