@@ -75,6 +75,44 @@ def cpu_baseline(pkg, g, c, o, params, budget_s=25.0):
     }
 
 
+def fit_bench(pkg, ctx, with_cpu=True):
+    """Second half of BASELINE.json's metric: per-frame ellipsoid-fit ms.
+    C2 = one box with ~50k in-range depth samples (1280x960, stride 1); C5 frame = 20 boxes on a 640x480 frame (stride 3)."""
+    out = {}
+    cases = {
+        "c2_1box_50k_points": (pkg.synth.make_depth_scene(width=1280, height=960, n_objs=1, seed=11, size=(0.4, 0.5)), dict(stride=1), [28]),
+        "c5_20boxes_640x480": (pkg.synth.make_depth_scene(n_objs=20, seed=7, spread=1.6, size=(0.1, 0.3)), dict(stride=3), None),
+    }
+    for name, (sc, kw, labels) in cases.items():
+        P = pkg.lib.default_fit_params(**kw)
+        lab = sc["labels"] if labels is None else labels
+        boxes = sc["bboxes"][:len(lab)]
+        args = (sc["depth"], boxes, lab, sc["Twc"], sc["intr"], sc["ground"], P)
+        for _ in range(3):
+            res = ctx.fit_frame(*args)
+        ctx.profile_enable(True)
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            res = ctx.fit_frame(*args)
+        dt = (time.perf_counter() - t0) / n
+        prof = ctx.profile_get().get("k5", dict(count=1, total_ms=0.0))
+        ctx.profile_enable(False)
+        entry = {"ms_per_frame_host_call": 1e3 * dt, "ms_per_frame_kernel": prof["total_ms"] / max(prof["count"], 1),
+                 "boxes": len(lab), "ok_boxes": int((res[2] == 0).sum()), "samples": int(res[3][:, 0].sum()),
+                 "note": "host call = hipMalloc + H2D of the depth image + kernel + D2H (PCIe-inclusive); kernel = HIP events"}
+        if with_cpu:
+            from oracle import pyoracle as po
+            Po = po.default_fit_params(**kw)
+            t0 = time.perf_counter()
+            m = 5
+            for _ in range(m):
+                po.fit_frame(sc["depth"], boxes, lab, sc["Twc"], sc["intr"], sc["ground"], Po)
+            entry["cpu_port_ms_per_frame"] = 1e3 * (time.perf_counter() - t0) / m
+        out[name] = entry
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +222,8 @@ def main():
             "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]},
             "roofline": roof,
         }
+        if world == 1:
+            out["fit"] = fit_bench(pkg, ctx, with_cpu=not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, g, c, o, pkg.default_lm_params())
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]

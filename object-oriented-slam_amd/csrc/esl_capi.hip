@@ -13,6 +13,7 @@
 
 #include "esl_ctx.hpp"
 #include "esl_kernels_map.hpp"
+#include "esl_kernels_chunk.hpp"
 #include "esl_slam.hpp"
 
 namespace esl {
@@ -110,6 +111,12 @@ int esl_ctx_create(int device_id, esl_ctx** out) {
   ESL_HIP_TRY(hipHostMalloc((void**)&c->host_part, 16 * sizeof(double), hipHostMallocDefault));
   ESL_HIP_TRY(hipMalloc((void**)&c->dev_part, 16 * sizeof(double)));
   ESL_HIP_TRY(hipMalloc((void**)&c->chol_info, 4 * sizeof(int)));
+  ESL_HIP_TRY(hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)));
+  ESL_HIP_TRY(hipMemset(c->tickets, 0, 4 * sizeof(unsigned int)));
+  ESL_HIP_TRY(hipMalloc((void**)&c->dev_scal, 8 * sizeof(double)));
+  ESL_HIP_TRY(hipHostMalloc(&c->host_scal, sizeof(LmScalars), hipHostMallocMapped));
+  ESL_HIP_TRY(hipHostGetDevicePointer(&c->host_scal_dev, c->host_scal, 0));
+  std::memset(c->host_scal, 0, sizeof(LmScalars));
   *out = c;
   return ESL_OK;
 }
@@ -125,6 +132,9 @@ static void free_graph(esl_ctx* c) {
   dev_free(&g.cod_start); dev_free(&g.cod_edge);
   dev_free(&g.ue_start); dev_free(&g.ue_id); dev_free(&g.ue_slot);
   dev_free(&c->Linv_ws); dev_free(&c->z_ws);
+  dev_free(&c->ck_obj); dev_free(&c->ck_type); dev_free(&c->ck_begin); dev_free(&c->ck_end); dev_free(&c->ck_ostart);
+  dev_free(&c->chunk_out); dev_free(&c->chunk_chi); dev_free(&c->blk_part);
+  c->n_chunks = 0;
   dev_free(&c->cams); dev_free(&c->cams_trial); dev_free(&c->objs); dev_free(&c->objs_trial);
   dev_free(&c->Hoo); dev_free(&c->bo); dev_free(&c->xo); dev_free(&c->obj_part);
   dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
@@ -145,6 +155,8 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (c->host_part) (void)hipHostFree(c->host_part);
   dev_free(&c->dev_part);
   dev_free(&c->chol_info);
+  dev_free(&c->tickets); dev_free(&c->dev_scal);
+  if (c->host_scal) (void)hipHostFree(c->host_scal);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ESL_OK;
@@ -216,7 +228,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     for (int k = 0; k < 4; ++k) { const double yaw = ang[k] * M_PI / 2.0; d.yt.s[k] = std::sin(yaw * 0.5); d.yt.c[k] = std::cos(yaw * 0.5); }
   }
   const int N = g->n_objs, F = g->n_cams;
-  std::vector<int> start, perm;
+  std::vector<int> start, perm, h_bb_start, h_e3_start;
   // bbox
   csr_by_key(g->bbox_obj, g->n_bbox, N, start, perm);
   {
@@ -229,6 +241,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
       for (int j = 0; j < 4; ++j) meas[(size_t)k * 4 + j] = g->bbox_meas[(size_t)i * 4 + j];
     }
     c->h_bb_cam = cam; c->h_bb_obj = obj;
+    h_bb_start = start;
     if ((rc = dev_upload(&d.bb_start, start.data(), start.size(), st))) return rc;
     if ((rc = dev_upload(&d.bb_cam, cam.data(), cam.size(), st))) return rc;
     if ((rc = dev_upload(&d.bb_obj, obj.data(), obj.size(), st))) return rc;
@@ -254,6 +267,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
       for (int j = 0; j < 10; ++j) meas[(size_t)k * 10 + j] = g->e3d_meas[(size_t)i * 10 + j];
     }
     c->h_e3_cam = cam; c->h_e3_obj = obj;
+    h_e3_start = start;
     if ((rc = dev_upload(&d.e3_start, start.data(), start.size(), st))) return rc;
     if ((rc = dev_upload(&d.e3_cam, cam.data(), cam.size(), st))) return rc;
     if ((rc = dev_upload(&d.e3_obj, obj.data(), obj.size(), st))) return rc;
@@ -274,6 +288,25 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
       if (cnt[o] > 64) { set_error("more than 64 gravity edges on one ellipsoid"); return ESL_ERR_INVALID; }
     if ((rc = dev_upload(&d.gr_cnt, cnt.data(), cnt.size(), st))) return rc;
     ESL_HIP_TRY(hipStreamSynchronize(st));
+    // chunk table: per ellipsoid, in g2o's edge order (gravity, bbox, 3-D), <= 64 edges of one type per chunk
+    std::vector<int> co, cty, cb, ce, cos((size_t)N + 1, 0);
+    for (int o = 0; o < N; ++o) {
+      cos[o] = (int)co.size();
+      if (cnt[o] > 0) { co.push_back(o); cty.push_back(2); cb.push_back(0); ce.push_back(cnt[o]); }
+      for (int b0 = h_bb_start[o]; b0 < h_bb_start[o + 1]; b0 += 64) { co.push_back(o); cty.push_back(0); cb.push_back(b0); ce.push_back(std::min(b0 + 64, h_bb_start[o + 1])); }
+      for (int b0 = h_e3_start[o]; b0 < h_e3_start[o + 1]; b0 += 64) { co.push_back(o); cty.push_back(1); cb.push_back(b0); ce.push_back(std::min(b0 + 64, h_e3_start[o + 1])); }
+    }
+    cos[N] = (int)co.size();
+    c->n_chunks = (int)co.size();
+    if ((rc = dev_upload(&c->ck_obj, co.data(), co.size(), st))) return rc;
+    if ((rc = dev_upload(&c->ck_type, cty.data(), cty.size(), st))) return rc;
+    if ((rc = dev_upload(&c->ck_begin, cb.data(), cb.size(), st))) return rc;
+    if ((rc = dev_upload(&c->ck_end, ce.data(), ce.size(), st))) return rc;
+    if ((rc = dev_upload(&c->ck_ostart, cos.data(), cos.size(), st))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = dev_alloc(&c->chunk_out, (size_t)c->n_chunks * kChunkOut))) return rc;
+    if ((rc = dev_alloc(&c->chunk_chi, (size_t)c->n_chunks))) return rc;
+    if ((rc = dev_alloc(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2))) return rc;
   }
   // cameras + odometry
   {
@@ -347,6 +380,62 @@ int esl_states_download(esl_ctx* c, double* cams, double* objs) {
   return ESL_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// chunked mapping-mode pipeline (esl_kernels_chunk.hpp): launch helpers
+// ---------------------------------------------------------------------------------------------------
+static ChunkTable chunk_table(const esl_ctx* c) {
+  ChunkTable t;
+  t.n_chunks = c->n_chunks; t.obj = c->ck_obj; t.type = c->ck_type; t.begin = c->ck_begin; t.end = c->ck_end; t.ostart = c->ck_ostart;
+  return t;
+}
+static int map_launch_linearize(esl_ctx* c, bool finalize) {
+  const DevGraph& g = c->g;
+  const ChunkTable ct = chunk_table(c);
+  if (ct.n_chunks > 0) {
+    ProfScope ps(c, 0);
+    const dim3 grid((ct.n_chunks + 3) / 4), block(256);
+    if (c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC)
+      hipLaunchKernelGGL(k_chunk_linearize<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, ct, c->cams, c->objs,
+                         c->lm.p.numeric_delta, c->chunk_out);
+    else
+      hipLaunchKernelGGL(k_chunk_linearize<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, ct, c->cams, c->objs,
+                         c->lm.p.numeric_delta, c->chunk_out);
+  }
+  ESL_HIP_TRY(hipGetLastError());
+  c->sys_combined = false;
+  if (finalize) {
+    ProfScope ps(c, 4);
+    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, ct, c->chunk_out, c->blk_part,
+                       c->tickets, c->dev_scal, (LmScalars*)c->host_scal_dev);
+    ESL_HIP_TRY(hipGetLastError());
+  }
+  return ESL_OK;
+}
+// lambda < 0: use tau * max_diag from device memory (first iteration)
+static int map_launch_try(esl_ctx* c, double lambda) {
+  const DevGraph& g = c->g;
+  const ChunkTable ct = chunk_table(c);
+  {
+    ProfScope ps(c, 1);
+    hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 3) / 4), dim3(256), 0, c->stream, g, ct, c->chunk_out, c->objs, lambda,
+                       c->lm.p.tau, c->dev_scal, c->xo, c->objs_trial, c->obj_part);
+    hipLaunchKernelGGL(k_chunk_chi2, dim3(std::max(1, (ct.n_chunks + 3) / 4)), dim3(256), 0, c->stream, g, ct, c->cams,
+                       c->objs_trial, c->obj_part, c->chunk_chi, c->tickets + 1, lambda, c->lm.p.tau, c->dev_scal,
+                       (LmScalars*)c->host_scal_dev);
+  }
+  ESL_HIP_TRY(hipGetLastError());
+  return ESL_OK;
+}
+static int map_combine(esl_ctx* c) {
+  if (c->sys_combined || c->g.n_objs == 0) return ESL_OK;
+  hipLaunchKernelGGL(k_chunk_combine, dim3((c->g.n_objs * 54 + 255) / 256), dim3(256), 0, c->stream, c->g, chunk_table(c),
+                     c->chunk_out, c->Hoo, c->bo);
+  ESL_HIP_TRY(hipGetLastError());
+  c->sys_combined = true;
+  return ESL_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // step API
 // ---------------------------------------------------------------------------------------------------
@@ -387,33 +476,20 @@ int esl_lm_linearize(esl_ctx* c, esl_lm_partials* out) {
   if (!c || !out) return ESL_ERR_INVALID;
   if (!c->lm.begun) { set_error("esl_lm_linearize before esl_lm_begin"); return ESL_ERR_STATE; }
   ESL_HIP_TRY(hipSetDevice(c->device));
-  const DevGraph& g = c->g;
-  const int N = g.n_objs;
   if (c->lm.slam) {
     int rc = slam_linearize(c);
     if (rc) return rc;
-  } else if (N > 0) {
-    const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-    {
-    ProfScope ps(c, 0);
-    if (c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC)
-      hipLaunchKernelGGL(k_map_linearize<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, c->cams, c->objs,
-                         c->lm.p.numeric_delta, c->Hoo, c->bo, c->obj_part);
-    else
-      hipLaunchKernelGGL(k_map_linearize<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, c->cams, c->objs,
-                         c->lm.p.numeric_delta, c->Hoo, c->bo, c->obj_part);
-    }
-    ESL_HIP_TRY(hipGetLastError());
-    ProfScope ps2(c, 4);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, N, c->dev_part, 0);
-    ESL_HIP_TRY(hipGetLastError());
-  } else {
-    ESL_HIP_TRY(hipMemsetAsync(c->dev_part, 0, 4 * sizeof(double), c->stream));
+    double v[4];
+    rc = read_parts(c, v);
+    if (rc) return rc;
+    out->chi2 = v[0]; out->max_diag = v[1]; out->scale = 0; out->solve_ok = 1; out->pad = 0;
+    return ESL_OK;
   }
-  double v[4];
-  int rc = read_parts(c, v);
+  int rc = map_launch_linearize(c, true);
   if (rc) return rc;
-  out->chi2 = v[0]; out->max_diag = v[1]; out->scale = 0; out->solve_ok = 1; out->pad = 0;
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  const LmScalars* h = (const LmScalars*)c->host_scal;
+  out->chi2 = h->chi2_lin; out->max_diag = h->max_diag; out->scale = 0; out->solve_ok = 1; out->pad = 0;
   return ESL_OK;
 }
 
@@ -421,29 +497,20 @@ int esl_lm_try_step(esl_ctx* c, double lambda, esl_lm_partials* out) {
   if (!c || !out) return ESL_ERR_INVALID;
   if (!c->lm.begun) { set_error("esl_lm_try_step before esl_lm_begin"); return ESL_ERR_STATE; }
   ESL_HIP_TRY(hipSetDevice(c->device));
-  const DevGraph& g = c->g;
-  const int N = g.n_objs;
   if (c->lm.slam) {
     int rc = slam_try_step(c, lambda);
     if (rc) return rc;
-  } else if (N > 0) {
-    const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-    {
-      ProfScope ps(c, 1);
-      hipLaunchKernelGGL(k_map_try_step, grid, block, 0, c->stream, g, c->cams, c->objs, lambda, c->Hoo, c->bo, c->xo,
-                         c->objs_trial, c->obj_part);
-    }
-    ESL_HIP_TRY(hipGetLastError());
-    ProfScope ps2(c, 4);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, N, c->dev_part, 0);
-    ESL_HIP_TRY(hipGetLastError());
+    double v[4];
+    rc = read_parts(c, v);
+    if (rc) return rc;
+    out->chi2 = v[0]; out->max_diag = 0; out->scale = v[2]; out->solve_ok = (c->g.n_objs == 0 || v[3] > 0.5) ? 1 : 0; out->pad = 0;
   } else {
-    ESL_HIP_TRY(hipMemsetAsync(c->dev_part, 0, 4 * sizeof(double), c->stream));
+    int rc = map_launch_try(c, lambda);
+    if (rc) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    const LmScalars* h = (const LmScalars*)c->host_scal;
+    out->chi2 = h->chi2_trial; out->max_diag = 0; out->scale = h->scale; out->solve_ok = h->ok > 0.5 ? 1 : 0; out->pad = 0;
   }
-  double v[4];
-  int rc = read_parts(c, v);
-  if (rc) return rc;
-  out->chi2 = v[0]; out->max_diag = 0; out->scale = v[2]; out->solve_ok = (N == 0 || v[3] > 0.5) ? 1 : 0; out->pad = 0;
   c->lm.lambda_used = lambda;
   c->lm.have_trial = true;
   return ESL_OK;
@@ -497,9 +564,24 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
   int nBad = 0, it = 0, total_trials = 0;
   bool ok_outer = true;
   double currentChi = 0;
+  const bool fused = !c->lm.slam;  // mapping mode: linearise + first trial enqueued back to back, one host sync
   for (it = 0; it < p->max_iters && ok_outer; ++it) {
     esl_lm_partials lin;
-    if ((rc = esl_lm_linearize(c, &lin))) return rc;
+    bool first_trial_done = false;
+    esl_lm_partials tr0;
+    if (fused) {
+      if ((rc = map_launch_linearize(c, it == 0))) return rc;
+      if ((rc = map_launch_try(c, it == 0 ? -1.0 : lambda))) return rc;
+      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+      const LmScalars* h = (const LmScalars*)c->host_scal;
+      if (it == 0) { lin.chi2 = h->chi2_lin; lin.max_diag = h->max_diag; }
+      else { lin.chi2 = currentChi; lin.max_diag = 0; }  // same state as the accepted trial: chi2 carries over
+      tr0.chi2 = h->chi2_trial; tr0.scale = h->scale; tr0.solve_ok = h->ok > 0.5 ? 1 : 0;
+      c->lm.have_trial = true;
+      first_trial_done = true;
+    } else {
+      if ((rc = esl_lm_linearize(c, &lin))) return rc;
+    }
     currentChi = lin.chi2;
     const double iniChi = currentChi;
     if (it == 0) {
@@ -512,7 +594,8 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
     int qmax = 0;
     do {
       esl_lm_partials tr;
-      if ((rc = esl_lm_try_step(c, lambda, &tr))) return rc;
+      if (first_trial_done) { tr = tr0; first_trial_done = false; }
+      else if ((rc = esl_lm_try_step(c, lambda, &tr))) return rc;
       double tempChi = tr.solve_ok ? tr.chi2 : DBL_MAX;
       rho = (currentChi - tempChi) / (tr.scale + 1e-3);
       if (rho > 0 && std::isfinite(tempChi)) {
@@ -616,6 +699,7 @@ int esl_lm_download(esl_ctx* c, int32_t which, double* dst, int64_t count) {
   }
   if (!src || count < n) { set_error("esl_lm_download: array not available or buffer too small"); return ESL_ERR_INVALID; }
   ESL_HIP_TRY(hipSetDevice(c->device));
+  if ((which == 0 || which == 1) && !c->lm.slam && c->lm.begun) { int rc = map_combine(c); if (rc) return rc; }
   if (n) ESL_HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   return ESL_OK;

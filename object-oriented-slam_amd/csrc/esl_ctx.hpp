@@ -55,6 +55,7 @@ struct DevGraph {
   int n_ue = 0;
 };
 
+struct ChunkTableFwd;
 struct LmState {
   bool begun = false;
   esl_lm_params p;
@@ -122,6 +123,17 @@ struct esl_ctx {
   size_t cap_cams = 0, cap_objs = 0;
   // host copies kept from upload (edge -> camera after sorting by ellipsoid)
   std::vector<int> h_bb_cam, h_bb_obj, h_e3_cam, h_e3_obj, h_cam_slot;
+  // chunked mapping-mode pipeline (esl_kernels_chunk.hpp)
+  int n_chunks = 0;
+  int *ck_obj = nullptr, *ck_type = nullptr, *ck_begin = nullptr, *ck_end = nullptr, *ck_ostart = nullptr;
+  double* chunk_out = nullptr;   // n_chunks x 56
+  double* chunk_chi = nullptr;   // n_chunks
+  double* blk_part = nullptr;    // per-workgroup partials of k_chunk_finalize
+  unsigned int* tickets = nullptr;  // 2 arrival counters
+  double* dev_scal = nullptr;    // {chi2_lin, max_diag}
+  void* host_scal = nullptr;     // mapped pinned LmScalars
+  void* host_scal_dev = nullptr; // its device alias
+  bool sys_combined = false;
   double* Linv_ws = nullptr;  // ceil(n/NB) x NB x NB
   double* z_ws = nullptr;
   int64_t S_lda = 0;
