@@ -292,7 +292,6 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     std::vector<int> co, cty, cb, ce, cos((size_t)N + 1, 0);
     for (int o = 0; o < N; ++o) {
       cos[o] = (int)co.size();
-      if (cnt[o] > 0) { co.push_back(o); cty.push_back(2); cb.push_back(0); ce.push_back(cnt[o]); }
       for (int b0 = h_bb_start[o]; b0 < h_bb_start[o + 1]; b0 += 64) { co.push_back(o); cty.push_back(0); cb.push_back(b0); ce.push_back(std::min(b0 + 64, h_bb_start[o + 1])); }
       for (int b0 = h_e3_start[o]; b0 < h_e3_start[o + 1]; b0 += 64) { co.push_back(o); cty.push_back(1); cb.push_back(b0); ce.push_back(std::min(b0 + 64, h_e3_start[o + 1])); }
     }
@@ -406,7 +405,8 @@ static int map_launch_linearize(esl_ctx* c, bool finalize) {
   c->sys_combined = false;
   if (finalize) {
     ProfScope ps(c, 4);
-    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, ct, c->chunk_out, c->blk_part,
+    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, ct, c->chunk_out, c->objs,
+                       c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part,
                        c->tickets, c->dev_scal, (LmScalars*)c->host_scal_dev);
     ESL_HIP_TRY(hipGetLastError());
   }
@@ -418,7 +418,8 @@ static int map_launch_try(esl_ctx* c, double lambda) {
   const ChunkTable ct = chunk_table(c);
   {
     ProfScope ps(c, 1);
-    hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 3) / 4), dim3(256), 0, c->stream, g, ct, c->chunk_out, c->objs, lambda,
+    hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 63) / 64), dim3(64), 0, c->stream, g, ct, c->chunk_out, c->objs,
+                       c->lm.p.jacobian_mode, c->lm.p.numeric_delta, lambda,
                        c->lm.p.tau, c->dev_scal, c->xo, c->objs_trial, c->obj_part);
     hipLaunchKernelGGL(k_chunk_chi2, dim3(std::max(1, (ct.n_chunks + 3) / 4)), dim3(256), 0, c->stream, g, ct, c->cams,
                        c->objs_trial, c->obj_part, c->chunk_chi, c->tickets + 1, lambda, c->lm.p.tau, c->dev_scal,
@@ -430,7 +431,7 @@ static int map_launch_try(esl_ctx* c, double lambda) {
 static int map_combine(esl_ctx* c) {
   if (c->sys_combined || c->g.n_objs == 0) return ESL_OK;
   hipLaunchKernelGGL(k_chunk_combine, dim3((c->g.n_objs * 54 + 255) / 256), dim3(256), 0, c->stream, c->g, chunk_table(c),
-                     c->chunk_out, c->Hoo, c->bo);
+                     c->chunk_out, c->objs, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->Hoo, c->bo);
   ESL_HIP_TRY(hipGetLastError());
   c->sys_combined = true;
   return ESL_OK;

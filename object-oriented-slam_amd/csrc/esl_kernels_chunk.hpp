@@ -36,7 +36,8 @@ constexpr int kChunkOut = 56;  // 45 packed H + 9 b + chi2 + pad
 // In: N values per lane.  Out: the wave-wide total of entry `idx` (returned) in the lanes whose low bits are 0.
 template <int N>
 struct WaveRS {
-  static __device__ __forceinline__ double run(const double* v, int lane, int& idx, int off) {
+  // cnt = number of REAL (non-padding) entries among the N this lane currently holds
+  static __device__ __forceinline__ double run(const double* v, int lane, int& idx, int& cnt, int off) {
     constexpr int H = (N + 1) / 2;
     const bool hi = (lane & off) != 0;
     double nv[H];
@@ -48,13 +49,14 @@ struct WaveRS {
       const double keep = hi ? hi_v : lo_v;
       nv[i] = keep + __shfl_xor(send, off, 64);
     }
-    if (hi) idx += H;
-    return WaveRS<H>::run(nv, lane, idx, off >> 1);
+    if (hi) { idx += H; cnt -= H; }
+    else cnt = cnt < H ? cnt : H;
+    return WaveRS<H>::run(nv, lane, idx, cnt, off >> 1);
   }
 };
 template <>
 struct WaveRS<1> {
-  static __device__ __forceinline__ double run(const double* v, int, int&, int off) {
+  static __device__ __forceinline__ double run(const double* v, int, int&, int&, int off) {
     double s = v[0];
     for (; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     return s;
@@ -100,16 +102,56 @@ __device__ __forceinline__ void fill_group(double* v, const double* J, const dou
   ((v[T] = hb_entry<D, G * 18 + T>(J, r, w)), ...);
 }
 
+// same for a 3-D edge, whose Jacobian is [[Jp 6x6, 0], [0, I3]] (Jp row-major 6x6, r has 9 rows)
+template <int P>
+__device__ __forceinline__ double hb_entry_e3d(const double* Jp, const double* r, double w) {
+  if constexpr (P < 45) {
+    constexpr int a = tri_a(P), c = tri_c(P);
+    if constexpr (c < 6) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += (w * Jp[k * 6 + a]) * Jp[k * 6 + c];
+      return s;
+    } else if constexpr (a == c) {
+      return w;
+    } else {
+      return 0.0;
+    }
+  } else if constexpr (P < 51) {
+    constexpr int a = P - 45;
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s -= Jp[k * 6 + a] * (w * r[k]);
+    return s;
+  } else if constexpr (P < 54) {
+    return -(w * r[P - 45]);
+  } else {
+    return 0.0;
+  }
+}
+template <int G, int... T>
+__device__ __forceinline__ void fill_group_e3d(double* v, const double* Jp, const double* r, double w, std::integer_sequence<int, T...>) {
+  ((v[T] = hb_entry_e3d<G * 18 + T>(Jp, r, w)), ...);
+}
+template <int G>
+__device__ __forceinline__ void reduce_group_e3d(const double* Jp, const double* r, double w, int lane, double* __restrict__ out) {
+  double v[18];
+  fill_group_e3d<G>(v, Jp, r, w, std::make_integer_sequence<int, 18>{});
+  int idx = 0, cnt = 18;
+  const double tot = WaveRS<18>::run(v, lane, idx, cnt, 32);
+  if ((lane & 1) == 0 && cnt >= 1) out[G * 18 + idx] = tot;
+}
+
 // entries [G*18, G*18+18) reduced over the wave; the owning lanes write the totals
 template <int D, int G>
 __device__ __forceinline__ void reduce_group(const double* J, const double* r, double w, int lane, double* __restrict__ out) {
   double v[18];
   fill_group<D, G>(v, J, r, w, std::make_integer_sequence<int, 18>{});
-  int idx = 0;
-  const double tot = WaveRS<18>::run(v, lane, idx, 32);
+  int idx = 0, cnt = 18;
+  const double tot = WaveRS<18>::run(v, lane, idx, cnt, 32);
   constexpr int used = rs_steps(18);               // 5 distributing steps: offsets 32..2
   const int low_mask = (64 >> used) - 1;           // remaining low bits (here: bit 0)
-  if ((lane & low_mask) == 0 && idx < 18) out[G * 18 + idx] = tot;
+  if ((lane & low_mask) == 0 && cnt >= 1) out[G * 18 + idx] = tot;   // cnt < 1: this lane ended on a padding slot
 }
 
 template <int JAC>
@@ -145,46 +187,38 @@ static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, Chun
     reduce_group<4, 0>(J, r, w, lane, out);
     reduce_group<4, 1>(J, r, w, lane, out);
     reduce_group<4, 2>(J, r, w, lane, out);
-  } else if (type == 1) {
-    double r[9], J[81], w = 0;
+  } else {
+    double r[9], Jp[36], w = 0;
     if (in) {
       const SE3 T = se3_load(cams + 7 * g.e3_cam[i]);
       const Ell m = ell_load(g.e3_meas + 10 * i);
       w = g.e3_w[i];
-      if (JAC == ESL_JAC_ANALYTIC) jac_e3d(T, e, m, g.yt, r, J, nullptr);
+      if (JAC == ESL_JAC_ANALYTIC) jac_e3d_pose(T, e, m, g.yt, r, Jp);
       else {
+        // g2o's central differences for the 6 pose columns; the scale block of this edge is exactly the identity
         res_e3d(T, e, m, g.yt, r);
-        numeric_jac_obj(e, delta, 9, J, [&](const Ell& ep, double* o9) { res_e3d(T, ep, m, g.yt, o9); });
+        const double scalar = 1.0 / (2 * delta);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+          double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rp[9], rm[9];
+          u[d] = delta; res_e3d(T, ell_oplus(e, u), m, g.yt, rp);
+          u[d] = -delta; res_e3d(T, ell_oplus(e, u), m, g.yt, rm);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Jp[k * 6 + d] = scalar * (rp[k] - rm[k]);
+        }
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) chi += r[k] * r[k];
       chi *= w;
     } else {
 #pragma unroll
-      for (int k = 0; k < 81; ++k) J[k] = 0;
+      for (int k = 0; k < 36; ++k) Jp[k] = 0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) r[k] = 0;
     }
-    reduce_group<9, 0>(J, r, w, lane, out);
-    reduce_group<9, 1>(J, r, w, lane, out);
-    reduce_group<9, 2>(J, r, w, lane, out);
-  } else {
-    double r[1] = {0}, J[9], w = 0;
-    if (in) {
-      w = g.grav_w;
-      if (JAC == ESL_JAC_ANALYTIC) r[0] = jac_grav(e, g.grav_n, J);
-      else {
-        r[0] = res_grav(e, g.grav_n);
-        numeric_jac_obj(e, delta, 1, J, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
-      }
-      chi = w * r[0] * r[0];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) J[k] = 0;
-    }
-    reduce_group<1, 0>(J, r, w, lane, out);
-    reduce_group<1, 1>(J, r, w, lane, out);
-    reduce_group<1, 2>(J, r, w, lane, out);
+    reduce_group_e3d<0>(Jp, r, w, lane, out);
+    reduce_group_e3d<1>(Jp, r, w, lane, out);
+    reduce_group_e3d<2>(Jp, r, w, lane, out);
   }
   chi = wave_sum(chi);
   if (lane == 0) out[54] = chi;
@@ -195,17 +229,36 @@ struct LmScalars {  // lives in mapped host memory
   double chi2_lin, max_diag, chi2_trial, scale, ok, lambda_used, pad0, pad1;
 };
 
+// Publish this workgroup's results and learn whether it is the last one.  Recipe of the CDNA guide (G16):
+// plain stores -> __syncthreads() -> ONE lane: agent-scope release + drained counter increment; the last
+// workgroup does ONE agent-scope acquire before reading the others' results.  (A __threadfence() in every
+// thread costs ~10-50 us per workgroup on gfx950.)
 __device__ __forceinline__ bool last_block_arrives(unsigned int* ticket) {
   __shared__ bool last;
-  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned int t = atomicAdd(ticket, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (t == gridDim.x - 1);
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  if (last) __threadfence();
   return last;
+}
+// Variant for payloads that were stored WRITE-THROUGH (relaxed agent-scope atomic stores = sc1): no release fence,
+// every storing wave only drains its stores (G16 recipe R1); ~5 us per workgroup cheaper than the release form.
+__device__ __forceinline__ bool last_block_arrives_wt(unsigned int* ticket) {
+  __shared__ bool last_wt;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_wt = (t == gridDim.x - 1);
+    if (last_wt) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  return last_wt;
 }
 __device__ double block256_sum(double v, double* sm) {
   sm[threadIdx.x] = v;
@@ -233,6 +286,7 @@ __device__ double block256_max(double v, double* sm) {
 // first iteration: chi2 of the linearisation point and max |H_kk| (computeLambdaInit); one thread per ellipsoid,
 // the last workgroup reduces the per-workgroup partials in fixed order
 static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
+                                                               const double* __restrict__ objs, int jac, double delta,
                                                                double* __restrict__ blk_part /* gridDim x 2 */,
                                                                unsigned int* __restrict__ ticket, double* __restrict__ dev_scal,
                                                                LmScalars* __restrict__ host) {
@@ -248,13 +302,29 @@ static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, Chunk
 #pragma unroll
       for (int a = 0; a < 9; ++a) { diag[a] += p[q]; q += 9 - a; }
     }
+    if (g.gr_cnt[o] > 0) {  // gravity prior lives on the ellipsoid itself (see k_obj_solve)
+      const Ell e = ell_load(objs + 10 * o);
+      const double wg = g.grav_w * g.gr_cnt[o];
+      double Jg[9], rg;
+      if (jac == ESL_JAC_ANALYTIC) rg = jac_grav(e, g.grav_n, Jg);
+      else {
+        rg = res_grav(e, g.grav_n);
+        numeric_jac_obj(e, delta, 1, Jg, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
+      }
+      chi += wg * rg * rg;
+#pragma unroll
+      for (int a = 0; a < 9; ++a) diag[a] += wg * Jg[a] * Jg[a];
+    }
 #pragma unroll
     for (int a = 0; a < 9; ++a) md = fmax(md, fabs(diag[a]));
   }
   chi = block256_sum(chi, sm);
   md = block256_max(md, sm);
-  if (threadIdx.x == 0) { blk_part[2 * blockIdx.x] = chi; blk_part[2 * blockIdx.x + 1] = md; }
-  if (last_block_arrives(ticket)) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&blk_part[2 * blockIdx.x], chi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&blk_part[2 * blockIdx.x + 1], md, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (last_block_arrives_wt(ticket)) {
     double c = 0, m = 0;
     for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { c += blk_part[2 * b]; m = fmax(m, blk_part[2 * b + 1]); }
     c = block256_sum(c, sm);
@@ -267,77 +337,61 @@ static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, Chunk
   }
 }
 
-// one wave per ellipsoid: H, b from the chunk partials (fixed order), (H + lambda I) x = b, retraction.
+// ONE LANE PER ELLIPSOID: H, b from the chunk partials (fixed order => deterministic), gravity prior added,
+// unrolled register LDL^T of the 9x9, retraction, trial state.  (A wave per ellipsoid left 63 lanes idle on a
+// serial dependency chain; 2k ellipsoids are 32 full waves this way.)
 // lambda < 0: lambda = tau * max_diag read from device memory (first LM iteration, computeLambdaInit).
-static __global__ __launch_bounds__(256) void k_obj_solve(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
-                                                          const double* __restrict__ objs, double lambda, double tau,
-                                                          const double* __restrict__ dev_scal, double* __restrict__ xo,
-                                                          double* __restrict__ objs_trial, double* __restrict__ part) {
-  __shared__ double sH[4][56];
-  __shared__ double sL[4][81];
-  __shared__ double sx[4][9];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int o = blockIdx.x * 4 + wv;
+static __global__ __launch_bounds__(64) void k_obj_solve(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
+                                                         const double* __restrict__ objs, int jac, double delta, double lambda, double tau,
+                                                         const double* __restrict__ dev_scal, double* __restrict__ xo,
+                                                         double* __restrict__ objs_trial, double* __restrict__ part) {
+  const int o = blockIdx.x * 64 + threadIdx.x;
   if (o >= g.n_objs) return;
   if (lambda < 0) lambda = tau * dev_scal[1];
   const int c0 = ct.ostart[o], c1 = ct.ostart[o + 1];
   const Ell e = ell_load(objs + 10 * o);
-  if (c0 == c1) {  // inactive vertex: never touched (sparse_optimizer.cpp:236-257)
-    if (lane == 0) { ell_store(e, objs_trial + 10 * o); part[o * 4 + 2] = 0; part[o * 4 + 3] = 1; }
+  const int ngrav = g.gr_cnt[o];
+  if (c0 == c1 && ngrav == 0) {  // inactive vertex: never touched (sparse_optimizer.cpp:236-257)
+    ell_store(e, objs_trial + 10 * o);
+    part[o * 4 + 0] = 0; part[o * 4 + 2] = 0; part[o * 4 + 3] = 1;
     return;
   }
-  if (lane < 54) {
-    double s = 0;
-    for (int ch = c0; ch < c1; ++ch) s += chunk_out[(size_t)ch * kChunkOut + lane];
-    sH[wv][lane] = s;
+  double hb[54];
+#pragma unroll
+  for (int k = 0; k < 54; ++k) hb[k] = 0;
+  for (int ch = c0; ch < c1; ++ch) {
+    const double* p = chunk_out + (size_t)ch * kChunkOut;
+#pragma unroll
+    for (int k = 0; k < 54; ++k) hb[k] += p[k];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  // row-parallel LDL^T: lane i (< 9) owns row i of L; D on the diagonal
-  double* L = sL[wv];
-  if (lane < 9) {
-    for (int j = 0; j <= lane; ++j) {
-      // packed index of (j, lane), j <= lane
-      const int p = j * 9 - j * (j - 1) / 2 + (lane - j);
-      L[lane * 9 + j] = sH[wv][p] + ((j == lane) ? lambda : 0.0);
+  const double wg = g.grav_w * ngrav;
+  if (ngrav > 0) {  // the gravity prior is a unary edge on this ellipsoid: linearise it here
+    double Jg[9], rg;
+    if (jac == ESL_JAC_ANALYTIC) rg = jac_grav(e, g.grav_n, Jg);
+    else {
+      rg = res_grav(e, g.grav_n);
+      numeric_jac_obj(e, delta, 1, Jg, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
+    }
+    int p = 0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+#pragma unroll
+      for (int cc = a; cc < 9; ++cc) hb[p++] += (wg * Jg[a]) * Jg[cc];
+      hb[45 + a] -= Jg[a] * (wg * rg);
     }
   }
-  int ok = 1;
-  for (int k = 0; k < 9; ++k) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane == k) {  // D_k
-      double v = L[k * 9 + k];
-      for (int j = 0; j < k; ++j) v -= L[k * 9 + j] * L[k * 9 + j] * L[j * 9 + j];
-      L[k * 9 + k] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane > k && lane < 9) {  // column k of L, one row per lane
-      double v = L[lane * 9 + k];
-      for (int j = 0; j < k; ++j) v -= L[lane * 9 + j] * L[k * 9 + j] * L[j * 9 + j];
-      L[lane * 9 + k] = v / L[k * 9 + k];
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (lane == 0) {
-    double y[9], x[9];
-    for (int i = 0; i < 9; ++i) { if (!(L[i * 9 + i] > 0)) ok = 0; }
-    for (int i = 0; i < 9; ++i) { double s = sH[wv][45 + i]; for (int j = 0; j < i; ++j) s -= L[i * 9 + j] * y[j]; y[i] = s; }
-    for (int i = 0; i < 9; ++i) y[i] /= L[i * 9 + i];
-    for (int i = 8; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 9; ++j) s -= L[j * 9 + i] * x[j]; x[i] = s; }
-    double scale = 0;
-    for (int i = 0; i < 9; ++i) { scale += x[i] * (lambda * x[i] + sH[wv][45 + i]); sx[wv][i] = x[i]; xo[(size_t)o * 9 + i] = x[i]; }
-    const Ell en = ell_oplus(e, x);
-    ell_store(en, objs_trial + 10 * o);
-    part[o * 4 + 2] = scale;
-    part[o * 4 + 3] = (double)ok;
-  }
+  double x[9];
+  const bool ok = ldlt_solve_packed<9>(hb, lambda, hb + 45, x);
+  double scale = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { scale += x[i] * (lambda * x[i] + hb[45 + i]); xo[(size_t)o * 9 + i] = x[i]; }
+  const Ell en = ell_oplus(e, x);
+  ell_store(en, objs_trial + 10 * o);
+  double cg = 0;
+  if (ngrav > 0) { const double rg = res_grav(en, g.grav_n); cg = wg * rg * rg; }
+  part[o * 4 + 0] = cg;   // chi2 of the gravity prior at the trial state
+  part[o * 4 + 2] = scale;
+  part[o * 4 + 3] = ok ? 1.0 : 0.0;
 }
 
 // one wave per chunk: chi2 of the trial states; last workgroup: fixed-order totals -> mapped host memory
@@ -361,25 +415,20 @@ static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTabl
         res_bbox(se3_load(cams + 7 * g.bb_cam[i]), e, g.K, g.bb_meas + 4 * i, r);
         chi = g.bb_w[i] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
       }
-    } else if (type == 1) {
-      if (in) {
-        double r[9];
-        res_e3d(se3_load(cams + 7 * g.e3_cam[i]), e, ell_load(g.e3_meas + 10 * i), g.yt, r);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) chi += r[k] * r[k];
-        chi *= g.e3_w[i];
-      }
     } else if (in) {
-      const double r = res_grav(e, g.grav_n);
-      chi = g.grav_w * r * r;
+      double r[9];
+      res_e3d(se3_load(cams + 7 * g.e3_cam[i]), e, ell_load(g.e3_meas + 10 * i), g.yt, r);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) chi += r[k] * r[k];
+      chi *= g.e3_w[i];
     }
     chi = wave_sum(chi);
-    if (lane == 0) chunk_chi[ch] = chi;
+    if (lane == 0) __hip_atomic_store(&chunk_chi[ch], chi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
   }
-  if (last_block_arrives(ticket)) {
+  if (last_block_arrives_wt(ticket)) {
     double c = 0, sc = 0, okv = 1;
     for (int k = threadIdx.x; k < ct.n_chunks; k += 256) c += chunk_chi[k];
-    for (int o = threadIdx.x; o < g.n_objs; o += 256) { sc += part[o * 4 + 2]; okv = fmin(okv, part[o * 4 + 3]); }
+    for (int o = threadIdx.x; o < g.n_objs; o += 256) { c += part[o * 4 + 0]; sc += part[o * 4 + 2]; okv = fmin(okv, part[o * 4 + 3]); }
     c = block256_sum(c, sm);
     sc = block256_sum(sc, sm);
     okv = -block256_max(-okv, sm);
@@ -392,13 +441,36 @@ static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTabl
 }
 
 // Hoo / b_o of every ellipsoid from the chunk partials (only used by esl_lm_download and the SLAM-free inspection path)
-static __global__ void k_chunk_combine(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out, double* __restrict__ Hoo,
+static __global__ void k_chunk_combine(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
+                                       const double* __restrict__ objs, int jac, double delta, double* __restrict__ Hoo,
                                        double* __restrict__ bo) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int o = t / 54, k = t % 54;
   if (o >= g.n_objs) return;
   double s = 0;
   for (int ch = ct.ostart[o]; ch < ct.ostart[o + 1]; ++ch) s += chunk_out[(size_t)ch * kChunkOut + k];
+  if (g.gr_cnt[o] > 0) {
+    const Ell e = ell_load(objs + 10 * o);
+    const double wg = g.grav_w * g.gr_cnt[o];
+    double Jg[9], rg;
+    if (jac == ESL_JAC_ANALYTIC) rg = jac_grav(e, g.grav_n, Jg);
+    else {
+      rg = res_grav(e, g.grav_n);
+      numeric_jac_obj(e, delta, 1, Jg, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
+    }
+    if (k < 45) {
+      int a = 0, base = 0;
+      while (k >= base + (9 - a)) { base += 9 - a; ++a; }
+      const int cc = a + (k - base);
+      double ja = 0, jc = 0;
+      for (int q = 0; q < 9; ++q) { if (q == a) ja = Jg[q]; if (q == cc) jc = Jg[q]; }
+      s += (wg * ja) * jc;
+    } else {
+      double ja = 0;
+      for (int q = 0; q < 9; ++q) if (q == k - 45) ja = Jg[q];
+      s -= ja * (wg * rg);
+    }
+  }
   if (k < 45) Hoo[(size_t)o * 45 + k] = s;
   else bo[(size_t)o * 9 + (k - 45)] = s;
 }

@@ -82,8 +82,8 @@ ESL_HD Quat q_from_R(const Mat3& Rm) {
 // SE3Quat::normalizeRotation: w >= 0, unit norm
 ESL_HD Quat q_normalize_pos(Quat q) {
   if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-  double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+  const double inv = 1.0 / sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);  // one reciprocal, not four divisions
+  q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
   return q;
 }
 
@@ -265,11 +265,12 @@ ESL_HD void res_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
 }
 
 // derivative of the 4 bbox coordinates given (dC00, dC02, dC22, dC11, dC12)
-ESL_HD void box_dcoords(const BoxGeom& g, const double bb[4], const double sq[2], double dC00, double dC02,
+// sq[2], sq[3] carry 1/(2 sqrt(du)), 1/(2 sqrt(dv)); sq[4] = 1/C22 (hoisted: this runs 9-15 times per edge)
+ESL_HD void box_dcoords(const BoxGeom& g, const double bb[4], const double sq[5], double dC00, double dC02,
                         double dC22, double dC11, double dC12, double out[4]) {
-  const double inv = 1.0 / g.C22;
-  const double ddu = (2 * g.C02 * dC02 - dC00 * g.C22 - g.C00 * dC22) / (2 * sq[0]);
-  const double ddv = (2 * g.C12 * dC12 - dC11 * g.C22 - g.C11 * dC22) / (2 * sq[1]);
+  const double inv = sq[4];
+  const double ddu = (2 * g.C02 * dC02 - dC00 * g.C22 - g.C00 * dC22) * sq[2];
+  const double ddv = (2 * g.C12 * dC12 - dC11 * g.C22 - g.C11 * dC22) * sq[3];
   out[0] = (dC02 + ddu - bb[0] * dC22) * inv;
   out[2] = (dC02 - ddu - bb[2] * dC22) * inv;
   out[1] = (dC12 + ddv - bb[1] * dC22) * inv;
@@ -282,8 +283,9 @@ ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
                      double* Jo, double* Jc) {
   BoxGeom g;
   box_geom(Tcw, e, K, g);
-  double bb[4], sq[2];
+  double bb[4], sq[5];
   box_from_conic(g, bb, sq);
+  sq[2] = 1.0 / (2 * sq[0]); sq[3] = 1.0 / (2 * sq[1]); sq[4] = 1.0 / g.C22;
   bool mask[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { mask[i] = meas[i] >= 5; r[i] = mask[i] ? bb[i] - meas[i] : 0.0; }
@@ -481,6 +483,13 @@ ESL_HD void se3_adj(const SE3& T, double A[36]) {
       A[(3 + a) * 6 + b] = tR.m[a * 3 + b];
       A[(3 + a) * 6 + 3 + b] = R.m[a * 3 + b];
     }
+}
+
+// The 3-D edge's Jacobian wrt the ellipsoid is [[Jp (6x6), 0], [0, I3]]: the scale rows are s - s_k.  Jp only:
+ESL_HD void jac_e3d_pose(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9], double Jp[36]) {
+  SE3 E;
+  res_e3d(Tcw, est, meas, yt, r, &E);
+  dlog_right(E, Jp);
 }
 
 // Analytic Jacobians of the 3-D edge.  Jo 9x9, Jc 9x6 (may be null).
