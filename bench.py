@@ -124,14 +124,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON).  Libraries (RCCL prints a banner at exit) write to fd 1 too,
+    # so keep a private copy of the real stdout and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("ESL_BENCH_FORCE_DIST") == "1"   # exercise the RCCL exchange on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -146,20 +154,35 @@ def main():
     ctx.upload_states(c, o)
     ctx.snapshot_states()
 
-    if world > 1:
-        par = importlib.import_module("object-oriented-slam_amd.parallel")
-        runner = par.ShardedLM(ctx, dist, device=torch.device("cuda", local_rank))
+    sharded = world > 1 or force_dist
+    exchange = "none"
+    runner = None
+    if sharded:
+        # preferred: the library's own RCCL exchange (one ncclAllGather per linearisation / trial on its stream);
+        # fallback: the Python step-API driver with torch.distributed collectives
+        try:
+            if os.environ.get("ESL_BENCH_PY_EXCHANGE") == "1":
+                raise RuntimeError("python exchange requested")
+            uid = [pkg.lib.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(world, rank, uid[0])
+            exchange = "rccl-native"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] native RCCL exchange unavailable ({e}); using torch.distributed step driver", file=sys.stderr)
+            par = importlib.import_module("object-oriented-slam_amd.parallel")
+            runner = par.ShardedLM(ctx, dist, device=torch.device("cuda", local_rank), force_collectives=force_dist)
+            exchange = "torch.distributed all_gather"
 
     def one_step():
         ctx.restore_states()
-        if world > 1:
+        if runner is not None:
             return runner.optimize(params)
         return ctx.optimize_resident(params)
 
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
 
     for _ in range(a.warmup):
@@ -177,7 +200,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_get()
     ctx.profile_enable(False)
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -217,7 +240,7 @@ def main():
                                    f"{'SLAM mode (free cameras, Schur)' if slam else 'mapping mode (cameras fixed, as shipped)'}; "
                                    f"{a.jacobian} Jacobians; optimize(10) per step",
                        "lm_iterations_per_step": iters / a.steps, "lm_trials_per_step": trials / a.steps,
-                       "parallelism": f"ellipsoid-sharded x{world}"},
+                       "parallelism": f"ellipsoid-sharded x{world}", "lm_scalar_exchange": exchange},
             "kernel_ms": prof,
             "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]},
             "roofline": roof,
@@ -227,10 +250,15 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, g, c, o, pkg.default_lm_params())
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if world > 1:
+        final_line = json.dumps(out)
+    else:
+        final_line = None
+    if sharded:
         dist.destroy_process_group()
     ctx.close()
+    if final_line is not None:
+        os.write(json_fd, (final_line + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

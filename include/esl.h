@@ -187,6 +187,17 @@ int esl_lm_commit(esl_ctx* ctx, int accept);
  *        8 trial cameras (n_cams x 7).  count = number of doubles the caller's buffer holds. */
 int esl_lm_download(esl_ctx* ctx, int32_t which, double* dst, int64_t count);
 
+/* ---- multi-GPU exchange inside the library (RCCL over xGMI) ---------------------------------------------------
+ * One process per GPU.  Rank 0 creates an id (esl_comm_unique_id), the host language ships its 128 bytes to the
+ * other ranks (torch.distributed / MPI / a file), every rank calls esl_comm_init.  Afterwards
+ * esl_optimize_resident is COLLECTIVE: each rank optimises its own shard (its ellipsoids with all their edges,
+ * cameras replicated) under g2o's single global LM control — the LM scalars of every linearisation / trial are
+ * exchanged with one ncclAllGather on the context's stream and reduced in rank order on every rank, so all ranks
+ * take bit-identical accept/reject decisions (SURVEY.md §8 e).  RCCL is dlopen()ed at esl_comm_init time. */
+int esl_comm_unique_id(char out[128]);
+int esl_comm_init(esl_ctx* ctx, int32_t n_ranks, int32_t rank, const char id[128]);
+int esl_comm_destroy(esl_ctx* ctx);
+
 /* host-only helper: balanced partition of ellipsoids (with all their edges) over n_parts shards.
  * part_of_obj receives n_objs entries.  (SURVEY.md §8 e) */
 int esl_partition_objects(const esl_graph* g, int32_t n_parts, int32_t* part_of_obj);

@@ -157,6 +157,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   dev_free(&c->chol_info);
   dev_free(&c->tickets); dev_free(&c->dev_scal);
   if (c->host_scal) (void)hipHostFree(c->host_scal);
+  esl_comm_destroy(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ESL_OK;
@@ -570,7 +571,21 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
     esl_lm_partials lin;
     bool first_trial_done = false;
     esl_lm_partials tr0;
-    if (fused) {
+    if (fused && c->comm) {
+      // sharded: same sequence, the scalars of all shards are all-gathered (RCCL) and reduced in rank order
+      double ex[5];
+      if ((rc = map_launch_linearize(c, it == 0))) return rc;
+      if (it == 0) {
+        if ((rc = comm_exchange(c, ex))) return rc;
+        lin.chi2 = ex[0]; lin.max_diag = ex[1];
+        lambda = p->tau * lin.max_diag;
+      } else { lin.chi2 = currentChi; lin.max_diag = 0; }
+      if ((rc = map_launch_try(c, lambda))) return rc;
+      if ((rc = comm_exchange(c, ex))) return rc;
+      tr0.chi2 = ex[2]; tr0.scale = ex[3]; tr0.solve_ok = ex[4] > 0.5 ? 1 : 0;
+      c->lm.have_trial = true;
+      first_trial_done = true;
+    } else if (fused) {
       if ((rc = map_launch_linearize(c, it == 0))) return rc;
       if ((rc = map_launch_try(c, it == 0 ? -1.0 : lambda))) return rc;
       ESL_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -596,6 +611,13 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
     do {
       esl_lm_partials tr;
       if (first_trial_done) { tr = tr0; first_trial_done = false; }
+      else if (fused && c->comm) {
+        double ex[5];
+        if ((rc = map_launch_try(c, lambda))) return rc;
+        if ((rc = comm_exchange(c, ex))) return rc;
+        tr.chi2 = ex[2]; tr.scale = ex[3]; tr.solve_ok = ex[4] > 0.5 ? 1 : 0;
+        c->lm.have_trial = true;
+      }
       else if ((rc = esl_lm_try_step(c, lambda, &tr))) return rc;
       double tempChi = tr.solve_ok ? tr.chi2 : DBL_MAX;
       rho = (currentChi - tempChi) / (tr.scale + 1e-3);

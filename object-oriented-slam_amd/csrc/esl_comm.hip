@@ -1,0 +1,109 @@
+// esl_comm.hip — RCCL exchange of the LM scalars between the per-GPU shards (SURVEY.md §8 e).
+// librccl is dlopen()ed on first use so that libesl_hip.so itself has no link-time dependency on it.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "esl_ctx.hpp"
+
+namespace {
+typedef struct { char internal[128]; } NcclUniqueId;
+typedef int (*fn_getid)(NcclUniqueId*);
+typedef int (*fn_init)(void**, int, NcclUniqueId, int);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+struct Rccl {
+  void* h = nullptr;
+  fn_getid getid = nullptr; fn_init init = nullptr; fn_allgather allgather = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
+};
+Rccl g_rccl;
+constexpr int kNcclDouble = 8;  // ncclFloat64 in rccl.h
+
+int load_rccl() {
+  if (g_rccl.h) return ESL_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.h) break;
+  }
+  if (!g_rccl.h) { esl::set_error(std::string("cannot dlopen librccl: ") + dlerror()); return ESL_ERR_STATE; }
+  g_rccl.getid = (fn_getid)dlsym(g_rccl.h, "ncclGetUniqueId");
+  g_rccl.init = (fn_init)dlsym(g_rccl.h, "ncclCommInitRank");
+  g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather");
+  g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
+  g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
+  if (!g_rccl.getid || !g_rccl.init || !g_rccl.allgather || !g_rccl.destroy) {
+    esl::set_error("librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather/ncclCommDestroy");
+    return ESL_ERR_STATE;
+  }
+  return ESL_OK;
+}
+int nccl_fail(int rc, const char* what) {
+  esl::set_error(std::string(what) + ": " + (g_rccl.errstr ? g_rccl.errstr(rc) : "rccl error"));
+  return ESL_ERR_HIP;
+}
+}  // namespace
+
+namespace esl {
+int comm_exchange(esl_ctx* c, double out[5]) {
+  const int n = c->comm_ranks;
+  int rc = g_rccl.allgather(c->dev_scal, c->dev_gather, 8, kNcclDouble, c->comm, c->stream);
+  if (rc != 0) return nccl_fail(rc, "ncclAllGather");
+  ESL_HIP_TRY(hipMemcpyAsync(c->host_gather, c->dev_gather, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; out[4] = 1;
+  for (int r = 0; r < n; ++r) {  // fixed rank order on every rank => identical decisions everywhere
+    const double* v = c->host_gather + 8 * r;
+    out[0] += v[0];
+    out[1] = v[1] > out[1] ? v[1] : out[1];
+    out[2] += v[2];
+    out[3] += v[3];
+    out[4] = v[4] < out[4] ? v[4] : out[4];
+  }
+  return ESL_OK;
+}
+}  // namespace esl
+
+extern "C" {
+
+int esl_comm_unique_id(char out[128]) {
+  if (!out) return ESL_ERR_INVALID;
+  int rc = load_rccl();
+  if (rc) return rc;
+  NcclUniqueId id;
+  rc = g_rccl.getid(&id);
+  if (rc != 0) return nccl_fail(rc, "ncclGetUniqueId");
+  std::memcpy(out, id.internal, 128);
+  return ESL_OK;
+}
+
+int esl_comm_init(esl_ctx* c, int32_t n_ranks, int32_t rank, const char id[128]) {
+  if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return ESL_ERR_INVALID;
+  int rc = load_rccl();
+  if (rc) return rc;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  if (c->comm) esl_comm_destroy(c);
+  NcclUniqueId uid;
+  std::memcpy(uid.internal, id, 128);
+  void* comm = nullptr;
+  rc = g_rccl.init(&comm, n_ranks, uid, rank);
+  if (rc != 0) return nccl_fail(rc, "ncclCommInitRank");
+  c->comm = comm; c->comm_ranks = n_ranks; c->comm_rank = rank;
+  ESL_HIP_TRY(hipMalloc((void**)&c->dev_gather, (size_t)n_ranks * 8 * sizeof(double)));
+  ESL_HIP_TRY(hipHostMalloc((void**)&c->host_gather, (size_t)n_ranks * 8 * sizeof(double), hipHostMallocDefault));
+  ESL_HIP_TRY(hipMemsetAsync(c->dev_scal, 0, 8 * sizeof(double), c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+
+int esl_comm_destroy(esl_ctx* c) {
+  if (!c) return ESL_ERR_INVALID;
+  if (c->comm && g_rccl.destroy) { (void)hipStreamSynchronize(c->stream); g_rccl.destroy(c->comm); }
+  c->comm = nullptr; c->comm_ranks = 1; c->comm_rank = 0;
+  if (c->dev_gather) { (void)hipFree(c->dev_gather); c->dev_gather = nullptr; }
+  if (c->host_gather) { (void)hipHostFree(c->host_gather); c->host_gather = nullptr; }
+  return ESL_OK;
+}
+
+}  // extern "C"

@@ -75,6 +75,9 @@ struct ProfScope {
   ~ProfScope();
 };
 int prof_drain(esl_ctx* c);
+// all-gather the 8-double dev_scal block of every rank and reduce in rank order:
+// out = {sum chi2_lin, max max_diag, sum chi2_trial, sum scale, min ok}
+int comm_exchange(esl_ctx* c, double out[5]);
 }  // namespace esl
 
 struct esl_ctx {
@@ -134,6 +137,11 @@ struct esl_ctx {
   void* host_scal = nullptr;     // mapped pinned LmScalars
   void* host_scal_dev = nullptr; // its device alias
   bool sys_combined = false;
+  // RCCL exchange (esl_comm.hip)
+  void* comm = nullptr;          // ncclComm_t
+  int comm_ranks = 1, comm_rank = 0;
+  double* dev_gather = nullptr;  // 8 x n_ranks
+  double* host_gather = nullptr; // pinned
   double* Linv_ws = nullptr;  // ceil(n/NB) x NB x NB
   double* z_ws = nullptr;
   int64_t S_lda = 0;

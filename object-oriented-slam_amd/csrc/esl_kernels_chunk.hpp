@@ -398,7 +398,7 @@ static __global__ __launch_bounds__(64) void k_obj_solve(DevGraph g, ChunkTable 
 static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTable ct, const double* __restrict__ cams,
                                                            const double* __restrict__ objs_trial, const double* __restrict__ part,
                                                            double* __restrict__ chunk_chi, unsigned int* __restrict__ ticket,
-                                                           double lambda, double tau, const double* __restrict__ dev_scal,
+                                                           double lambda, double tau, double* __restrict__ dev_scal,
                                                            LmScalars* __restrict__ host) {
   __shared__ double sm[256];
   const int lane = threadIdx.x & 63;
@@ -434,6 +434,7 @@ static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTabl
     okv = -block256_max(-okv, sm);
     if (threadIdx.x == 0) {
       host->chi2_trial = c; host->scale = sc; host->ok = okv;
+      dev_scal[2] = c; dev_scal[3] = sc; dev_scal[4] = okv;   // send buffer of the RCCL exchange
       host->lambda_used = (lambda < 0) ? tau * dev_scal[1] : lambda;
       *ticket = 0;
     }

@@ -20,7 +20,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug",
     "esl_init_quadric",
 ]
 
@@ -195,8 +195,22 @@ class Context:
                                           st.ctypes.data_as(C.POINTER(C.c_int32)), dbg.ctypes.data_as(_dp)), "esl_fit_frame")
         return ell, prob, st, dbg
 
+    def comm_init(self, n_ranks, rank, unique_id):
+        """Join the RCCL communicator; afterwards optimize_resident() is collective over all ranks."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(load().esl_comm_init(self._h, C.c_int32(n_ranks), C.c_int32(rank), buf), "esl_comm_init")
+
+    def comm_destroy(self):
+        _check(load().esl_comm_destroy(self._h), "esl_comm_destroy")
+
     def synchronize(self):
         _check(load().esl_ctx_synchronize(self._h), "esl_ctx_synchronize")
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    _check(load().esl_comm_unique_id(buf), "esl_comm_unique_id")
+    return bytes(buf.raw)
 
 
 def default_fit_params(**kw):

@@ -21,9 +21,10 @@ _DBL_MAX = 1.7976931348623157e308
 
 
 class ShardedLM:
-    def __init__(self, engine, dist=None, device=None):
+    def __init__(self, engine, dist=None, device=None, force_collectives=False):
         self.engine = engine
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        use = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives)
+        self.dist = dist if use else None
         self.device = device if device is not None else torch.device("cpu")
         self.world = self.dist.get_world_size() if self.dist else 1
         self.n_collectives = 0
