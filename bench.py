@@ -80,7 +80,7 @@ def fit_bench(pkg, ctx, with_cpu=True):
     C2 = one box with ~50k in-range depth samples (1280x960, stride 1); C5 frame = 20 boxes on a 640x480 frame (stride 3)."""
     out = {}
     cases = {
-        "c2_1box_50k_points": (pkg.synth.make_depth_scene(width=1280, height=960, n_objs=1, seed=11, size=(0.4, 0.5)), dict(stride=1), [28]),
+        "c2_1box_50k_points": (pkg.synth.make_depth_scene(width=1280, height=960, n_objs=1, seed=11, size=(0.23, 0.28)), dict(stride=1), [28]),
         "c5_20boxes_640x480": (pkg.synth.make_depth_scene(n_objs=20, seed=7, spread=1.6, size=(0.1, 0.3)), dict(stride=3), None),
     }
     for name, (sc, kw, labels) in cases.items():
@@ -215,7 +215,7 @@ def main():
         if dom_name == "linearize":
             abytes = algorithmic_bytes_linearize(g, slam)
             achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roof = {"kernel": "k_map_linearize" if not slam else "slam_linearize", "bound": "hbm",
+            roof = {"kernel": "k_chunk_linearize" if not slam else "k_slam_linearize", "bound": "hbm",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms,
                     "launches": dom["count"]}
