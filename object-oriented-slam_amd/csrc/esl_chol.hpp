@@ -25,59 +25,112 @@ constexpr int kLdsPad = 129;   // column stride of the LDS copy of the diagonal 
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// ---- diagonal block: Cholesky in LDS, then triangular inverse -----------------------------------------
-// info[0] |= 1 when a pivot is not positive (g2o: LDLT not positive => solve fails => step rejected)
+// ---- diagonal block: blocked Cholesky in LDS (32-wide sub-blocks), then blocked triangular inverse --------------
+// info[0] |= 1 when a pivot is not positive (g2o: LDLT not positive => solve fails => step rejected).
+// The serial chain is 4 x 32 small column steps; the rank-32 updates and the 32x32 block products of the
+// inverse use all 256 threads.  (The first version ran 128 full-size column steps + a serial trtri: 793 us.)
+constexpr int kSB = 32;
 static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ M, long lda, int k0, int nb,
                                                     double* __restrict__ Linv /* kNB x kNB col-major */,
                                                     int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* L = sm;                    // nb x nb, column stride kLdsPad
-  double* v = sm + kNB * kLdsPad;    // nb
+  double* L = sm;                          // nb x nb, column stride kLdsPad
+  double* T = sm + kNB * kLdsPad;          // 3 x (32 x 33) temporaries for the inverse
   const int t = threadIdx.x;
-  for (int idx = t; idx < nb * nb; idx += 256) {
-    const int i = idx % nb, j = idx / nb;
-    L[i + j * kLdsPad] = (i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : 0.0;
+#define LL(i, j) L[(i) + (j) * kLdsPad]
+  for (int idx = t; idx < kNB * kNB; idx += 256) {
+    const int i = idx % kNB, j = idx / kNB;
+    LL(i, j) = (i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    const double d = L[j + j * kLdsPad];
-    if (!(d > 0)) {
-      if (t == 0) atomicOr(info, 1);
+  for (int c0 = 0; c0 < nb; c0 += kSB) {
+    const int w = (nb - c0 < kSB) ? (nb - c0) : kSB;
+    // 1. unblocked factorisation of the w x w diagonal sub-block
+    for (int j = c0; j < c0 + w; ++j) {
+      const double d = LL(j, j);
+      if (!(d > 0) && t == 0) atomicOr(info, 1);
+      const double s = sqrt(d), is = 1.0 / s;
+      __syncthreads();
+      if (t < c0 + w - j) { const int i = j + t; LL(i, j) = (i == j) ? s : LL(i, j) * is; }
+      __syncthreads();
+      const int m = c0 + w - j - 1;   // remaining columns inside the sub-block
+      for (int idx = t; idx < m * m; idx += 256) {
+        const int c = j + 1 + idx / m, i = j + 1 + idx % m;
+        if (i >= c) LL(i, c) -= LL(i, j) * LL(c, j);
+      }
+      __syncthreads();
     }
-    const double s = sqrt(d);
+    const int r0 = c0 + w;            // rows below the sub-block
+    // 2. sub-panel solve: X D^T = A, one thread per row
+    for (int i = r0 + t; i < nb; i += 256) {
+      for (int c = c0; c < c0 + w; ++c) {
+        double v = LL(i, c);
+        for (int k = c0; k < c; ++k) v -= LL(i, k) * LL(c, k);
+        LL(i, c) = v / LL(c, c);
+      }
+    }
     __syncthreads();
-    for (int i = j + t; i < nb; i += 256) L[i + j * kLdsPad] = (i == j) ? s : L[i + j * kLdsPad] / s;
-    __syncthreads();
-    // trailing update: columns c > j, rows i >= c
-    const int m = nb - j - 1;
-    for (int idx = t; idx < m * m; idx += 256) {
-      const int c = j + 1 + idx / m, i = j + 1 + idx % m;
-      if (i >= c) L[i + c * kLdsPad] -= L[i + j * kLdsPad] * L[c + j * kLdsPad];
+    // 3. rank-w update of the trailing lower triangle
+    const int m2 = nb - r0;
+    for (int idx = t; idx < m2 * m2; idx += 256) {
+      const int c = r0 + idx / m2, i = r0 + idx % m2;
+      if (i >= c) {
+        double v = 0;
+        for (int k = c0; k < c0 + w; ++k) v += LL(i, k) * LL(c, k);
+        LL(i, c) -= v;
+      }
     }
     __syncthreads();
   }
   // write L11 back (the factor itself is part of the result)
   for (int idx = t; idx < nb * nb; idx += 256) {
     const int i = idx % nb, j = idx / nb;
-    if (i >= j) M[(long)(k0 + i) + (long)(k0 + j) * lda] = L[i + j * kLdsPad];
+    if (i >= j) M[(long)(k0 + i) + (long)(k0 + j) * lda] = LL(i, j);
   }
-  // in-place inverse of the lower-triangular L (LAPACK dtrti2, lower): columns last to first
-  for (int j = nb - 1; j >= 0; --j) {
-    const double ajj = 1.0 / L[j + j * kLdsPad];
-    for (int i = j + 1 + t; i < nb; i += 256) v[i] = L[i + j * kLdsPad];
-    __syncthreads();
-    for (int i = j + 1 + t; i < nb; i += 256) {
-      double s = 0;
-      for (int k = j + 1; k <= i; ++k) s += L[i + k * kLdsPad] * v[k];
-      L[i + j * kLdsPad] = -s * ajj;
+  // ---- Linv = L^-1, blocked 32 x 32 (unused rows/cols of a short last panel are identity) ------------------------
+#define LI(i, j) Linv[(i) + (j) * kNB]
+  for (int idx = t; idx < kNB * kNB; idx += 256) Linv[idx] = 0.0;
+  __syncthreads();
+  // 4. diagonal blocks: thread c solves D x = e_c by forward substitution (its column lives in Linv itself)
+  if (t < kNB) {
+    const int b0 = (t / kSB) * kSB, c = t;
+    for (int i = c; i < b0 + kSB; ++i) {
+      double v = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) v -= LL(i, k) * LI(k, c);
+      LI(i, c) = v / LL(i, i);
     }
-    if (t == 0) L[j + j * kLdsPad] = ajj;
+  }
+  __syncthreads();
+  // 5. off-diagonal blocks by block anti-diagonals: Linv_IJ = -Linv_II * (sum_{K=J}^{I-1} L_IK Linv_KJ)
+  constexpr int nB = kNB / kSB;
+  for (int dgl = 1; dgl < nB; ++dgl) {
+    const int nblk = nB - dgl;   // blocks (I = J + dgl), J = 0 .. nblk-1
+    for (int idx = t; idx < nblk * kSB * kSB; idx += 256) {
+      const int q = idx / (kSB * kSB), e = idx % (kSB * kSB);
+      const int J = q, I = q + dgl, i = e % kSB, j = e / kSB;
+      double v = 0;
+      for (int K = J; K < I; ++K)
+        for (int k = 0; k < kSB; ++k) v += LL(I * kSB + i, K * kSB + k) * LI(K * kSB + k, J * kSB + j);
+      T[q * (kSB * (kSB + 1)) + i + j * (kSB + 1)] = v;
+    }
+    __syncthreads();
+    for (int idx = t; idx < nblk * kSB * kSB; idx += 256) {
+      const int q = idx / (kSB * kSB), e = idx % (kSB * kSB);
+      const int J = q, I = q + dgl, i = e % kSB, j = e / kSB;
+      double v = 0;
+      for (int k = 0; k <= i; ++k) v += LI(I * kSB + i, I * kSB + k) * T[q * (kSB * (kSB + 1)) + k + j * (kSB + 1)];
+      LI(I * kSB + i, J * kSB + j) = -v;
+    }
     __syncthreads();
   }
-  for (int idx = t; idx < kNB * kNB; idx += 256) {
-    const int i = idx % kNB, j = idx / kNB;
-    Linv[i + j * kNB] = (i < nb && j < nb && i >= j) ? L[i + j * kLdsPad] : 0.0;
-  }
+  // rows / columns beyond nb must not contribute to the panel product
+  if (nb < kNB)
+    for (int idx = t; idx < kNB * kNB; idx += 256) {
+      const int i = idx % kNB, j = idx / kNB;
+      if (i >= nb || j >= nb) Linv[idx] = 0.0;
+    }
+#undef LL
+#undef LI
 }
 
 // ---- MFMA micro-kernel: acc(64x64 per wave) += X[i0.., 0..K) * Y[j0.., 0..K)^T ------------------------------
@@ -88,26 +141,37 @@ __device__ __forceinline__ void mfma_xyT_64x64(const double* __restrict__ X, lon
                                                int K, double4_t acc[4][4]) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, kq = lane >> 4;
-  long xr[4], yr[4];
+  const double* xp[4];
+  const double* yp[4];
   bool xv[4], yv[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    xr[m] = xrow0 + m * 16 + r; xv[m] = xr[m] < xrows;
-    yr[m] = yrow0 + m * 16 + r; yv[m] = yr[m] < yrows;
+    const long xr = xrow0 + m * 16 + r, yr = yrow0 + m * 16 + r;
+    xv[m] = xr < xrows; yv[m] = yr < yrows;
+    xp[m] = X + (xv[m] ? xr : 0) + (long)kq * ldx;
+    yp[m] = Y + (yv[m] ? yr : 0) + (long)kq * ldy;
+  }
+  // software pipeline: the operands of step kk+4 are in flight while the 16 MFMAs of step kk issue
+  double a[4], b[4], an[4], bn[4];
+  {
+    const bool kv = kq < K;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { a[m] = (xv[m] && kv) ? xp[m][0] : 0.0; b[m] = (yv[m] && kv) ? yp[m][0] : 0.0; }
   }
   for (int kk = 0; kk < K; kk += 4) {
-    double a[4], b[4];
-    const long kcol = kk + kq;
-    const bool kv = kcol < K;  // K need not be a multiple of 4 (last panel)
+    const int kn = kk + 4;
+    const bool kv = (kn + kq) < K;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      a[m] = (xv[m] && kv) ? X[xr[m] + kcol * ldx] : 0.0;
-      b[m] = (yv[m] && kv) ? Y[yr[m] + kcol * ldy] : 0.0;
+      an[m] = (xv[m] && kv) ? xp[m][(long)kn * ldx] : 0.0;
+      bn[m] = (yv[m] && kv) ? yp[m][(long)kn * ldy] : 0.0;
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { a[m] = an[m]; b[m] = bn[m]; }
   }
 }
 
@@ -145,15 +209,23 @@ static __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ 
 }
 
 // ---- trailing update: C <- C - P_i P_j^T over lower-triangle 128x128 tiles --------------------------------
-// grid.x enumerates tile pairs (ti >= tj) of the trailing matrix; 4 waves = 2x2 sub-tiles of 64x64.
+// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8, each XCD has its own 4 MiB L2.  Tiles are
+// grouped into 8x8 SUPER-TILES (1024 x 1024 elements; operand working set 2 x 1024 x 128 x 8 B = 2 MiB, fits one
+// L2) and a super-tile is handed to ONE XCD: workgroup b -> xcd = b % 8, q = b / 8, super-tile (q / 64) * 8 + xcd,
+// tile q % 64 inside it.  4 waves = 2x2 sub-tiles of 64x64 each.
 static __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, long lda, long rows, long ncols, int k0,
-                                                     int nb, int ntiles) {
-  // decode (ti, tj) with ti >= tj from the linear index
+                                                     int nb, int nst /* super-tile rows */) {
   const long b = blockIdx.x;
-  long ti = (long)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-  while (ti * (ti + 1) / 2 > b) --ti;
-  while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
-  const long tj = b - ti * (ti + 1) / 2;
+  const long xcd = b & 7, q = b >> 3;
+  const long sb = (q >> 6) * 8 + xcd;         // super-tile index in the lower triangle of super-tiles
+  const long nsb = (long)nst * (nst + 1) / 2;
+  if (sb >= nsb) return;
+  long SI = (long)((sqrt(8.0 * (double)sb + 1.0) - 1.0) * 0.5);
+  while (SI * (SI + 1) / 2 > sb) --SI;
+  while ((SI + 1) * (SI + 2) / 2 <= sb) ++SI;
+  const long SJ = sb - SI * (SI + 1) / 2;
+  const long ti = SI * 8 + ((q & 63) >> 3), tj = SJ * 8 + (q & 7);
+  if (tj > ti) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long base = (long)k0 + nb;
   const long i0 = base + ti * 128 + (wave >> 1) * 64;
@@ -178,7 +250,6 @@ static __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__
         const long col = j0 + nj * 16 + c;
         if (row < rows && col < ncols && row >= col) M[row + col * lda] -= acc[mi][nj][g];
       }
-  (void)ntiles;
 }
 
 // ---- backward substitution L^T x = y, panel by panel from the last ------------------------------------------
@@ -199,14 +270,16 @@ static __global__ __launch_bounds__(256) void k_chol_backdot(const double* __res
   }
   if (threadIdx.x == 0) z[c] = col[n] - red[0];  // row n holds y^T
 }
-// x[k0 + r] = sum_c Linv[c][r] z[c]  (Linv^T z)
-static __global__ __launch_bounds__(128) void k_chol_backsolve(const double* __restrict__ Linv, int k0, int nb,
+// x[k0 + r] = sum_c Linv[c][r] z[c]  (Linv^T z): one wave per r, lanes over c (contiguous in memory)
+static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ Linv, int k0, int nb,
                                                         const double* __restrict__ z, double* __restrict__ x) {
-  const int r = threadIdx.x;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= nb) return;
   double s = 0;
-  for (int c = r; c < nb; ++c) s += Linv[c + r * kNB] * z[c];
-  x[k0 + r] = s;
+  for (int c = lane; c < nb; c += 64) s += Linv[c + r * kNB] * z[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) x[k0 + r] = s;
 }
 
 // Host driver.  M: (n+1) x n col-major (lda), Linv_ws: ceil(n/NB) * NB*NB doubles, z_ws: NB doubles,
@@ -214,7 +287,7 @@ static __global__ __launch_bounds__(128) void k_chol_backsolve(const double* __r
 inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws, double* z_ws, double* x, int* info,
                                     hipStream_t st) {
   const long rows = (long)n + 1;
-  const size_t lds = (size_t)(kNB * kLdsPad + kNB) * sizeof(double);
+  const size_t lds = (size_t)(kNB * kLdsPad + 3 * kSB * (kSB + 1)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -233,15 +306,17 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
       const long tcols = (long)n - (k0 + nb);
       if (tcols > 0) {
         const long nt = (below + 127) / 128;  // row tiles (includes the b row)
-        const long nblk = nt * (nt + 1) / 2;
-        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)nblk), dim3(256), 0, st, M, lda, rows, (long)n, k0, nb, (int)nt);
+        const long nst = (nt + 7) / 8;         // super-tile rows
+        const long nsb = nst * (nst + 1) / 2;
+        const long nblk = ((nsb + 7) / 8) * 8 * 64;
+        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)nblk), dim3(256), 0, st, M, lda, rows, (long)n, k0, nb, (int)nst);
       }
     }
   }
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
     hipLaunchKernelGGL(k_chol_backdot, dim3(nb), dim3(256), 0, st, M, lda, n, k0, nb, x, z_ws);
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(128), 0, st, Linv_ws + (size_t)p * kNB * kNB, k0, nb, z_ws, x);
+    hipLaunchKernelGGL(k_chol_backsolve, dim3((nb + 3) / 4), dim3(256), 0, st, Linv_ws + (size_t)p * kNB * kNB, k0, nb, z_ws, x);
   }
   return hipGetLastError();
 }
