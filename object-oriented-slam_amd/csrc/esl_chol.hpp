@@ -252,6 +252,115 @@ static __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__
       }
 }
 
+// ---- trailing update, LDS-staged: C[base.., base..) -= P P^T with P = columns [kcol0, kcol0 + K) -------------------
+// Workgroup tile 256 (rows) x 128 (cols), 8 waves as 4 x 2 sub-tiles of 64 x 64; the K dimension is streamed
+// through LDS in chunks of 16 (double-buffered: global -> registers while the MFMAs of the previous chunk issue,
+// registers -> LDS, one barrier per chunk).  Operand traffic per tile is (256 + 128) x K doubles instead of the
+// 4 x (64 + 64) x K each wave used to pull on its own, and K itself is 256 (two 128-wide inner panels per
+// trailing update), which halves the read-modify-write traffic on C per flop.
+// The product is formed TRANSPOSED (B-fragment as the MFMA A operand): in the f64 D layout lane & 15 is then the
+// row index of C, so 16 lanes touch 128 contiguous bytes of the column-major matrix.
+constexpr int kBM = 256, kBN = 128, kKC = 16, kLdA = 272, kLdB = 144;
+static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
+                                                                int kcol0, int K, long base, int ntJ) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* As = sm;                               // [2][kKC][kLdA]
+  double* Bs = sm + 2 * kKC * kLdA;              // [2][kKC][kLdB]
+  const long b = blockIdx.x;
+  long ti = (long)((sqrt(1.0 + 4.0 * (double)b) - 1.0) * 0.5);
+  while (ti * (ti + 1) > b) --ti;
+  while ((ti + 1) * (ti + 2) <= b) ++ti;
+  const long tj = b - ti * (ti + 1);             // 0 .. 2 ti + 1
+  if (tj >= ntJ) return;
+  const long i0 = base + ti * kBM, j0 = base + tj * kBN;
+  if (i0 >= rows || j0 >= ncols) return;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int wi = wave >> 1, wj = wave & 1;
+  const double* P = M + (long)kcol0 * lda;
+  // global -> register staging: A chunk = 256 x 16 doubles = 2048 double2 (4 per thread), B chunk = 1024 double2 (2 per thread)
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  double2_t ra[4], rb[2];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = t + 512 * q, pr = e & 127, k = e >> 7;
+      const long row = i0 + 2 * pr;
+      const bool kv = (kc + k) < K;
+      double2_t v = {0.0, 0.0};
+      if (kv && row + 1 < rows) v = *reinterpret_cast<const double2_t*>(P + row + (long)(kc + k) * lda);
+      else if (kv && row < rows) v[0] = P[row + (long)(kc + k) * lda];
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = t + 512 * q, pr = e & 63, k = e >> 6;
+      const long row = j0 + 2 * pr;
+      const bool kv = (kc + k) < K;
+      double2_t v = {0.0, 0.0};
+      if (kv && row + 1 < rows) v = *reinterpret_cast<const double2_t*>(P + row + (long)(kc + k) * lda);
+      else if (kv && row < rows) v[0] = P[row + (long)(kc + k) * lda];
+      rb[q] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = t + 512 * q, pr = e & 127, k = e >> 7;
+      *reinterpret_cast<double2_t*>(As + (buf * kKC + k) * kLdA + 2 * pr) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = t + 512 * q, pr = e & 63, k = e >> 6;
+      *reinterpret_cast<double2_t*>(Bs + (buf * kKC + k) * kLdB + 2 * pr) = rb[q];
+    }
+  };
+  double4_t acc[4][4];   // acc[nj][mi]: rows = j (tile columns), cols = i (tile rows)
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = double4_t{0, 0, 0, 0};
+  const bool skip = (j0 + wj * 64) > (i0 + wi * 64 + 63) || (i0 + wi * 64) >= rows || (j0 + wj * 64) >= ncols;  // sub-tile above the diagonal / outside
+  const int r = lane & 15, kq = lane >> 4;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kc = 0; kc < K; kc += kKC) {
+    const bool more = kc + kKC < K;
+    if (more) gload(kc + kKC);
+    if (!skip) {
+      const double* Ab = As + buf * kKC * kLdA + wi * 64 + r;
+      const double* Bb = Bs + buf * kKC * kLdB + wj * 64 + r;
+#pragma unroll
+      for (int kk = 0; kk < kKC; kk += 4) {
+        double a[4], bq[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { a[m] = Ab[(kk + kq) * kLdA + m * 16]; bq[m] = Bb[(kk + kq) * kLdB + m * 16]; }
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc[nj][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[nj], a[mi], acc[nj][mi], 0, 0, 0);
+      }
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (skip) return;
+  const long iw = i0 + wi * 64, jw = j0 + wj * 64;
+  const int rq = lane >> 4;
+#pragma unroll
+  for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long col = jw + nj * 16 + rq + 4 * g;   // D row  -> j
+        const long row = iw + mi * 16 + r;            // D col  -> i (contiguous across lanes)
+        if (row < rows && col < ncols && row >= col) M[row + col * lda] -= acc[nj][mi][g];
+      }
+}
+
 // ---- backward substitution L^T x = y, panel by panel from the last ------------------------------------------
 // z[c] = y[k0+c] - sum_{i >= k0+nb}^{n-1} L[i][k0+c] x[i]   (one workgroup per column: contiguous dot product)
 static __global__ __launch_bounds__(256) void k_chol_backdot(const double* __restrict__ M, long lda, int n, int k0, int nb,
@@ -295,23 +404,40 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     attr_set = true;
   }
   int np = (n + kNB - 1) / kNB;
-  for (int p = 0; p < np; ++p) {
-    const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
-    double* Linv = Linv_ws + (size_t)p * kNB * kNB;
-    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb, Linv, info);
-    const long below = rows - (k0 + nb);
-    if (below > 0) {
-      const int pb = (int)((below + 255) / 256);
-      hipLaunchKernelGGL(k_chol_panel, dim3(pb), dim3(256), 0, st, M, lda, rows, k0, nb, Linv);
-      const long tcols = (long)n - (k0 + nb);
-      if (tcols > 0) {
-        const long nt = (below + 127) / 128;  // row tiles (includes the b row)
-        const long nst = (nt + 7) / 8;         // super-tile rows
-        const long nsb = nst * (nst + 1) / 2;
-        const long nblk = ((nsb + 7) / 8) * 8 * 64;
-        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)nblk), dim3(256), 0, st, M, lda, rows, (long)n, k0, nb, (int)nst);
-      }
-    }
+  const size_t lds_u = (size_t)(2 * kKC * (kLdA + kLdB)) * sizeof(double);
+  static bool attr2_set = false;
+  if (!attr2_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_chol_update_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_u);
+    if (e != hipSuccess) return e;
+    attr2_set = true;
+  }
+  auto launch_update = [&](int kcol0, int K, long base, long col_limit) {
+    // trailing region: rows [base, rows), cols [base, col_limit)
+    const long nrows = rows - base, nc = col_limit - base;
+    if (nrows <= 0 || nc <= 0) return;
+    const long ntI = (nrows + kBM - 1) / kBM, ntJ = (nc + kBN - 1) / kBN;
+    const long nblk = ntI * (ntI + 1);   // sum over ti of (2 ti + 2) tiles; tiles with tj >= ntJ exit immediately
+    hipLaunchKernelGGL(k_chol_update_lds, dim3((unsigned)nblk), dim3(512), lds_u, st, M, lda, rows, col_limit, kcol0, K, base,
+                       (int)ntJ);
+  };
+  for (int p = 0; p < np; p += 2) {
+    // outer panel = up to two 128-wide inner panels; the big trailing update uses K = 256
+    const int k0 = p * kNB, nb1 = (n - k0 < kNB) ? (n - k0) : kNB;
+    double* Linv1 = Linv_ws + (size_t)p * kNB * kNB;
+    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb1, Linv1, info);
+    long below = rows - (k0 + nb1);
+    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 255) / 256)), dim3(256), 0, st, M, lda, rows, k0, nb1, Linv1);
+    const int k1 = k0 + nb1;
+    if (k1 >= n) break;
+    const int nb2 = (n - k1 < kNB) ? (n - k1) : kNB;
+    // bring the second inner panel's columns up to date (rank-nb1 update restricted to those columns)
+    launch_update(k0, nb1, (long)k1, (long)k1 + nb2);
+    double* Linv2 = Linv_ws + (size_t)(p + 1) * kNB * kNB;
+    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k1, nb2, Linv2, info);
+    below = rows - (k1 + nb2);
+    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 255) / 256)), dim3(256), 0, st, M, lda, rows, k1, nb2, Linv2);
+    // rank-(nb1+nb2) update of everything to the right of the outer panel
+    launch_update(k0, nb1 + nb2, (long)k1 + nb2, (long)n);
   }
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
