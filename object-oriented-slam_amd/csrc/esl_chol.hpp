@@ -35,7 +35,7 @@ static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ 
                                                     int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* L = sm;                          // nb x nb, column stride kLdsPad
-  double* T = sm + kNB * kLdsPad;          // 3 x (32 x 33) temporaries for the inverse
+  double* T = sm + kNB * kLdsPad;          // 96 x 32 temporary + 32-vector for the in-place inverse
   const int t = threadIdx.x;
 #define LL(i, j) L[(i) + (j) * kLdsPad]
   for (int idx = t; idx < kNB * kNB; idx += 256) {
@@ -87,50 +87,49 @@ static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ 
     const int i = idx % nb, j = idx / nb;
     if (i >= j) M[(long)(k0 + i) + (long)(k0 + j) * lda] = LL(i, j);
   }
-  // ---- Linv = L^-1, blocked 32 x 32 (unused rows/cols of a short last panel are identity) ------------------------
-#define LI(i, j) Linv[(i) + (j) * kNB]
-  for (int idx = t; idx < kNB * kNB; idx += 256) Linv[idx] = 0.0;
+  // ---- Linv = L^-1 IN PLACE in LDS (blocked dtrtri, lower): block columns right to left ---------------------------
+  // (the first blocked version kept Linv in global memory: store-to-load round trips made it 355 us per panel)
   __syncthreads();
-  // 4. diagonal blocks: thread c solves D x = e_c by forward substitution (its column lives in Linv itself)
-  if (t < kNB) {
-    const int b0 = (t / kSB) * kSB, c = t;
-    for (int i = c; i < b0 + kSB; ++i) {
-      double v = (i == c) ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) v -= LL(i, k) * LI(k, c);
-      LI(i, c) = v / LL(i, i);
-    }
-  }
-  __syncthreads();
-  // 5. off-diagonal blocks by block anti-diagonals: Linv_IJ = -Linv_II * (sum_{K=J}^{I-1} L_IK Linv_KJ)
   constexpr int nB = kNB / kSB;
-  for (int dgl = 1; dgl < nB; ++dgl) {
-    const int nblk = nB - dgl;   // blocks (I = J + dgl), J = 0 .. nblk-1
-    for (int idx = t; idx < nblk * kSB * kSB; idx += 256) {
-      const int q = idx / (kSB * kSB), e = idx % (kSB * kSB);
-      const int J = q, I = q + dgl, i = e % kSB, j = e / kSB;
-      double v = 0;
-      for (int K = J; K < I; ++K)
-        for (int k = 0; k < kSB; ++k) v += LL(I * kSB + i, K * kSB + k) * LI(K * kSB + k, J * kSB + j);
-      T[q * (kSB * (kSB + 1)) + i + j * (kSB + 1)] = v;
+  double* v = T + 96 * kSB;   // 32 doubles: column copy for the unblocked diagonal inverse
+  for (int J = nB - 1; J >= 0; --J) {
+    const int c0 = J * kSB, r0 = c0 + kSB, mrows = kNB - r0;
+    // (a) T = Linv[r0.., r0..] * L[r0.., c0..c0+32)    (lower-triangular times panel)
+    for (int idx = t; idx < mrows * kSB; idx += 256) {
+      const int i = idx % mrows, c = idx / mrows;
+      double acc = 0;
+      for (int k = 0; k <= i; ++k) acc += LL(r0 + i, r0 + k) * LL(r0 + k, c0 + c);
+      T[i + c * 96] = acc;
     }
     __syncthreads();
-    for (int idx = t; idx < nblk * kSB * kSB; idx += 256) {
-      const int q = idx / (kSB * kSB), e = idx % (kSB * kSB);
-      const int J = q, I = q + dgl, i = e % kSB, j = e / kSB;
-      double v = 0;
-      for (int k = 0; k <= i; ++k) v += LI(I * kSB + i, I * kSB + k) * T[q * (kSB * (kSB + 1)) + k + j * (kSB + 1)];
-      LI(I * kSB + i, J * kSB + j) = -v;
+    // (b) diagonal block inverted in place (dtrti2, lower): columns right to left, rows in parallel
+    for (int jj = kSB - 1; jj >= 0; --jj) {
+      const int j = c0 + jj;
+      const double ajj = 1.0 / LL(j, j);
+      if (t > jj && t < kSB) v[t] = LL(c0 + t, j);
+      __syncthreads();
+      if (t > jj && t < kSB) {
+        double acc = 0;
+        for (int k = jj + 1; k <= t; ++k) acc += LL(c0 + t, c0 + k) * v[k];
+        LL(c0 + t, j) = -acc * ajj;
+      }
+      if (t == 0) LL(j, j) = ajj;
+      __syncthreads();
+    }
+    // (c) panel = -T * Dinv
+    for (int idx = t; idx < mrows * kSB; idx += 256) {
+      const int i = idx % mrows, c = idx / mrows;
+      double acc = 0;
+      for (int k = c; k < kSB; ++k) acc += T[i + k * 96] * LL(c0 + k, c0 + c);
+      LL(r0 + i, c0 + c) = -acc;
     }
     __syncthreads();
   }
-  // rows / columns beyond nb must not contribute to the panel product
-  if (nb < kNB)
-    for (int idx = t; idx < kNB * kNB; idx += 256) {
-      const int i = idx % kNB, j = idx / kNB;
-      if (i >= nb || j >= nb) Linv[idx] = 0.0;
-    }
+  for (int idx = t; idx < kNB * kNB; idx += 256) {
+    const int i = idx % kNB, j = idx / kNB;
+    Linv[idx] = (i < nb && j < nb && i >= j) ? LL(i, j) : 0.0;
+  }
 #undef LL
-#undef LI
 }
 
 // ---- MFMA micro-kernel: acc(64x64 per wave) += X[i0.., 0..K) * Y[j0.., 0..K)^T ------------------------------
@@ -396,7 +395,7 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
 inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws, double* z_ws, double* x, int* info,
                                     hipStream_t st) {
   const long rows = (long)n + 1;
-  const size_t lds = (size_t)(kNB * kLdsPad + 3 * kSB * (kSB + 1)) * sizeof(double);
+  const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kSB) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
