@@ -250,9 +250,15 @@ def main():
         if dom_name == "linearize":
             abytes = algorithmic_bytes_linearize(g, slam)
             achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roof = {"kernel": "k_chunk_linearize" if not slam else "k_slam_linearize", "bound": "hbm",
+            traffic = None
+            try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) — same workload only
+                if not slam and a.config == "C4" and a.jacobian == "analytic":
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["k_chunk_linearize"]["traffic_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
+            roof = {"kernel": "k_chunk_linearize<bbox> + k_chunk_linearize<3-D>" if not slam else "k_slam_linearize", "bound": "hbm",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms,
                     "launches": dom["count"]}
         else:
             n = 6 * int((~g.cam_fixed.astype(bool)).sum())

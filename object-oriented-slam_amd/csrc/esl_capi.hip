@@ -133,7 +133,7 @@ static void free_graph(esl_ctx* c) {
   dev_free(&g.ue_start); dev_free(&g.ue_id); dev_free(&g.ue_slot);
   dev_free(&c->Linv_ws); dev_free(&c->z_ws);
   dev_free(&c->ck_obj); dev_free(&c->ck_type); dev_free(&c->ck_begin); dev_free(&c->ck_end); dev_free(&c->ck_ostart);
-  dev_free(&c->chunk_out); dev_free(&c->chunk_chi); dev_free(&c->blk_part);
+  dev_free(&c->chunk_out); dev_free(&c->chunk_chi); dev_free(&c->blk_part); dev_free(&c->ck_ids_bb); dev_free(&c->ck_ids_e3);
   c->n_chunks = 0;
   dev_free(&c->cams); dev_free(&c->cams_trial); dev_free(&c->objs); dev_free(&c->objs_trial);
   dev_free(&c->Hoo); dev_free(&c->bo); dev_free(&c->xo); dev_free(&c->obj_part);
@@ -303,6 +303,13 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     if ((rc = dev_upload(&c->ck_begin, cb.data(), cb.size(), st))) return rc;
     if ((rc = dev_upload(&c->ck_end, ce.data(), ce.size(), st))) return rc;
     if ((rc = dev_upload(&c->ck_ostart, cos.data(), cos.size(), st))) return rc;
+    {
+      std::vector<int> ib, ie;
+      for (int k = 0; k < (int)cty.size(); ++k) (cty[k] == 0 ? ib : ie).push_back(k);
+      c->n_ids_bb = (int)ib.size(); c->n_ids_e3 = (int)ie.size();
+      if ((rc = dev_upload(&c->ck_ids_bb, ib.data(), ib.size(), st))) return rc;
+      if ((rc = dev_upload(&c->ck_ids_e3, ie.data(), ie.size(), st))) return rc;
+    }
     ESL_HIP_TRY(hipStreamSynchronize(st));
     if ((rc = dev_alloc(&c->chunk_out, (size_t)c->n_chunks * kChunkOut))) return rc;
     if ((rc = dev_alloc(&c->chunk_chi, (size_t)c->n_chunks))) return rc;
@@ -394,13 +401,22 @@ static int map_launch_linearize(esl_ctx* c, bool finalize) {
   const ChunkTable ct = chunk_table(c);
   if (ct.n_chunks > 0) {
     ProfScope ps(c, 0);
-    const dim3 grid((ct.n_chunks + 3) / 4), block(256);
-    if (c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC)
-      hipLaunchKernelGGL(k_chunk_linearize<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, ct, c->cams, c->objs,
-                         c->lm.p.numeric_delta, c->chunk_out);
-    else
-      hipLaunchKernelGGL(k_chunk_linearize<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, ct, c->cams, c->objs,
-                         c->lm.p.numeric_delta, c->chunk_out);
+    const dim3 block(256);
+    const bool an = c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC;
+    if (c->n_ids_e3 > 0) {   // the long tasks first
+      const dim3 grid((c->n_ids_e3 + 3) / 4);
+      if (an) hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_ANALYTIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
+                                 c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+      else hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
+                              c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+    }
+    if (c->n_ids_bb > 0) {
+      const dim3 grid((c->n_ids_bb + 3) / 4);
+      if (an) hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_ANALYTIC, 0>), grid, block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb,
+                                 c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+      else hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 0>), grid, block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb,
+                              c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+    }
   }
   ESL_HIP_TRY(hipGetLastError());
   c->sys_combined = false;

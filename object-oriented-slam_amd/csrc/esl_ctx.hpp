@@ -129,6 +129,7 @@ struct esl_ctx {
   // chunked mapping-mode pipeline (esl_kernels_chunk.hpp)
   int n_chunks = 0;
   int *ck_obj = nullptr, *ck_type = nullptr, *ck_begin = nullptr, *ck_end = nullptr, *ck_ostart = nullptr;
+  int *ck_ids_bb = nullptr, *ck_ids_e3 = nullptr; int n_ids_bb = 0, n_ids_e3 = 0;
   double* chunk_out = nullptr;   // n_chunks x 56
   double* chunk_chi = nullptr;   // n_chunks
   double* blk_part = nullptr;    // per-workgroup partials of k_chunk_finalize

@@ -154,14 +154,20 @@ __device__ __forceinline__ void reduce_group(const double* J, const double* r, d
   if ((lane & low_mask) == 0 && cnt >= 1) out[G * 18 + idx] = tot;   // cnt < 1: this lane ended on a padding slot
 }
 
-template <int JAC>
-static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, ChunkTable ct, const double* __restrict__ cams,
+// One instantiation per edge type: the bbox and the 3-D code paths have very different register needs, and a
+// kernel is allocated for the worse of its branches (the fused version spilled 304 B/lane = 69 MB of HBM
+// writes per launch at C4, profiles/r1_pmc_traffic.json).  `ids` lists the chunks of this type.
+template <int JAC, int TYPE>
+static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, ChunkTable ct, const int* __restrict__ ids, int n_ids,
+                                                                const double* __restrict__ cams,
                                                                 const double* __restrict__ objs, double delta,
                                                                 double* __restrict__ chunk_out) {
   const int lane = threadIdx.x & 63;
-  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ch >= ct.n_chunks) return;
-  const int o = ct.obj[ch], type = ct.type[ch];
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_ids) return;
+  const int ch = ids[w];
+  const int o = ct.obj[ch];
+  constexpr int type = TYPE;
   const int i = ct.begin[ch] + lane;
   const bool in = i < ct.end[ch];
   const Ell e = ell_load(objs + 10 * o);
@@ -174,7 +180,7 @@ static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, Chun
       const SE3 T = se3_load(cams + 7 * g.bb_cam[i]);
       double meas[4] = {g.bb_meas[4 * i], g.bb_meas[4 * i + 1], g.bb_meas[4 * i + 2], g.bb_meas[4 * i + 3]};
       w = g.bb_w[i];
-      if (JAC == ESL_JAC_ANALYTIC) jac_bbox(T, e, g.K, meas, r, J, nullptr);
+      if (JAC == ESL_JAC_ANALYTIC) jac_bbox_t<true, false>(T, e, g.K, meas, r, J, nullptr);
       else {
         res_bbox(T, e, g.K, meas, r);
         numeric_jac_obj(e, delta, 4, J, [&](const Ell& ep, double* o4) { res_bbox(T, ep, g.K, meas, o4); });

@@ -279,8 +279,11 @@ ESL_HD void box_dcoords(const BoxGeom& g, const double bb[4], const double sq[5]
 
 // Analytic Jacobians of the bbox residual.  Jo: 4x9 row-major wrt the ellipsoid retraction
 // (pose * exp([w,v]), s + ds); Jc: 4x6 wrt the camera retraction exp([w,v]) * Tcw (may be null).
-ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4],
-                     double* Jo, double* Jc) {
+// (template flags instead of null-pointer tests: a pointer comparison on Jo/Jc keeps the arrays from being
+// promoted to registers — the kernel then streams its Jacobian through scratch, i.e. through HBM)
+template <bool WITH_JO, bool WITH_JC>
+ESL_HD void jac_bbox_t(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4],
+                       double* Jo, double* Jc) {
   BoxGeom g;
   box_geom(Tcw, e, K, g);
   double bb[4], sq[5];
@@ -291,11 +294,12 @@ ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
   for (int i = 0; i < 4; ++i) { mask[i] = meas[i] >= 5; r[i] = mask[i] ? bb[i] - meas[i] : 0.0; }
   const double d[3] = {e.s[0] * e.s[0], e.s[1] * e.s[1], e.s[2] * e.s[2]};
   double col[4];
+  (void)Jo; (void)Jc;
   // symmetric outer-sum helper: entries (0,0),(0,2),(2,2),(1,1),(1,2) of a b^T + b a^T
 #define ESL_SYM5(a, b, f, o00, o02, o22, o11, o12)                                    \
   o00 = (f) * 2 * a[0] * b[0]; o02 = (f) * (a[0] * b[2] + a[2] * b[0]); o22 = (f) * 2 * a[2] * b[2]; \
   o11 = (f) * 2 * a[1] * b[1]; o12 = (f) * (a[1] * b[2] + a[2] * b[1]);
-  if (Jo) {
+  if constexpr (WITH_JO) {
     double c00, c02, c22, c11, c12;
     // rotations: dC/dwx = (d1-d2)(m1 m2^T + m2 m1^T), dwy = (d2-d0)(m0 m2^T+..), dwz = (d0-d1)(m0 m1^T+..)
     ESL_SYM5(g.m[1], g.m[2], (d[1] - d[2]), c00, c02, c22, c11, c12)
@@ -329,7 +333,7 @@ ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
       for (int i = 0; i < 4; ++i) Jo[i * 9 + 6 + k] = mask[i] ? col[i] : 0.0;
     }
   }
-  if (Jc) {
+  if constexpr (WITH_JC) {
     // B = N D M^T (3x3): B[a][b] = sum_k d_k n_k[a] m_k[b] - n3[a] m3[b]
     double B[3][3];
 #pragma unroll
@@ -370,6 +374,15 @@ ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
     }
   }
 #undef ESL_SYM5
+}
+
+// runtime-pointer front end (either Jacobian may be null)
+ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4],
+                     double* Jo, double* Jc) {
+  if (Jo && Jc) jac_bbox_t<true, true>(Tcw, e, K, meas, r, Jo, Jc);
+  else if (Jo) jac_bbox_t<true, false>(Tcw, e, K, meas, r, Jo, nullptr);
+  else if (Jc) jac_bbox_t<false, true>(Tcw, e, K, meas, r, nullptr, Jc);
+  else res_bbox(Tcw, e, K, meas, r);
 }
 
 // ------------------------------------------------------------------------------------------------
