@@ -294,7 +294,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     for (int o = 0; o < N; ++o) {
       cos[o] = (int)co.size();
       for (int b0 = h_bb_start[o]; b0 < h_bb_start[o + 1]; b0 += 64) { co.push_back(o); cty.push_back(0); cb.push_back(b0); ce.push_back(std::min(b0 + 64, h_bb_start[o + 1])); }
-      for (int b0 = h_e3_start[o]; b0 < h_e3_start[o + 1]; b0 += 64) { co.push_back(o); cty.push_back(1); cb.push_back(b0); ce.push_back(std::min(b0 + 64, h_e3_start[o + 1])); }
+      for (int b0 = h_e3_start[o]; b0 < h_e3_start[o + 1]; b0 += 32) { co.push_back(o); cty.push_back(1); cb.push_back(b0); ce.push_back(std::min(b0 + 32, h_e3_start[o + 1])); }
     }
     cos[N] = (int)co.size();
     c->n_chunks = (int)co.size();
@@ -404,7 +404,7 @@ static int map_launch_linearize(esl_ctx* c, bool finalize) {
     const dim3 block(256);
     const bool an = c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC;
     if (c->n_ids_e3 > 0) {   // the long tasks first
-      const dim3 grid((c->n_ids_e3 + 3) / 4);
+      const dim3 grid((c->n_ids_e3 + 7) / 8);   // two 32-edge chunks per wave
       if (an) hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_ANALYTIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
                                  c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
       else hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
@@ -438,8 +438,13 @@ static int map_launch_try(esl_ctx* c, double lambda) {
     hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 63) / 64), dim3(64), 0, c->stream, g, ct, c->chunk_out, c->objs,
                        c->lm.p.jacobian_mode, c->lm.p.numeric_delta, lambda,
                        c->lm.p.tau, c->dev_scal, c->xo, c->objs_trial, c->obj_part);
-    hipLaunchKernelGGL(k_chunk_chi2, dim3(std::max(1, (ct.n_chunks + 3) / 4)), dim3(256), 0, c->stream, g, ct, c->cams,
-                       c->objs_trial, c->obj_part, c->chunk_chi, c->tickets + 1, lambda, c->lm.p.tau, c->dev_scal,
+    // chi2 of the trial state: 3-D chunks first (no reduction), then the bbox chunks whose last workgroup reduces everything
+    if (c->n_ids_e3 > 0)
+      hipLaunchKernelGGL((k_chunk_chi2<1, false>), dim3((c->n_ids_e3 + 7) / 8), dim3(256), 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
+                         c->cams, c->objs_trial, c->obj_part, c->chunk_chi, c->tickets + 1, lambda, c->lm.p.tau, c->dev_scal,
+                         (LmScalars*)c->host_scal_dev);
+    hipLaunchKernelGGL((k_chunk_chi2<0, true>), dim3(std::max(1, (c->n_ids_bb + 3) / 4)), dim3(256), 0, c->stream, g, ct, c->ck_ids_bb,
+                       c->n_ids_bb, c->cams, c->objs_trial, c->obj_part, c->chunk_chi, c->tickets + 1, lambda, c->lm.p.tau, c->dev_scal,
                        (LmScalars*)c->host_scal_dev);
   }
   ESL_HIP_TRY(hipGetLastError());

@@ -133,13 +133,16 @@ template <int G, int... T>
 __device__ __forceinline__ void fill_group_e3d(double* v, const double* Jp, const double* r, double w, std::integer_sequence<int, T...>) {
   ((v[T] = hb_entry_e3d<G * 18 + T>(Jp, r, w)), ...);
 }
+// half-wave version: `lane` is the lane inside the 32-lane segment; 18 -> 9 -> 5 -> 3 -> 2 -> 1 uses exactly the
+// five offsets 16..1, so every lane of the segment ends up owning (at most) one entry
 template <int G>
-__device__ __forceinline__ void reduce_group_e3d(const double* Jp, const double* r, double w, int lane, double* __restrict__ out) {
+__device__ __forceinline__ void reduce_group_e3d(const double* Jp, const double* r, double w, int lane, double* __restrict__ out,
+                                                 bool seg_on) {
   double v[18];
   fill_group_e3d<G>(v, Jp, r, w, std::make_integer_sequence<int, 18>{});
   int idx = 0, cnt = 18;
-  const double tot = WaveRS<18>::run(v, lane, idx, cnt, 32);
-  if ((lane & 1) == 0 && cnt >= 1) out[G * 18 + idx] = tot;
+  const double tot = WaveRS<18>::run(v, lane, idx, cnt, 16);
+  if (seg_on && cnt >= 1) out[G * 18 + idx] = tot;
 }
 
 // entries [G*18, G*18+18) reduced over the wave; the owning lanes write the totals
@@ -162,14 +165,19 @@ static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, Chun
                                                                 const double* __restrict__ cams,
                                                                 const double* __restrict__ objs, double delta,
                                                                 double* __restrict__ chunk_out) {
-  const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= n_ids) return;
-  const int ch = ids[w];
+  // bbox chunks hold <= 64 edges (one wave each); 3-D chunks hold <= 32 edges and TWO of them share a wave
+  // (an ellipsoid has ~20 3-D edges: a whole wave per chunk ran at 31 % lane use).  Offsets < 32 keep the
+  // shuffles of the reduce-scatter inside a half wave.
+  constexpr int kSeg = (TYPE == 1) ? 32 : 64;
+  const int lane = threadIdx.x & (kSeg - 1);
+  const int seg = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / kSeg) + ((threadIdx.x & 63) / kSeg);
+  const bool seg_on = seg < n_ids;
+  if (!seg_on) return;   // (3-D: the other half wave carries on; its shuffles never leave its 32 lanes)
+  const int ch = ids[seg];
   const int o = ct.obj[ch];
   constexpr int type = TYPE;
   const int i = ct.begin[ch] + lane;
-  const bool in = i < ct.end[ch];
+  const bool in = seg_on && i < ct.end[ch];
   const Ell e = ell_load(objs + 10 * o);
   double* out = chunk_out + (size_t)ch * kChunkOut;
   double chi = 0;
@@ -222,9 +230,13 @@ static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, Chun
 #pragma unroll
       for (int k = 0; k < 9; ++k) r[k] = 0;
     }
-    reduce_group_e3d<0>(Jp, r, w, lane, out);
-    reduce_group_e3d<1>(Jp, r, w, lane, out);
-    reduce_group_e3d<2>(Jp, r, w, lane, out);
+    reduce_group_e3d<0>(Jp, r, w, lane, out, seg_on);
+    reduce_group_e3d<1>(Jp, r, w, lane, out, seg_on);
+    reduce_group_e3d<2>(Jp, r, w, lane, out, seg_on);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) chi += __shfl_xor(chi, off, 64);
+    if (lane == 0 && seg_on) out[54] = chi;
+    return;
   }
   chi = wave_sum(chi);
   if (lane == 0) out[54] = chi;
@@ -400,22 +412,28 @@ static __global__ __launch_bounds__(64) void k_obj_solve(DevGraph g, ChunkTable 
   part[o * 4 + 3] = ok ? 1.0 : 0.0;
 }
 
-// one wave per chunk: chi2 of the trial states; last workgroup: fixed-order totals -> mapped host memory
-static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTable ct, const double* __restrict__ cams,
+// chi2 of the trial states, one instantiation per edge type (bbox: one wave per chunk; 3-D: two 32-edge chunks per
+// wave).  FINAL: the last workgroup to arrive reduces all partials in fixed order -> mapped host memory.
+template <int TYPE, bool FINAL>
+static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTable ct, const int* __restrict__ ids, int n_ids,
+                                                           const double* __restrict__ cams,
                                                            const double* __restrict__ objs_trial, const double* __restrict__ part,
                                                            double* __restrict__ chunk_chi, unsigned int* __restrict__ ticket,
                                                            double lambda, double tau, double* __restrict__ dev_scal,
                                                            LmScalars* __restrict__ host) {
   __shared__ double sm[256];
-  const int lane = threadIdx.x & 63;
-  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ch < ct.n_chunks) {
-    const int o = ct.obj[ch], type = ct.type[ch];
+  constexpr int kSeg = (TYPE == 1) ? 32 : 64;
+  const int lane = threadIdx.x & (kSeg - 1);
+  const int seg = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / kSeg) + ((threadIdx.x & 63) / kSeg);
+  const bool seg_on = seg < n_ids;
+  if (seg_on) {
+    const int ch = ids[seg];
+    const int o = ct.obj[ch];
     const int i = ct.begin[ch] + lane;
-    const bool in = i < ct.end[ch];
+    const bool in = seg_on && i < ct.end[ch];
     const Ell e = ell_load(objs_trial + 10 * o);
     double chi = 0;
-    if (type == 0) {
+    if (TYPE == 0) {
       if (in && g.bb_valid[i]) {
         double r[4];
         res_bbox(se3_load(cams + 7 * g.bb_cam[i]), e, g.K, g.bb_meas + 4 * i, r);
@@ -428,9 +446,11 @@ static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTabl
       for (int k = 0; k < 9; ++k) chi += r[k] * r[k];
       chi *= g.e3_w[i];
     }
-    chi = wave_sum(chi);
-    if (lane == 0) __hip_atomic_store(&chunk_chi[ch], chi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+#pragma unroll
+    for (int off = kSeg / 2; off > 0; off >>= 1) chi += __shfl_xor(chi, off, 64);
+    if (lane == 0 && seg_on) __hip_atomic_store(&chunk_chi[ch], chi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
   }
+  if (!FINAL) return;
   if (last_block_arrives_wt(ticket)) {
     double c = 0, sc = 0, okv = 1;
     for (int k = threadIdx.x; k < ct.n_chunks; k += 256) c += chunk_chi[k];
