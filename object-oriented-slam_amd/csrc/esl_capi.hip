@@ -26,6 +26,7 @@ using namespace esl;
 namespace esl {
 ProfScope::ProfScope(esl_ctx* ctx, int kind) : c(ctx), slot(-1) {
   if (!c->prof_on) return;
+  if (c->prof_level < 2 && kind != 0) return;
   if (c->prof_used + 2 > c->prof_ev.size()) {
     if (c->prof_ev.size() >= 16384) { prof_drain(c); }
     else {
@@ -114,6 +115,7 @@ int esl_ctx_create(int device_id, esl_ctx** out) {
   ESL_HIP_TRY(hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)));
   ESL_HIP_TRY(hipMemset(c->tickets, 0, 4 * sizeof(unsigned int)));
   ESL_HIP_TRY(hipMalloc((void**)&c->dev_scal, 8 * sizeof(double)));
+  ESL_HIP_TRY(hipEventCreateWithFlags(&c->ev_try, hipEventDisableTiming));
   ESL_HIP_TRY(hipHostMalloc(&c->host_scal, sizeof(LmScalars), hipHostMallocMapped));
   ESL_HIP_TRY(hipHostGetDevicePointer(&c->host_scal_dev, c->host_scal, 0));
   std::memset(c->host_scal, 0, sizeof(LmScalars));
@@ -133,7 +135,7 @@ static void free_graph(esl_ctx* c) {
   dev_free(&g.ue_start); dev_free(&g.ue_id); dev_free(&g.ue_slot);
   dev_free(&c->Linv_ws); dev_free(&c->z_ws);
   dev_free(&c->ck_obj); dev_free(&c->ck_type); dev_free(&c->ck_begin); dev_free(&c->ck_end); dev_free(&c->ck_ostart);
-  dev_free(&c->chunk_out); dev_free(&c->chunk_chi); dev_free(&c->blk_part); dev_free(&c->ck_ids_bb); dev_free(&c->ck_ids_e3);
+  dev_free(&c->chunk_out); dev_free(&c->chunk_out2); dev_free(&c->chunk_chi); dev_free(&c->blk_part); dev_free(&c->ck_ids_bb); dev_free(&c->ck_ids_e3);
   c->n_chunks = 0;
   dev_free(&c->cams); dev_free(&c->cams_trial); dev_free(&c->objs); dev_free(&c->objs_trial);
   dev_free(&c->Hoo); dev_free(&c->bo); dev_free(&c->xo); dev_free(&c->obj_part);
@@ -157,6 +159,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   dev_free(&c->chol_info);
   dev_free(&c->tickets); dev_free(&c->dev_scal);
   if (c->host_scal) (void)hipHostFree(c->host_scal);
+  if (c->ev_try) (void)hipEventDestroy(c->ev_try);
   esl_comm_destroy(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -312,6 +315,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     }
     ESL_HIP_TRY(hipStreamSynchronize(st));
     if ((rc = dev_alloc(&c->chunk_out, (size_t)c->n_chunks * kChunkOut))) return rc;
+    if ((rc = dev_alloc(&c->chunk_out2, (size_t)c->n_chunks * kChunkOut))) return rc;
     if ((rc = dev_alloc(&c->chunk_chi, (size_t)c->n_chunks))) return rc;
     if ((rc = dev_alloc(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2))) return rc;
   }
@@ -396,8 +400,10 @@ static ChunkTable chunk_table(const esl_ctx* c) {
   t.n_chunks = c->n_chunks; t.obj = c->ck_obj; t.type = c->ck_type; t.begin = c->ck_begin; t.end = c->ck_end; t.ostart = c->ck_ostart;
   return t;
 }
-static int map_launch_linearize(esl_ctx* c, bool finalize) {
+static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_objs = nullptr, double* dst_chunk = nullptr) {
   const DevGraph& g = c->g;
+  if (!src_objs) src_objs = c->objs;
+  if (!dst_chunk) dst_chunk = c->chunk_out;
   const ChunkTable ct = chunk_table(c);
   if (ct.n_chunks > 0) {
     ProfScope ps(c, 0);
@@ -406,23 +412,23 @@ static int map_launch_linearize(esl_ctx* c, bool finalize) {
     if (c->n_ids_e3 > 0) {   // the long tasks first
       const dim3 grid((c->n_ids_e3 + 7) / 8);   // two 32-edge chunks per wave
       if (an) hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_ANALYTIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
-                                 c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+                                 c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
       else hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
-                              c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+                              c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
     }
     if (c->n_ids_bb > 0) {
       const dim3 grid((c->n_ids_bb + 3) / 4);
       if (an) hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_ANALYTIC, 0>), grid, block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb,
-                                 c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+                                 c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
       else hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 0>), grid, block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb,
-                              c->cams, c->objs, c->lm.p.numeric_delta, c->chunk_out);
+                              c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
     }
   }
   ESL_HIP_TRY(hipGetLastError());
   c->sys_combined = false;
   if (finalize) {
     ProfScope ps(c, 4);
-    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, ct, c->chunk_out, c->objs,
+    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, ct, dst_chunk, src_objs,
                        c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part,
                        c->tickets, c->dev_scal, (LmScalars*)c->host_scal_dev);
     ESL_HIP_TRY(hipGetLastError());
@@ -430,12 +436,13 @@ static int map_launch_linearize(esl_ctx* c, bool finalize) {
   return ESL_OK;
 }
 // lambda < 0: use tau * max_diag from device memory (first iteration)
-static int map_launch_try(esl_ctx* c, double lambda) {
+static int map_launch_try(esl_ctx* c, double lambda, const double* chunk = nullptr) {
   const DevGraph& g = c->g;
+  if (!chunk) chunk = c->chunk_out;
   const ChunkTable ct = chunk_table(c);
   {
     ProfScope ps(c, 1);
-    hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 63) / 64), dim3(64), 0, c->stream, g, ct, c->chunk_out, c->objs,
+    hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 63) / 64), dim3(64), 0, c->stream, g, ct, chunk, c->objs,
                        c->lm.p.jacobian_mode, c->lm.p.numeric_delta, lambda,
                        c->lm.p.tau, c->dev_scal, c->xo, c->objs_trial, c->obj_part);
     // chi2 of the trial state: 3-D chunks first (no reduction), then the bbox chunks whose last workgroup reduces everything
@@ -565,6 +572,72 @@ int esl_lm_reduced_system(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n,
 // ---------------------------------------------------------------------------------------------------
 // the LM loop (optimization_algorithm_levenberg.cpp:61-164 + sparse_optimizer.cpp:354-419)
 // ---------------------------------------------------------------------------------------------------
+// Mapping mode, single shard: the LM loop with the next linearisation launched SPECULATIVELY on the trial state while
+// the host waits (on an event) for the trial's scalars.  Accepted step (the common case): the speculative result
+// is the next iteration's system (buffers swap), the GPU never idles across the host's decision; rejected step:
+// the old system is still intact in the other buffer and only the damped solve is repeated.  Control flow and
+// arithmetic are exactly those of optimization_algorithm_levenberg.cpp:61-164.
+static int optimize_mapping_pipelined(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
+  int rc;
+  double* chunk[2] = {c->chunk_out, c->chunk_out2};
+  int cur = 0;
+  double lambda = -1, ni = 2, currentChi = 0;
+  int nBad = 0, it = 0, total_trials = 0;
+  bool ok_outer = true;
+  const LmScalars* h = (const LmScalars*)c->host_scal;
+  if ((rc = map_launch_linearize(c, true, c->objs, chunk[cur]))) return rc;
+  for (it = 0; it < p->max_iters && ok_outer; ++it) {
+    double iniChi = currentChi, rho = 0;
+    int qmax = 0;
+    do {
+      if ((rc = map_launch_try(c, (it == 0 && qmax == 0) ? -1.0 : lambda, chunk[cur]))) return rc;
+      ESL_HIP_TRY(hipEventRecord(c->ev_try, c->stream));
+      if ((rc = map_launch_linearize(c, false, c->objs_trial, chunk[cur ^ 1]))) return rc;   // speculative
+      ESL_HIP_TRY(hipEventSynchronize(c->ev_try));
+      if (it == 0 && qmax == 0) {
+        currentChi = h->chi2_lin; iniChi = currentChi;
+        out->chi2_initial = currentChi;
+        lambda = p->tau * h->max_diag;  // computeLambdaInit (the device formed the same product)
+        ni = 2; nBad = 0;
+      }
+      const double tempChi = (h->ok > 0.5) ? h->chi2_trial : DBL_MAX;
+      rho = (currentChi - tempChi) / (h->scale + 1e-3);
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        std::swap(c->objs, c->objs_trial);   // discardTop
+        cur ^= 1;                            // the speculative linearisation is the new system
+      } else {
+        lambda *= ni;
+        ni *= 2;                             // pop: objs untouched, chunk[cur] still describes it
+      }
+      qmax++;
+    } while (rho < 0 && qmax < p->max_trials);
+    total_trials += qmax;
+    if (it < ESL_MAX_TRACE) {
+      out->trace_chi2[it] = currentChi; out->trace_lambda[it] = lambda; out->trace_trials[it] = qmax;
+      out->trace_len = it + 1;
+    }
+    if (qmax == p->max_trials || rho == 0) { ok_outer = false; out->stop_reason = 1; }
+    else {
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      if (nBad >= 3) { ok_outer = false; out->stop_reason = 2; }
+    }
+  }
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // a speculative launch may still be in flight
+  if (cur != 0) std::swap(c->chunk_out, c->chunk_out2);   // keep chunk_out = system of the current estimate (inspection API)
+  c->sys_combined = false;
+  c->lm.have_trial = false;
+  out->iterations = it;
+  out->total_trials = total_trials;
+  out->chi2_final = currentChi;
+  out->lambda_final = lambda;
+  return ESL_OK;
+}
+
 int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
   if (!c || !p || !out) return ESL_ERR_INVALID;
   std::memset(out, 0, sizeof(*out));
@@ -582,6 +655,8 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
     for (int o = 0; o < g.n_objs; ++o) any_grav = any_grav || cnt[o] > 0;
   }
   if (!any_edge && !any_grav) { out->stop_reason = 3; return ESL_OK; }
+
+  if (!c->lm.slam && !c->comm) return optimize_mapping_pipelined(c, p, out);
 
   double lambda = -1, ni = 2;
   int nBad = 0, it = 0, total_trials = 0;
@@ -710,6 +785,7 @@ int esl_profile_enable(esl_ctx* c, int enable) {
   ESL_HIP_TRY(hipSetDevice(c->device));
   if (c->prof_on) prof_drain(c);
   c->prof_on = enable != 0;
+  c->prof_level = enable;
   for (int k = 0; k < ESL_PROF_KINDS; ++k) { c->prof_count[k] = 0; c->prof_ms[k] = 0; }
   return ESL_OK;
 }

@@ -118,6 +118,7 @@ struct esl_ctx {
   double* cams_snap = nullptr; double* objs_snap = nullptr;
   // profiling (HIP events on this stream)
   bool prof_on = false;
+  int prof_level = 0;   // 1: only kernel class 0 (linearise) is bracketed; 2: every class
   std::vector<hipEvent_t> prof_ev;   // pairs
   std::vector<int> prof_kind;
   size_t prof_used = 0;
@@ -131,6 +132,8 @@ struct esl_ctx {
   int *ck_obj = nullptr, *ck_type = nullptr, *ck_begin = nullptr, *ck_end = nullptr, *ck_ostart = nullptr;
   int *ck_ids_bb = nullptr, *ck_ids_e3 = nullptr; int n_ids_bb = 0, n_ids_e3 = 0;
   double* chunk_out = nullptr;   // n_chunks x 56
+  double* chunk_out2 = nullptr;  // second buffer: speculative linearisation of the trial state
+  hipEvent_t ev_try = nullptr;
   double* chunk_chi = nullptr;   // n_chunks
   double* blk_part = nullptr;    // per-workgroup partials of k_chunk_finalize
   unsigned int* tickets = nullptr;  // 2 arrival counters

@@ -155,8 +155,10 @@ class Context:
     def restore_states(self):
         _check(load().esl_states_restore(self._h), "esl_states_restore")
 
-    def profile_enable(self, on=True):
-        _check(load().esl_profile_enable(self._h, C.c_int(1 if on else 0)), "esl_profile_enable")
+    def profile_enable(self, level=2):
+        """0/False off; 1 only the linearise kernels (cheap, for timed regions); 2/True every kernel class."""
+        lv = 2 if level is True else int(level)
+        _check(load().esl_profile_enable(self._h, C.c_int(lv)), "esl_profile_enable")
 
     def profile_get(self):
         cnt = (C.c_int64 * 8)()
