@@ -161,7 +161,7 @@ int esl_states_restore(esl_ctx* ctx);
 
 /* per-kernel timing with HIP events recorded on the context's own stream.
  * kernel ids: 0 linearise, 1 LM trial (solve + retract + chi2), 2 reduced-system build (Schur),
- *             3 dense Cholesky + solves, 4 reductions / misc.
+ *             3 dense Cholesky + solves, 4 reductions / misc, 6 RCCL all-reduce of the reduced system (sharded SLAM).
  * esl_profile_enable(ctx, 0) off; 1 = bracket only kernel class 0 (two event records per LM iteration: cheap enough
  * to stay on inside a timed region); 2 = bracket every class (adds ~20 % host overhead to a 130 us LM iteration).
  * esl_profile_get drains the events: count[k] launches, total_ms[k] summed durations. */
@@ -195,9 +195,20 @@ int esl_lm_download(esl_ctx* ctx, int32_t which, double* dst, int64_t count);
  * esl_optimize_resident is COLLECTIVE: each rank optimises its own shard (its ellipsoids with all their edges,
  * cameras replicated) under g2o's single global LM control — the LM scalars of every linearisation / trial are
  * exchanged with one ncclAllGather on the context's stream and reduced in rank order on every rank, so all ranks
- * take bit-identical accept/reject decisions (SURVEY.md §8 e).  RCCL is dlopen()ed at esl_comm_init time. */
+ * take bit-identical accept/reject decisions (SURVEY.md §8 e).  RCCL is dlopen()ed at esl_comm_init time.
+ * SLAM mode (free cameras): the shards additionally ncclAllReduce(sum) the camera blocks Hcc, b_c once per
+ * linearisation and the partial reduced camera system S (+ b_s row) once per trial; odometry edges, lambda I on
+ * the camera blocks and the camera part of the LM scale are counted on rank 0 only, so the summed system equals
+ * the single-GPU one up to summation order.  Every rank then factorises the same S (replicated Cholesky: it is
+ * O(n^3) but 0.2-3 s at the C4 size, while the sharded part is the O(edges) linearise + Schur build). */
 int esl_comm_unique_id(char out[128]);
 int esl_comm_init(esl_ctx* ctx, int32_t n_ranks, int32_t rank, const char id[128]);
+/* Same collective semantics over a transport the HOST supplies (MPI, gloo, a test harness): `fn` must sum
+ * `count` doubles of `host_buf` in place over all ranks and return 0; every rank calls it in the same order with
+ * the same count.  The library stages device buffers through pinned host memory in <= 64 MiB pieces.  Meant for
+ * hosts without a GPU-aware transport and for tests; RCCL (esl_comm_init) is the fast path. */
+typedef int (*esl_host_allreduce_fn)(void* user, double* host_buf, int64_t count);
+int esl_comm_init_host(esl_ctx* ctx, int32_t n_ranks, int32_t rank, esl_host_allreduce_fn fn, void* user);
 int esl_comm_destroy(esl_ctx* ctx);
 
 /* host-only helper: balanced partition of ellipsoids (with all their edges) over n_parts shards.

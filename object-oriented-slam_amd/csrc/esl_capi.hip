@@ -510,7 +510,7 @@ int esl_lm_linearize(esl_ctx* c, esl_lm_partials* out) {
     int rc = slam_linearize(c);
     if (rc) return rc;
     double v[4];
-    rc = read_parts(c, v);
+    rc = c->comm ? comm_reduce4(c, c->dev_part, v) : read_parts(c, v);
     if (rc) return rc;
     out->chi2 = v[0]; out->max_diag = v[1]; out->scale = 0; out->solve_ok = 1; out->pad = 0;
     return ESL_OK;
@@ -531,7 +531,7 @@ int esl_lm_try_step(esl_ctx* c, double lambda, esl_lm_partials* out) {
     int rc = slam_try_step(c, lambda);
     if (rc) return rc;
     double v[4];
-    rc = read_parts(c, v);
+    rc = c->comm ? comm_reduce4(c, c->dev_part, v) : read_parts(c, v);
     if (rc) return rc;
     out->chi2 = v[0]; out->max_diag = 0; out->scale = v[2]; out->solve_ok = (c->g.n_objs == 0 || v[3] > 0.5) ? 1 : 0; out->pad = 0;
   } else {

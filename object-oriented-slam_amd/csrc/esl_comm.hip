@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <string>
 
 #include "esl_ctx.hpp"
 
@@ -11,11 +12,12 @@ typedef struct { char internal[128]; } NcclUniqueId;
 typedef int (*fn_getid)(NcclUniqueId*);
 typedef int (*fn_init)(void**, int, NcclUniqueId, int);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
   void* h = nullptr;
-  fn_getid getid = nullptr; fn_init init = nullptr; fn_allgather allgather = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
+  fn_getid getid = nullptr; fn_init init = nullptr; fn_allgather allgather = nullptr; fn_allreduce allreduce = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
 };
 Rccl g_rccl;
 constexpr int kNcclDouble = 8;  // ncclFloat64 in rccl.h
@@ -31,9 +33,10 @@ int load_rccl() {
   g_rccl.getid = (fn_getid)dlsym(g_rccl.h, "ncclGetUniqueId");
   g_rccl.init = (fn_init)dlsym(g_rccl.h, "ncclCommInitRank");
   g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather");
+  g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.h, "ncclAllReduce");
   g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
   g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
-  if (!g_rccl.getid || !g_rccl.init || !g_rccl.allgather || !g_rccl.destroy) {
+  if (!g_rccl.getid || !g_rccl.init || !g_rccl.allgather || !g_rccl.allreduce || !g_rccl.destroy) {
     esl::set_error("librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather/ncclCommDestroy");
     return ESL_ERR_STATE;
   }
@@ -46,12 +49,32 @@ int nccl_fail(int rc, const char* what) {
 }  // namespace
 
 namespace esl {
-int comm_exchange(esl_ctx* c, double out[5]) {
+// host-staged transport (esl_comm_init_host): the caller's callback sums a host buffer over the ranks
+static int host_fail(int rc) {
+  set_error("host all-reduce callback failed with code " + std::to_string(rc));
+  return ESL_ERR_STATE;
+}
+// all ranks' 8-double dev_scal blocks -> c->host_gather (n_ranks x 8), on either transport
+static int gather_scalars(esl_ctx* c) {
   const int n = c->comm_ranks;
+  if (c->host_allreduce) {
+    // all-gather as a sum of zero-padded rows: x + 0 is exact, so the gathered values are bit-identical
+    std::memset(c->host_gather, 0, (size_t)n * 8 * sizeof(double));
+    ESL_HIP_TRY(hipMemcpyAsync(c->host_gather + 8 * c->comm_rank, c->dev_scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    const int rc = c->host_allreduce(c->host_user, c->host_gather, (int64_t)n * 8);
+    return rc ? host_fail(rc) : ESL_OK;
+  }
   int rc = g_rccl.allgather(c->dev_scal, c->dev_gather, 8, kNcclDouble, c->comm, c->stream);
   if (rc != 0) return nccl_fail(rc, "ncclAllGather");
   ESL_HIP_TRY(hipMemcpyAsync(c->host_gather, c->dev_gather, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+int comm_exchange(esl_ctx* c, double out[5]) {
+  const int n = c->comm_ranks;
+  int rc = gather_scalars(c);
+  if (rc) return rc;
   out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; out[4] = 1;
   for (int r = 0; r < n; ++r) {  // fixed rank order on every rank => identical decisions everywhere
     const double* v = c->host_gather + 8 * r;
@@ -60,6 +83,41 @@ int comm_exchange(esl_ctx* c, double out[5]) {
     out[2] += v[2];
     out[3] += v[3];
     out[4] = v[4] < out[4] ? v[4] : out[4];
+  }
+  return ESL_OK;
+}
+int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count) {
+  if (!c->comm || count == 0) return ESL_OK;
+  if (c->host_allreduce) {
+    constexpr size_t kStage = (size_t)8 << 20;   // doubles per staging chunk (64 MiB pinned)
+    if (!c->host_stage) ESL_HIP_TRY(hipHostMalloc((void**)&c->host_stage, kStage * sizeof(double), hipHostMallocDefault));
+    for (size_t off = 0; off < count; off += kStage) {
+      const size_t m = count - off < kStage ? count - off : kStage;
+      ESL_HIP_TRY(hipMemcpyAsync(c->host_stage, dev_buf + off, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+      const int rc = c->host_allreduce(c->host_user, c->host_stage, (int64_t)m);
+      if (rc) return host_fail(rc);
+      ESL_HIP_TRY(hipMemcpyAsync(dev_buf + off, c->host_stage, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ESL_OK;
+  }
+  const int rc = g_rccl.allreduce(dev_buf, dev_buf, count, kNcclDouble, /*ncclSum*/ 0, c->comm, c->stream);
+  if (rc != 0) return nccl_fail(rc, "ncclAllReduce");
+  return ESL_OK;
+}
+int comm_reduce4(esl_ctx* c, const double* dev_src4, double out[4]) {
+  const int n = c->comm_ranks;
+  ESL_HIP_TRY(hipMemcpyAsync(c->dev_scal, dev_src4, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  int rc = gather_scalars(c);
+  if (rc) return rc;
+  out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 1;
+  for (int r = 0; r < n; ++r) {
+    const double* v = c->host_gather + 8 * r;
+    out[0] += v[0];
+    out[1] = v[1] > out[1] ? v[1] : out[1];
+    out[2] += v[2];
+    out[3] = v[3] < out[3] ? v[3] : out[3];
   }
   return ESL_OK;
 }
@@ -90,7 +148,22 @@ int esl_comm_init(esl_ctx* c, int32_t n_ranks, int32_t rank, const char id[128])
   rc = g_rccl.init(&comm, n_ranks, uid, rank);
   if (rc != 0) return nccl_fail(rc, "ncclCommInitRank");
   c->comm = comm; c->comm_ranks = n_ranks; c->comm_rank = rank;
+  c->g.shard_rank = rank;
   ESL_HIP_TRY(hipMalloc((void**)&c->dev_gather, (size_t)n_ranks * 8 * sizeof(double)));
+  ESL_HIP_TRY(hipHostMalloc((void**)&c->host_gather, (size_t)n_ranks * 8 * sizeof(double), hipHostMallocDefault));
+  ESL_HIP_TRY(hipMemsetAsync(c->dev_scal, 0, 8 * sizeof(double), c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+
+int esl_comm_init_host(esl_ctx* c, int32_t n_ranks, int32_t rank, esl_host_allreduce_fn fn, void* user) {
+  if (!c || !fn || n_ranks < 1 || rank < 0 || rank >= n_ranks) return ESL_ERR_INVALID;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  if (c->comm) esl_comm_destroy(c);
+  c->host_allreduce = fn; c->host_user = user;
+  c->comm = (void*)c;   // non-null marks "exchange active"; never handed to RCCL on this transport
+  c->comm_ranks = n_ranks; c->comm_rank = rank;
+  c->g.shard_rank = rank;
   ESL_HIP_TRY(hipHostMalloc((void**)&c->host_gather, (size_t)n_ranks * 8 * sizeof(double), hipHostMallocDefault));
   ESL_HIP_TRY(hipMemsetAsync(c->dev_scal, 0, 8 * sizeof(double), c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -99,8 +172,11 @@ int esl_comm_init(esl_ctx* c, int32_t n_ranks, int32_t rank, const char id[128])
 
 int esl_comm_destroy(esl_ctx* c) {
   if (!c) return ESL_ERR_INVALID;
-  if (c->comm && g_rccl.destroy) { (void)hipStreamSynchronize(c->stream); g_rccl.destroy(c->comm); }
+  if (c->comm && !c->host_allreduce && g_rccl.destroy) { (void)hipStreamSynchronize(c->stream); g_rccl.destroy(c->comm); }
+  c->host_allreduce = nullptr; c->host_user = nullptr;
+  if (c->host_stage) { (void)hipHostFree(c->host_stage); c->host_stage = nullptr; }
   c->comm = nullptr; c->comm_ranks = 1; c->comm_rank = 0;
+  c->g.shard_rank = 0;
   if (c->dev_gather) { (void)hipFree(c->dev_gather); c->dev_gather = nullptr; }
   if (c->host_gather) { (void)hipHostFree(c->host_gather); c->host_gather = nullptr; }
   return ESL_OK;

@@ -53,6 +53,9 @@ struct DevGraph {
   // per ellipsoid: unified list of edges whose camera is free (u = bbox index, or n_bbox + 3-D index)
   int* ue_start = nullptr; int* ue_id = nullptr; int* ue_slot = nullptr;
   int n_ue = 0;
+  // sharding (SLAM mode): odometry edges, the camera blocks' lambda and the camera part of the LM scale are
+  // replicated on every rank and must enter the summed system once -> only shard_rank 0 contributes them
+  int shard_rank = 0;
 };
 
 struct ChunkTableFwd;
@@ -78,6 +81,10 @@ int prof_drain(esl_ctx* c);
 // all-gather the 8-double dev_scal block of every rank and reduce in rank order:
 // out = {sum chi2_lin, max max_diag, sum chi2_trial, sum scale, min ok}
 int comm_exchange(esl_ctx* c, double out[5]);
+// SLAM mode: in-place sum over ranks of a device buffer (RCCL all-reduce); no-op without a communicator
+int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count);
+// {sum, max, sum, min} of 4 device scalars over ranks -> host
+int comm_reduce4(esl_ctx* c, const double* dev_src4, double out[4]);
 }  // namespace esl
 
 struct esl_ctx {
@@ -144,6 +151,9 @@ struct esl_ctx {
   // RCCL exchange (esl_comm.hip)
   void* comm = nullptr;          // ncclComm_t
   int comm_ranks = 1, comm_rank = 0;
+  esl_host_allreduce_fn host_allreduce = nullptr;   // host-staged transport (esl_comm_init_host)
+  void* host_user = nullptr;
+  double* host_stage = nullptr;
   double* dev_gather = nullptr;  // 8 x n_ranks
   double* host_gather = nullptr; // pinned
   double* Linv_ws = nullptr;  // ceil(n/NB) x NB x NB

@@ -230,7 +230,7 @@ static __global__ void k_slam_cam_gather(DevGraph g, const double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] += A[(long)k * EU + u];
   }
-  for (int q = g.cod_start[cidx]; q < g.cod_start[cidx + 1]; ++q) {
+  for (int q = g.cod_start[cidx]; q < g.cod_start[cidx + 1] && g.shard_rank == 0; ++q) {
     const int es = g.cod_edge[q];
     const double* src = Aod + (size_t)(es >> 1) * 90 + ((es & 1) ? 27 : 0);
 #pragma unroll
@@ -252,12 +252,24 @@ static __global__ void k_slam_cam_gather(DevGraph g, const double* __restrict__ 
   cam_part[cidx * 4 + 1] = md;
 }
 
+// max |Hcc_kk| per camera from the (possibly rank-summed) blocks
+static __global__ void k_slam_cam_maxdiag(DevGraph g, const double* __restrict__ Hcc, double* __restrict__ cam_part) {
+  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cidx >= g.n_cams) return;
+  const int slot = g.cam_slot[cidx];
+  double md = 0;
+  if (slot >= 0)
+    for (int a = 0; a < 6; ++a) md = fmax(md, fabs(Hcc[(size_t)slot * 36 + a * 6 + a]));
+  cam_part[cidx * 4 + 1] = md;
+}
+
 // S <- 0 is done by memset; this adds the camera blocks: diagonal Hcc + lambda I, b_c into row n,
 // odometry off-diagonal blocks into the LOWER triangle.
 static __global__ void k_slam_S_init(DevGraph g, const double* __restrict__ Hcc, const double* __restrict__ bc,
                               const double* __restrict__ Aod, double lambda, double* __restrict__ S, long lda, long n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int nf = g.n_free_cams;
+  if (g.shard_rank != 0) return;   // Hcc / b_c are rank-summed beforehand; they enter the summed S once
   if (t < nf) {
     for (int a = 0; a < 6; ++a) {
       for (int c = 0; c < 6; ++c)
@@ -439,6 +451,7 @@ static __global__ void k_slam_cam_update(DevGraph g, double lambda, const double
     double u[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) { u[a] = xc[(size_t)slot * 6 + a]; scale += u[a] * (lambda * u[a] + bc[(size_t)slot * 6 + a]); }
+    if (g.shard_rank != 0) scale = 0;   // camera part of computeScale counted once (b_c is the rank-summed vector)
     se3_store(cam_oplus(T, u), cams_trial + 7 * cidx);
   }
   cam_part[cidx * 4 + 0] = 0; cam_part[cidx * 4 + 1] = 0; cam_part[cidx * 4 + 2] = scale; cam_part[cidx * 4 + 3] = 1;

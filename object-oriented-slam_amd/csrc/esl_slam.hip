@@ -79,7 +79,7 @@ static int reduce_all(esl_ctx* c) {
   const DevGraph& g = c->g;
   hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, g.n_objs, c->dev_part, 0);
   hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->cam_part, g.n_cams, c->dev_part, 1);
-  if (g.n_odom) hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(256), 0, c->stream, c->od_part, g.n_odom, c->dev_part);
+  if (g.n_odom && g.shard_rank == 0) hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(256), 0, c->stream, c->od_part, g.n_odom, c->dev_part);
   ESL_HIP_TRY(hipGetLastError());
   return ESL_OK;
 }
@@ -107,6 +107,12 @@ int slam_linearize(esl_ctx* c) {
     }
     hipLaunchKernelGGL(k_slam_cam_gather, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, c->Abb, c->Aod, c->Hcc, c->bc,
                        c->cam_part);
+    if (c->comm) {   // camera blocks of all shards: every rank ends up with the TOTAL Hcc, b_c (3.4 MB at 10k cameras)
+      int rc2 = comm_allreduce_sum(c, c->Hcc, (size_t)g.n_free_cams * 36);
+      if (!rc2) rc2 = comm_allreduce_sum(c, c->bc, (size_t)g.n_free_cams * 6);
+      if (rc2) return rc2;
+      hipLaunchKernelGGL(k_slam_cam_maxdiag, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, c->Hcc, c->cam_part);
+    }
   }
   ESL_HIP_TRY(hipGetLastError());
   ProfScope ps2(c, 4);
@@ -131,6 +137,11 @@ int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out
     }
   }
   ESL_HIP_TRY(hipGetLastError());
+  if (c->comm) {   // sum of the shards' partial reduced systems (and b_s row): the RCCL all-reduce over xGMI of SURVEY.md §8 e
+    ProfScope ps(c, 6);
+    int rc2 = comm_allreduce_sum(c, c->S, (size_t)lda * (size_t)n);
+    if (rc2) return rc2;
+  }
   if (dev_ptr) *dev_ptr = c->S;
   if (n_out) *n_out = n;
   c->lm.lambda_used = lambda;

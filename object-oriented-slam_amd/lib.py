@@ -20,7 +20,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug",
     "esl_init_quadric",
 ]
 
@@ -164,7 +164,7 @@ class Context:
         cnt = (C.c_int64 * 8)()
         ms = (C.c_double * 8)()
         _check(load().esl_profile_get(self._h, cnt, ms), "esl_profile_get")
-        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "k6", "k7"]
+        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "shard_allreduce", "k7"]
         return {n: dict(count=int(cnt[i]), total_ms=float(ms[i])) for i, n in enumerate(names) if cnt[i]}
 
     def init_quadric(self, poses_Twc, bboxes, K, rows=480, cols=640, faithful=1):
@@ -202,11 +202,26 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _check(load().esl_comm_init(self._h, C.c_int32(n_ranks), C.c_int32(rank), buf), "esl_comm_init")
 
+    def comm_init_host(self, n_ranks, rank, allreduce):
+        """Collective mode over a host-supplied transport: allreduce(np.ndarray float64) sums in place over ranks."""
+        def _cb(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:   # an exception must not unwind through the C frames
+                import traceback; traceback.print_exc()
+                return 1
+        self._host_cb = HOST_ALLREDUCE_FN(_cb)   # keep alive as long as the context uses it
+        _check(load().esl_comm_init_host(self._h, C.c_int32(n_ranks), C.c_int32(rank), self._host_cb, None), "esl_comm_init_host")
+
     def comm_destroy(self):
         _check(load().esl_comm_destroy(self._h), "esl_comm_destroy")
 
     def synchronize(self):
         _check(load().esl_ctx_synchronize(self._h), "esl_ctx_synchronize")
+
+
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 
 def comm_unique_id():

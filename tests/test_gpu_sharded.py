@@ -1,0 +1,167 @@
+"""Sharded optimisation inside the library (SURVEY.md §8 e) on ONE GPU: two contexts, one shard each, driven by
+two host threads; the exchange runs over the host-staged transport (esl_comm_init_host) with a thread barrier
+standing in for the wire.  The sharded run must reproduce the single-context run: same accept/reject sequence,
+same chi2 trace (up to summation order), same final states.
+
+Mapping mode: only the LM scalars cross.  SLAM mode: the camera blocks Hcc, b_c and the partial reduced camera
+systems are summed over the shards; odometry, lambda I and the camera part of the LM scale are counted once."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadAllreduce:
+    """In-place sum over `n` threads, rank order fixed (rank 0 adds 0,1,2,...), result identical on all ranks."""
+
+    def __init__(self, n):
+        self.n = n
+        self.bar = threading.Barrier(n, timeout=60)
+        self.bufs = [None] * n
+        self.total = None
+        self.calls = [0] * n
+        self.doubles = [0] * n
+
+    def make(self, rank):
+        def fn(arr):
+            self.calls[rank] += 1
+            self.doubles[rank] += arr.size
+            self.bufs[rank] = arr
+            self.bar.wait()
+            if rank == 0:
+                sizes = {b.size for b in self.bufs}
+                assert len(sizes) == 1, "ranks disagree on the collective's size: %r" % sizes
+                tot = self.bufs[0].copy()
+                for r in range(1, self.n):
+                    tot += self.bufs[r]
+                self.total = tot
+            self.bar.wait()
+            arr[:] = self.total
+            self.bar.wait()
+        return fn
+
+
+def run_sharded(pkg, g, cams, objs, params, n_shards=2):
+    part = pkg.lib.partition_objects(g, n_shards)
+    ar = ThreadAllreduce(n_shards)
+    ctxs, ids, reps, errs = [], [], [None] * n_shards, [None] * n_shards
+    for r in range(n_shards):
+        idx = np.nonzero(part == r)[0]
+        c = pkg.Context(0)
+        c.upload_graph(g.subset_objects(idx)); c.upload_states(cams, objs[idx])
+        c.comm_init_host(n_shards, r, ar.make(r))
+        ctxs.append(c); ids.append(idx)
+
+    def work(r):
+        try:
+            reps[r] = ctxs[r].optimize_resident(params)
+        except Exception as e:   # surfaced below; a dead rank must not leave the other one in the barrier
+            errs[r] = e
+            ar.bar.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_shards)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th), "sharded run hung"
+    assert errs == [None] * n_shards, errs
+    out_objs = np.zeros_like(objs)
+    out_cams = []
+    for r, c in enumerate(ctxs):
+        cc, oo = c.download_states()
+        out_objs[ids[r]] = oo
+        out_cams.append(cc)
+        c.comm_destroy(); c.close()
+    return reps, out_cams, out_objs, ar
+
+
+def test_mapping_two_shards_match_single_context(pkg, ctx):
+    g, c, o, _ = pkg.synth.make_graph(40, 10, 400, seed=11)
+    p = pkg.default_lm_params(jacobian_mode=1)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ref = ctx.optimize_resident(p)
+    _, ro = ctx.download_states()
+    reps, cams, objs, ar = run_sharded(pkg, g, c, o, p)
+    for rep in reps:
+        assert rep["iterations"] == ref["iterations"]
+        assert rep["trace_trials"] == ref["trace_trials"]
+        np.testing.assert_allclose(rep["trace_chi2"], ref["trace_chi2"], rtol=1e-12)
+    assert reps[0]["trace_chi2"] == reps[1]["trace_chi2"]          # bit-identical decisions on every rank
+    assert reps[0]["trace_lambda"] == reps[1]["trace_lambda"]
+    # block-diagonal system: an ellipsoid's arithmetic does not depend on which shard holds it
+    np.testing.assert_array_equal(objs, ro)
+    assert ar.calls[0] == ar.calls[1] > 0
+
+
+@pytest.mark.parametrize("jac", [0, 1])
+def test_slam_two_shards_match_single_context(pkg, ctx, jac):
+    g, c, o, _ = pkg.synth.make_graph(30, 8, 300, seed=5, slam=True)
+    p = pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ref = ctx.optimize_resident(p)
+    rc, ro = ctx.download_states()
+    assert ref["chi2_final"] < 0.5 * ref["chi2_initial"]
+    reps, cams, objs, ar = run_sharded(pkg, g, c, o, p)
+    n = len(ref["trace_chi2"])
+    for rep in reps:
+        assert rep["chi2_initial"] == pytest.approx(ref["chi2_initial"], rel=1e-12)
+        # same trajectory while chi2 is still moving (summation order differs by shard: ~1e-13 relative)
+        k = next((i for i in range(1, n) if abs(ref["trace_chi2"][i] - ref["trace_chi2"][i - 1]) < 1e-7 * ref["trace_chi2"][i]), n)
+        k = max(k, 3)
+        np.testing.assert_allclose(rep["trace_chi2"][:k], ref["trace_chi2"][:k], rtol=1e-8)
+        assert rep["trace_trials"][:k] == ref["trace_trials"][:k]
+        assert rep["chi2_final"] == pytest.approx(ref["chi2_final"], rel=1e-6)
+    assert reps[0]["trace_chi2"] == reps[1]["trace_chi2"]
+    assert reps[0]["trace_lambda"] == reps[1]["trace_lambda"]
+    # every rank solved the same summed camera system: identical camera trajectories on both, equal to single-GPU
+    np.testing.assert_array_equal(cams[0], cams[1])
+    np.testing.assert_allclose(cams[0], rc, atol=2e-7)
+    np.testing.assert_allclose(objs, ro, atol=2e-6)
+    # traffic: the reduced system dominates what crosses (lda*n doubles per trial)
+    assert ar.doubles[0] == ar.doubles[1] > 0
+
+
+def test_slam_first_reduced_system_is_the_sum_of_the_shards(pkg, ctx):
+    """One linearisation + one reduced system, compared entry by entry with the single-context one."""
+    g, c, o, _ = pkg.synth.make_graph(24, 6, 200, seed=9, slam=True)
+    p = pkg.default_lm_params(jacobian_mode=1)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ctx.lm_begin(p)
+    lin = ctx.lm_linearize()
+    lam = 1e-5 * lin.max_diag
+    _, n, lda = ctx.lm_reduced_system(lam)
+    S_ref = ctx.lm_download(6, lda * n)
+    Hcc_ref = ctx.lm_download(3, n * 6)
+
+    part = pkg.lib.partition_objects(g, 2)
+    ar = ThreadAllreduce(2)
+    out = [None, None]
+    errs = [None, None]
+
+    def work(r):
+        try:
+            idx = np.nonzero(part == r)[0]
+            cx = pkg.Context(0)
+            cx.upload_graph(g.subset_objects(idx)); cx.upload_states(c, o[idx])
+            cx.comm_init_host(2, r, ar.make(r))
+            cx.lm_begin(p)
+            l2 = cx.lm_linearize()
+            cx.lm_reduced_system(lam)
+            out[r] = (l2.chi2, l2.max_diag, cx.lm_download(6, lda * n), cx.lm_download(3, n * 6))
+            cx.comm_destroy(); cx.close()
+        except Exception as e:
+            errs[r] = e
+            ar.bar.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert errs == [None, None], errs
+    for r in range(2):
+        chi2, md, S, Hcc = out[r]
+        assert chi2 == pytest.approx(lin.chi2, rel=1e-12)
+        assert md == pytest.approx(lin.max_diag, rel=1e-12)
+        np.testing.assert_allclose(Hcc, Hcc_ref, rtol=1e-11, atol=1e-9 * np.abs(Hcc_ref).max())
+        np.testing.assert_allclose(S, S_ref, rtol=0, atol=1e-10 * np.abs(S_ref).max())
+    np.testing.assert_array_equal(out[0][2], out[1][2])
