@@ -39,6 +39,27 @@ def algorithmic_bytes_linearize(g, slam):
     return b
 
 
+def valu_issue_floor(g, avg_ms):
+    """What actually bounds the linearisation: FP64 VALU issue, not HBM (DESIGN.md 'kernel rooflines').
+    floor = sum over waves of their VALU instruction count x 4 cycles (a wave64 op on a 16-lane SIMD) spread over
+    1024 SIMDs at 2.4 GHz; instruction counts are the static ones of profiles/r1_isa_counts.json."""
+    try:
+        isa = json.load(open(os.path.join(ROOT, "profiles", "r1_isa_counts.json")))
+        bb, e3 = isa["k_chunk_linearize<1, 0, false>"], isa["k_chunk_linearize<1, 1, false>"]
+    except Exception:  # noqa: BLE001
+        return None
+    cb = np.bincount(g.bbox_obj, minlength=g.n_objs) if len(g.bbox_obj) else np.zeros(1, int)
+    ce = np.bincount(g.e3d_obj, minlength=g.n_objs) if len(g.e3d_obj) else np.zeros(1, int)
+    waves_bb = int(np.ceil(cb / 64).sum())
+    waves_e3 = int(np.ceil(np.ceil(ce / 32).sum() / 2))
+    v_bb, v_e3 = bb["f64"] + bb["valu_other"], e3["f64"] + e3["valu_other"]
+    cycles = (waves_bb * v_bb + waves_e3 * v_e3) * 4.0 / 1024.0
+    floor_ms = cycles / 2.4e9 * 1e3
+    return {"bbox_waves": waves_bb, "bbox_valu_instr_per_wave": v_bb, "e3d_waves": waves_e3, "e3d_valu_instr_per_wave": v_e3,
+            "simds": 1024, "clock_ghz": 2.4, "floor_ms": floor_ms, "frac": floor_ms / avg_ms if avg_ms > 0 else None,
+            "note": "kernel duration includes ~4 us of dispatch; static instruction counts (both sides of branches)"}
+
+
 def cpu_baseline(pkg, g, c, o, params, budget_s=25.0):
     """The CPU restatement (oracle/, single thread) timed on a bounded sample of the same workload."""
     from oracle import pyoracle as po
@@ -270,13 +291,18 @@ def main():
             traffic = None
             try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) — same workload only
                 if not slam and a.config == "C4" and a.jacobian == "analytic":
-                    traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["k_chunk_linearize"]["traffic_bytes_per_launch"]
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_device_lm.json")))["kernels"]
+                    traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, false>" in k][0]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
                 traffic = None
-            roof = {"kernel": "k_chunk_linearize<bbox> + k_chunk_linearize<3-D>" if not slam else "k_slam_linearize", "bound": "hbm",
+            roof = {"kernel": "k_chunk_linearize_both (bbox + 3-D chunks, one launch)" if not slam else "k_slam_linearize", "bound": "hbm",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms,
-                    "launches": dom["count"]}
+                    "launches": dom["count"],
+                    "sampling": "HIP events around ONE linearisation launch per optimize() (the second trial's); bracketing "
+                                "every launch costs 13 % of the run because each event record splits two back-to-back dispatches"}
+            if not slam and a.jacobian == "analytic":
+                roof["valu_issue_floor"] = valu_issue_floor(g, avg_ms)
         else:
             n = 6 * int((~g.cam_fixed.astype(bool)).sum())
             flops = n ** 3 / 3.0 + 2.0 * n * n

@@ -162,8 +162,9 @@ int esl_states_restore(esl_ctx* ctx);
 /* per-kernel timing with HIP events recorded on the context's own stream.
  * kernel ids: 0 linearise, 1 LM trial (solve + retract + chi2), 2 reduced-system build (Schur),
  *             3 dense Cholesky + solves, 4 reductions / misc, 6 RCCL all-reduce of the reduced system (sharded SLAM).
- * esl_profile_enable(ctx, 0) off; 1 = bracket only kernel class 0 (two event records per LM iteration: cheap enough
- * to stay on inside a timed region); 2 = bracket every class (adds ~20 % host overhead to a 130 us LM iteration).
+ * esl_profile_enable(ctx, 0) off; 1 = bracket only kernel class 0, and inside esl_optimize_resident's device-driven
+ * mapping run only ONE linearisation launch per run (cheap enough to stay on inside a timed region: an event record
+ * is a barrier packet between two otherwise back-to-back dispatches); 2 = bracket every launch of every class.
  * esl_profile_get drains the events: count[k] launches, total_ms[k] summed durations. */
 #define ESL_PROF_KINDS 8
 int esl_profile_enable(esl_ctx* ctx, int enable);

@@ -26,7 +26,7 @@ using namespace esl;
 namespace esl {
 ProfScope::ProfScope(esl_ctx* ctx, int kind) : c(ctx), slot(-1) {
   if (!c->prof_on) return;
-  if (c->prof_level < 2 && kind != 0) return;
+  if (c->prof_level < 2 && (kind != 0 || !c->prof_gate)) return;
   if (c->prof_used + 2 > c->prof_ev.size()) {
     if (c->prof_ev.size() >= 16384) { prof_drain(c); }
     else {
@@ -112,6 +112,7 @@ int esl_ctx_create(int device_id, esl_ctx** out) {
   ESL_HIP_TRY(hipHostMalloc((void**)&c->host_part, 16 * sizeof(double), hipHostMallocDefault));
   ESL_HIP_TRY(hipMalloc((void**)&c->dev_part, 16 * sizeof(double)));
   ESL_HIP_TRY(hipMalloc((void**)&c->chol_info, 4 * sizeof(int)));
+  ESL_HIP_TRY(hipMemset(c->chol_info, 0, 4 * sizeof(int)));
   ESL_HIP_TRY(hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)));
   ESL_HIP_TRY(hipMemset(c->tickets, 0, 4 * sizeof(unsigned int)));
   ESL_HIP_TRY(hipMalloc((void**)&c->dev_scal, 8 * sizeof(double)));
@@ -119,6 +120,11 @@ int esl_ctx_create(int device_id, esl_ctx** out) {
   ESL_HIP_TRY(hipHostMalloc(&c->host_scal, sizeof(LmScalars), hipHostMallocMapped));
   ESL_HIP_TRY(hipHostGetDevicePointer(&c->host_scal_dev, c->host_scal, 0));
   std::memset(c->host_scal, 0, sizeof(LmScalars));
+  ESL_HIP_TRY(hipMalloc(&c->lm_dev, 2 * sizeof(LmCore)));   // ping-pong pair
+  ESL_HIP_TRY(hipMemset(c->lm_dev, 0, 2 * sizeof(LmCore)));
+  ESL_HIP_TRY(hipHostMalloc(&c->lm_host, sizeof(LmHostView), hipHostMallocMapped));
+  ESL_HIP_TRY(hipHostGetDevicePointer(&c->lm_host_dev, c->lm_host, 0));
+  std::memset(c->lm_host, 0, sizeof(LmHostView));
   *out = c;
   return ESL_OK;
 }
@@ -135,7 +141,7 @@ static void free_graph(esl_ctx* c) {
   dev_free(&g.ue_start); dev_free(&g.ue_id); dev_free(&g.ue_slot);
   dev_free(&c->Linv_ws); dev_free(&c->z_ws);
   dev_free(&c->ck_obj); dev_free(&c->ck_type); dev_free(&c->ck_begin); dev_free(&c->ck_end); dev_free(&c->ck_ostart);
-  dev_free(&c->chunk_out); dev_free(&c->chunk_out2); dev_free(&c->chunk_chi); dev_free(&c->blk_part); dev_free(&c->ck_ids_bb); dev_free(&c->ck_ids_e3);
+  dev_free(&c->chunk_out); dev_free(&c->chunk_out2); dev_free(&c->chunk_chi); dev_free(&c->blk_part); dev_free(&c->solve_part); dev_free(&c->blk_chi); dev_free(&c->ck_ids_bb); dev_free(&c->ck_ids_e3);
   c->n_chunks = 0;
   dev_free(&c->cams); dev_free(&c->cams_trial); dev_free(&c->objs); dev_free(&c->objs_trial);
   dev_free(&c->Hoo); dev_free(&c->bo); dev_free(&c->xo); dev_free(&c->obj_part);
@@ -159,6 +165,8 @@ int esl_ctx_destroy(esl_ctx* c) {
   dev_free(&c->chol_info);
   dev_free(&c->tickets); dev_free(&c->dev_scal);
   if (c->host_scal) (void)hipHostFree(c->host_scal);
+  if (c->lm_host) (void)hipHostFree(c->lm_host);
+  if (c->lm_dev) (void)hipFree(c->lm_dev);
   if (c->ev_try) (void)hipEventDestroy(c->ev_try);
   esl_comm_destroy(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -229,7 +237,9 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   d.grav_w = g->grav_weight;
   {  // rotate_ellipsoid's yaw table (src/core/Ellipsoid.cpp:78, 100): yaw = k*pi/2, k = -1,0,1,2
     const double ang[4] = {-1, 0, 1, 2};
-    for (int k = 0; k < 4; ++k) { const double yaw = ang[k] * M_PI / 2.0; d.yt.s[k] = std::sin(yaw * 0.5); d.yt.c[k] = std::cos(yaw * 0.5); }
+    double hs[4], hc[4];
+    for (int k = 0; k < 4; ++k) { const double yaw = ang[k] * M_PI / 2.0; hs[k] = std::sin(yaw * 0.5); hc[k] = std::cos(yaw * 0.5); }
+    yaw_table_fill(d.yt, hs, hc);
   }
   const int N = g->n_objs, F = g->n_cams;
   std::vector<int> start, perm, h_bb_start, h_e3_start;
@@ -288,6 +298,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   {
     std::vector<int> cnt((size_t)N, 0);
     for (int i = 0; i < g->n_grav; ++i) cnt[g->grav_obj[i]]++;
+    c->n_grav_edges = g->n_grav;
     for (int o = 0; o < N; ++o)
       if (cnt[o] > 64) { set_error("more than 64 gravity edges on one ellipsoid"); return ESL_ERR_INVALID; }
     if ((rc = dev_upload(&d.gr_cnt, cnt.data(), cnt.size(), st))) return rc;
@@ -318,6 +329,8 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     if ((rc = dev_alloc(&c->chunk_out2, (size_t)c->n_chunks * kChunkOut))) return rc;
     if ((rc = dev_alloc(&c->chunk_chi, (size_t)c->n_chunks))) return rc;
     if ((rc = dev_alloc(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2))) return rc;
+    if ((rc = dev_alloc(&c->solve_part, (size_t)((N + 63) / 64 + 1) * 4 * 2))) return rc;   // x2: ping-pong of k_lm_step
+    if ((rc = dev_alloc(&c->blk_chi, (size_t)(c->n_chunks + 2)))) return rc;                 // <= one workgroup per chunk
   }
   // cameras + odometry
   {
@@ -378,6 +391,7 @@ int esl_states_upload(esl_ctx* c, const double* cams, const double* objs) {
   if (c->g.n_objs) ESL_HIP_TRY(hipMemcpyAsync(c->objs, objs, (size_t)c->g.n_objs * 10 * sizeof(double), hipMemcpyHostToDevice, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   c->states_loaded = true;
+  c->cams_match_snap = false;
   c->lm.begun = false;
   return ESL_OK;
 }
@@ -400,28 +414,47 @@ static ChunkTable chunk_table(const esl_ctx* c) {
   t.n_chunks = c->n_chunks; t.obj = c->ck_obj; t.type = c->ck_type; t.begin = c->ck_begin; t.end = c->ck_end; t.ostart = c->ck_ostart;
   return t;
 }
-static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_objs = nullptr, double* dst_chunk = nullptr) {
+// Linearise at `src_objs` into `dst_chunk` (defaults: the context's current estimate and chunk_out).
+// st != null: the device-resident LM state picks the buffers instead -- the linearisation point is the TRIAL state of
+// the pair (c->objs/chunk_out, c->objs_trial/chunk_out2) and the launch is a no-op once the run is done.
+// validate: first linearisation of a device-driven run -- also performs the NaN pre-check of the bbox edges.
+static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_objs = nullptr, double* dst_chunk = nullptr,
+                                const LmCore* st = nullptr, bool validate = false) {
   const DevGraph& g = c->g;
   if (!src_objs) src_objs = c->objs;
   if (!dst_chunk) dst_chunk = c->chunk_out;
+  const double* objs_b = st ? c->objs_trial : nullptr;
+  double* chunk_b = st ? c->chunk_out2 : nullptr;
+  if (st) { src_objs = c->objs; dst_chunk = c->chunk_out; }
   const ChunkTable ct = chunk_table(c);
+  const bool an = c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC;
+  const int nb_e3 = (c->n_ids_e3 + 2 * kLinWaves - 1) / (2 * kLinWaves);   // two 32-edge chunks per wave
+  const int nb_bb = (c->n_ids_bb + kLinWaves - 1) / kLinWaves;
   if (ct.n_chunks > 0) {
     ProfScope ps(c, 0);
-    const dim3 block(256);
-    const bool an = c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC;
-    if (c->n_ids_e3 > 0) {   // the long tasks first
-      const dim3 grid((c->n_ids_e3 + 7) / 8);   // two 32-edge chunks per wave
-      if (an) hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_ANALYTIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
-                                 c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
-      else hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1>), grid, block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
-                              c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
-    }
-    if (c->n_ids_bb > 0) {
-      const dim3 grid((c->n_ids_bb + 3) / 4);
-      if (an) hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_ANALYTIC, 0>), grid, block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb,
-                                 c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
-      else hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 0>), grid, block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb,
-                              c->cams, src_objs, c->lm.p.numeric_delta, dst_chunk);
+    const dim3 block(64 * kLinWaves);
+    int* cnt = c->chol_info + 2;
+    if (an) {   // both edge types in one launch, 3-D workgroups first
+      if (validate)
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+                           c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
+                           chunk_b, c->blk_chi, st, cnt);
+      else
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, false>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+                           c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
+                           chunk_b, c->blk_chi, st, cnt);
+    } else {    // numeric Jacobians: one kernel per edge type (very different register needs), the long tasks first
+      if (nb_e3 > 0)
+        hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1, false>), dim3(nb_e3), block, 0, c->stream, g, ct, c->ck_ids_e3,
+                           c->n_ids_e3, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, 0, st, cnt);
+      if (nb_bb > 0) {
+        if (validate)
+          hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 0, true>), dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb,
+                             c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, nb_e3, st, cnt);
+        else
+          hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 0, false>), dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb,
+                             c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, nb_e3, st, cnt);
+      }
     }
   }
   ESL_HIP_TRY(hipGetLastError());
@@ -430,22 +463,33 @@ static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_obj
     ProfScope ps(c, 4);
     hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, ct, dst_chunk, src_objs,
                        c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part,
-                       c->tickets, c->dev_scal, (LmScalars*)c->host_scal_dev);
+                       c->tickets, c->dev_scal, (LmScalars*)c->host_scal_dev, c->lm.p.tau, (LmCore*)nullptr, (int*)nullptr, 0,
+                       (LmHostView*)nullptr);
     ESL_HIP_TRY(hipGetLastError());
   }
   return ESL_OK;
 }
+// solve (H + lambda I) x = b per ellipsoid from the chunk partials, retract -> objs_trial.
 // lambda < 0: use tau * max_diag from device memory (first iteration)
-static int map_launch_try(esl_ctx* c, double lambda, const double* chunk = nullptr) {
+static int map_launch_solve(esl_ctx* c, double lambda, const double* chunk = nullptr) {
   const DevGraph& g = c->g;
   if (!chunk) chunk = c->chunk_out;
+  ProfScope ps(c, 1);
+  hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 63) / 64), dim3(64), 0, c->stream, g, chunk_table(c), chunk, c->objs,
+                     c->lm.p.jacobian_mode, c->lm.p.numeric_delta, lambda,
+                     c->lm.p.tau, c->dev_scal, c->xo, c->objs_trial, c->obj_part, c->solve_part);
+  ESL_HIP_TRY(hipGetLastError());
+  return ESL_OK;
+}
+// solve + chi2 of the trial state with the residual-only kernels (step API / sharded loop: H, b of the trial are not wanted)
+static int map_launch_try(esl_ctx* c, double lambda, const double* chunk = nullptr) {
+  const DevGraph& g = c->g;
   const ChunkTable ct = chunk_table(c);
+  int rc = map_launch_solve(c, lambda, chunk);
+  if (rc) return rc;
   {
     ProfScope ps(c, 1);
-    hipLaunchKernelGGL(k_obj_solve, dim3((g.n_objs + 63) / 64), dim3(64), 0, c->stream, g, ct, chunk, c->objs,
-                       c->lm.p.jacobian_mode, c->lm.p.numeric_delta, lambda,
-                       c->lm.p.tau, c->dev_scal, c->xo, c->objs_trial, c->obj_part);
-    // chi2 of the trial state: 3-D chunks first (no reduction), then the bbox chunks whose last workgroup reduces everything
+    // 3-D chunks first (no reduction), then the bbox chunks whose last workgroup reduces everything
     if (c->n_ids_e3 > 0)
       hipLaunchKernelGGL((k_chunk_chi2<1, false>), dim3((c->n_ids_e3 + 7) / 8), dim3(256), 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3,
                          c->cams, c->objs_trial, c->obj_part, c->chunk_chi, c->tickets + 1, lambda, c->lm.p.tau, c->dev_scal,
@@ -476,29 +520,43 @@ static int read_parts(esl_ctx* c, double out[4]) {
   return ESL_OK;
 }
 
-int esl_lm_begin(esl_ctx* c, const esl_lm_params* p, int32_t* n_valid, int32_t* n_dropped) {
-  if (!c || !p) return ESL_ERR_INVALID;
+// NaN pre-check of the bbox edges at the start state (Optimizer.cpp:234-243); the dropped count stays on the device
+// (c->chol_info + 2) -- the synchronous caller reads it back, the device-driven run lets k_chunk_finalize report it.
+static int lm_begin_enqueue(esl_ctx* c, const esl_lm_params* p, bool validate_in_linearize = false) {
   if (!c->graph_loaded || !c->states_loaded) { set_error("esl_lm_begin: upload graph and states first"); return ESL_ERR_STATE; }
   ESL_HIP_TRY(hipSetDevice(c->device));
   c->lm.p = *p;
   c->lm.slam = c->g.n_free_cams > 0;
   c->lm.have_trial = false;
-  int dropped = 0;
+  int* cnt = c->chol_info + 2;
+  if (validate_in_linearize && c->g.n_bbox && p->drop_nan_bbox) {   // counter is zero (context creation / k_chunk_finalize)
+    c->lm.begun = true;
+    return ESL_OK;
+  }
+  ESL_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
   if (c->g.n_bbox) {
     if (p->drop_nan_bbox) {
-      int* cnt = c->chol_info + 2;
-      ESL_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
       hipLaunchKernelGGL(k_bbox_validate, dim3((c->g.n_bbox + 255) / 256), dim3(256), 0, c->stream, c->g, c->cams, c->objs, cnt);
       ESL_HIP_TRY(hipGetLastError());
-      ESL_HIP_TRY(hipMemcpyAsync(&dropped, cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
     } else {
       ESL_HIP_TRY(hipMemsetAsync(c->g.bb_valid, 1, (size_t)c->g.n_bbox, c->stream));
     }
   }
+  c->lm.begun = true;
+  return ESL_OK;
+}
+
+int esl_lm_begin(esl_ctx* c, const esl_lm_params* p, int32_t* n_valid, int32_t* n_dropped) {
+  if (!c || !p) return ESL_ERR_INVALID;
+  int rc = lm_begin_enqueue(c, p);
+  if (rc) return rc;
+  int dropped = 0;
+  if (c->g.n_bbox && p->drop_nan_bbox) {
+    ESL_HIP_TRY(hipMemcpyAsync(&dropped, c->chol_info + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   if (n_valid) *n_valid = c->g.n_bbox - dropped;
   if (n_dropped) *n_dropped = dropped;
-  c->lm.begun = true;
   return ESL_OK;
 }
 
@@ -551,7 +609,7 @@ int esl_lm_commit(esl_ctx* c, int accept) {
   if (!c->lm.begun || !c->lm.have_trial) { set_error("esl_lm_commit without a trial step"); return ESL_ERR_STATE; }
   if (accept) {  // discardTop: the trial states become the estimate
     std::swap(c->objs, c->objs_trial);
-    if (c->lm.slam) std::swap(c->cams, c->cams_trial);
+    if (c->lm.slam) { std::swap(c->cams, c->cams_trial); c->cams_match_snap = false; }
   }
   c->lm.have_trial = false;
   return ESL_OK;
@@ -569,78 +627,118 @@ int esl_lm_reduced_system(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n,
   return ESL_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// the LM loop (optimization_algorithm_levenberg.cpp:61-164 + sparse_optimizer.cpp:354-419)
-// ---------------------------------------------------------------------------------------------------
-// Mapping mode, single shard: the LM loop with the next linearisation launched SPECULATIVELY on the trial state while
-// the host waits (on an event) for the trial's scalars.  Accepted step (the common case): the speculative result
-// is the next iteration's system (buffers swap), the GPU never idles across the host's decision; rejected step:
-// the old system is still intact in the other buffer and only the damped solve is repeated.  Control flow and
-// arithmetic are exactly those of optimization_algorithm_levenberg.cpp:61-164.
-static int optimize_mapping_pipelined(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
+// Mapping mode on one GPU: the whole LM run is enqueued ahead of the device.  One trial = two launches:
+//   k_lm_step              decide the previous trial (accept / reject, lambda, stop test -- on the device), then solve
+//                          per ellipsoid for the new lambda -> next trial state
+//   k_chunk_linearize_*    linearisation AT the trial state: its chi2 sum is the trial's chi2 (no separate residual
+//                          pass) and, if the trial gets accepted, its H, b are already the next iteration's system
+// The host keeps a few trials queued, watches the progress counter in mapped memory and stops enqueueing when the
+// device reports `done`; launches already queued behind a finished run exit at their first instruction.
+static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
   int rc;
-  double* chunk[2] = {c->chunk_out, c->chunk_out2};
-  int cur = 0;
-  double lambda = -1, ni = 2, currentChi = 0;
-  int nBad = 0, it = 0, total_trials = 0;
-  bool ok_outer = true;
-  const LmScalars* h = (const LmScalars*)c->host_scal;
-  if ((rc = map_launch_linearize(c, true, c->objs, chunk[cur]))) return rc;
-  for (it = 0; it < p->max_iters && ok_outer; ++it) {
-    double iniChi = currentChi, rho = 0;
-    int qmax = 0;
-    do {
-      if ((rc = map_launch_try(c, (it == 0 && qmax == 0) ? -1.0 : lambda, chunk[cur]))) return rc;
-      ESL_HIP_TRY(hipEventRecord(c->ev_try, c->stream));
-      if ((rc = map_launch_linearize(c, false, c->objs_trial, chunk[cur ^ 1]))) return rc;   // speculative
-      ESL_HIP_TRY(hipEventSynchronize(c->ev_try));
-      if (it == 0 && qmax == 0) {
-        currentChi = h->chi2_lin; iniChi = currentChi;
-        out->chi2_initial = currentChi;
-        lambda = p->tau * h->max_diag;  // computeLambdaInit (the device formed the same product)
-        ni = 2; nBad = 0;
-      }
-      const double tempChi = (h->ok > 0.5) ? h->chi2_trial : DBL_MAX;
-      rho = (currentChi - tempChi) / (h->scale + 1e-3);
-      if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
-        alpha = std::min(alpha, 2. / 3.);
-        lambda *= std::max(1. / 3., alpha);
-        ni = 2;
-        currentChi = tempChi;
-        std::swap(c->objs, c->objs_trial);   // discardTop
-        cur ^= 1;                            // the speculative linearisation is the new system
-      } else {
-        lambda *= ni;
-        ni *= 2;                             // pop: objs untouched, chunk[cur] still describes it
-      }
-      qmax++;
-    } while (rho < 0 && qmax < p->max_trials);
-    total_trials += qmax;
-    if (it < ESL_MAX_TRACE) {
-      out->trace_chi2[it] = currentChi; out->trace_lambda[it] = lambda; out->trace_trials[it] = qmax;
-      out->trace_len = it + 1;
-    }
-    if (qmax == p->max_trials || rho == 0) { ok_outer = false; out->stop_reason = 1; }
-    else {
-      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-      if (nBad >= 3) { ok_outer = false; out->stop_reason = 2; }
-    }
+  const DevGraph& g = c->g;
+  LmHostView* hv = (LmHostView*)c->lm_host;
+  LmCore* core = (LmCore*)c->lm_dev;   // [2]
+  if (g.n_objs == 0 || (g.n_bbox == 0 && g.n_e3d == 0 && c->n_grav_edges == 0)) {   // empty graph
+    out->stop_reason = 3;
+    return ESL_OK;
   }
-  ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // a speculative launch may still be in flight
-  if (cur != 0) std::swap(c->chunk_out, c->chunk_out2);   // keep chunk_out = system of the current estimate (inspection API)
+  hv->trace_len = 0;
+  __atomic_store_n(&hv->seq, 0, __ATOMIC_RELAXED);
+  __atomic_store_n(&hv->done, 0, __ATOMIC_RELEASE);
+  // linearisation of the start state + chi2, max diag, LM state initialisation (computeLambdaInit) into core[0]
+  c->prof_gate = false;
+  rc = map_launch_linearize(c, false, nullptr, nullptr, nullptr, g.n_bbox > 0 && p->drop_nan_bbox != 0);
+  c->prof_gate = true;
+  if (rc) return rc;
+  {
+    ProfScope ps(c, 4);
+    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out, c->objs,
+                       c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part, c->tickets, c->dev_scal,
+                       (LmScalars*)c->host_scal_dev, p->tau, core, c->chol_info + 2, c->n_grav_edges,
+                       (LmHostView*)c->lm_host_dev);
+    ESL_HIP_TRY(hipGetLastError());
+  }
+  if (p->max_iters <= 0) {   // nothing to iterate: report the start state
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    const LmScalars* h = (const LmScalars*)c->host_scal;
+    out->chi2_initial = out->chi2_final = h->chi2_lin;
+    out->n_bbox_dropped = hv->n_dropped;
+    out->n_bbox_valid = g.n_bbox - hv->n_dropped;
+    if (hv->done) out->stop_reason = hv->core.stop_reason;
+    return ESL_OK;
+  }
+  const int max_total = p->max_iters * std::max(1, p->max_trials);
+  const int depth = 2;   // trials kept in flight ahead of the device's progress counter
+  const int n_step_blocks = (g.n_objs + 255) / 256;
+  const int n_lin_blocks = (c->n_ids_e3 + 2 * kLinWaves - 1) / (2 * kLinWaves) + (c->n_ids_bb + kLinWaves - 1) / kLinWaves;
+  // launch k carries trial k's solve and trial k-1's decision: one launch more than there are trials
+  int enq = 0, seen = 0;
+  bool done = false;
+  while (!done) {
+    while (enq <= max_total && enq - seen < depth) {
+      const LmCore* in = core + (enq & 1);
+      LmCore* nxt = core + ((enq + 1) & 1);
+      {
+        ProfScope ps(c, 1);
+        hipLaunchKernelGGL(k_lm_step, dim3(n_step_blocks), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out, c->chunk_out2,
+                           c->objs, c->objs_trial, in, nxt, c->blk_chi, n_lin_blocks, c->solve_part + 4 * n_step_blocks * (enq & 1),
+                           c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? 1 : 0, p->max_iters, p->max_trials,
+                           (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo, c->obj_part);
+        ESL_HIP_TRY(hipGetLastError());
+      }
+      c->prof_gate = (enq == 1);   // the second trial's linearisation is the sampled one (always a live launch when it exists)
+      rc = map_launch_linearize(c, false, nullptr, nullptr, nxt);
+      c->prof_gate = true;
+      if (rc) return rc;
+      ++enq;
+    }
+    // wait for the device to decide at least one more trial: spin on the mapped counter, fall back to a stream sync
+    int s = seen;
+    for (int spin = 0; spin < 400000; ++spin) {
+      s = __atomic_load_n(&hv->seq, __ATOMIC_ACQUIRE);
+      if (s > seen || __atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) break;
+    }
+    if (s == seen && !__atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) {
+      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+      s = __atomic_load_n(&hv->seq, __ATOMIC_ACQUIRE);
+      if (s == seen && !hv->done) { set_error("device-side LM made no progress"); return ESL_ERR_STATE; }
+    }
+    seen = s;
+    done = __atomic_load_n(&hv->done, __ATOMIC_ACQUIRE) != 0;
+  }
+  // `done` was stored with release semantics after the results: they are visible without draining the stream (the
+  // one or two no-op launches still queued touch nothing the caller can see)
+  const LmCore& r = hv->core;
+  out->n_bbox_dropped = hv->n_dropped;
+  out->n_bbox_valid = g.n_bbox - hv->n_dropped;
+  if (r.cur) {   // the current estimate (and its system, for the inspection API) live in the second pair
+    std::swap(c->objs, c->objs_trial);
+    std::swap(c->chunk_out, c->chunk_out2);
+  }
   c->sys_combined = false;
   c->lm.have_trial = false;
-  out->iterations = it;
-  out->total_trials = total_trials;
-  out->chi2_final = currentChi;
-  out->lambda_final = lambda;
+  out->iterations = r.it;
+  out->total_trials = r.total_trials;
+  out->stop_reason = r.stop_reason;
+  out->chi2_initial = r.chi2_initial;
+  out->chi2_final = r.currentChi;
+  out->lambda_final = r.lambda;
+  out->trace_len = hv->trace_len;
+  for (int k = 0; k < hv->trace_len && k < ESL_MAX_TRACE; ++k) {
+    out->trace_chi2[k] = hv->trace_chi2[k]; out->trace_lambda[k] = hv->trace_lambda[k]; out->trace_trials[k] = hv->trace_trials[k];
+  }
   return ESL_OK;
 }
 
 int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
   if (!c || !p || !out) return ESL_ERR_INVALID;
   std::memset(out, 0, sizeof(*out));
+  if (c->graph_loaded && c->g.n_free_cams == 0 && !c->comm) {   // mapping mode, one GPU: nothing waits on the host
+    int rc0 = lm_begin_enqueue(c, p, true);
+    if (rc0) return rc0;
+    return optimize_mapping_device(c, p, out);
+  }
   int32_t nv = 0, nd = 0;
   int rc = esl_lm_begin(c, p, &nv, &nd);
   if (rc) return rc;
@@ -656,7 +754,6 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
   }
   if (!any_edge && !any_grav) { out->stop_reason = 3; return ESL_OK; }
 
-  if (!c->lm.slam && !c->comm) return optimize_mapping_pipelined(c, p, out);
 
   double lambda = -1, ni = 2;
   int nBad = 0, it = 0, total_trials = 0;
@@ -767,6 +864,7 @@ int esl_states_snapshot(esl_ctx* c) {
   if (!c->objs_snap) ESL_HIP_TRY(hipMalloc((void**)&c->objs_snap, std::max<size_t>(no, 1) * sizeof(double)));
   if (nc) ESL_HIP_TRY(hipMemcpyAsync(c->cams_snap, c->cams, nc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   if (no) ESL_HIP_TRY(hipMemcpyAsync(c->objs_snap, c->objs, no * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  c->cams_match_snap = true;
   return ESL_OK;
 }
 
@@ -774,7 +872,8 @@ int esl_states_restore(esl_ctx* c) {
   if (!c || !c->cams_snap || !c->objs_snap) { set_error("esl_states_restore: no snapshot"); return ESL_ERR_STATE; }
   ESL_HIP_TRY(hipSetDevice(c->device));
   const size_t nc = (size_t)c->g.n_cams * 7, no = (size_t)c->g.n_objs * 10;
-  if (nc) ESL_HIP_TRY(hipMemcpyAsync(c->cams, c->cams_snap, nc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  if (nc && !c->cams_match_snap) ESL_HIP_TRY(hipMemcpyAsync(c->cams, c->cams_snap, nc * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  c->cams_match_snap = true;
   if (no) ESL_HIP_TRY(hipMemcpyAsync(c->objs, c->objs_snap, no * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   c->lm.begun = false;
   return ESL_OK;
@@ -849,3 +948,16 @@ int esl_partition_objects(const esl_graph* g, int32_t n_parts, int32_t* part_of_
 }
 
 }  // extern "C"
+
+#ifdef ESL_ISA_PROBE
+// scripts/isa_count.py compiles this TU with -DESL_ISA_PROBE to get the per-edge-type instruction streams of the
+// fused linearisation kernel as separate symbols (analysis only; never part of libesl_hip.so).
+namespace esl {
+template __global__ void k_chunk_linearize<ESL_JAC_ANALYTIC, 0, false>(DevGraph, ChunkTable, const int*, int, const double*, const double*,
+                                                                       const double*, double, double*, double*, double*, int,
+                                                                       const LmCore*, int*);
+template __global__ void k_chunk_linearize<ESL_JAC_ANALYTIC, 1, false>(DevGraph, ChunkTable, const int*, int, const double*, const double*,
+                                                                       const double*, double, double*, double*, double*, int,
+                                                                       const LmCore*, int*);
+}  // namespace esl
+#endif

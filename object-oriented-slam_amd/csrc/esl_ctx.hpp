@@ -126,6 +126,8 @@ struct esl_ctx {
   // profiling (HIP events on this stream)
   bool prof_on = false;
   int prof_level = 0;   // 1: only kernel class 0 (linearise) is bracketed; 2: every class
+  bool prof_gate = true; // level 1 inside a device-driven run: bracket ONE linearisation per run (event records break
+                         // the back-to-back dispatch: bracketing all of them cost 13 % of the C4 run)
   std::vector<hipEvent_t> prof_ev;   // pairs
   std::vector<int> prof_kind;
   size_t prof_used = 0;
@@ -143,8 +145,15 @@ struct esl_ctx {
   hipEvent_t ev_try = nullptr;
   double* chunk_chi = nullptr;   // n_chunks
   double* blk_part = nullptr;    // per-workgroup partials of k_chunk_finalize
+  double* solve_part = nullptr;  // per-workgroup partials of k_obj_solve / k_lm_step (4 each)
+  double* blk_chi = nullptr;     // per-workgroup chi2 of the last linearisation
   unsigned int* tickets = nullptr;  // 2 arrival counters
   double* dev_scal = nullptr;    // {chi2_lin, max_diag}
+  bool cams_match_snap = false;  // cameras untouched since the snapshot: esl_states_restore skips their copy
+  int n_grav_edges = 0;
+  void* lm_dev = nullptr;        // device-resident LM state (LmCore[2], esl_kernels_chunk.hpp)
+  void* lm_host = nullptr;       // mapped pinned LmHostView the host polls
+  void* lm_host_dev = nullptr;   // its device alias
   void* host_scal = nullptr;     // mapped pinned LmScalars
   void* host_scal_dev = nullptr; // its device alias
   bool sys_combined = false;

@@ -15,6 +15,7 @@
 //                       everything in fixed order and writes the LM scalars straight into mapped host memory
 // Reference pieces replaced: see esl_kernels_map.hpp.
 #pragma once
+#include <cfloat>
 #include <utility>
 
 #include "esl_kernels_map.hpp"
@@ -31,6 +32,9 @@ struct ChunkTable {
 };
 
 constexpr int kChunkOut = 56;  // 45 packed H + 9 b + chi2 + pad
+// waves per workgroup of the linearisation kernels.  Measured at C4: 1-wave workgroups make the launch 0.8 us shorter
+// (finer spreading over the 1024 SIMDs) and k_lm_step 0.8 us longer (4x the per-workgroup chi2 partials to add): a wash.
+constexpr int kLinWaves = 4;
 
 // ---- reduce-scatter across the wave by recursive halving ------------------------------------------------
 // In: N values per lane.  Out: the wave-wide total of entry `idx` (returned) in the lanes whose low bits are 0.
@@ -160,17 +164,20 @@ __device__ __forceinline__ void reduce_group(const double* J, const double* r, d
 // One instantiation per edge type: the bbox and the 3-D code paths have very different register needs, and a
 // kernel is allocated for the worse of its branches (the fused version spilled 304 B/lane = 69 MB of HBM
 // writes per launch at C4, profiles/r1_pmc_traffic.json).  `ids` lists the chunks of this type.
-template <int JAC, int TYPE>
-static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, ChunkTable ct, const int* __restrict__ ids, int n_ids,
-                                                                const double* __restrict__ cams,
-                                                                const double* __restrict__ objs, double delta,
-                                                                double* __restrict__ chunk_out) {
+// VALIDATE (bbox only): this is the first linearisation of a run and doubles as the reference's NaN pre-check of the
+// bbox edges (Optimizer.cpp:234-243): an edge whose residual is NaN at the start state is marked invalid for the
+// whole run and counted in *n_dropped (same residual code as k_bbox_validate, which the synchronous API still uses).
+template <int JAC, int TYPE, bool VALIDATE = false>
+__device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const ChunkTable& ct, const int* __restrict__ ids, int n_ids,
+                                                     const double* __restrict__ cams, const double* __restrict__ objs, double delta,
+                                                     double* __restrict__ chunk_out, double* __restrict__ wg_chi /* LDS, 8 slots */,
+                                                     int block, int* __restrict__ n_dropped = nullptr) {
   // bbox chunks hold <= 64 edges (one wave each); 3-D chunks hold <= 32 edges and TWO of them share a wave
   // (an ellipsoid has ~20 3-D edges: a whole wave per chunk ran at 31 % lane use).  Offsets < 32 keep the
   // shuffles of the reduce-scatter inside a half wave.
   constexpr int kSeg = (TYPE == 1) ? 32 : 64;
   const int lane = threadIdx.x & (kSeg - 1);
-  const int seg = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / kSeg) + ((threadIdx.x & 63) / kSeg);
+  const int seg = (block * kLinWaves + (threadIdx.x >> 6)) * (64 / kSeg) + ((threadIdx.x & 63) / kSeg);
   const bool seg_on = seg < n_ids;
   if (!seg_on) return;   // (3-D: the other half wave carries on; its shuffles never leave its 32 lanes)
   const int ch = ids[seg];
@@ -183,7 +190,7 @@ static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, Chun
   double chi = 0;
   if (type == 0) {
     double r[4] = {0, 0, 0, 0}, J[36], w = 0;
-    const bool act = in && g.bb_valid[i];
+    const bool act = in && (VALIDATE || g.bb_valid[i]);
     if (act) {
       const SE3 T = se3_load(cams + 7 * g.bb_cam[i]);
       double meas[4] = {g.bb_meas[4 * i], g.bb_meas[4 * i + 1], g.bb_meas[4 * i + 2], g.bb_meas[4 * i + 3]};
@@ -194,6 +201,18 @@ static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, Chun
         numeric_jac_obj(e, delta, 4, J, [&](const Ell& ep, double* o4) { res_bbox(T, ep, g.K, meas, o4); });
       }
       chi = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+      if (VALIDATE) {
+        const bool bad = (chi != chi);
+        g.bb_valid[i] = bad ? 0 : 1;
+        if (bad) {   // dropped: contributes nothing (its J / r may hold NaN)
+          atomicAdd(n_dropped, 1);
+          chi = 0; w = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r[k] = 0;
+#pragma unroll
+          for (int k = 0; k < 36; ++k) J[k] = 0;
+        }
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 36; ++k) J[k] = 0;
@@ -235,16 +254,54 @@ static __global__ __launch_bounds__(256) void k_chunk_linearize(DevGraph g, Chun
     reduce_group_e3d<2>(Jp, r, w, lane, out, seg_on);
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) chi += __shfl_xor(chi, off, 64);
-    if (lane == 0 && seg_on) out[54] = chi;
+    if (lane == 0 && seg_on) {
+      out[54] = chi;
+      wg_chi[(threadIdx.x >> 6) * 2 + ((threadIdx.x & 63) >> 5)] = chi;
+    }
     return;
   }
   chi = wave_sum(chi);
-  if (lane == 0) out[54] = chi;
+  if (lane == 0) {
+    out[54] = chi;
+    wg_chi[(threadIdx.x >> 6) * 2] = chi;
+  }
+}
+// chi2 of the chunks one workgroup linearised, summed in slot order -> blk_chi[workgroup]  (the LM step kernel adds
+// these ~1.3k numbers instead of one per chunk)
+__device__ __forceinline__ void wg_chi_begin(double* wg_chi) {
+  if (threadIdx.x < 2 * kLinWaves) wg_chi[threadIdx.x] = 0;
+  __syncthreads();
+}
+__device__ __forceinline__ void wg_chi_end(const double* wg_chi, double* __restrict__ blk_chi, int slot) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * kLinWaves; ++k) t += wg_chi[k];
+    blk_chi[slot] = t;
+  }
 }
 
 // fixed-order block reduction helpers for the "last workgroup finishes" pattern
 struct LmScalars {  // lives in mapped host memory
   double chi2_lin, max_diag, chi2_trial, scale, ok, lambda_used, pad0, pad1;
+};
+
+// Device-resident Levenberg-Marquardt control (g2o's OptimizationAlgorithmLevenberg::solve + the ORB-SLAM style
+// stop rule of Optimizer.cpp): the accept / reject decision, the lambda update and the stop test of every trial run
+// at the head of k_lm_step, so the host only enqueues launches and never sits between two kernels.
+struct LmCore {
+  double lambda, ni, currentChi, iniChi, chi2_initial, rho;
+  int cur;            // which (ellipsoid buffer, chunk buffer) pair holds the current estimate and its system
+  int it, qmax, nBad, total_trials, done, stop_reason, trial_seq;
+};
+struct LmHostView {   // mapped host memory, written by the device only: progress flags the host polls + the results
+  int seq, done;
+  int n_dropped, pad0;   // bbox edges dropped by the NaN pre-check (written by k_chunk_finalize)
+  LmCore core;        // final state (valid once done)
+  double trace_chi2[ESL_MAX_TRACE], trace_lambda[ESL_MAX_TRACE];
+  int trace_trials[ESL_MAX_TRACE];
+  int trace_len, pad;
 };
 
 // Publish this workgroup's results and learn whether it is the last one.  Recipe of the CDNA guide (G16):
@@ -301,13 +358,61 @@ __device__ double block256_max(double v, double* sm) {
   return r;
 }
 
+// Buffer selection shared by the LM kernels: without `st` a launch works on (objs_a -> chunk_a); with it, the
+// device-resident LM state says which pair is current and the linearisation point is the TRIAL buffer.
+//
+// Both edge types in ONE launch: the first nb_e3 workgroups take the 3-D chunks (longest instruction stream first),
+// the rest the bbox chunks.  Launched back to back the two kernels ran 18 + 17.5 us at C4 although neither fills the
+// chip for long (3-D: ~0.7 waves per SIMD on a 4.8k-instruction stream; bbox: 3 waves per SIMD, 1.7k instructions);
+// together they take 27 us.
+template <int JAC, bool VALIDATE = false>
+static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize_both(DevGraph g, ChunkTable ct, const int* __restrict__ ids_e3, int n_e3,
+                                                                     int nb_e3, const int* __restrict__ ids_bb, int n_bb,
+                                                                     const double* __restrict__ cams,
+                                                                     const double* __restrict__ objs_a, const double* __restrict__ objs_b,
+                                                                     double delta, double* __restrict__ chunk_a, double* __restrict__ chunk_b,
+                                                                     double* __restrict__ blk_chi, const LmCore* __restrict__ st,
+                                                                     int* __restrict__ n_dropped) {
+  __shared__ double wg_chi[2 * kLinWaves];
+  const double* objs = objs_a;
+  double* chunk_out = chunk_a;
+  if (st) {
+    if (st->done) return;
+    if (st->cur == 0) { objs = objs_b; chunk_out = chunk_b; }   // trial = the pair that is NOT current
+  }
+  wg_chi_begin(wg_chi);
+  if ((int)blockIdx.x < nb_e3) chunk_linearize_body<JAC, 1>(g, ct, ids_e3, n_e3, cams, objs, delta, chunk_out, wg_chi, blockIdx.x);
+  else chunk_linearize_body<JAC, 0, VALIDATE>(g, ct, ids_bb, n_bb, cams, objs, delta, chunk_out, wg_chi, blockIdx.x - nb_e3, n_dropped);
+  wg_chi_end(wg_chi, blk_chi, blockIdx.x);
+}
+template <int JAC, int TYPE, bool VALIDATE = false>
+static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize(DevGraph g, ChunkTable ct, const int* __restrict__ ids, int n_ids,
+                                                                const double* __restrict__ cams,
+                                                                const double* __restrict__ objs_a, const double* __restrict__ objs_b,
+                                                                double delta, double* __restrict__ chunk_a, double* __restrict__ chunk_b,
+                                                                double* __restrict__ blk_chi, int blk_offset,
+                                                                const LmCore* __restrict__ st, int* __restrict__ n_dropped) {
+  __shared__ double wg_chi[2 * kLinWaves];
+  const double* objs = objs_a;
+  double* chunk_out = chunk_a;
+  if (st) {
+    if (st->done) return;
+    if (st->cur == 0) { objs = objs_b; chunk_out = chunk_b; }
+  }
+  wg_chi_begin(wg_chi);
+  chunk_linearize_body<JAC, TYPE, VALIDATE>(g, ct, ids, n_ids, cams, objs, delta, chunk_out, wg_chi, blockIdx.x, n_dropped);
+  wg_chi_end(wg_chi, blk_chi, blk_offset + blockIdx.x);
+}
+
 // first iteration: chi2 of the linearisation point and max |H_kk| (computeLambdaInit); one thread per ellipsoid,
 // the last workgroup reduces the per-workgroup partials in fixed order
 static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
                                                                const double* __restrict__ objs, int jac, double delta,
                                                                double* __restrict__ blk_part /* gridDim x 2 */,
                                                                unsigned int* __restrict__ ticket, double* __restrict__ dev_scal,
-                                                               LmScalars* __restrict__ host) {
+                                                               LmScalars* __restrict__ host, double tau, LmCore* __restrict__ st,
+                                                               int* __restrict__ n_dropped, int n_grav,
+                                                               LmHostView* __restrict__ hv) {
   __shared__ double sm[256];
   const int o = blockIdx.x * 256 + threadIdx.x;
   double chi = 0, md = 0;
@@ -350,29 +455,37 @@ static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, Chunk
     if (threadIdx.x == 0) {
       dev_scal[0] = c; dev_scal[1] = m;
       host->chi2_lin = c; host->max_diag = m;
+      if (st) {   // start of a device-driven LM run: computeLambdaInit and the bookkeeping of iteration 0
+        LmCore s;
+        s.lambda = tau * m; s.ni = 2; s.currentChi = c; s.iniChi = c; s.chi2_initial = c; s.rho = 0;
+        s.cur = 0; s.it = 0; s.qmax = 0; s.nBad = 0; s.total_trials = 0; s.done = 0; s.stop_reason = 0; s.trial_seq = 0;
+        const int nd = *n_dropped;
+        hv->n_dropped = nd;
+        *n_dropped = 0;   // ready for the next run (the first linearisation of a run counts into it)
+        if (g.n_bbox - nd <= 0 && g.n_e3d == 0 && n_grav == 0) {   // no active edge: nothing to optimise (stop_reason 3)
+          s.done = 1; s.stop_reason = 3;
+          hv->core = s;
+          hv->trace_len = 0;
+          __hip_atomic_store(&hv->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        *st = s;
+      }
       *ticket = 0;
     }
   }
 }
 
-// ONE LANE PER ELLIPSOID: H, b from the chunk partials (fixed order => deterministic), gravity prior added,
-// unrolled register LDL^T of the 9x9, retraction, trial state.  (A wave per ellipsoid left 63 lanes idle on a
-// serial dependency chain; 2k ellipsoids are 32 full waves this way.)
-// lambda < 0: lambda = tau * max_diag read from device memory (first LM iteration, computeLambdaInit).
-static __global__ __launch_bounds__(64) void k_obj_solve(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
-                                                         const double* __restrict__ objs, int jac, double delta, double lambda, double tau,
-                                                         const double* __restrict__ dev_scal, double* __restrict__ xo,
-                                                         double* __restrict__ objs_trial, double* __restrict__ part) {
-  const int o = blockIdx.x * 64 + threadIdx.x;
-  if (o >= g.n_objs) return;
-  if (lambda < 0) lambda = tau * dev_scal[1];
+__device__ __forceinline__ void obj_solve_one(const DevGraph& g, const ChunkTable& ct, const double* __restrict__ chunk_out,
+                                              const double* __restrict__ objs, int jac, double delta, double lambda,
+                                              double* __restrict__ xo, double* __restrict__ objs_trial, double* __restrict__ part, int o,
+                                              double& cg_out, double& scale_out, double& ok_out) {
   const int c0 = ct.ostart[o], c1 = ct.ostart[o + 1];
   const Ell e = ell_load(objs + 10 * o);
   const int ngrav = g.gr_cnt[o];
   if (c0 == c1 && ngrav == 0) {  // inactive vertex: never touched (sparse_optimizer.cpp:236-257)
     ell_store(e, objs_trial + 10 * o);
     part[o * 4 + 0] = 0; part[o * 4 + 2] = 0; part[o * 4 + 3] = 1;
-    return;
+    return;   // contributes cg = 0, scale = 0, ok = 1
   }
   double hb[54];
 #pragma unroll
@@ -410,6 +523,142 @@ static __global__ __launch_bounds__(64) void k_obj_solve(DevGraph g, ChunkTable 
   part[o * 4 + 0] = cg;   // chi2 of the gravity prior at the trial state
   part[o * 4 + 2] = scale;
   part[o * 4 + 3] = ok ? 1.0 : 0.0;
+  cg_out = cg; scale_out = scale; ok_out = ok ? 1.0 : 0.0;
+}
+
+
+// ONE LANE PER ELLIPSOID: H, b from the chunk partials (fixed order => deterministic), gravity prior added,
+// unrolled register LDL^T of the 9x9, retraction, trial state.  (A wave per ellipsoid left 63 lanes idle on a
+// serial dependency chain; 2k ellipsoids are 32 full waves this way.)
+// lambda < 0: lambda = tau * max_diag read from device memory (first LM iteration, computeLambdaInit).
+static __global__ __launch_bounds__(64) void k_obj_solve(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
+                                                         const double* __restrict__ objs, int jac, double delta, double lambda, double tau,
+                                                         const double* __restrict__ dev_scal, double* __restrict__ xo,
+                                                         double* __restrict__ objs_trial, double* __restrict__ part,
+                                                         double* __restrict__ solve_part /* gridDim x 4 */) {
+  if (lambda < 0) lambda = tau * dev_scal[1];
+  const int o = blockIdx.x * 64 + threadIdx.x;
+  double cg = 0, scale = 0, okd = 1;
+  if (o < g.n_objs) obj_solve_one(g, ct, chunk_out, objs, jac, delta, lambda, xo, objs_trial, part, o, cg, scale, okd);
+  // this workgroup's share of the trial scalars (fixed order: shuffle tree over the 64 lanes)
+  cg = wave_sum(cg); scale = wave_sum(scale);
+  okd = -wave_max(-okd);
+  if (threadIdx.x == 0) {
+    solve_part[blockIdx.x * 4 + 0] = cg; solve_part[blockIdx.x * 4 + 1] = 0;
+    solve_part[blockIdx.x * 4 + 2] = scale; solve_part[blockIdx.x * 4 + 3] = okd;
+  }
+}
+
+// block-wide reductions with ONE barrier pair: wave shuffle tree, then every thread adds the 4 wave totals in wave order
+__device__ __forceinline__ double block256_sum1(double v, double* sm4) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
+}
+__device__ __forceinline__ double block256_min1(double v, double* sm4) {
+  v = -wave_max(-v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmin(fmin(sm4[0], sm4[1]), fmin(sm4[2], sm4[3]));
+}
+
+// One LM trial's accept / reject decision.  Control flow restated from g2o optimization_algorithm_levenberg.cpp:69-141
+// (rho, lambda update, <= max_trials per iteration), the iteration loop of sparse_optimizer.cpp:357-425 and the
+// "nBad >= 3" early stop; same order of operations as the host loop in esl_optimize_resident.  Every thread of every
+// workgroup evaluates it on the same inputs (identical result); `writer` alone records trace / progress for the host.
+__device__ __forceinline__ void lm_decide(LmCore& s, double chi, double sc, double okv, int max_iters, int max_trials, bool writer,
+                                          LmHostView* __restrict__ host) {
+  const double tempChi = (okv > 0.5) ? chi : DBL_MAX;
+  const double rho = (s.currentChi - tempChi) / (sc + 1e-3);
+  if (rho > 0 && isfinite(tempChi)) {
+    double alpha = 1. - pow((2 * rho - 1), 3.0);
+    alpha = fmin(alpha, 2. / 3.);
+    s.lambda *= fmax(1. / 3., alpha);
+    s.ni = 2;
+    s.currentChi = tempChi;
+    s.cur ^= 1;          // discardTop: the trial pair (state + its linearisation) becomes the current one
+  } else {
+    s.lambda *= s.ni;    // pop: the current pair is untouched
+    s.ni *= 2;
+  }
+  s.rho = rho;
+  s.qmax++;
+  s.trial_seq++;
+  if (!(rho < 0 && s.qmax < max_trials)) {   // this LM iteration is over
+    s.total_trials += s.qmax;
+    if (writer && s.it < ESL_MAX_TRACE) {
+      host->trace_chi2[s.it] = s.currentChi; host->trace_lambda[s.it] = s.lambda; host->trace_trials[s.it] = s.qmax;
+      host->trace_len = s.it + 1;
+    }
+    if (s.qmax == max_trials || rho == 0) { s.done = 1; s.stop_reason = 1; }
+    else {
+      if ((s.iniChi - s.currentChi) * 1e3 < s.iniChi) s.nBad++; else s.nBad = 0;
+      if (s.nBad >= 3) { s.done = 1; s.stop_reason = 2; }
+    }
+    s.it++;
+    if (s.it >= max_iters) s.done = 1;
+    s.iniChi = s.currentChi;
+    s.qmax = 0;
+  }
+}
+
+// One LM trial, device-driven: (1) decide the PREVIOUS trial from the chi2 its linearisation left in blk_chi and the
+// partials the previous k_lm_step left in sp_in -- every workgroup does this redundantly, so there is no grid-wide
+// handshake; (2) solve (H + lambda I) x = b per ellipsoid for the new lambda from the now-current chunk partials and
+// write the next trial state.  LM state ping-pongs between `in` and `out` (other workgroups may still be reading `in`).
+// first != 0: nothing to decide yet (state initialised by k_chunk_finalize).
+static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_a,
+                                                        const double* __restrict__ chunk_b, double* __restrict__ objs_a,
+                                                        double* __restrict__ objs_b, const LmCore* __restrict__ in,
+                                                        LmCore* __restrict__ out, const double* __restrict__ blk_chi, int n_lin_blocks,
+                                                        const double* __restrict__ sp_in, double* __restrict__ sp_out, int first,
+                                                        int max_iters, int max_trials, LmHostView* __restrict__ host, int jac,
+                                                        double delta, double* __restrict__ xo, double* __restrict__ part) {
+  __shared__ double sm4[4];
+  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+  // all loads of the decision go out together (each is an HBM / fabric round trip: the producers ran on other XCDs)
+  double c = 0, sc = 0, okv = 1;
+  if (!first) {
+#pragma unroll 8
+    for (int k = threadIdx.x; k < n_lin_blocks; k += 256) c += blk_chi[k];
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { c += sp_in[b * 4 + 0]; sc += sp_in[b * 4 + 2]; okv = fmin(okv, sp_in[b * 4 + 3]); }
+  }
+  LmCore s = *in;
+  if (s.done) {   // queued behind a finished run: pass the state on and leave
+    if (writer) *out = s;
+    return;
+  }
+  if (!first) {
+    c = block256_sum1(c, sm4);
+    sc = block256_sum1(sc, sm4);
+    okv = block256_min1(okv, sm4);
+    lm_decide(s, c, sc, okv, max_iters, max_trials, writer, host);
+    if (writer) {
+      if (s.done) {   // results first, then the flag with release semantics: the host reads them as soon as it sees it
+        host->core = s;
+        __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (writer) *out = s;
+  if (s.done) return;
+  const double* chunk_out = s.cur ? chunk_b : chunk_a;
+  const double* objs = s.cur ? objs_b : objs_a;
+  double* objs_trial = s.cur ? objs_a : objs_b;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  double cg = 0, scale = 0, okd = 1;
+  if (o < g.n_objs) obj_solve_one(g, ct, chunk_out, objs, jac, delta, s.lambda, xo, objs_trial, part, o, cg, scale, okd);
+  cg = block256_sum1(cg, sm4);
+  scale = block256_sum1(scale, sm4);
+  okd = block256_min1(okd, sm4);
+  if (threadIdx.x == 0) {
+    sp_out[blockIdx.x * 4 + 0] = cg; sp_out[blockIdx.x * 4 + 1] = 0;
+    sp_out[blockIdx.x * 4 + 2] = scale; sp_out[blockIdx.x * 4 + 3] = okd;
+  }
 }
 
 // chi2 of the trial states, one instantiation per edge type (bbox: one wave per chunk; 3-D: two 32-edge chunks per

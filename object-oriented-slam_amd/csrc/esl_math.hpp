@@ -170,31 +170,43 @@ ESL_HD SE3 se3_exp(const double u[6]) {
   return T;
 }
 
+// Coefficients of SE3Quat::log (se3quat.h:205-240) from d = (trace R - 1) / 2:
+//   omega = f * vee(R - R^T),  f = theta / (2 sin theta);   V^-1 = I - Omega/2 + c Omega^2,
+//   c = (1 - theta / (2 tan(theta/2))) / theta^2.   tan(theta/2) = sin theta / (1 + cos theta) turns the reference's
+// tan() into quantities already at hand (same value to rounding; FP64 tan costs ~200 instructions on gfx950).
+struct LogAux { double d, theta, st, f, c; bool small; };
+ESL_HD void so3_log_coeffs(double d, LogAux& a) {
+  const bool small = d > 0.99999;   // the reference's small-angle branch
+  double theta = 0, st = 0, f = 0.5, c = 1. / 12.;
+  if (!small) {   // (locals, not the struct, inside the branch: the struct form was lowered to indexed scratch stores)
+    theta = acos(d);
+    st = sqrt(1 - d * d);
+    const double inv2st = 0.5 / st;
+    f = theta * inv2st;
+    c = (1 - theta * (1 + d) * inv2st) / (theta * theta);
+  }
+  a.d = d; a.small = small; a.theta = theta; a.st = st; a.f = f; a.c = c;
+}
+ESL_HD void vcross3(const double a[3], const double b[3], double o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// log of (R, t) given as a matrix: out = [omega, V^-1 t];  V^-1 t = t - (w x t)/2 + c w x (w x t)
+ESL_HD void se3_log_R(const Mat3& R, const double t[3], double out[6], LogAux& a) {
+  so3_log_coeffs(0.5 * (R.m[0] + R.m[4] + R.m[8] - 1), a);
+  const double w[3] = {a.f * (R.m[7] - R.m[5]), a.f * (R.m[2] - R.m[6]), a.f * (R.m[3] - R.m[1])};
+  double wt[3], wwt[3];
+  vcross3(w, t, wt);
+  vcross3(w, wt, wwt);
+  out[0] = w[0]; out[1] = w[1]; out[2] = w[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[3 + i] = t[i] - 0.5 * wt[i] + a.c * wwt[i];
+}
 // SE3Quat::log
 ESL_HD void se3_log(const SE3& T, double out[6]) {
-  const Mat3 R = q_to_R(T.r);
-  const double d = 0.5 * (R.m[0] + R.m[4] + R.m[8] - 1);
-  const double dR[3] = {R.m[7] - R.m[5], R.m[2] - R.m[6], R.m[3] - R.m[1]};
-  double f, c;
-  if (d > 0.99999) { f = 0.5; c = 1. / 12.; }
-  else {
-    const double theta = acos(d);
-    f = theta / (2 * sqrt(1 - d * d));
-    c = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
-  }
-  const double w[3] = {f * dR[0], f * dR[1], f * dR[2]};
-  const Mat3 Om = skew(w);
-  const Mat3 Om2 = m3_mul(Om, Om);
-  Mat3 Vinv;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const double id = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
-    Vinv.m[i] = id - 0.5 * Om.m[i] + c * Om2.m[i];
-  }
-  double ups[3];
-  m3_vec(Vinv, T.t, ups);
-  out[0] = w[0]; out[1] = w[1]; out[2] = w[2];
-  out[3] = ups[0]; out[4] = ups[1]; out[5] = ups[2];
+  LogAux a;
+  se3_log_R(q_to_R(T.r), T.t, out, a);
 }
 
 ESL_HD Ell ell_oplus(const Ell& e, const double u[9]) {  // ellipsoid::exp_update
@@ -388,23 +400,50 @@ ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
 // ------------------------------------------------------------------------------------------------
 // 9-DoF 3-D edge
 // ------------------------------------------------------------------------------------------------
-struct YawTable { double s[4], c[4]; };  // sin/cos of k*pi/4 for k = -1,0,1,2, computed once on the host
+// sin/cos of yaw/2 for yaw = k*pi/2, k = -1,0,1,2, and the entries of the yaw rotation matrix Rz built from the
+// NORMALISED quaternion (0,0,s,c) exactly as q_to_R would: cy = 1 - 2 z^2, sy = 2 z w.  Filled once on the host.
+struct YawTable { double s[4], c[4], cy[4], sy[4]; };
+ESL_HD void yaw_table_fill(YawTable& yt, const double half_sin[4], const double half_cos[4]) {
+  for (int k = 0; k < 4; ++k) {
+    const Quat q = q_normalize_pos(Quat{0, 0, half_sin[k], half_cos[k]});
+    yt.s[k] = half_sin[k]; yt.c[k] = half_cos[k];
+    yt.cy[k] = 1 - 2 * q.z * q.z;
+    yt.sy[k] = 2 * q.z * q.w;
+  }
+}
 
-// residual and the chosen hypothesis' relative pose E = T_k^-1 T_est
-ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9],
-                    SE3* E_out = nullptr) {
+// Relative pose of one yaw hypothesis:  E_k = (T_wc T_meas Rz_k)^-1 T_est = Rz_k^T E_0  with  E_0 = (T_wc T_meas)^-1 T_est
+// (EdgeSE3EllipsoidProj-free 3-D edge, Edge.cpp: the measured ellipsoid is tried at 4 yaws and the smallest
+// 9-norm of the error wins).  The reference multiplies everything out per hypothesis; E_0 is shared here and the
+// hypothesis only mixes its first two rows / translation components.
+struct E3dHyp { Mat3 R; double t[3]; LogAux a; };
+ESL_HD void e3d_hypothesis(const Mat3& R0, const double t0[3], double cy, double sy, E3dHyp& h) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    h.R.m[c] = cy * R0.m[c] + sy * R0.m[3 + c];
+    h.R.m[3 + c] = cy * R0.m[3 + c] - sy * R0.m[c];
+    h.R.m[6 + c] = R0.m[6 + c];
+  }
+  h.t[0] = cy * t0[0] + sy * t0[1];
+  h.t[1] = cy * t0[1] - sy * t0[0];
+  h.t[2] = t0[2];
+}
+
+// residual of the 3-D edge; `best` (optional) receives the chosen hypothesis' relative pose and log coefficients
+ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9], E3dHyp* best_out = nullptr) {
   const SE3 Twc = se3_inv(Tcw);
   const SE3 mw = se3_mul(Twc, meas.pose);
-  double best = 0;
+  const SE3 E0 = se3_mul(se3_inv(mw), est.pose);
+  const Mat3 R0 = q_to_R(E0.r);
+  double best = 0, b_cy = 1, b_sy = 0;
+  LogAux b_a;
+  b_a.d = 1; b_a.theta = 0; b_a.st = 0; b_a.f = 0.5; b_a.c = 1. / 12.; b_a.small = true;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    SE3 rot;
-    rot.r = q_normalize_pos(Quat{0, 0, yt.s[k], yt.c[k]});
-    rot.t[0] = rot.t[1] = rot.t[2] = 0;
-    const SE3 Tk = se3_mul(mw, rot);
-    const SE3 E = se3_mul(se3_inv(Tk), est.pose);
+    E3dHyp h;
+    e3d_hypothesis(R0, E0.t, yt.cy[k], yt.sy[k], h);
     double e[9];
-    se3_log(E, e);
+    se3_log_R(h.R, h.t, e, h.a);
     const bool swap = (k == 0 || k == 2);  // yaw = -90 or +90 degrees: a/b swapped
     e[6] = est.s[0] - (swap ? meas.s[1] : meas.s[0]);
     e[7] = est.s[1] - (swap ? meas.s[0] : meas.s[1]);
@@ -413,43 +452,44 @@ ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTa
 #pragma unroll
     for (int i = 0; i < 9; ++i) n2 += e[i] * e[i];
     const double nn = sqrt(n2);
-    if (k == 0 || nn < best) {
-      best = nn;
+    const bool take = (k == 0) || (nn < best);
+    best = take ? nn : best;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) r[i] = e[i];
-      if (E_out) *E_out = E;
-    }
+    for (int i = 0; i < 9; ++i) r[i] = take ? e[i] : r[i];
+    // remember the winner by its scalars only (a conditional copy of the whole hypothesis went through scratch)
+    b_cy = take ? yt.cy[k] : b_cy; b_sy = take ? yt.sy[k] : b_sy;
+    b_a.d = take ? h.a.d : b_a.d; b_a.theta = take ? h.a.theta : b_a.theta; b_a.st = take ? h.a.st : b_a.st;
+    b_a.f = take ? h.a.f : b_a.f; b_a.c = take ? h.a.c : b_a.c; b_a.small = take ? h.a.small : b_a.small;
+  }
+  if (best_out) {
+    e3d_hypothesis(R0, E0.t, b_cy, b_sy, *best_out);
+    best_out->a = b_a;
   }
 }
 
-// d log(E exp(delta)) / d delta at 0 (6x6, row-major; rows/cols ordered [omega, upsilon])
-ESL_HD void dlog_right(const SE3& E, double J[36]) {
-  const Mat3 R = q_to_R(E.r);
-  const double d = 0.5 * (R.m[0] + R.m[4] + R.m[8] - 1);
+// d log(E exp(delta)) / d delta at 0 (6x6, row-major; rows/cols ordered [omega, upsilon]) for E = (R, t) whose log
+// coefficients `a` are already known (so3_log_coeffs of the same R)
+ESL_HD void dlog_right_R(const Mat3& R, const double t[3], const LogAux& a, double J[36]) {
   const double dRv[3] = {R.m[7] - R.m[5], R.m[2] - R.m[6], R.m[3] - R.m[1]};
-  double f, fp, c, cp, theta;
-  const bool small = d > 0.99999;
-  if (small) { f = 0.5; fp = 0.0; c = 1. / 12.; cp = 0.0; theta = 0.0; }
-  else {
-    theta = acos(d);
-    const double st = sqrt(1 - d * d), ct = d;
-    f = theta / (2 * st);
+  const double f = a.f, c = a.c, theta = a.theta;
+  double fp = 0.0, cp = 0.0, inv_theta = 0.0;
+  if (!a.small) {
+    const double st = a.st, ct = a.d;
+    const double inv_st = 1.0 / st;
+    inv_theta = 1.0 / theta;
     // f(d) = theta/(2 sin theta), d theta/dd = -1/sin theta
-    fp = -(st - theta * ct) / (2 * st * st * st);
-    const double th2 = theta * theta;
-    const double tn = tan(theta / 2);
-    c = (1 - theta / (2 * tn)) / th2;
-    // dc/dtheta
-    const double g = theta / (2 * tn);
-    const double gp = 1 / (2 * tn) - theta / (4 * tn * tn) * (1 + tn * tn);
-    cp = (-gp) / th2 - 2 * (1 - g) / (th2 * theta);
+    fp = -(st - theta * ct) * (0.5 * inv_st * inv_st * inv_st);
+    // g = theta / (2 tan(theta/2)), 1/tan(theta/2) = (1 + cos theta) / sin theta
+    const double it = (1 + ct) * inv_st;
+    const double g = 0.5 * theta * it;
+    const double gp = 0.5 * it - 0.25 * theta * (it * it + 1);
+    const double ith2 = inv_theta * inv_theta;
+    cp = (-gp) * ith2 - 2 * (1 - g) * (ith2 * inv_theta);
   }
   const double w[3] = {f * dRv[0], f * dRv[1], f * dRv[2]};
-  const Mat3 Om = skew(w);
-  const Mat3 Om2 = m3_mul(Om, Om);
-  Mat3 Vinv;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) Vinv.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) - 0.5 * Om.m[i] + c * Om2.m[i];
+  double wt[3], wwt[3];
+  vcross3(w, t, wt);
+  vcross3(w, wt, wwt);
   // rotation directions: dR = R [e_j]x
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -457,30 +497,40 @@ ESL_HD void dlog_right(const SE3& E, double J[36]) {
     // columns of R [e_j]x : col j = 0, col j1 = R col j2, col j2 = -R col j1   ([e_j]x e_j1 = e_j2, [e_j]x e_j2 = -e_j1)
     Mat3 dRm;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { dRm.m[a * 3 + j] = 0; dRm.m[a * 3 + j1] = R.m[a * 3 + j2]; dRm.m[a * 3 + j2] = -R.m[a * 3 + j1]; }
+    for (int q = 0; q < 3; ++q) { dRm.m[q * 3 + j] = 0; dRm.m[q * 3 + j1] = R.m[q * 3 + j2]; dRm.m[q * 3 + j2] = -R.m[q * 3 + j1]; }
     const double dd = 0.5 * (dRm.m[0] + dRm.m[4] + dRm.m[8]);
     const double ddR[3] = {dRm.m[7] - dRm.m[5], dRm.m[2] - dRm.m[6], dRm.m[3] - dRm.m[1]};
     double dw[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) dw[a] = fp * dd * dRv[a] + f * ddR[a];
-    // d upsilon = dVinv * t ; dVinv = -0.5 dOm + cp dtheta Om2 + c (dOm Om + Om dOm)
-    const Mat3 dOm = skew(dw);
-    const Mat3 A1 = m3_mul(dOm, Om), A2 = m3_mul(Om, dOm);
-    const double dtheta = small ? 0.0 : (w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2]) / theta;
-    Mat3 dV;
+    for (int q = 0; q < 3; ++q) dw[q] = fp * dd * dRv[q] + f * ddR[q];
+    // d upsilon = dVinv t,  dVinv = -dOm/2 + cp dtheta Om^2 + c (dOm Om + Om dOm)   -- as cross products
+    const double dtheta = a.small ? 0.0 : (w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2]) * inv_theta;
+    double dwt[3], dw_wt[3], w_dwt[3];
+    vcross3(dw, t, dwt);
+    vcross3(dw, wt, dw_wt);
+    vcross3(w, dwt, w_dwt);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) dV.m[i] = -0.5 * dOm.m[i] + cp * dtheta * Om2.m[i] + c * (A1.m[i] + A2.m[i]);
-    double du[3];
-    m3_vec(dV, E.t, du);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { J[a * 6 + j] = dw[a]; J[(3 + a) * 6 + j] = du[a]; }
+    for (int q = 0; q < 3; ++q) {
+      J[q * 6 + j] = dw[q];
+      J[(3 + q) * 6 + j] = -0.5 * dwt[q] + (cp * dtheta) * wwt[q] + c * (dw_wt[q] + w_dwt[q]);
+    }
   }
   // translation directions: dt = R e_j -> d upsilon = Vinv R e_j ; d omega = 0
-  const Mat3 VR = m3_mul(Vinv, R);
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < 3; ++j) {
+    const double col[3] = {R.m[j], R.m[3 + j], R.m[6 + j]};
+    double wc[3], wwc[3];
+    vcross3(w, col, wc);
+    vcross3(w, wc, wwc);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { J[a * 6 + 3 + j] = 0.0; J[(3 + a) * 6 + 3 + j] = VR.m[a * 3 + j]; }
+    for (int q = 0; q < 3; ++q) { J[q * 6 + 3 + j] = 0.0; J[(3 + q) * 6 + 3 + j] = col[q] - 0.5 * wc[q] + c * wwc[q]; }
+  }
+}
+ESL_HD void dlog_right(const SE3& E, double J[36]) {
+  const Mat3 R = q_to_R(E.r);
+  LogAux a;
+  so3_log_coeffs(0.5 * (R.m[0] + R.m[4] + R.m[8] - 1), a);
+  dlog_right_R(R, E.t, a, J);
 }
 
 // Ad(T) for twists ordered [omega, upsilon]  (SE3Quat::adj, se3quat.h:324-333)
@@ -500,18 +550,18 @@ ESL_HD void se3_adj(const SE3& T, double A[36]) {
 
 // The 3-D edge's Jacobian wrt the ellipsoid is [[Jp (6x6), 0], [0, I3]]: the scale rows are s - s_k.  Jp only:
 ESL_HD void jac_e3d_pose(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9], double Jp[36]) {
-  SE3 E;
-  res_e3d(Tcw, est, meas, yt, r, &E);
-  dlog_right(E, Jp);
+  E3dHyp h;
+  res_e3d(Tcw, est, meas, yt, r, &h);
+  dlog_right_R(h.R, h.t, h.a, Jp);
 }
 
 // Analytic Jacobians of the 3-D edge.  Jo 9x9, Jc 9x6 (may be null).
 ESL_HD void jac_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9],
                     double* Jo, double* Jc) {
-  SE3 E;
-  res_e3d(Tcw, est, meas, yt, r, &E);
+  E3dHyp h;
+  res_e3d(Tcw, est, meas, yt, r, &h);
   double Jp[36];
-  dlog_right(E, Jp);
+  dlog_right_R(h.R, h.t, h.a, Jp);
   if (Jo) {
 #pragma unroll
     for (int a = 0; a < 9; ++a)

@@ -89,8 +89,10 @@ def test_mapping_two_shards_match_single_context(pkg, ctx):
         np.testing.assert_allclose(rep["trace_chi2"], ref["trace_chi2"], rtol=1e-12)
     assert reps[0]["trace_chi2"] == reps[1]["trace_chi2"]          # bit-identical decisions on every rank
     assert reps[0]["trace_lambda"] == reps[1]["trace_lambda"]
-    # block-diagonal system: an ellipsoid's arithmetic does not depend on which shard holds it
-    np.testing.assert_array_equal(objs, ro)
+    # block-diagonal system: an ellipsoid's arithmetic does not depend on which shard holds it.  (Not bit-equal: the
+    # single-context run is device-driven and its first linearisation is the instantiation that also validates the
+    # bbox edges, the sharded run is host-driven -- two compilations of the same formulas, last-ulp differences.)
+    np.testing.assert_allclose(objs, ro, rtol=1e-11, atol=1e-13)
     assert ar.calls[0] == ar.calls[1] > 0
 
 
