@@ -639,7 +639,8 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   const DevGraph& g = c->g;
   LmHostView* hv = (LmHostView*)c->lm_host;
   LmCore* core = (LmCore*)c->lm_dev;   // [2]
-  if (g.n_objs == 0 || (g.n_bbox == 0 && g.n_e3d == 0 && c->n_grav_edges == 0)) {   // empty graph
+  const bool sharded = c->comm != nullptr;   // collective run: every rank issues the same sequence of all-gathers
+  if (!sharded && (g.n_objs == 0 || (g.n_bbox == 0 && g.n_e3d == 0 && c->n_grav_edges == 0))) {   // empty graph
     out->stop_reason = 3;
     return ESL_OK;
   }
@@ -653,12 +654,13 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   if (rc) return rc;
   {
     ProfScope ps(c, 4);
-    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out, c->objs,
-                       c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part, c->tickets, c->dev_scal,
-                       (LmScalars*)c->host_scal_dev, p->tau, core, c->chol_info + 2, c->n_grav_edges,
+    hipLaunchKernelGGL(k_chunk_finalize, dim3(std::max(1, (g.n_objs + 255) / 256)), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out,
+                       c->objs, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part, c->tickets, c->dev_scal,
+                       (LmScalars*)c->host_scal_dev, p->tau, sharded ? (LmCore*)nullptr : core, c->chol_info + 2, c->n_grav_edges,
                        (LmHostView*)c->lm_host_dev);
     ESL_HIP_TRY(hipGetLastError());
   }
+  if (sharded && (rc = comm_gather_scalars_device(c))) return rc;   // collective: every rank's {chi2, max diag, has_edges}
   if (p->max_iters <= 0) {   // nothing to iterate: report the start state
     ESL_HIP_TRY(hipStreamSynchronize(c->stream));
     const LmScalars* h = (const LmScalars*)c->host_scal;
@@ -670,45 +672,60 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   }
   const int max_total = p->max_iters * std::max(1, p->max_trials);
   const int depth = 2;   // trials kept in flight ahead of the device's progress counter
-  const int n_step_blocks = (g.n_objs + 255) / 256;
+  const int n_step_blocks = std::max(1, (g.n_objs + 255) / 256);
+  const int batch = 4;   // sharded: trials enqueued per round (a fixed number, so that all ranks issue the same collectives)
   const int n_lin_blocks = (c->n_ids_e3 + 2 * kLinWaves - 1) / (2 * kLinWaves) + (c->n_ids_bb + kLinWaves - 1) / kLinWaves;
   // launch k carries trial k's solve and trial k-1's decision: one launch more than there are trials
   int enq = 0, seen = 0;
   bool done = false;
   while (!done) {
-    while (enq <= max_total && enq - seen < depth) {
+    const int enq_limit = sharded ? enq + batch : max_total + 1;
+    if (sharded && enq > max_total + batch) { set_error("device-side LM did not terminate"); return ESL_ERR_STATE; }
+    while (enq < enq_limit && (sharded || enq - seen < depth)) {
       const LmCore* in = core + (enq & 1);
       LmCore* nxt = core + ((enq + 1) & 1);
       {
         ProfScope ps(c, 1);
         hipLaunchKernelGGL(k_lm_step, dim3(n_step_blocks), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out, c->chunk_out2,
                            c->objs, c->objs_trial, in, nxt, c->blk_chi, n_lin_blocks, c->solve_part + 4 * n_step_blocks * (enq & 1),
-                           c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? 1 : 0, p->max_iters, p->max_trials,
-                           (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo, c->obj_part);
+                           c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? (sharded ? 2 : 1) : 0, p->max_iters,
+                           p->max_trials, (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo, c->obj_part,
+                           sharded ? c->dev_gather : (const double*)nullptr, sharded ? c->comm_ranks : 0, p->tau);
         ESL_HIP_TRY(hipGetLastError());
       }
       c->prof_gate = (enq == 1);   // the second trial's linearisation is the sampled one (always a live launch when it exists)
       rc = map_launch_linearize(c, false, nullptr, nullptr, nxt);
       c->prof_gate = true;
       if (rc) return rc;
+      if (sharded) {   // this rank's share of the trial's scalars, then everybody's (one small all-gather on the stream)
+        hipLaunchKernelGGL(k_lm_partials, dim3(1), dim3(256), 0, c->stream, c->blk_chi, n_lin_blocks,
+                           c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), n_step_blocks, c->dev_scal);
+        ESL_HIP_TRY(hipGetLastError());
+        ProfScope ps(c, 6);
+        if ((rc = comm_gather_scalars_device(c))) return rc;
+      }
       ++enq;
     }
-    // wait for the device to decide at least one more trial: spin on the mapped counter, fall back to a stream sync
+    // wait for the device to decide at least one more trial (sharded: all but the last of the trials enqueued so far --
+    // a condition every rank evaluates on the same sequence of decisions): spin on the mapped counter, fall back to a
+    // stream sync
+    const int want = sharded ? enq - 1 : seen + 1;
     int s = seen;
     for (int spin = 0; spin < 400000; ++spin) {
       s = __atomic_load_n(&hv->seq, __ATOMIC_ACQUIRE);
-      if (s > seen || __atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) break;
+      if (s >= want || __atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) break;
     }
-    if (s == seen && !__atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) {
+    if (s < want && !__atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) {
       ESL_HIP_TRY(hipStreamSynchronize(c->stream));
       s = __atomic_load_n(&hv->seq, __ATOMIC_ACQUIRE);
-      if (s == seen && !hv->done) { set_error("device-side LM made no progress"); return ESL_ERR_STATE; }
+      if (s < want && !hv->done) { set_error("device-side LM made no progress"); return ESL_ERR_STATE; }
     }
     seen = s;
     done = __atomic_load_n(&hv->done, __ATOMIC_ACQUIRE) != 0;
   }
   // `done` was stored with release semantics after the results: they are visible without draining the stream (the
   // one or two no-op launches still queued touch nothing the caller can see)
+  if (sharded) ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // leave no collective in flight behind the caller's back
   const LmCore& r = hv->core;
   out->n_bbox_dropped = hv->n_dropped;
   out->n_bbox_valid = g.n_bbox - hv->n_dropped;
@@ -734,7 +751,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
 int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
   if (!c || !p || !out) return ESL_ERR_INVALID;
   std::memset(out, 0, sizeof(*out));
-  if (c->graph_loaded && c->g.n_free_cams == 0 && !c->comm) {   // mapping mode, one GPU: nothing waits on the host
+  if (c->graph_loaded && c->g.n_free_cams == 0) {   // mapping mode: the LM runs on the device, nothing waits on the host
     int rc0 = lm_begin_enqueue(c, p, true);
     if (rc0) return rc0;
     return optimize_mapping_device(c, p, out);
@@ -754,43 +771,15 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
   }
   if (!any_edge && !any_grav) { out->stop_reason = 3; return ESL_OK; }
 
-
+  // SLAM mode (free cameras): host-driven LM over the step API -- each trial's dense factorisation dwarfs the host
+  // round trip (optimization_algorithm_levenberg.cpp:69-141, statement for statement)
   double lambda = -1, ni = 2;
   int nBad = 0, it = 0, total_trials = 0;
   bool ok_outer = true;
   double currentChi = 0;
-  const bool fused = !c->lm.slam;  // mapping mode: linearise + first trial enqueued back to back, one host sync
   for (it = 0; it < p->max_iters && ok_outer; ++it) {
     esl_lm_partials lin;
-    bool first_trial_done = false;
-    esl_lm_partials tr0;
-    if (fused && c->comm) {
-      // sharded: same sequence, the scalars of all shards are all-gathered (RCCL) and reduced in rank order
-      double ex[5];
-      if ((rc = map_launch_linearize(c, it == 0))) return rc;
-      if (it == 0) {
-        if ((rc = comm_exchange(c, ex))) return rc;
-        lin.chi2 = ex[0]; lin.max_diag = ex[1];
-        lambda = p->tau * lin.max_diag;
-      } else { lin.chi2 = currentChi; lin.max_diag = 0; }
-      if ((rc = map_launch_try(c, lambda))) return rc;
-      if ((rc = comm_exchange(c, ex))) return rc;
-      tr0.chi2 = ex[2]; tr0.scale = ex[3]; tr0.solve_ok = ex[4] > 0.5 ? 1 : 0;
-      c->lm.have_trial = true;
-      first_trial_done = true;
-    } else if (fused) {
-      if ((rc = map_launch_linearize(c, it == 0))) return rc;
-      if ((rc = map_launch_try(c, it == 0 ? -1.0 : lambda))) return rc;
-      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
-      const LmScalars* h = (const LmScalars*)c->host_scal;
-      if (it == 0) { lin.chi2 = h->chi2_lin; lin.max_diag = h->max_diag; }
-      else { lin.chi2 = currentChi; lin.max_diag = 0; }  // same state as the accepted trial: chi2 carries over
-      tr0.chi2 = h->chi2_trial; tr0.scale = h->scale; tr0.solve_ok = h->ok > 0.5 ? 1 : 0;
-      c->lm.have_trial = true;
-      first_trial_done = true;
-    } else {
-      if ((rc = esl_lm_linearize(c, &lin))) return rc;
-    }
+    if ((rc = esl_lm_linearize(c, &lin))) return rc;
     currentChi = lin.chi2;
     const double iniChi = currentChi;
     if (it == 0) {
@@ -803,15 +792,7 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
     int qmax = 0;
     do {
       esl_lm_partials tr;
-      if (first_trial_done) { tr = tr0; first_trial_done = false; }
-      else if (fused && c->comm) {
-        double ex[5];
-        if ((rc = map_launch_try(c, lambda))) return rc;
-        if ((rc = comm_exchange(c, ex))) return rc;
-        tr.chi2 = ex[2]; tr.scale = ex[3]; tr.solve_ok = ex[4] > 0.5 ? 1 : 0;
-        c->lm.have_trial = true;
-      }
-      else if ((rc = esl_lm_try_step(c, lambda, &tr))) return rc;
+      if ((rc = esl_lm_try_step(c, lambda, &tr))) return rc;
       double tempChi = tr.solve_ok ? tr.chi2 : DBL_MAX;
       rho = (currentChi - tempChi) / (tr.scale + 1e-3);
       if (rho > 0 && std::isfinite(tempChi)) {

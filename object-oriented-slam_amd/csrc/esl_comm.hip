@@ -71,19 +71,19 @@ static int gather_scalars(esl_ctx* c) {
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   return ESL_OK;
 }
-int comm_exchange(esl_ctx* c, double out[5]) {
+// every rank's 8-double dev_scal block -> c->dev_gather (device, n_ranks x 8), ordered on the context's stream.
+// RCCL: one ncclAllGather enqueued on the stream (no host involvement).  Host transport: staged through the callback.
+int comm_gather_scalars_device(esl_ctx* c) {
   const int n = c->comm_ranks;
-  int rc = gather_scalars(c);
-  if (rc) return rc;
-  out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; out[4] = 1;
-  for (int r = 0; r < n; ++r) {  // fixed rank order on every rank => identical decisions everywhere
-    const double* v = c->host_gather + 8 * r;
-    out[0] += v[0];
-    out[1] = v[1] > out[1] ? v[1] : out[1];
-    out[2] += v[2];
-    out[3] += v[3];
-    out[4] = v[4] < out[4] ? v[4] : out[4];
+  if (c->host_allreduce) {
+    int rc = gather_scalars(c);   // -> c->host_gather
+    if (rc) return rc;
+    ESL_HIP_TRY(hipMemcpyAsync(c->dev_gather, c->host_gather, (size_t)n * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // host_gather is reused by the next exchange
+    return ESL_OK;
   }
+  const int rc = g_rccl.allgather(c->dev_scal, c->dev_gather, 8, kNcclDouble, c->comm, c->stream);
+  if (rc != 0) return nccl_fail(rc, "ncclAllGather");
   return ESL_OK;
 }
 int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count) {
@@ -164,6 +164,7 @@ int esl_comm_init_host(esl_ctx* c, int32_t n_ranks, int32_t rank, esl_host_allre
   c->comm = (void*)c;   // non-null marks "exchange active"; never handed to RCCL on this transport
   c->comm_ranks = n_ranks; c->comm_rank = rank;
   c->g.shard_rank = rank;
+  ESL_HIP_TRY(hipMalloc((void**)&c->dev_gather, (size_t)n_ranks * 8 * sizeof(double)));
   ESL_HIP_TRY(hipHostMalloc((void**)&c->host_gather, (size_t)n_ranks * 8 * sizeof(double), hipHostMallocDefault));
   ESL_HIP_TRY(hipMemsetAsync(c->dev_scal, 0, 8 * sizeof(double), c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));

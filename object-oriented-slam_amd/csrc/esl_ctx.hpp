@@ -78,9 +78,8 @@ struct ProfScope {
   ~ProfScope();
 };
 int prof_drain(esl_ctx* c);
-// all-gather the 8-double dev_scal block of every rank and reduce in rank order:
-// out = {sum chi2_lin, max max_diag, sum chi2_trial, sum scale, min ok}
-int comm_exchange(esl_ctx* c, double out[5]);
+// all-gather the 8-double dev_scal block of every rank into c->dev_gather (device), ordered on the context's stream
+int comm_gather_scalars_device(esl_ctx* c);
 // SLAM mode: in-place sum over ranks of a device buffer (RCCL all-reduce); no-op without a communicator
 int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count);
 // {sum, max, sum, min} of 4 device scalars over ranks -> host

@@ -304,6 +304,12 @@ struct LmHostView {   // mapped host memory, written by the device only: progres
   int trace_len, pad;
 };
 
+__device__ __forceinline__ void lm_core_init(LmCore& s, double chi2, double max_diag, double tau) {
+  s.lambda = tau * max_diag;   // computeLambdaInit
+  s.ni = 2; s.currentChi = chi2; s.iniChi = chi2; s.chi2_initial = chi2; s.rho = 0;
+  s.cur = 0; s.it = 0; s.qmax = 0; s.nBad = 0; s.total_trials = 0; s.done = 0; s.stop_reason = 0; s.trial_seq = 0;
+}
+
 // Publish this workgroup's results and learn whether it is the last one.  Recipe of the CDNA guide (G16):
 // plain stores -> __syncthreads() -> ONE lane: agent-scope release + drained counter increment; the last
 // workgroup does ONE agent-scope acquire before reading the others' results.  (A __threadfence() in every
@@ -455,20 +461,23 @@ static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, Chunk
     if (threadIdx.x == 0) {
       dev_scal[0] = c; dev_scal[1] = m;
       host->chi2_lin = c; host->max_diag = m;
-      if (st) {   // start of a device-driven LM run: computeLambdaInit and the bookkeeping of iteration 0
-        LmCore s;
-        s.lambda = tau * m; s.ni = 2; s.currentChi = c; s.iniChi = c; s.chi2_initial = c; s.rho = 0;
-        s.cur = 0; s.it = 0; s.qmax = 0; s.nBad = 0; s.total_trials = 0; s.done = 0; s.stop_reason = 0; s.trial_seq = 0;
+      if (hv) {   // start of a device-driven LM run
         const int nd = *n_dropped;
         hv->n_dropped = nd;
         *n_dropped = 0;   // ready for the next run (the first linearisation of a run counts into it)
-        if (g.n_bbox - nd <= 0 && g.n_e3d == 0 && n_grav == 0) {   // no active edge: nothing to optimise (stop_reason 3)
-          s.done = 1; s.stop_reason = 3;
-          hv->core = s;
-          hv->trace_len = 0;
-          __hip_atomic_store(&hv->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const bool any_edge = (g.n_bbox - nd > 0) || g.n_e3d > 0 || n_grav > 0;
+        dev_scal[5] = any_edge ? 1.0 : 0.0;   // sharded run: the ranks' flags are gathered, k_lm_step initialises
+        if (st) {   // single GPU: computeLambdaInit and the bookkeeping of iteration 0 right here
+          LmCore s;
+          lm_core_init(s, c, m, tau);
+          if (!any_edge) {   // no active edge: nothing to optimise (stop_reason 3)
+            s.done = 1; s.stop_reason = 3;
+            hv->core = s;
+            hv->trace_len = 0;
+            __hip_atomic_store(&hv->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          *st = s;
         }
-        *st = s;
       }
       *ticket = 0;
     }
@@ -616,32 +625,55 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
                                                         LmCore* __restrict__ out, const double* __restrict__ blk_chi, int n_lin_blocks,
                                                         const double* __restrict__ sp_in, double* __restrict__ sp_out, int first,
                                                         int max_iters, int max_trials, LmHostView* __restrict__ host, int jac,
-                                                        double delta, double* __restrict__ xo, double* __restrict__ part) {
+                                                        double delta, double* __restrict__ xo, double* __restrict__ part,
+                                                        const double* __restrict__ gathered, int n_ranks, double tau) {
+  // Sharded run (n_ranks > 0): `gathered` holds every rank's 8-double block {chi2_lin, max_diag, chi2_trial, scale, ok,
+  // has_edges, -, -} (all-gathered on this stream); the decision adds them in rank order, so every rank decides alike.
+  // first: 1 = state in `in` is initialised (single GPU), 2 = initialise it here from the gathered linearisation scalars.
   __shared__ double sm4[4];
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   // all loads of the decision go out together (each is an HBM / fabric round trip: the producers ran on other XCDs)
   double c = 0, sc = 0, okv = 1;
-  if (!first) {
+  if (!first && n_ranks == 0) {
 #pragma unroll 8
     for (int k = threadIdx.x; k < n_lin_blocks; k += 256) c += blk_chi[k];
     for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { c += sp_in[b * 4 + 0]; sc += sp_in[b * 4 + 2]; okv = fmin(okv, sp_in[b * 4 + 3]); }
   }
-  LmCore s = *in;
+  LmCore s;
+  if (first == 2) {
+    double chi = 0, md = 0, any = 0;
+    for (int r = 0; r < n_ranks; ++r) { chi += gathered[r * 8 + 0]; md = fmax(md, gathered[r * 8 + 1]); any = fmax(any, gathered[r * 8 + 5]); }
+    lm_core_init(s, chi, md, tau);
+    if (any < 0.5) {   // no rank has an active edge
+      s.done = 1; s.stop_reason = 3;
+      if (writer) {
+        host->core = s;
+        host->trace_len = 0;
+        __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  } else {
+    s = *in;
+  }
   if (s.done) {   // queued behind a finished run: pass the state on and leave
     if (writer) *out = s;
     return;
   }
   if (!first) {
-    c = block256_sum1(c, sm4);
-    sc = block256_sum1(sc, sm4);
-    okv = block256_min1(okv, sm4);
+    if (n_ranks > 0) {
+      for (int r = 0; r < n_ranks; ++r) { c += gathered[r * 8 + 2]; sc += gathered[r * 8 + 3]; okv = fmin(okv, gathered[r * 8 + 4]); }
+    } else {
+      c = block256_sum1(c, sm4);
+      sc = block256_sum1(sc, sm4);
+      okv = block256_min1(okv, sm4);
+    }
     lm_decide(s, c, sc, okv, max_iters, max_trials, writer, host);
     if (writer) {
       if (s.done) {   // results first, then the flag with release semantics: the host reads them as soon as it sees it
         host->core = s;
         __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   if (writer) *out = s;
@@ -659,6 +691,21 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
     sp_out[blockIdx.x * 4 + 0] = cg; sp_out[blockIdx.x * 4 + 1] = 0;
     sp_out[blockIdx.x * 4 + 2] = scale; sp_out[blockIdx.x * 4 + 3] = okd;
   }
+}
+
+// Sharded run: this rank's share of a trial's scalars -> dev_scal[2..4], the send buffer of the all-gather
+static __global__ __launch_bounds__(256) void k_lm_partials(const double* __restrict__ blk_chi, int n_lin_blocks,
+                                                            const double* __restrict__ sp, int n_step_blocks,
+                                                            double* __restrict__ dev_scal) {
+  __shared__ double sm4[4];
+  double c = 0, sc = 0, okv = 1;
+#pragma unroll 8
+  for (int k = threadIdx.x; k < n_lin_blocks; k += 256) c += blk_chi[k];
+  for (int b = threadIdx.x; b < n_step_blocks; b += 256) { c += sp[b * 4 + 0]; sc += sp[b * 4 + 2]; okv = fmin(okv, sp[b * 4 + 3]); }
+  c = block256_sum1(c, sm4);
+  sc = block256_sum1(sc, sm4);
+  okv = block256_min1(okv, sm4);
+  if (threadIdx.x == 0) { dev_scal[2] = c; dev_scal[3] = sc; dev_scal[4] = okv; }
 }
 
 // chi2 of the trial states, one instantiation per edge type (bbox: one wave per chunk; 3-D: two 32-edge chunks per

@@ -167,3 +167,33 @@ def test_slam_first_reduced_system_is_the_sum_of_the_shards(pkg, ctx):
         np.testing.assert_allclose(Hcc, Hcc_ref, rtol=1e-11, atol=1e-9 * np.abs(Hcc_ref).max())
         np.testing.assert_allclose(S, S_ref, rtol=0, atol=1e-10 * np.abs(S_ref).max())
     np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("slam", [False, True])
+def test_rccl_single_rank_communicator_matches_plain_run(pkg, ctx, slam):
+    """The RCCL transport itself (ncclAllGather / ncclAllReduce enqueued on the context's stream) with a 1-rank
+    communicator: same LM run as without a communicator (the partial sums are formed in a different order: ~1e-15)."""
+    g, c, o, _ = pkg.synth.make_graph(30, 8, 300, seed=21, slam=slam)
+    p = pkg.default_lm_params(jacobian_mode=1)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ref = ctx.optimize_resident(p)
+    rc, ro = ctx.download_states()
+    cx = pkg.Context(0)
+    try:
+        cx.upload_graph(g); cx.upload_states(c, o)
+        cx.comm_init(1, 0, pkg.lib.comm_unique_id())
+        rep = cx.optimize_resident(p)
+        cc, oo = cx.download_states()
+        # a second collective run on the same communicator (state of the exchange buffers carries nothing over)
+        cx.upload_states(c, o)
+        rep2 = cx.optimize_resident(p)
+        cx.comm_destroy()
+    finally:
+        cx.close()
+    for r in (rep, rep2):
+        assert r["iterations"] == ref["iterations"]
+        assert r["trace_trials"] == ref["trace_trials"]
+        np.testing.assert_allclose(r["trace_chi2"], ref["trace_chi2"], rtol=1e-9)
+        assert r["stop_reason"] == ref["stop_reason"]
+    np.testing.assert_allclose(oo, ro, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(cc, rc, rtol=1e-8, atol=1e-10)
