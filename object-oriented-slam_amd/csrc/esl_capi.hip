@@ -75,6 +75,66 @@ static void dev_free(T** p) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
+template <class T>
+static void forget(T** p) { *p = nullptr; }   // interior pointer of an arena
+
+// ---- arenas ---------------------------------------------------------------------------------------
+// Device pointers handed out by the stages are INTERIOR pointers of c->arena_graph / c->arena_work: never hipFree()d
+// one by one (free_graph only forgets them), the arenas grow and are released with the context.
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static int arena_reserve(char** dev, size_t* cap, size_t need) {
+  if (need <= *cap) return ESL_OK;
+  if (*dev) { (void)hipFree(*dev); *dev = nullptr; *cap = 0; }
+  const size_t want = need + need / 2 + 4096;
+  ESL_HIP_TRY(hipMalloc((void**)dev, want));
+  *cap = want;
+  return ESL_OK;
+}
+struct UploadStage {
+  struct Fix { void** dst; size_t off; };
+  std::vector<char> blob;
+  std::vector<Fix> fixes;
+  template <class T>
+  void add(T** dst, const T* src, size_t n) {
+    const size_t off = align_up(blob.size(), 256);
+    blob.resize(off + std::max<size_t>(n, 1) * sizeof(T));
+    if (n) std::memcpy(blob.data() + off, src, n * sizeof(T));
+    fixes.push_back({(void**)dst, off});
+  }
+  int commit(esl_ctx* c) {
+    const size_t need = std::max<size_t>(blob.size(), 256);
+    int rc = arena_reserve(&c->arena_graph, &c->arena_graph_cap, need);
+    if (rc) return rc;
+    if (need > c->stage_host_cap) {
+      if (c->stage_host) { (void)hipHostFree(c->stage_host); c->stage_host = nullptr; c->stage_host_cap = 0; }
+      const size_t want = need + need / 2 + 4096;
+      ESL_HIP_TRY(hipHostMalloc((void**)&c->stage_host, want, hipHostMallocDefault));
+      c->stage_host_cap = want;
+    }
+    std::memcpy(c->stage_host, blob.data(), blob.size());
+    ESL_HIP_TRY(hipMemcpyAsync(c->arena_graph, c->stage_host, blob.size(), hipMemcpyHostToDevice, c->stream));
+    for (const Fix& f : fixes) *f.dst = c->arena_graph + f.off;
+    return ESL_OK;
+  }
+};
+struct WorkStage {
+  struct Fix { void** dst; size_t off; };
+  size_t total = 0;
+  std::vector<Fix> fixes;
+  template <class T>
+  void add(T** dst, size_t n) {
+    const size_t off = align_up(total, 256);
+    total = off + std::max<size_t>(n, 1) * sizeof(T);
+    fixes.push_back({(void**)dst, off});
+  }
+  int commit(esl_ctx* c) {
+    int rc = arena_reserve(&c->arena_work, &c->arena_work_cap, std::max<size_t>(total, 256));
+    if (rc) return rc;
+    for (const Fix& f : fixes) *f.dst = c->arena_work + f.off;
+    return ESL_OK;
+  }
+};
+
 extern "C" {
 
 int esl_abi_version(void) { return ESL_ABI_VERSION; }
@@ -131,20 +191,23 @@ int esl_ctx_create(int device_id, esl_ctx** out) {
 
 static void free_graph(esl_ctx* c) {
   DevGraph& g = c->g;
-  dev_free(&g.bb_start); dev_free(&g.e3_start); dev_free(&g.gr_cnt);
-  dev_free(&g.bb_cam); dev_free(&g.bb_obj); dev_free(&g.bb_meas); dev_free(&g.bb_w); dev_free(&g.bb_valid);
-  dev_free(&g.e3_cam); dev_free(&g.e3_obj); dev_free(&g.e3_meas); dev_free(&g.e3_w);
-  dev_free(&g.od_i); dev_free(&g.od_j); dev_free(&g.od_meas); dev_free(&g.od_info);
-  dev_free(&g.cam_fixed); dev_free(&g.cam_slot);
-  dev_free(&g.cbb_start); dev_free(&g.cbb_edge); dev_free(&g.ce3_start); dev_free(&g.ce3_edge);
-  dev_free(&g.cod_start); dev_free(&g.cod_edge);
+  (void)hipStreamSynchronize(c->stream);   // nothing may still read the arenas that are about to be rewritten
+  forget(&g.bb_start); forget(&g.e3_start); forget(&g.gr_cnt);
+  forget(&g.bb_cam); forget(&g.bb_obj); forget(&g.bb_meas); forget(&g.bb_w); forget(&g.bb_valid);
+  forget(&g.e3_cam); forget(&g.e3_obj); forget(&g.e3_meas); forget(&g.e3_w);
+  forget(&g.od_i); forget(&g.od_j); forget(&g.od_meas); forget(&g.od_info);
+  forget(&g.cam_fixed); forget(&g.cam_slot);
+  forget(&g.cbb_start); forget(&g.cbb_edge); forget(&g.ce3_start); forget(&g.ce3_edge);
+  forget(&g.cod_start); forget(&g.cod_edge);
+  forget(&c->ck_obj); forget(&c->ck_type); forget(&c->ck_begin); forget(&c->ck_end); forget(&c->ck_ostart);
+  forget(&c->chunk_out); forget(&c->chunk_out2); forget(&c->chunk_chi); forget(&c->blk_part); forget(&c->solve_part); forget(&c->blk_chi);
+  forget(&c->ck_ids_bb); forget(&c->ck_ids_e3);
+  c->n_chunks = 0;
+  forget(&c->cams); forget(&c->cams_trial); forget(&c->objs); forget(&c->objs_trial);
+  forget(&c->Hoo); forget(&c->bo); forget(&c->xo); forget(&c->obj_part);
+  // SLAM-mode buffers and snapshots are separate allocations (esl_slam.hip, esl_states_snapshot)
   dev_free(&g.ue_start); dev_free(&g.ue_id); dev_free(&g.ue_slot);
   dev_free(&c->Linv_ws); dev_free(&c->z_ws);
-  dev_free(&c->ck_obj); dev_free(&c->ck_type); dev_free(&c->ck_begin); dev_free(&c->ck_end); dev_free(&c->ck_ostart);
-  dev_free(&c->chunk_out); dev_free(&c->chunk_out2); dev_free(&c->chunk_chi); dev_free(&c->blk_part); dev_free(&c->solve_part); dev_free(&c->blk_chi); dev_free(&c->ck_ids_bb); dev_free(&c->ck_ids_e3);
-  c->n_chunks = 0;
-  dev_free(&c->cams); dev_free(&c->cams_trial); dev_free(&c->objs); dev_free(&c->objs_trial);
-  dev_free(&c->Hoo); dev_free(&c->bo); dev_free(&c->xo); dev_free(&c->obj_part);
   dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
   dev_free(&c->Abb); dev_free(&c->Ae3); dev_free(&c->Aod); dev_free(&c->Dinv); dev_free(&c->Yb); dev_free(&c->Ye3);
   dev_free(&c->S); dev_free(&c->cam_part); dev_free(&c->od_part);
@@ -159,6 +222,10 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (!c) return ESL_OK;
   (void)hipSetDevice(c->device);
   free_graph(c);
+  if (c->arena_graph) (void)hipFree(c->arena_graph);
+  if (c->arena_work) (void)hipFree(c->arena_work);
+  if (c->stage_host) (void)hipHostFree(c->stage_host);
+  if (c->fit_slab) (void)hipFree(c->fit_slab);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->host_part) (void)hipHostFree(c->host_part);
   dev_free(&c->dev_part);
@@ -231,6 +298,10 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   free_graph(c);
   DevGraph& d = c->g;
   hipStream_t st = c->stream;
+  // every array of the device-resident graph goes into ONE staging blob -> one H2D copy into a grow-only arena;
+  // work buffers come from a second arena (a per-frame esl_optimize used to pay ~45 hipMalloc/hipFree pairs here)
+  UploadStage up;
+  WorkStage wk;
   d.n_cams = g->n_cams; d.n_objs = g->n_objs; d.n_bbox = g->n_bbox; d.n_e3d = g->n_e3d; d.n_odom = g->n_odom;
   d.K[0] = g->fx; d.K[1] = g->fy; d.K[2] = g->cx; d.K[3] = g->cy;
   d.grav_n[0] = g->grav_normal[0]; d.grav_n[1] = g->grav_normal[1]; d.grav_n[2] = g->grav_normal[2];
@@ -256,19 +327,17 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     }
     c->h_bb_cam = cam; c->h_bb_obj = obj;
     h_bb_start = start;
-    if ((rc = dev_upload(&d.bb_start, start.data(), start.size(), st))) return rc;
-    if ((rc = dev_upload(&d.bb_cam, cam.data(), cam.size(), st))) return rc;
-    if ((rc = dev_upload(&d.bb_obj, obj.data(), obj.size(), st))) return rc;
-    if ((rc = dev_upload(&d.bb_meas, meas.data(), meas.size(), st))) return rc;
-    if ((rc = dev_upload(&d.bb_w, w.data(), w.size(), st))) return rc;
-    if ((rc = dev_upload(&d.bb_valid, valid.data(), valid.size(), st))) return rc;
-    ESL_HIP_TRY(hipStreamSynchronize(st));
+    up.add(&d.bb_start, start.data(), start.size());
+    up.add(&d.bb_cam, cam.data(), cam.size());
+    up.add(&d.bb_obj, obj.data(), obj.size());
+    up.add(&d.bb_meas, meas.data(), meas.size());
+    up.add(&d.bb_w, w.data(), w.size());
+    up.add(&d.bb_valid, valid.data(), valid.size());
     // camera-side CSR over the SORTED bbox edges
     std::vector<int> cs, cp;
     csr_by_key(cam.data(), g->n_bbox, F, cs, cp);
-    if ((rc = dev_upload(&d.cbb_start, cs.data(), cs.size(), st))) return rc;
-    if ((rc = dev_upload(&d.cbb_edge, cp.data(), cp.size(), st))) return rc;
-    ESL_HIP_TRY(hipStreamSynchronize(st));
+    up.add(&d.cbb_start, cs.data(), cs.size());
+    up.add(&d.cbb_edge, cp.data(), cp.size());
   }
   // 3-D edges
   csr_by_key(g->e3d_obj, g->n_e3d, N, start, perm);
@@ -282,17 +351,15 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     }
     c->h_e3_cam = cam; c->h_e3_obj = obj;
     h_e3_start = start;
-    if ((rc = dev_upload(&d.e3_start, start.data(), start.size(), st))) return rc;
-    if ((rc = dev_upload(&d.e3_cam, cam.data(), cam.size(), st))) return rc;
-    if ((rc = dev_upload(&d.e3_obj, obj.data(), obj.size(), st))) return rc;
-    if ((rc = dev_upload(&d.e3_meas, meas.data(), meas.size(), st))) return rc;
-    if ((rc = dev_upload(&d.e3_w, w.data(), w.size(), st))) return rc;
-    ESL_HIP_TRY(hipStreamSynchronize(st));
+    up.add(&d.e3_start, start.data(), start.size());
+    up.add(&d.e3_cam, cam.data(), cam.size());
+    up.add(&d.e3_obj, obj.data(), obj.size());
+    up.add(&d.e3_meas, meas.data(), meas.size());
+    up.add(&d.e3_w, w.data(), w.size());
     std::vector<int> cs, cp;
     csr_by_key(cam.data(), g->n_e3d, F, cs, cp);
-    if ((rc = dev_upload(&d.ce3_start, cs.data(), cs.size(), st))) return rc;
-    if ((rc = dev_upload(&d.ce3_edge, cp.data(), cp.size(), st))) return rc;
-    ESL_HIP_TRY(hipStreamSynchronize(st));
+    up.add(&d.ce3_start, cs.data(), cs.size());
+    up.add(&d.ce3_edge, cp.data(), cp.size());
   }
   // gravity
   {
@@ -301,8 +368,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     c->n_grav_edges = g->n_grav;
     for (int o = 0; o < N; ++o)
       if (cnt[o] > 64) { set_error("more than 64 gravity edges on one ellipsoid"); return ESL_ERR_INVALID; }
-    if ((rc = dev_upload(&d.gr_cnt, cnt.data(), cnt.size(), st))) return rc;
-    ESL_HIP_TRY(hipStreamSynchronize(st));
+    up.add(&d.gr_cnt, cnt.data(), cnt.size());
     // chunk table: per ellipsoid, in g2o's edge order (gravity, bbox, 3-D), <= 64 edges of one type per chunk
     std::vector<int> co, cty, cb, ce, cos((size_t)N + 1, 0);
     for (int o = 0; o < N; ++o) {
@@ -312,25 +378,24 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     }
     cos[N] = (int)co.size();
     c->n_chunks = (int)co.size();
-    if ((rc = dev_upload(&c->ck_obj, co.data(), co.size(), st))) return rc;
-    if ((rc = dev_upload(&c->ck_type, cty.data(), cty.size(), st))) return rc;
-    if ((rc = dev_upload(&c->ck_begin, cb.data(), cb.size(), st))) return rc;
-    if ((rc = dev_upload(&c->ck_end, ce.data(), ce.size(), st))) return rc;
-    if ((rc = dev_upload(&c->ck_ostart, cos.data(), cos.size(), st))) return rc;
+    up.add(&c->ck_obj, co.data(), co.size());
+    up.add(&c->ck_type, cty.data(), cty.size());
+    up.add(&c->ck_begin, cb.data(), cb.size());
+    up.add(&c->ck_end, ce.data(), ce.size());
+    up.add(&c->ck_ostart, cos.data(), cos.size());
     {
       std::vector<int> ib, ie;
       for (int k = 0; k < (int)cty.size(); ++k) (cty[k] == 0 ? ib : ie).push_back(k);
       c->n_ids_bb = (int)ib.size(); c->n_ids_e3 = (int)ie.size();
-      if ((rc = dev_upload(&c->ck_ids_bb, ib.data(), ib.size(), st))) return rc;
-      if ((rc = dev_upload(&c->ck_ids_e3, ie.data(), ie.size(), st))) return rc;
+      up.add(&c->ck_ids_bb, ib.data(), ib.size());
+      up.add(&c->ck_ids_e3, ie.data(), ie.size());
     }
-    ESL_HIP_TRY(hipStreamSynchronize(st));
-    if ((rc = dev_alloc(&c->chunk_out, (size_t)c->n_chunks * kChunkOut))) return rc;
-    if ((rc = dev_alloc(&c->chunk_out2, (size_t)c->n_chunks * kChunkOut))) return rc;
-    if ((rc = dev_alloc(&c->chunk_chi, (size_t)c->n_chunks))) return rc;
-    if ((rc = dev_alloc(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2))) return rc;
-    if ((rc = dev_alloc(&c->solve_part, (size_t)((N + 63) / 64 + 1) * 4 * 2))) return rc;   // x2: ping-pong of k_lm_step
-    if ((rc = dev_alloc(&c->blk_chi, (size_t)(c->n_chunks + 2)))) return rc;                 // <= one workgroup per chunk
+    wk.add(&c->chunk_out, (size_t)c->n_chunks * kChunkOut);
+    wk.add(&c->chunk_out2, (size_t)c->n_chunks * kChunkOut);
+    wk.add(&c->chunk_chi, (size_t)c->n_chunks);
+    wk.add(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2);
+    wk.add(&c->solve_part, (size_t)((N + 63) / 64 + 1) * 4 * 2);   // x2: ping-pong of k_lm_step
+    wk.add(&c->blk_chi, (size_t)(c->n_chunks + 2));                 // <= one workgroup per chunk
   }
   // cameras + odometry
   {
@@ -349,31 +414,32 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
       if (!fixed[i] && touched[i]) slot[i] = nf++;
     d.n_free_cams = nf;
     c->h_cam_slot = slot;
-    if ((rc = dev_upload(&d.cam_fixed, fixed.data(), fixed.size(), st))) return rc;
-    if ((rc = dev_upload(&d.cam_slot, slot.data(), slot.size(), st))) return rc;
+    up.add(&d.cam_fixed, fixed.data(), fixed.size());
+    up.add(&d.cam_slot, slot.data(), slot.size());
     std::vector<double> info((size_t)g->n_odom * 6, 1.0);
     if (g->odom_info) std::copy(g->odom_info, g->odom_info + (size_t)g->n_odom * 6, info.begin());
-    if ((rc = dev_upload(&d.od_i, g->odom_i, (size_t)g->n_odom, st))) return rc;
-    if ((rc = dev_upload(&d.od_j, g->odom_j, (size_t)g->n_odom, st))) return rc;
-    if ((rc = dev_upload(&d.od_meas, g->odom_meas, (size_t)g->n_odom * 7, st))) return rc;
-    if ((rc = dev_upload(&d.od_info, info.data(), info.size(), st))) return rc;
+    up.add(&d.od_i, g->odom_i, (size_t)g->n_odom);
+    up.add(&d.od_j, g->odom_j, (size_t)g->n_odom);
+    up.add(&d.od_meas, g->odom_meas, (size_t)g->n_odom * 7);
+    up.add(&d.od_info, info.data(), info.size());
     // camera-side CSR over odometry edges: entry = edge*2 + side
     std::vector<int> key((size_t)g->n_odom * 2), cs, cp;
     for (int i = 0; i < g->n_odom; ++i) { key[(size_t)2 * i] = g->odom_i[i]; key[(size_t)2 * i + 1] = g->odom_j[i]; }
     csr_by_key(key.data(), g->n_odom * 2, F, cs, cp);
-    if ((rc = dev_upload(&d.cod_start, cs.data(), cs.size(), st))) return rc;
-    if ((rc = dev_upload(&d.cod_edge, cp.data(), cp.size(), st))) return rc;
-    ESL_HIP_TRY(hipStreamSynchronize(st));
+    up.add(&d.cod_start, cs.data(), cs.size());
+    up.add(&d.cod_edge, cp.data(), cp.size());
   }
   // states + mapping-mode system
-  if ((rc = dev_alloc(&c->cams, (size_t)F * 7))) return rc;
-  if ((rc = dev_alloc(&c->cams_trial, (size_t)F * 7))) return rc;
-  if ((rc = dev_alloc(&c->objs, (size_t)N * 10))) return rc;
-  if ((rc = dev_alloc(&c->objs_trial, (size_t)N * 10))) return rc;
-  if ((rc = dev_alloc(&c->Hoo, (size_t)N * 45))) return rc;
-  if ((rc = dev_alloc(&c->bo, (size_t)N * 9))) return rc;
-  if ((rc = dev_alloc(&c->xo, (size_t)N * 9))) return rc;
-  if ((rc = dev_alloc(&c->obj_part, (size_t)N * 4))) return rc;
+  wk.add(&c->cams, (size_t)F * 7);
+  wk.add(&c->cams_trial, (size_t)F * 7);
+  wk.add(&c->objs, (size_t)N * 10);
+  wk.add(&c->objs_trial, (size_t)N * 10);
+  wk.add(&c->Hoo, (size_t)N * 45);
+  wk.add(&c->bo, (size_t)N * 9);
+  wk.add(&c->xo, (size_t)N * 9);
+  wk.add(&c->obj_part, (size_t)N * 4);
+  if ((rc = up.commit(c))) return rc;
+  if ((rc = wk.commit(c))) return rc;
   ESL_HIP_TRY(hipMemsetAsync(c->obj_part, 0, std::max<size_t>(N, 1) * 4 * sizeof(double), st));
   if (d.n_free_cams > 0) {
     if ((rc = slam_alloc(c))) return rc;

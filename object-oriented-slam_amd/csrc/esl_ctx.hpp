@@ -148,6 +148,11 @@ struct esl_ctx {
   double* blk_chi = nullptr;     // per-workgroup chi2 of the last linearisation
   unsigned int* tickets = nullptr;  // 2 arrival counters
   double* dev_scal = nullptr;    // {chi2_lin, max_diag}
+  // grow-only arenas behind esl_graph_upload (esl_capi.hip)
+  char* arena_graph = nullptr; size_t arena_graph_cap = 0;
+  char* arena_work = nullptr;  size_t arena_work_cap = 0;
+  char* stage_host = nullptr;  size_t stage_host_cap = 0;   // pinned staging blob
+  char* fit_slab = nullptr; size_t fit_slab_cap = 0;        // esl_fit_frame's device slab (esl_fit.hip)
   bool cams_match_snap = false;  // cameras untouched since the snapshot: esl_states_restore skips their copy
   int n_grav_edges = 0;
   void* lm_dev = nullptr;        // device-resident LM state (LmCore[2], esl_kernels_chunk.hpp)

@@ -19,6 +19,7 @@
 // agent-scope fence + barrier; reductions are wave shuffles + one LDS hop.  The 9 symmetry hypotheses
 // each get their own wavefront (lanes over mirrored points).
 #include <algorithm>
+#include <cstring>
 #include <cmath>
 #include <vector>
 
@@ -796,8 +797,15 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   const size_t o_cs = take(B * cap * 4), o_cmk = take(B * cap * 8), o_cmd = take(B * cap * 8);
   const size_t o_po = take(B * cap * 12 * 8), o_pof = take(B * cap * 3 * 4);
   const size_t o_ell = take(B * 80), o_prob = take(B * 8), o_st = take(B * 4), o_dbg = take(B * 128);
-  char* slab = nullptr;
-  ESL_HIP_TRY(hipMalloc((void**)&slab, off));
+  // grow-only slab owned by the context: a per-frame call pays no hipMalloc / hipFree
+  if (off > c->fit_slab_cap) {
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->fit_slab) { (void)hipFree(c->fit_slab); c->fit_slab = nullptr; c->fit_slab_cap = 0; }
+    const size_t want = off + off / 4;
+    ESL_HIP_TRY(hipMalloc((void**)&c->fit_slab, want));
+    c->fit_slab_cap = want;
+  }
+  char* slab = c->fit_slab;
   a.depth = (const uint16_t*)(slab + o_depth); a.bboxes = (const double*)(slab + o_bb); a.labels = (const int*)(slab + o_lab);
   a.hk = (unsigned long long*)(slab + o_hk); a.hsx = (long long*)(slab + o_hsx); a.hsy = (long long*)(slab + o_hsy);
   a.hsz = (long long*)(slab + o_hsz); a.hcnt = (unsigned int*)(slab + o_hcnt);
@@ -823,14 +831,16 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
     hipLaunchKernelGGL(k_fit_frame, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
     if ((e = hipGetLastError()) != hipSuccess) fail(e, "k_fit_frame");
   }
-  std::vector<double> dbg(B * 16);
-  if (!rc && (e = hipMemcpyAsync(ellipsoids_out, slab + o_ell, B * 80, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
-  if (!rc && (e = hipMemcpyAsync(prob_out, slab + o_prob, B * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
-  if (!rc && (e = hipMemcpyAsync(status_out, slab + o_st, B * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
-  if (!rc && (e = hipMemcpyAsync(dbg.data(), slab + o_dbg, B * 128, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
+  // the four output arrays are contiguous in the slab: one D2H copy, scattered on the host
+  std::vector<char> outs(off - o_ell);
+  if (!rc && (e = hipMemcpyAsync(outs.data(), slab + o_ell, outs.size(), hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
   if ((e = hipStreamSynchronize(st)) != hipSuccess && !rc) fail(e, "sync");
-  (void)hipFree(slab);
-  if (!rc && debug_out) std::copy(dbg.begin(), dbg.end(), debug_out);
+  if (!rc) {
+    std::memcpy(ellipsoids_out, outs.data(), B * 80);
+    std::memcpy(prob_out, outs.data() + (o_prob - o_ell), B * 8);
+    std::memcpy(status_out, outs.data() + (o_st - o_ell), B * 4);
+    if (debug_out) std::memcpy(debug_out, outs.data() + (o_dbg - o_ell), B * 128);
+  }
   return rc;
 }
 
