@@ -19,7 +19,10 @@
 // agent-scope fence + barrier; reductions are wave shuffles + one LDS hop.  The 9 symmetry hypotheses
 // each get their own wavefront (lanes over mirrored points).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <cmath>
 #include <vector>
 
@@ -32,6 +35,7 @@ constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kKeyOff = 1 << 20;
 #define ESL_FIX 1073741824.0  // 2^30
 
+struct FitShared;
 struct FitArgs {
   const uint16_t* depth; int w, h;
   const double* bboxes; const int* labels; int n_boxes;
@@ -45,13 +49,34 @@ struct FitArgs {
   int* csize; unsigned long long* cminkey; unsigned long long* cmind;
   double* po; float* pof;
   double* out_ell; double* out_prob; int* out_status; double* out_dbg;
+  struct FitShared* state;   // per box: the first kernel's shared block, read by the symmetry and the completion kernels
+  long long* clk;   // optional (ESL_FIT_TIMING=1): 16 wall_clock64() marks per box written by thread 0 at the stage boundaries
 };
 
 __device__ __forceinline__ unsigned long long hash64(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
   return k;
 }
-__device__ __forceinline__ void stage_sync() { __threadfence(); __syncthreads(); }
+// Stage boundary.  All traffic between stages stays inside ONE workgroup (= one CU, one vector L1): the barrier's
+// workgroup-scope release drains this wave's stores / atomics to L2, and an agent-scope ACQUIRE drops L1 lines that an
+// L2 atomic of another wave may have outdated.  The agent-scope RELEASE of a full __threadfence() (L2 write-back,
+// issued by all 1024 threads) is what cross-CU visibility would need -- not this kernel -- and cost 10-50 us per stage.
+__device__ __forceinline__ void stage_sync() {
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// symmetry-grid points of the box (object frame, float) staged in LDS for the brute-force 1-NN of the symmetry cost
+constexpr int kSymLds = 1024;
+// One raw LDS buffer, carved per stage (the stages are separated by barriers):
+//   clustering (M <= kClLds points):  cell keys u32[kClCells] | cell heads i32[kClCells] | next i32[kClLds] | parent i32[kClLds]
+//                       afterwards:   min centre distance u64[kClLds] | min voxel key u64[kClLds] | size i32[kClLds] | parent
+//   symmetry:                         candidate points float[3 * kSymLds]
+constexpr int kClLds = 2048, kClCells = 4096;
+constexpr unsigned int kEmpty32 = 0xFFFFFFFFu;
+__shared__ __attribute__((aligned(16))) unsigned char g_fit_lds[(kClCells * 2 + kClLds * 2) * 4];
+#define g_sym_pof ((float*)g_fit_lds)
+static_assert(sizeof(float) * 3 * kSymLds <= sizeof(g_fit_lds), "symmetry candidates must fit the shared buffer");
+#define ESL_FIT_MARK(k) do { if (a.clk && tid == 0) a.clk[16 * b + (k)] = (long long)wall_clock64(); } while (0)
 
 // block-wide sum, result to every thread (wave shuffle + LDS)
 __device__ double block_sum(double v, double* red) {
@@ -154,26 +179,28 @@ __device__ __forceinline__ void xform(const Mat3& R, const double* t, const doub
 
 // ---- g2o::plane (include/core/Plane.h:46-129) --------------------------------------------------------------
 struct PlaneT { double p[4]; double dual; };
-__device__ void plane_oplus3(PlaneT& pl, double az, double el, double dd) {
-  const double s = sin(el), c = cos(el);
-  const double n[3] = {c * cos(az), c * sin(az), s};
-  const double paz = atan2(pl.p[1], pl.p[0]), pel = atan2(pl.p[2], sqrt(pl.p[0] * pl.p[0] + pl.p[1] * pl.p[1]));
-  const double ca = cos(paz), sa = sin(paz), cb = cos(-pel), sb = sin(-pel);
-  const double R[9] = {ca * cb, -sa, ca * sb, sa * cb, ca, sa * sb, -sb, 0, cb};
-  const double d = -pl.p[3] + dd;
-  double q[3];
-  for (int i = 0; i < 3; ++i) q[i] = R[i * 3] * n[0] + R[i * 3 + 1] * n[1] + R[i * 3 + 2] * n[2];
-  pl.p[0] = q[0]; pl.p[1] = q[1]; pl.p[2] = q[2]; pl.p[3] = -d;
-  const double nn = sqrt(pl.p[0] * pl.p[0] + pl.p[1] * pl.p[1] + pl.p[2] * pl.p[2]);
-  for (int i = 0; i < 4; ++i) pl.p[i] *= (1. / nn);
-}
+// g2o::plane::oplus(Vector3(az, 0, d)) as the symmetry LM uses it (elevation update always 0; Plane.cpp / SymmetrySolver
+// retraction): the reference goes through atan2 -> cos/sin of the current normal's azimuth and elevation; those are
+// algebraic in the normal (cos(atan2(y,x)) = x/r, ...), so only sincos(az) of the UPDATE is transcendental here.
+// Same values to rounding; an FP64 atan2/sin/cos chain is ~2k serial instructions per call on one wave.
 __device__ __forceinline__ void plane_update(PlaneT& pl, const double* u, bool dual) {
-  plane_oplus3(pl, u[0], 0.0, u[1]);
+  const double az = u[0], dd = u[1];
+  const double r2 = pl.p[0] * pl.p[0] + pl.p[1] * pl.p[1];
+  const double r = sqrt(r2), n3 = sqrt(r2 + pl.p[2] * pl.p[2]);
+  const double ca = r > 0 ? pl.p[0] / r : 1.0, sa = r > 0 ? pl.p[1] / r : 0.0;   // azimuth of the current normal
+  const double cb = n3 > 0 ? r / n3 : 1.0, sb = n3 > 0 ? -pl.p[2] / n3 : 0.0;     // cos / sin of MINUS its elevation
+  double sz, cz;
+  sincos(az, &sz, &cz);
+  const double q[3] = {ca * cb * cz - sa * sz, sa * cb * cz + ca * sz, -sb * cz};
+  const double d = -pl.p[3] + dd;
+  pl.p[0] = q[0]; pl.p[1] = q[1]; pl.p[2] = q[2]; pl.p[3] = -d;
+  const double inv = 1. / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  for (int i = 0; i < 4; ++i) pl.p[i] *= inv;
   if (dual) pl.dual += u[2];
 }
 __device__ __forceinline__ void plane_another(const PlaneT& pl, double* out) {
-  const double az = atan2(pl.p[1], pl.p[0]);
-  out[0] = sin(az); out[1] = -cos(az); out[2] = 0; out[3] = -pl.dual;
+  const double r = sqrt(pl.p[0] * pl.p[0] + pl.p[1] * pl.p[1]);
+  out[0] = r > 0 ? pl.p[1] / r : 0.0; out[1] = r > 0 ? -pl.p[0] / r : -1.0; out[2] = 0; out[3] = -pl.dual;   // (sin az, -cos az, 0, -d2)
 }
 __device__ __forceinline__ void mirror_point(const double* p, const double* pl, double* r) {
   const double nn = sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
@@ -228,10 +255,18 @@ __device__ double sym_error_wave(const SymCtx& c, const PlaneT& pl, bool dual) {
       if (!finite_pt) invalid += 1;
       else {
         double best = 1e300;
-        for (int j = 0; j < c.n; ++j) {
-          const double dx = p[0] - (double)c.pof[3 * j], dy = p[1] - (double)c.pof[3 * j + 1], dz = p[2] - (double)c.pof[3 * j + 2];
-          const double d2 = dx * dx + dy * dy + dz * dz;
-          if (d2 < best) best = d2;
+        if (c.n <= kSymLds) {   // candidates broadcast from LDS (was: three dependent global loads per candidate)
+          for (int j = 0; j < c.n; ++j) {
+            const double dx = p[0] - (double)g_sym_pof[3 * j], dy = p[1] - (double)g_sym_pof[3 * j + 1], dz = p[2] - (double)g_sym_pof[3 * j + 2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) best = d2;
+          }
+        } else {
+          for (int j = 0; j < c.n; ++j) {
+            const double dx = p[0] - (double)c.pof[3 * j], dy = p[1] - (double)c.pof[3 * j + 1], dz = p[2] - (double)c.pof[3 * j + 2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) best = d2;
+          }
         }
         dis = sqrt(best);
       }
@@ -357,6 +392,8 @@ __device__ __forceinline__ int symmetry_type(int label) {  // EllipsoidExtractor
 struct FitShared {
   double red[kFitThreads / 64];
   int M, n0, n1, ncl, chosen, maxsize, only, status, ns0, npo, cnt;
+  int cmin[3], cmax[3];   // cell-coordinate extent of the box's points (LDS clustering path)
+  int nc, pre_ok, run_sym, stype;   // carried from the first kernel to the later ones
   unsigned long long minkey;
   double center[3], cen[3], cov[6];
   double Two[7], Tow[7];
@@ -368,7 +405,7 @@ struct FitShared {
   SymCtx sc;
 };
 
-static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
+static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   __shared__ FitShared S;
   const int b = blockIdx.x, tid = threadIdx.x;
   const long base = (long)b * a.H, pbase = (long)b * a.cap;
@@ -376,6 +413,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
   const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
   if (tid == 0) { S.M = 0; S.n0 = 0; S.n1 = 0; S.ncl = 0; S.chosen = -1; S.maxsize = 0; S.only = -1; S.status = 0; S.ns0 = 0; S.npo = 0; S.cnt = 0; S.minkey = kEmpty; }
   __syncthreads();
+  ESL_FIT_MARK(0);
   // 1 + 2. scan the box, voxel-hash at voxel_leaf
   const int x1 = (int)bbox[0], y1 = (int)bbox[1], x2 = (int)bbox[2], y2 = (int)bbox[3];
   const int st = a.p.stride;
@@ -396,6 +434,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
     if (mine) atomicAdd(&S.n0, mine);
   }
   stage_sync();
+  ESL_FIT_MARK(1);
   // 3 + 4. centroids -> world -> supporting-plane filter
   const SE3 Twc = se3_load(a.Twc);
   const Mat3 Rwc = q_to_R(Twc.r);
@@ -419,6 +458,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
   __syncthreads();
   const int M = S.M;
   if (M < 1) { if (tid == 0) { a.out_status[b] = 4; a.out_dbg[16 * b] = S.n0; a.out_dbg[16 * b + 1] = S.n1; } return; }
+  ESL_FIT_MARK(2);
   // 5. GetCenter: 10 x 10 samples around the box centre (first two waves)
   {
     double sx = 0, sy = 0, sz = 0, cn = 0;
@@ -438,62 +478,155 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
     if (cn < 2) { if (tid == 0) a.out_status[b] = 1; return; }
     if (tid == 0) { const double c[3] = {sx / cn, sy / cn, sz / cn}; xform(Rwc, Twc.t, c, S.center); }
   }
+  ESL_FIT_MARK(3);
   // 6. Euclidean clustering: cell hash + lock-free union-find
   const double tol = a.p.cluster_tolerance, tol2 = tol * tol;
-  for (long s = tid; s < a.H; s += kFitThreads) { a.ck[base + s] = kEmpty; a.chead[base + s] = -1; }
-  for (int i = tid; i < M; i += kFitThreads) { a.parent[pbase + i] = i; a.csize[pbase + i] = 0; a.cminkey[pbase + i] = kEmpty; a.cmind[pbase + i] = kEmpty; }
-  stage_sync();
+  // Same definition on two substrates: with M <= kClLds points and a cell extent that fits 10 bits per axis the cell
+  // hash, the per-cell lists and the union-find forest live in LDS (the global-memory version is pointer chasing
+  // through L2 at ~1 us a hop: 27 cells x probe + list walk per point made this stage 150-330 us per box).
+  if (tid == 0) { for (int k = 0; k < 3; ++k) { S.cmin[k] = INT_MAX; S.cmax[k] = INT_MIN; } }
+  __syncthreads();
   for (int i = tid; i < M; i += kFitThreads) {
-    const unsigned long long key = cell_key(a.pwx[pbase + i], a.pwy[pbase + i], a.pwz[pbase + i], tol, 0, 0, 0);
-    unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
-    for (;;) {
-      const unsigned long long prev = atomicCAS(&a.ck[base + slot], kEmpty, key);
-      if (prev == kEmpty || prev == key) break;
-      slot = (slot + 1) & (unsigned long long)(a.H - 1);
-    }
-    a.nxt[pbase + i] = atomicExch(&a.chead[base + slot], i);
+    const int cx_ = (int)(long long)floor((double)a.pwx[pbase + i] / tol), cy_ = (int)(long long)floor((double)a.pwy[pbase + i] / tol),
+              cz_ = (int)(long long)floor((double)a.pwz[pbase + i] / tol);
+    atomicMin(&S.cmin[0], cx_); atomicMax(&S.cmax[0], cx_);
+    atomicMin(&S.cmin[1], cy_); atomicMax(&S.cmax[1], cy_);
+    atomicMin(&S.cmin[2], cz_); atomicMax(&S.cmax[2], cz_);
   }
-  stage_sync();
-  for (int i = tid; i < M; i += kFitThreads) {
-    const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const unsigned long long key = cell_key(xi, yi, zi, tol, dx, dy, dz);
-          unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
-          int head = -1;
-          for (;;) {
-            const unsigned long long k = __hip_atomic_load(&a.ck[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k == key) { head = __hip_atomic_load(&a.chead[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            if (k == kEmpty) break;
-            slot = (slot + 1) & (unsigned long long)(a.H - 1);
-          }
-          for (int j = head; j >= 0; j = a.nxt[pbase + j]) {
-            if (j <= i) continue;
-            const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
-            if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
-              int ra = i, rb = j;
-              for (;;) {
-                ra = uf_find(a.parent + pbase, ra); rb = uf_find(a.parent + pbase, rb);
-                if (ra == rb) break;
-                if (ra < rb) { const int t = ra; ra = rb; rb = t; }
-                if (atomicCAS(&a.parent[pbase + ra], ra, rb) == ra) break;
+  __syncthreads();
+  const bool lds_path = M <= kClLds && (long)S.cmax[0] - S.cmin[0] < 1020 && (long)S.cmax[1] - S.cmin[1] < 1020 &&
+                        (long)S.cmax[2] - S.cmin[2] < 1020;
+  if (lds_path) {
+    unsigned int* ckey = (unsigned int*)g_fit_lds;
+    int* chead = (int*)(g_fit_lds + kClCells * 4);
+    int* lnxt = (int*)(g_fit_lds + kClCells * 8);
+    int* lpar = (int*)(g_fit_lds + kClCells * 8 + kClLds * 4);
+    const int mx = S.cmin[0] - 1, my = S.cmin[1] - 1, mz = S.cmin[2] - 1;   // neighbour offsets stay >= 0
+    for (int sidx = tid; sidx < kClCells; sidx += kFitThreads) { ckey[sidx] = kEmpty32; chead[sidx] = -1; }
+    for (int i = tid; i < M; i += kFitThreads) lpar[i] = i;
+    __syncthreads();
+    auto key_of = [&](float x, float y, float z, int dx, int dy, int dz) -> unsigned int {
+      const int cx_ = (int)(long long)floor((double)x / tol) + dx - mx, cy_ = (int)(long long)floor((double)y / tol) + dy - my,
+                cz_ = (int)(long long)floor((double)z / tol) + dz - mz;
+      return ((unsigned int)cz_ << 20) | ((unsigned int)cy_ << 10) | (unsigned int)cx_;
+    };
+    for (int i = tid; i < M; i += kFitThreads) {
+      const unsigned int key = key_of(a.pwx[pbase + i], a.pwy[pbase + i], a.pwz[pbase + i], 0, 0, 0);
+      unsigned int slot = (unsigned int)hash64(key) & (kClCells - 1);
+      for (;;) {
+        const unsigned int prev = atomicCAS(&ckey[slot], kEmpty32, key);
+        if (prev == kEmpty32 || prev == key) break;
+        slot = (slot + 1) & (kClCells - 1);
+      }
+      lnxt[i] = atomicExch(&chead[slot], i);
+    }
+    __syncthreads();
+    for (int i = tid; i < M; i += kFitThreads) {
+      const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const unsigned int key = key_of(xi, yi, zi, dx, dy, dz);
+            unsigned int slot = (unsigned int)hash64(key) & (kClCells - 1);
+            int head = -1;
+            for (;;) {
+              const unsigned int k = ckey[slot];
+              if (k == key) { head = chead[slot]; break; }
+              if (k == kEmpty32) break;
+              slot = (slot + 1) & (kClCells - 1);
+            }
+            for (int j = head; j >= 0; j = lnxt[j]) {
+              if (j <= i) continue;
+              const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
+              if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
+                int ra = i, rb = j;
+                for (;;) {
+                  while (true) { const int pp = __hip_atomic_load(&lpar[ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (pp == ra) break; ra = pp; }
+                  while (true) { const int pp = __hip_atomic_load(&lpar[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (pp == rb) break; rb = pp; }
+                  if (ra == rb) break;
+                  if (ra < rb) { const int t = ra; ra = rb; rb = t; }
+                  if (atomicCAS(&lpar[ra], ra, rb) == ra) break;
+                }
               }
             }
           }
-        }
+    }
+    __syncthreads();
+    // per-root statistics (the cell tables are dead now: their space holds the three statistics arrays)
+    unsigned long long* lmind = (unsigned long long*)g_fit_lds;
+    unsigned long long* lmink = (unsigned long long*)(g_fit_lds + kClCells * 4);
+    int* lsize = (int*)(g_fit_lds + kClCells * 8);
+    for (int i = tid; i < M; i += kFitThreads) { lmind[i] = kEmpty; lmink[i] = kEmpty; lsize[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < M; i += kFitThreads) {
+      int r = i;
+      while (true) { const int pp = lpar[r]; if (pp == r) break; r = pp; }
+      a.nxt[pbase + i] = r;  // root of every point
+      atomicAdd(&lsize[r], 1);
+      atomicMin(&lmink[r], a.pkey[pbase + i]);
+      const double dx = S.center[0] - a.pwx[pbase + i], dy = S.center[1] - a.pwy[pbase + i], dz = S.center[2] - a.pwz[pbase + i];
+      const double d = sqrt(dx * dx + dy * dy + dz * dz);
+      atomicMin(&lmind[r], (unsigned long long)__double_as_longlong(d));
+    }
+    __syncthreads();
+    for (int i = tid; i < M; i += kFitThreads) { a.csize[pbase + i] = lsize[i]; a.cminkey[pbase + i] = lmink[i]; a.cmind[pbase + i] = lmind[i]; }
+    stage_sync();
+  } else {
+    for (long s = tid; s < a.H; s += kFitThreads) { a.ck[base + s] = kEmpty; a.chead[base + s] = -1; }
+    for (int i = tid; i < M; i += kFitThreads) { a.parent[pbase + i] = i; a.csize[pbase + i] = 0; a.cminkey[pbase + i] = kEmpty; a.cmind[pbase + i] = kEmpty; }
+    stage_sync();
+    for (int i = tid; i < M; i += kFitThreads) {
+      const unsigned long long key = cell_key(a.pwx[pbase + i], a.pwy[pbase + i], a.pwz[pbase + i], tol, 0, 0, 0);
+      unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
+      for (;;) {
+        const unsigned long long prev = atomicCAS(&a.ck[base + slot], kEmpty, key);
+        if (prev == kEmpty || prev == key) break;
+        slot = (slot + 1) & (unsigned long long)(a.H - 1);
+      }
+      a.nxt[pbase + i] = atomicExch(&a.chead[base + slot], i);
+    }
+    stage_sync();
+    for (int i = tid; i < M; i += kFitThreads) {
+      const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const unsigned long long key = cell_key(xi, yi, zi, tol, dx, dy, dz);
+            unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
+            int head = -1;
+            for (;;) {
+              const unsigned long long k = __hip_atomic_load(&a.ck[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (k == key) { head = __hip_atomic_load(&a.chead[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+              if (k == kEmpty) break;
+              slot = (slot + 1) & (unsigned long long)(a.H - 1);
+            }
+            for (int j = head; j >= 0; j = a.nxt[pbase + j]) {
+              if (j <= i) continue;
+              const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
+              if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
+                int ra = i, rb = j;
+                for (;;) {
+                  ra = uf_find(a.parent + pbase, ra); rb = uf_find(a.parent + pbase, rb);
+                  if (ra == rb) break;
+                  if (ra < rb) { const int t = ra; ra = rb; rb = t; }
+                  if (atomicCAS(&a.parent[pbase + ra], ra, rb) == ra) break;
+                }
+              }
+            }
+          }
+    }
+    stage_sync();
+    for (int i = tid; i < M; i += kFitThreads) {
+      const int r = uf_find(a.parent + pbase, i);
+      a.nxt[pbase + i] = r;  // root of every point (the list links are no longer needed)
+      atomicAdd(&a.csize[pbase + r], 1);
+      atomicMin(&a.cminkey[pbase + r], a.pkey[pbase + i]);
+      const double dx = S.center[0] - a.pwx[pbase + i], dy = S.center[1] - a.pwy[pbase + i], dz = S.center[2] - a.pwz[pbase + i];
+      const double d = sqrt(dx * dx + dy * dy + dz * dz);
+      atomicMin(&a.cmind[pbase + r], (unsigned long long)__double_as_longlong(d));
+    }
+    stage_sync();
   }
-  stage_sync();
-  for (int i = tid; i < M; i += kFitThreads) {
-    const int r = uf_find(a.parent + pbase, i);
-    a.nxt[pbase + i] = r;  // root of every point (the list links are no longer needed)
-    atomicAdd(&a.csize[pbase + r], 1);
-    atomicMin(&a.cminkey[pbase + r], a.pkey[pbase + i]);
-    const double dx = S.center[0] - a.pwx[pbase + i], dy = S.center[1] - a.pwy[pbase + i], dz = S.center[2] - a.pwz[pbase + i];
-    const double d = sqrt(dx * dx + dy * dy + dz * dz);
-    atomicMin(&a.cmind[pbase + r], (unsigned long long)__double_as_longlong(d));
-  }
-  stage_sync();
   // choose the cluster: the only one, else the largest (ties: smaller voxel key) within center_dis of the centre
   for (int r = tid; r < M; r += kFitThreads) {
     const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -527,6 +660,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
     return;
   }
   const int nc = a.csize[pbase + chosen];
+  ESL_FIT_MARK(4);
   // 7. PCA of the chosen cluster (two passes like PCL: centroid, then normalised covariance)
   {
     double sx = 0, sy = 0, sz = 0;
@@ -601,6 +735,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
       for (int i = 0; i < 9; ++i) S.Row[i] = Row.m[i];
     }
   }
+  ESL_FIT_MARK(5);
   // 8. voxel grid at symmetry_grid over the cluster, then into the object frame
   for (long s = tid; s < a.H; s += kFitThreads) { a.hk[base + s] = kEmpty; a.hsx[base + s] = 0; a.hsy[base + s] = 0; a.hsz[base + s] = 0; a.hcnt[base + s] = 0; }
   stage_sync();
@@ -631,8 +766,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
   }
   stage_sync();
   const int ns0 = S.ns0;
-  int npo = ns0;
-  double prob_sym = 1.0;
+  ESL_FIT_MARK(6);
   // 9. symmetry: 9 hypotheses, one wavefront each
   const int stype = symmetry_type(a.labels ? a.labels[b] : -1);
   const bool run_sym = a.p.symmetry_open && stype > 0 && ns0 > 0;
@@ -652,17 +786,151 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
       c.camc[0] = Toc.t[0]; c.camc[1] = Toc.t[1]; c.camc[2] = Toc.t[2];
       c.po = po; c.pof = pof; c.n = ns0;
     }
-    __syncthreads();
-    const int wv = tid >> 6;
-    if (wv < 9) {
-      PlaneT pl;
-      const int i = wv / 3, m = wv % 3;
-      const double dis = -0.2 + 0.2 * i, ang = -(M_PI / 180.0 * 5) + (M_PI / 180.0 * 5) * m;
-      pl.p[0] = sin(ang); pl.p[1] = -cos(ang); pl.p[2] = 0; pl.p[3] = -dis; pl.dual = 0;
-      const double e = sym_optimize_wave(S.sc, pl, stype == 2, a.p.symmetry_lm_iters);
-      if ((tid & 63) == 0) { S.prob[wv] = exp(-e); S.planes[wv] = pl; }
+  }
+  // hand the box over to k_fit_sym / k_fit_post
+  __syncthreads();
+  if (tid == 0) { S.nc = nc; S.M = M; S.pre_ok = 1; S.run_sym = run_sym ? 1 : 0; S.stype = stype; }
+  __syncthreads();
+  {
+    const unsigned long long* src = (const unsigned long long*)&S;
+    unsigned long long* dst = (unsigned long long*)(a.state + b);
+    for (int k = tid; k < (int)(sizeof(FitShared) / 8); k += kFitThreads) dst[k] = src[k];
+  }
+}
+
+// ---- symmetry: one workgroup per (box, plane hypothesis), 8 waves -------------------------------------------
+// SymmetrySolver's 1-edge LM (delta = 1e-9 central differences) is a chain of ~40 cost evaluations per hypothesis;
+// run by a single wave inside the box's workgroup it was the longest stage of a frame (180 us mean, 460 us worst).
+// Here the 1 + 2 dim evaluations of an iteration's linearisation run on separate waves at once, and so do the LM's
+// trials: wave k evaluates the step for the lambda that k rejections in a row would lead to (lambda *= ni, ni *= 2),
+// the results are then consumed in the sequential order -- same arithmetic, same accept/reject sequence, same e_last.
+constexpr int kSymThreads = 512, kSymWaves = kSymThreads / 64;
+static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
+  __shared__ SymCtx sc;
+  __shared__ double ev[kSymWaves];
+  const int b = blockIdx.x / 9, h = blockIdx.x % 9, tid = threadIdx.x, wv = tid >> 6;
+  FitShared* st = a.state + b;
+  if (!st->pre_ok || !st->run_sym) return;
+  {
+    const unsigned long long* src = (const unsigned long long*)&st->sc;
+    unsigned long long* dst = (unsigned long long*)&sc;
+    for (int k = tid; k < (int)(sizeof(SymCtx) / 8); k += kSymThreads) dst[k] = src[k];
+  }
+  __syncthreads();
+  const int n = sc.n;
+  if (n <= kSymLds)
+    for (int i = tid; i < 3 * n; i += kSymThreads) g_sym_pof[i] = sc.pof[i];
+  __syncthreads();
+  const bool dual = st->stype == 2;
+  const int dim = dual ? 3 : 2, iters = a.p.symmetry_lm_iters;
+  const double delta = 1e-9;
+  PlaneT pl;
+  {
+    const int i = h / 3, m = h % 3;
+    const double dis = -0.2 + 0.2 * i, ang = -(M_PI / 180.0 * 5) + (M_PI / 180.0 * 5) * m;
+    pl.p[0] = sin(ang); pl.p[1] = -cos(ang); pl.p[2] = 0; pl.p[3] = -dis; pl.dual = 0;
+  }
+  // every thread carries the LM state; the evaluations come from ev[] -> identical decisions in all threads
+  double lambda = 0, ni = 2;
+  int nbad = 0;
+  if (wv == 0) { const double e = sym_error_wave(sc, pl, dual); if ((tid & 63) == 0) ev[0] = e; }
+  __syncthreads();
+  double e_last = ev[0];
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    // linearisation: wave 0 -> E(pl), wave 1 + 2d -> E(pl + delta e_d), wave 2 + 2d -> E(pl - delta e_d)
+    if (wv < 1 + 2 * dim) {
+      PlaneT pp = pl;
+      if (wv > 0) {
+        double u[3] = {0, 0, 0};
+        const int d = (wv - 1) >> 1;
+        u[d] = ((wv - 1) & 1) ? -delta : delta;
+        plane_update(pp, u, dual);
+      }
+      const double e = sym_error_wave(sc, pp, dual);
+      if ((tid & 63) == 0) ev[wv] = e;
     }
     __syncthreads();
+    const double e0 = ev[0];
+    e_last = e0;
+    double cur = e0 * e0;
+    const double ini = cur;
+    double J[3] = {0, 0, 0}, H[9], bvec[3];
+    for (int d = 0; d < dim; ++d) J[d] = (1.0 / (2 * delta)) * (ev[1 + 2 * d] - ev[2 + 2 * d]);
+    __syncthreads();
+    for (int r = 0; r < dim; ++r) { bvec[r] = J[r] * (-(1.0 * e0)); for (int k = 0; k < dim; ++k) H[r * dim + k] = J[r] * 1.0 * J[k]; }
+    if (it == 0) {
+      double md = 0;
+      for (int r = 0; r < dim; ++r) md = fmax(md, fabs(H[r * dim + r]));
+      lambda = 1e-5 * md; ni = 2; nbad = 0;
+    }
+    double rho = 0;
+    int q = 0;
+    bool more = true;
+    while (more) {
+      // speculative batch: wave k tries the lambda reached after k further rejections
+      {
+        double lam_k = lambda, ni_k = ni;
+        for (int k = 0; k < wv; ++k) { lam_k *= ni_k; ni_k *= 2; }
+        double Mx[9], x[3] = {0, 0, 0};
+        for (int r = 0; r < dim * dim; ++r) Mx[r] = H[r];
+        for (int r = 0; r < dim; ++r) Mx[r * dim + r] += lam_k;
+        (void)ldlt_small(Mx, dim, bvec, x);
+        PlaneT pt = pl;
+        plane_update(pt, x, dual);
+        const double e = sym_error_wave(sc, pt, dual);
+        if ((tid & 63) == 0) ev[wv] = e;
+      }
+      __syncthreads();
+      for (int k = 0; k < kSymWaves && more; ++k) {   // consume in the sequential order
+        const PlaneT bak = pl;
+        double Mx[9], x[3] = {0, 0, 0};
+        for (int r = 0; r < dim * dim; ++r) Mx[r] = H[r];
+        for (int r = 0; r < dim; ++r) Mx[r * dim + r] += lambda;
+        const bool ok = ldlt_small(Mx, dim, bvec, x);
+        plane_update(pl, x, dual);
+        const double et = ev[k];
+        e_last = et;
+        const double tmp = ok ? et * et : 1.7976931348623157e308;
+        double scale = 0;
+        for (int r = 0; r < dim; ++r) scale += x[r] * (lambda * x[r] + bvec[r]);
+        rho = (cur - tmp) / (scale + 1e-3);
+        if (rho > 0 && isfinite(tmp)) {
+          double alpha = 1. - pow((2 * rho - 1), 3);
+          alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+          lambda *= (1. / 3. > alpha ? 1. / 3. : alpha);
+          ni = 2; cur = tmp;
+        } else { lambda *= ni; ni *= 2; pl = bak; }
+        q++;
+        more = (rho < 0 && q < 10);
+      }
+      __syncthreads();   // ev[] is rewritten by the next batch / the next linearisation
+    }
+    if (q == 10 || rho == 0) break;
+    if ((ini - cur) * 1e3 < ini) nbad++; else nbad = 0;
+    if (nbad >= 3) break;
+  }
+  if (tid == 0) { st->prob[h] = exp(-e_last); st->planes[h] = pl; }
+}
+
+// ---- completion: best hypothesis, mirrored points, extents, ellipsoid (one workgroup per box) ----------------
+static __global__ __launch_bounds__(kFitThreads) void k_fit_post(FitArgs a) {
+  __shared__ FitShared S;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long pbase = (long)b * a.cap;
+  if (!a.state[b].pre_ok) return;   // the first kernel already reported why this box has no ellipsoid
+  {
+    const unsigned long long* src = (const unsigned long long*)(a.state + b);
+    unsigned long long* dst = (unsigned long long*)&S;
+    for (int k = tid; k < (int)(sizeof(FitShared) / 8); k += kFitThreads) dst[k] = src[k];
+  }
+  __syncthreads();
+  double* po = a.po + 12 * pbase;
+  const int M = S.M, nc = S.nc, ns0 = S.ns0, stype = S.stype;
+  const bool run_sym = S.run_sym != 0;
+  int npo = ns0;
+  double prob_sym = 1.0;
+  if (run_sym) {
     if (tid == 0) {
       int best = 0;
       for (int k = 1; k < 9; ++k) if (S.prob[k] > S.prob[best]) best = k;
@@ -717,6 +985,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
     }
     __syncthreads();
   }
+  ESL_FIT_MARK(7);
   // 10. extents in the (re-centred) object frame, ellipsoid, back to the camera frame
   double mx = 0, my = 0, mz = 0;
   for (int i = tid; i < npo; i += kFitThreads) {
@@ -740,6 +1009,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_frame(FitArgs a) {
     o[7] = mx; o[8] = my; o[9] = mz;
     a.out_prob[b] = prob_sym;
     a.out_status[b] = 0;
+    ESL_FIT_MARK(8);
     double* dbg = a.out_dbg + 16 * b;
     dbg[0] = S.n0; dbg[1] = S.n1; dbg[2] = M; dbg[3] = S.ncl; dbg[4] = nc; dbg[5] = ns0;
     for (int k = 0; k < 9; ++k) dbg[6 + k] = run_sym ? S.prob[k] : 0.0;
@@ -796,7 +1066,9 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   const size_t o_ck = take(B * H * 8), o_chead = take(B * H * 4), o_nxt = take(B * cap * 4), o_par = take(B * cap * 4);
   const size_t o_cs = take(B * cap * 4), o_cmk = take(B * cap * 8), o_cmd = take(B * cap * 8);
   const size_t o_po = take(B * cap * 12 * 8), o_pof = take(B * cap * 3 * 4);
-  const size_t o_ell = take(B * 80), o_prob = take(B * 8), o_st = take(B * 4), o_dbg = take(B * 128);
+  const size_t o_state = take(B * sizeof(FitShared));
+  const size_t o_ell = take(B * 80), o_prob = take(B * 8), o_st = take(B * 4), o_dbg = take(B * 128), o_clk = take(B * 128);
+  const bool timing = std::getenv("ESL_FIT_TIMING") != nullptr;
   // grow-only slab owned by the context: a per-frame call pays no hipMalloc / hipFree
   if (off > c->fit_slab_cap) {
     ESL_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -813,6 +1085,8 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   a.ck = (unsigned long long*)(slab + o_ck); a.chead = (int*)(slab + o_chead); a.nxt = (int*)(slab + o_nxt); a.parent = (int*)(slab + o_par);
   a.csize = (int*)(slab + o_cs); a.cminkey = (unsigned long long*)(slab + o_cmk); a.cmind = (unsigned long long*)(slab + o_cmd);
   a.po = (double*)(slab + o_po); a.pof = (float*)(slab + o_pof);
+  a.state = (FitShared*)(slab + o_state);
+  a.clk = timing ? (long long*)(slab + o_clk) : nullptr;
   a.out_ell = (double*)(slab + o_ell); a.out_prob = (double*)(slab + o_prob); a.out_status = (int*)(slab + o_st); a.out_dbg = (double*)(slab + o_dbg);
   hipStream_t st = c->stream;
   std::vector<int32_t> lab((size_t)n_boxes, -1);
@@ -828,8 +1102,12 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   if (!rc && (e = hipMemsetAsync(slab + o_ell, 0, off - o_ell, st)) != hipSuccess) fail(e, "clear outputs");
   if (!rc) {
     ProfScope ps(c, 5);
-    hipLaunchKernelGGL(k_fit_frame, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
-    if ((e = hipGetLastError()) != hipSuccess) fail(e, "k_fit_frame");
+    // three launches: per-box segmentation + PCA, the 9 plane hypotheses of every box side by side, completion
+    if ((e = hipMemsetAsync(slab + o_state, 0, B * sizeof(FitShared), st)) != hipSuccess) fail(e, "clear state");
+    hipLaunchKernelGGL(k_fit_pre, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
+    if (p->symmetry_open) hipLaunchKernelGGL(k_fit_sym, dim3(n_boxes * 9), dim3(kSymThreads), 0, st, a);
+    hipLaunchKernelGGL(k_fit_post, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) fail(e, "k_fit_*");
   }
   // the four output arrays are contiguous in the slab: one D2H copy, scattered on the host
   std::vector<char> outs(off - o_ell);
@@ -840,6 +1118,31 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
     std::memcpy(prob_out, outs.data() + (o_prob - o_ell), B * 8);
     std::memcpy(status_out, outs.data() + (o_st - o_ell), B * 4);
     if (debug_out) std::memcpy(debug_out, outs.data() + (o_dbg - o_ell), B * 128);
+    if (timing) {   // diagnostic: mean stage durations over the boxes (wall_clock64 ticks at 100 MHz)
+      static const char* names[8] = {"scan+voxel", "plane filter", "centre", "cluster", "pca", "sym grid", "symmetry", "extents"};
+      const long long* clk = (const long long*)(outs.data() + (o_clk - o_ell));
+      double sum[8] = {0}; int cnt[8] = {0};
+      for (size_t bx = 0; bx < B; ++bx)
+        for (int k = 0; k < 8; ++k) {
+          const long long t0 = clk[16 * bx + k], t1 = clk[16 * bx + k + 1];
+          if (t0 > 0 && t1 >= t0) { sum[k] += (double)(t1 - t0) * 0.01; cnt[k]++; }
+        }
+      fprintf(stderr, "[esl_fit timing, us per box]");
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f", names[k], cnt[k] ? sum[k] / cnt[k] : 0.0);
+      size_t slow = 0; double slow_t = 0;
+      for (size_t bx = 0; bx < B; ++bx) {
+        long long last = clk[16 * bx];
+        for (int k = 1; k <= 8; ++k) if (clk[16 * bx + k] > last) last = clk[16 * bx + k];
+        const double t = (double)(last - clk[16 * bx]) * 0.01;
+        if (t > slow_t) { slow_t = t; slow = bx; }
+      }
+      fprintf(stderr, "\n[esl_fit timing] slowest box %zu: %.1f us:", slow, slow_t);
+      for (int k = 0; k < 8; ++k) {
+        const long long t0 = clk[16 * slow + k], t1 = clk[16 * slow + k + 1];
+        fprintf(stderr, " %s=%.1f", names[k], (t0 > 0 && t1 >= t0) ? (double)(t1 - t0) * 0.01 : 0.0);
+      }
+      fprintf(stderr, "\n");
+    }
   }
   return rc;
 }
