@@ -49,6 +49,7 @@ struct FitArgs {
   int* csize; unsigned long long* cminkey; unsigned long long* cmind;
   double* po; float* pof;
   double* out_ell; double* out_prob; int* out_status; double* out_dbg;
+  int wide;   // != 0: centre + clustering already ran as grid-wide kernels (boxes with many samples)
   struct FitShared* state;   // per box: the first kernel's shared block, read by the symmetry and the completion kernels
   long long* clk;   // optional (ESL_FIT_TIMING=1): 16 wall_clock64() marks per box written by thread 0 at the stage boundaries
 };
@@ -122,11 +123,28 @@ __device__ __forceinline__ unsigned long long cell_key(float x, float y, float z
                   cz = (long long)floor((double)z / tol) + dz;
   return ((unsigned long long)(cz + kKeyOff) << 42) | ((unsigned long long)(cy + kKeyOff) << 21) | (unsigned long long)(cx + kKeyOff);
 }
+// find with path halving: a node is re-pointed at its grandparent (CAS, so a concurrent link is never undone; an
+// ancestor stays an ancestor).  Linking by index (larger root under smaller) alone grows chains hundreds of hops long
+// inside a 4.5k-point cluster, and every hop is an L2 round trip.
 __device__ __forceinline__ int uf_find(int* parent, int i) {
   for (;;) {
     const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == i) return i;
-    i = p;
+    const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp == p) return p;
+    (void)atomicCAS(&parent[i], p, gp);
+    i = gp;
+  }
+}
+
+__device__ __forceinline__ int uf_find_lds(int* parent, int i) {   // same, forest in LDS
+  for (;;) {
+    const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (p == i) return i;
+    const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gp == p) return p;
+    (void)atomicCAS(&parent[i], p, gp);
+    i = gp;
   }
 }
 
@@ -405,44 +423,139 @@ struct FitShared {
   SymCtx sc;
 };
 
-static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
-  __shared__ FitShared S;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const long base = (long)b * a.H, pbase = (long)b * a.cap;
+// ---- Euclidean clustering on global-memory tables (cell hash -> per-cell lists -> lock-free union-find) -------
+// Thread t0 of `stride` cooperating threads; one workgroup (the box's) or a whole (tile, box) grid.
+__device__ void cl_init(const FitArgs& a, long base, long pbase, int M, long t0, long stride) {
+  for (long s = t0; s < a.H; s += stride) { a.ck[base + s] = kEmpty; a.chead[base + s] = -1; }
+  for (long i = t0; i < M; i += stride) { a.parent[pbase + i] = (int)i; a.csize[pbase + i] = 0; a.cminkey[pbase + i] = kEmpty; a.cmind[pbase + i] = kEmpty; }
+}
+__device__ void cl_insert(const FitArgs& a, long base, long pbase, int M, double tol, long t0, long stride) {
+  for (long i = t0; i < M; i += stride) {
+    const unsigned long long key = cell_key(a.pwx[pbase + i], a.pwy[pbase + i], a.pwz[pbase + i], tol, 0, 0, 0);
+    unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
+    for (;;) {
+      const unsigned long long prev = atomicCAS(&a.ck[base + slot], kEmpty, key);
+      if (prev == kEmpty || prev == key) break;
+      slot = (slot + 1) & (unsigned long long)(a.H - 1);
+    }
+    a.nxt[pbase + i] = atomicExch(&a.chead[base + slot], (int)i);
+  }
+}
+// work item = (point i, one of its 27 neighbour cells): a point's own chain of 27 probes + list walks + unions was a
+// 300 us serial path per thread at 8.5k points; split this way the longest chain is one cell's list
+__device__ void cl_union(const FitArgs& a, long base, long pbase, int M, double tol, long t0, long stride) {
+  const double tol2 = tol * tol;
+  for (long w = t0; w < 27L * M; w += stride) {
+    const int i = (int)(w / 27), cidx = (int)(w % 27);
+    const int dx = cidx % 3 - 1, dy = (cidx / 3) % 3 - 1, dz = cidx / 9 - 1;
+    const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
+    const unsigned long long key = cell_key(xi, yi, zi, tol, dx, dy, dz);
+    unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
+    int head = -1;
+    for (;;) {
+      const unsigned long long k = a.ck[base + slot];   // cell table and lists are read-only in this stage: cached loads
+      if (k == key) { head = a.chead[base + slot]; break; }
+      if (k == kEmpty) break;
+      slot = (slot + 1) & (unsigned long long)(a.H - 1);
+    }
+    int ri = i;   // last known root of i
+    for (int j = head; j >= 0; j = a.nxt[pbase + j]) {
+      if (j <= i) continue;
+      const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
+      if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
+        // cheap pre-check with cached loads: equal parents (even stale ones) mean the two were joined already --
+        // components only ever merge, so a stale value can cost a redundant union, never a wrong skip
+        if (a.parent[pbase + ri] == a.parent[pbase + j]) continue;
+        int ra = ri, rb = j;
+        for (;;) {
+          ra = uf_find(a.parent + pbase, ra); rb = uf_find(a.parent + pbase, rb);
+          if (ra == rb) break;
+          if (ra < rb) { const int t = ra; ra = rb; rb = t; }
+          if (atomicCAS(&a.parent[pbase + ra], ra, rb) == ra) { ra = rb; break; }
+        }
+        ri = ra;
+      }
+    }
+  }
+}
+__device__ void cl_stats(const FitArgs& a, long pbase, int M, const double* center, long t0, long stride) {
+  // all lanes of a wave run the same number of rounds (t0's of a wave are consecutive, M is uniform)
+  for (long i0 = t0 - (threadIdx.x & 63); i0 < M; i0 += stride) {
+    const long i = i0 + (threadIdx.x & 63);
+    const bool on = i < M;
+    int r = -1;
+    unsigned long long key = kEmpty, dbits = kEmpty;
+    if (on) {
+      r = uf_find(a.parent + pbase, (int)i);
+      a.nxt[pbase + i] = r;  // root of every point (the list links are no longer needed)
+      key = a.pkey[pbase + i];
+      const double dx = center[0] - a.pwx[pbase + i], dy = center[1] - a.pwy[pbase + i], dz = center[2] - a.pwz[pbase + i];
+      dbits = (unsigned long long)__double_as_longlong(sqrt(dx * dx + dy * dy + dz * dz));
+    }
+    // most waves see ONE root (the big cluster): combine in the wave, one lane issues the three atomics
+    const int r0 = __shfl(r, __ffsll((long long)__ballot(on)) - 1, 64);
+    if (__all(!on || r == r0)) {
+      int cnt = on ? 1 : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off, 64);
+        const unsigned long long k2 = __shfl_xor(key, off, 64), d2 = __shfl_xor(dbits, off, 64);
+        key = k2 < key ? k2 : key; dbits = d2 < dbits ? d2 : dbits;
+      }
+      if ((threadIdx.x & 63) == 0 && cnt > 0) {
+        atomicAdd(&a.csize[pbase + r0], cnt);
+        atomicMin(&a.cminkey[pbase + r0], key);
+        atomicMin(&a.cmind[pbase + r0], dbits);
+      }
+    } else if (on) {
+      atomicAdd(&a.csize[pbase + r], 1);
+      atomicMin(&a.cminkey[pbase + r], key);
+      atomicMin(&a.cmind[pbase + r], dbits);
+    }
+  }
+}
+
+// ---- 1-4 as grid-wide kernels: blockIdx.y = box, blockIdx.x = tile of the box's samples / hash slots ----------
+// (a single 50k-sample box kept ONE compute unit busy for 0.7 ms here; the tables are global-memory hashes built with
+// atomics anyway, so nothing ties these stages to one workgroup)
+static __global__ __launch_bounds__(256) void k_fit_scan(FitArgs a) {
+  const int b = blockIdx.y;
+  const long base = (long)b * a.H;
   const double* bbox = a.bboxes + 4 * b;
   const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
-  if (tid == 0) { S.M = 0; S.n0 = 0; S.n1 = 0; S.ncl = 0; S.chosen = -1; S.maxsize = 0; S.only = -1; S.status = 0; S.ns0 = 0; S.npo = 0; S.cnt = 0; S.minkey = kEmpty; }
-  __syncthreads();
-  ESL_FIT_MARK(0);
+  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[16 * b + 0] = (long long)wall_clock64();
   // 1 + 2. scan the box, voxel-hash at voxel_leaf
   const int x1 = (int)bbox[0], y1 = (int)bbox[1], x2 = (int)bbox[2], y2 = (int)bbox[3];
   const int st = a.p.stride;
   const int nsx = x2 > x1 ? (x2 - x1 + st - 1) / st : 0, nsy = y2 > y1 ? (y2 - y1 + st - 1) / st : 0;
-  {
-    const float inv = 1.0f / (float)a.p.voxel_leaf;
-    int mine = 0;
-    for (long idx = tid; idx < (long)nsx * nsy; idx += kFitThreads) {
-      const int x = x1 + (int)(idx % nsx) * st, y = y1 + (int)(idx / nsx) * st;
-      if (x < 0 || y < 0 || x >= a.w || y >= a.h) continue;
-      const uint16_t d = a.depth[(size_t)y * a.w + x];
-      const double z = d / scale;
-      if (z <= a.p.depth_min || z > a.p.depth_max) continue;
-      const float px = (float)((x - cx) * z / fx), py = (float)((y - cy) * z / fy), pz = (float)z;
-      vox_insert(a, base, vox_key(px, py, pz, inv), px, py, pz);
-      ++mine;
-    }
-    if (mine) atomicAdd(&S.n0, mine);
+  const float inv = 1.0f / (float)a.p.voxel_leaf;
+  int mine = 0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)nsx * nsy; idx += (long)gridDim.x * blockDim.x) {
+    const int x = x1 + (int)(idx % nsx) * st, y = y1 + (int)(idx / nsx) * st;
+    if (x < 0 || y < 0 || x >= a.w || y >= a.h) continue;
+    const uint16_t d = a.depth[(size_t)y * a.w + x];
+    const double z = d / scale;
+    if (z <= a.p.depth_min || z > a.p.depth_max) continue;
+    const float px = (float)((x - cx) * z / fx), py = (float)((y - cy) * z / fy), pz = (float)z;
+    vox_insert(a, base, vox_key(px, py, pz, inv), px, py, pz);
+    ++mine;
   }
-  stage_sync();
-  ESL_FIT_MARK(1);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&a.state[b].n0, mine);
+}
+static __global__ __launch_bounds__(256) void k_fit_plane(FitArgs a) {
+  const int b = blockIdx.y;
+  const long base = (long)b * a.H, pbase = (long)b * a.cap;
+  if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[16 * b + 1] = (long long)wall_clock64();
   // 3 + 4. centroids -> world -> supporting-plane filter
   const SE3 Twc = se3_load(a.Twc);
   const Mat3 Rwc = q_to_R(Twc.r);
   const double gn = sqrt(a.ground[0] * a.ground[0] + a.ground[1] * a.ground[1] + a.ground[2] * a.ground[2]);
-  for (long s = tid; s < a.H; s += kFitThreads) {
-    const unsigned int cnt = __hip_atomic_load(&a.hcnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < a.H; s += (long)gridDim.x * blockDim.x) {
+    const unsigned int cnt = a.hcnt[base + s];
     if (!cnt) continue;
-    atomicAdd(&S.n1, 1);
+    atomicAdd(&a.state[b].n1, 1);
     const double c = (double)cnt;
     const double p[3] = {(double)(float)((double)a.hsx[base + s] / c / ESL_FIX), (double)(float)((double)a.hsy[base + s] / c / ESL_FIX),
                          (double)(float)((double)a.hsz[base + s] / c / ESL_FIX)};
@@ -450,15 +563,96 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
     xform(Rwc, Twc.t, p, q);
     const double dis = (a.ground[0] * q[0] + a.ground[1] * q[1] + a.ground[2] * q[2] + a.ground[3]) / gn;
     if (dis > a.p.plane_dist) {
-      const int i = atomicAdd(&S.M, 1);
+      const int i = atomicAdd(&a.state[b].M, 1);
       a.pwx[pbase + i] = (float)q[0]; a.pwy[pbase + i] = (float)q[1]; a.pwz[pbase + i] = (float)q[2];
       a.pkey[pbase + i] = a.hk[base + s];
     }
   }
+}
+
+// ---- 5-6 as grid-wide kernels (boxes with many samples): centre + table reset, cell hash, union, statistics ----
+static __global__ __launch_bounds__(256) void k_fit_cl_init(FitArgs a) {
+  __shared__ double red[4][4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const long base = (long)b * a.H, pbase = (long)b * a.cap;
+  FitShared* st = a.state + b;
+  const int M = st->M;
+  if (blockIdx.x == 0) {
+    if (a.clk && tid == 0) a.clk[16 * b + 2] = (long long)wall_clock64();
+    if (M < 1) { if (tid == 0) { a.out_status[b] = 4; a.out_dbg[16 * b] = st->n0; a.out_dbg[16 * b + 1] = st->n1; } }
+    else {
+      // 5. GetCenter: 10 x 10 samples around the box centre
+      const double* bbox = a.bboxes + 4 * b;
+      const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
+      double v[4] = {0, 0, 0, 0};
+      if (tid < 100) {
+        const int x = (int)((bbox[0] + bbox[2]) / 2.0), y = (int)((bbox[1] + bbox[3]) / 2.0);
+        const int xd = (int)(fabs(bbox[0] - bbox[2]) / 4.0 / 10), yd = (int)(fabs(bbox[1] - bbox[3]) / 4.0 / 10);
+        const int x_ = x + (tid / 10 - 5) * xd, y_ = y + (tid % 10 - 5) * yd;
+        if (x_ >= 0 && y_ >= 0 && x_ < a.w && y_ < a.h) {
+          const uint16_t d = a.depth[(size_t)y_ * a.w + x_];
+          const float pz = (float)(d / scale);
+          if (!(pz <= 0.1 || pz > a.p.depth_max)) {
+            v[0] = (float)((x_ - cx) * pz / fx); v[1] = (float)((y_ - cy) * pz / fy); v[2] = pz; v[3] = 1;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+        if ((tid & 63) == 0) red[tid >> 6][k] = v[k];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double t[4];
+        for (int k = 0; k < 4; ++k) t[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+        if (t[3] < 2) a.out_status[b] = 1;
+        else {
+          const SE3 Twc = se3_load(a.Twc);
+          const Mat3 Rwc = q_to_R(Twc.r);
+          const double c[3] = {t[0] / t[3], t[1] / t[3], t[2] / t[3]};
+          xform(Rwc, Twc.t, c, st->center);
+        }
+      }
+    }
+  }
+  cl_init(a, base, pbase, M, (long)blockIdx.x * blockDim.x + tid, (long)gridDim.x * blockDim.x);
+}
+static __global__ __launch_bounds__(256) void k_fit_cl_insert(FitArgs a) {
+  const int b = blockIdx.y;
+  if (a.out_status[b] != 0) return;
+  cl_insert(a, (long)b * a.H, (long)b * a.cap, a.state[b].M, a.p.cluster_tolerance, (long)blockIdx.x * blockDim.x + threadIdx.x,
+            (long)gridDim.x * blockDim.x);
+}
+static __global__ __launch_bounds__(256) void k_fit_cl_union(FitArgs a) {
+  const int b = blockIdx.y;
+  if (a.out_status[b] != 0) return;
+  cl_union(a, (long)b * a.H, (long)b * a.cap, a.state[b].M, a.p.cluster_tolerance, (long)blockIdx.x * blockDim.x + threadIdx.x,
+           (long)gridDim.x * blockDim.x);
+}
+static __global__ __launch_bounds__(256) void k_fit_cl_stats(FitArgs a) {
+  const int b = blockIdx.y;
+  if (a.out_status[b] != 0) return;
+  cl_stats(a, (long)b * a.cap, a.state[b].M, a.state[b].center, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
+  __shared__ FitShared S;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long base = (long)b * a.H, pbase = (long)b * a.cap;
+  const SE3 Twc = se3_load(a.Twc);
+  const Mat3 Rwc = q_to_R(Twc.r);
+  const double gn = sqrt(a.ground[0] * a.ground[0] + a.ground[1] * a.ground[1] + a.ground[2] * a.ground[2]);
+  const double* bbox = a.bboxes + 4 * b;
+  const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
+  if (tid == 0) { S.M = a.state[b].M; S.n0 = a.state[b].n0; S.n1 = a.state[b].n1; for (int k = 0; k < 3; ++k) S.center[k] = a.state[b].center[k]; S.ncl = 0; S.chosen = -1; S.maxsize = 0; S.only = -1; S.status = 0; S.ns0 = 0; S.npo = 0; S.cnt = 0; S.minkey = kEmpty; }
   __syncthreads();
   const int M = S.M;
   if (M < 1) { if (tid == 0) { a.out_status[b] = 4; a.out_dbg[16 * b] = S.n0; a.out_dbg[16 * b + 1] = S.n1; } return; }
   ESL_FIT_MARK(2);
+  if (a.wide && a.out_status[b] != 0) return;   // the grid-wide centre stage already gave up on this box
+  if (!a.wide) {
   // 5. GetCenter: 10 x 10 samples around the box centre (first two waves)
   {
     double sx = 0, sy = 0, sz = 0, cn = 0;
@@ -541,8 +735,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
               if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
                 int ra = i, rb = j;
                 for (;;) {
-                  while (true) { const int pp = __hip_atomic_load(&lpar[ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (pp == ra) break; ra = pp; }
-                  while (true) { const int pp = __hip_atomic_load(&lpar[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (pp == rb) break; rb = pp; }
+                  ra = uf_find_lds(lpar, ra); rb = uf_find_lds(lpar, rb);
                   if (ra == rb) break;
                   if (ra < rb) { const int t = ra; ra = rb; rb = t; }
                   if (atomicCAS(&lpar[ra], ra, rb) == ra) break;
@@ -559,8 +752,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
     for (int i = tid; i < M; i += kFitThreads) { lmind[i] = kEmpty; lmink[i] = kEmpty; lsize[i] = 0; }
     __syncthreads();
     for (int i = tid; i < M; i += kFitThreads) {
-      int r = i;
-      while (true) { const int pp = lpar[r]; if (pp == r) break; r = pp; }
+      const int r = uf_find_lds(lpar, i);
       a.nxt[pbase + i] = r;  // root of every point
       atomicAdd(&lsize[r], 1);
       atomicMin(&lmink[r], a.pkey[pbase + i]);
@@ -572,61 +764,16 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
     for (int i = tid; i < M; i += kFitThreads) { a.csize[pbase + i] = lsize[i]; a.cminkey[pbase + i] = lmink[i]; a.cmind[pbase + i] = lmind[i]; }
     stage_sync();
   } else {
-    for (long s = tid; s < a.H; s += kFitThreads) { a.ck[base + s] = kEmpty; a.chead[base + s] = -1; }
-    for (int i = tid; i < M; i += kFitThreads) { a.parent[pbase + i] = i; a.csize[pbase + i] = 0; a.cminkey[pbase + i] = kEmpty; a.cmind[pbase + i] = kEmpty; }
+    cl_init(a, base, pbase, M, tid, kFitThreads);
     stage_sync();
-    for (int i = tid; i < M; i += kFitThreads) {
-      const unsigned long long key = cell_key(a.pwx[pbase + i], a.pwy[pbase + i], a.pwz[pbase + i], tol, 0, 0, 0);
-      unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
-      for (;;) {
-        const unsigned long long prev = atomicCAS(&a.ck[base + slot], kEmpty, key);
-        if (prev == kEmpty || prev == key) break;
-        slot = (slot + 1) & (unsigned long long)(a.H - 1);
-      }
-      a.nxt[pbase + i] = atomicExch(&a.chead[base + slot], i);
-    }
+    cl_insert(a, base, pbase, M, tol, tid, kFitThreads);
     stage_sync();
-    for (int i = tid; i < M; i += kFitThreads) {
-      const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
-      for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-          for (int dx = -1; dx <= 1; ++dx) {
-            const unsigned long long key = cell_key(xi, yi, zi, tol, dx, dy, dz);
-            unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
-            int head = -1;
-            for (;;) {
-              const unsigned long long k = __hip_atomic_load(&a.ck[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (k == key) { head = __hip_atomic_load(&a.chead[base + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-              if (k == kEmpty) break;
-              slot = (slot + 1) & (unsigned long long)(a.H - 1);
-            }
-            for (int j = head; j >= 0; j = a.nxt[pbase + j]) {
-              if (j <= i) continue;
-              const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
-              if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
-                int ra = i, rb = j;
-                for (;;) {
-                  ra = uf_find(a.parent + pbase, ra); rb = uf_find(a.parent + pbase, rb);
-                  if (ra == rb) break;
-                  if (ra < rb) { const int t = ra; ra = rb; rb = t; }
-                  if (atomicCAS(&a.parent[pbase + ra], ra, rb) == ra) break;
-                }
-              }
-            }
-          }
-    }
+    cl_union(a, base, pbase, M, tol, tid, kFitThreads);
     stage_sync();
-    for (int i = tid; i < M; i += kFitThreads) {
-      const int r = uf_find(a.parent + pbase, i);
-      a.nxt[pbase + i] = r;  // root of every point (the list links are no longer needed)
-      atomicAdd(&a.csize[pbase + r], 1);
-      atomicMin(&a.cminkey[pbase + r], a.pkey[pbase + i]);
-      const double dx = S.center[0] - a.pwx[pbase + i], dy = S.center[1] - a.pwy[pbase + i], dz = S.center[2] - a.pwz[pbase + i];
-      const double d = sqrt(dx * dx + dy * dy + dz * dz);
-      atomicMin(&a.cmind[pbase + r], (unsigned long long)__double_as_longlong(d));
-    }
+    cl_stats(a, pbase, M, S.center, tid, kFitThreads);
     stage_sync();
   }
+  }   // !a.wide
   // choose the cluster: the only one, else the largest (ties: smaller voxel key) within center_dis of the centre
   for (int r = tid; r < M; r += kFitThreads) {
     const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -737,20 +884,28 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   }
   ESL_FIT_MARK(5);
   // 8. voxel grid at symmetry_grid over the cluster, then into the object frame
-  for (long s = tid; s < a.H; s += kFitThreads) { a.hk[base + s] = kEmpty; a.hsx[base + s] = 0; a.hsy[base + s] = 0; a.hsz[base + s] = 0; a.hcnt[base + s] = 0; }
+  // (the grid has at most nc cells: a table of >= 2 nc slots carved from the box's voxel table is enough -- clearing and
+  // scanning all H slots cost a 50k-sample box 120 us here)
+  FitArgs ag = a;
+  {
+    long Hs = 1024;
+    while (Hs < 2L * nc) Hs <<= 1;
+    ag.H = Hs < a.H ? Hs : a.H;
+  }
+  for (long s = tid; s < ag.H; s += kFitThreads) { a.hk[base + s] = kEmpty; a.hsx[base + s] = 0; a.hsy[base + s] = 0; a.hsz[base + s] = 0; a.hcnt[base + s] = 0; }
   stage_sync();
   {
     const float inv = 1.0f / (float)a.p.symmetry_grid;
     for (int i = tid; i < M; i += kFitThreads)
       if (a.nxt[pbase + i] == chosen) {
         const float px = a.pwx[pbase + i], py = a.pwy[pbase + i], pz = a.pwz[pbase + i];
-        vox_insert(a, base, vox_key(px, py, pz, inv), px, py, pz);
+        vox_insert(ag, base, vox_key(px, py, pz, inv), px, py, pz);
       }
   }
   stage_sync();
   double* po = a.po + 12 * pbase;   // up to 4 * cap points
   float* pof = a.pof + 3 * pbase;
-  for (long s = tid; s < a.H; s += kFitThreads) {
+  for (long s = tid; s < ag.H; s += kFitThreads) {
     const unsigned int cnt = __hip_atomic_load(&a.hcnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!cnt) continue;
     const double c = (double)cnt;
@@ -1056,6 +1211,7 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   long H = 1024;
   while (H < 2 * cap) H <<= 1;
   a.cap = cap; a.H = H;
+  a.wide = cap > 4 * kClLds ? 1 : 0;   // a box may hold more voxels than the LDS clustering path takes: go grid-wide
   // one slab for everything
   const size_t B = (size_t)n_boxes;
   size_t off = 0;
@@ -1102,8 +1258,23 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   if (!rc && (e = hipMemsetAsync(slab + o_ell, 0, off - o_ell, st)) != hipSuccess) fail(e, "clear outputs");
   if (!rc) {
     ProfScope ps(c, 5);
-    // three launches: per-box segmentation + PCA, the 9 plane hypotheses of every box side by side, completion
+    // five launches: box scan + voxel hash and plane filter over (tile, box) grids; per-box clustering + PCA; the 9 plane
+    // hypotheses of every box side by side; completion
     if ((e = hipMemsetAsync(slab + o_state, 0, B * sizeof(FitShared), st)) != hipSuccess) fail(e, "clear state");
+    {
+      const long tiles_scan = std::min<long>(64, std::max<long>(1, (cap + 2047) / 2048));   // ~8 samples per thread
+      const long tiles_hash = std::min<long>(64, std::max<long>(1, H / 2048));
+      hipLaunchKernelGGL(k_fit_scan, dim3((unsigned)tiles_scan, n_boxes), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_fit_plane, dim3((unsigned)tiles_hash, n_boxes), dim3(256), 0, st, a);
+    }
+    if (a.wide) {   // boxes with many samples: centre + clustering over (tile, box) grids as well
+      const long tiles_pts = std::min<long>(64, std::max<long>(1, cap / 1024));
+      const long tiles_hash = std::min<long>(64, std::max<long>(1, H / 2048));
+      hipLaunchKernelGGL(k_fit_cl_init, dim3((unsigned)tiles_hash, n_boxes), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_fit_cl_insert, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_fit_cl_union, dim3((unsigned)std::min<long>(1024, tiles_pts * 27), n_boxes), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_fit_cl_stats, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
+    }
     hipLaunchKernelGGL(k_fit_pre, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
     if (p->symmetry_open) hipLaunchKernelGGL(k_fit_sym, dim3(n_boxes * 9), dim3(kSymThreads), 0, st, a);
     hipLaunchKernelGGL(k_fit_post, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
