@@ -121,7 +121,7 @@ def fit_bench(pkg, ctx, with_cpu=True):
         ctx.profile_enable(False)
         entry = {"ms_per_frame_host_call": 1e3 * dt, "ms_per_frame_kernel": prof["total_ms"] / max(prof["count"], 1),
                  "boxes": len(lab), "ok_boxes": int((res[2] == 0).sum()), "samples": int(res[3][:, 0].sum()),
-                 "note": "host call = hipMalloc + H2D of the depth image + kernel + D2H (PCIe-inclusive); kernel = HIP events"}
+                 "note": "host call = H2D of the depth image + kernels + D2H (PCIe-inclusive); kernel = HIP events around the launches"}
         if with_cpu:
             from oracle import pyoracle as po
             Po = po.default_fit_params(**kw)
