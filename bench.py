@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_MFMA_PEAK_TF = 78.6    # SURVEY.md §8 d (vendor sheet): FP64 matrix
+FP64_MFMA_PEAK_TF = 78.6          # SURVEY.md §8 d (vendor sheet): FP64 matrix
+FP64_MFMA_MEASURED_TF = 35.9      # scripts/mfma_peak.hip on the GPU box (profiles/r1_fp64_ceilings.txt)
 
 
 def algorithmic_bytes_linearize(g, slam):
@@ -309,7 +310,11 @@ def main():
             achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             roof = {"kernel": "dense_cholesky_f64", "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF,
                     "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None,
-                    "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": dom["count"]}
+                    "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": dom["count"],
+                    "measured_ceiling": {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_MEASURED_TF,
+                                         "note": "register-only v_mfma_f64_16x16x4_f64 stream on this MI355X at 2.39 GHz "
+                                                 "(scripts/mfma_peak.hip): one MFMA per 128 cycles per SIMD, half the 78.6 TFLOP/s "
+                                                 "of the spec sheet; v_fma_f64 tops out at 55 TFLOP/s (clock drops to 1.9 GHz)"}}
         out = {
             "metric": "LM iterations/sec (cams+ellipsoids)",
             "value": world * iters / dt,

@@ -254,6 +254,12 @@ int esl_init_quadric(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const do
                      int32_t n, const double K[4], int32_t rows, int32_t cols, int32_t faithful,
                      double ellipsoid_out[10], double qstar_out[16], int32_t* ok);
 
+/* ---- diagnostics ---------------------------------------------------------------------------------*/
+/* Dense FP64-MFMA Cholesky factor + solve (the reduced-camera solver of SLAM mode) on a procedurally generated,
+ * strictly diagonally dominant n x n system; returns the time of factor + solve (HIP events) and |A x - b| / |b|.
+ * A known-answer test of the solver and the micro-benchmark behind the "mfma" roofline numbers. */
+int esl_selftest_cholesky(esl_ctx* ctx, int32_t n, double* ms_out, double* rel_residual_out);
+
 #ifdef __cplusplus
 }
 #endif

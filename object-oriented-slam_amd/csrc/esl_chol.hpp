@@ -30,105 +30,201 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // The serial chain is 4 x 32 small column steps; the rank-32 updates and the 32x32 block products of the
 // inverse use all 256 threads.  (The first version ran 128 full-size column steps + a serial trtri: 793 us.)
 constexpr int kSB = 32;
+// value of `v` in lane `src` (a compile-time constant after unrolling) -> every lane: two v_readlane_b32 (a few cycles
+// each); __shfl() would go through ds_bpermute, ~100 cycles of LDS-crossbar latency on a dependent chain
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// 32x32 diagonal sub-block, wave-synchronous in registers (no workgroup barriers inside the 32 column steps):
+// lane r holds row r of the sub-block.  Returns the factor in `row` and 1/L(j,j) in invd[j] (uniform).
+__device__ __forceinline__ void potrf32_wave(double (&row)[kSB], double (&invd)[kSB], int lane, int* info) {
+#pragma unroll
+  for (int j = 0; j < kSB; ++j) {
+    const double d = readlane_f64(row[j], j);
+    if (!(d > 0) && lane == 0) atomicOr(info, 1);
+    const double s = sqrt(d), is = 1.0 / s;
+    invd[j] = is;
+    const double lij = (lane == j) ? s : row[j] * is;   // lanes above the diagonal carry unused values
+    row[j] = lij;
+#pragma unroll
+    for (int c = j + 1; c < kSB; ++c) row[c] -= lij * readlane_f64(lij, c);
+  }
+}
+// X = D^-1 for the lower-triangular 32x32 factor held row-per-lane in `row`: lane c computes column c of X by forward
+// substitution (L X = I); L(i,k) comes from lane i by shuffle.
+__device__ __forceinline__ void trtri32_wave(const double (&row)[kSB], const double (&invd)[kSB], int lane, double (&x)[kSB]) {
+#pragma unroll
+  for (int i = 0; i < kSB; ++i) {
+    double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) acc -= readlane_f64(row[k], i) * x[k];
+    x[i] = acc * invd[i];
+  }
+}
+
+// diagnostic: wall_clock64() marks (100 MHz) of the last k_chol_potrf launch, read by esl_selftest_cholesky when
+// ESL_CHOL_TIMING is set
+__device__ long long g_potrf_clk[16];
+#define POTRF_MARK(k) do { if (t == 0) g_potrf_clk[k] = (long long)wall_clock64(); } while (0)
 static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ M, long lda, int k0, int nb,
                                                     double* __restrict__ Linv /* kNB x kNB col-major */,
                                                     int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* L = sm;                          // nb x nb, column stride kLdsPad
-  double* T = sm + kNB * kLdsPad;          // 96 x 32 temporary + 32-vector for the in-place inverse
-  const int t = threadIdx.x;
+  double* L = sm;                          // kNB x kNB, column stride kLdsPad: the factor, later its inverse
+  double* T = sm + kNB * kLdsPad;          // 96 x 32 temporary
+  double* dinv = T + 96 * kSB;             // kNB reciprocals of the diagonal
+  // The inverse X_J of diagonal sub-block J is parked in the block's own (otherwise unused) strictly upper triangle,
+  // transposed: X_J(i,c), i > c, lives at L(c0 + c, c0 + i); its diagonal is dinv.  (157.9 of the 160 KB of LDS are taken.)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #define LL(i, j) L[(i) + (j) * kLdsPad]
+#define DV(J, i, j) (((i) == (j)) ? dinv[(J) * kSB + (i)] : LL((J) * kSB + (j), (J) * kSB + (i)))
+  POTRF_MARK(0);
   for (int idx = t; idx < kNB * kNB; idx += 256) {
     const int i = idx % kNB, j = idx / kNB;
     LL(i, j) = (i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int c0 = 0; c0 < nb; c0 += kSB) {
-    const int w = (nb - c0 < kSB) ? (nb - c0) : kSB;
-    // 1. unblocked factorisation of the w x w diagonal sub-block
-    for (int j = c0; j < c0 + w; ++j) {
-      const double d = LL(j, j);
-      if (!(d > 0) && t == 0) atomicOr(info, 1);
-      const double s = sqrt(d), is = 1.0 / s;
-      __syncthreads();
-      if (t < c0 + w - j) { const int i = j + t; LL(i, j) = (i == j) ? s : LL(i, j) * is; }
-      __syncthreads();
-      const int m = c0 + w - j - 1;   // remaining columns inside the sub-block
-      for (int idx = t; idx < m * m; idx += 256) {
-        const int c = j + 1 + idx / m, i = j + 1 + idx % m;
-        if (i >= c) LL(i, c) -= LL(i, j) * LL(c, j);
-      }
-      __syncthreads();
-    }
-    const int r0 = c0 + w;            // rows below the sub-block
-    // 2. sub-panel solve: X D^T = A, one thread per row
-    for (int i = r0 + t; i < nb; i += 256) {
-      for (int c = c0; c < c0 + w; ++c) {
-        double v = LL(i, c);
-        for (int k = c0; k < c; ++k) v -= LL(i, k) * LL(c, k);
-        LL(i, c) = v / LL(c, c);
+  POTRF_MARK(1);
+  for (int c0 = 0; c0 < kNB; c0 += kSB) {   // rows/columns >= nb are identity padding: factoring them is a no-op
+    // 1. the 32 x 32 diagonal sub-block: wave 0, in registers (the only serial part: 32 dependent column steps)
+    if (wave == 0) {
+      double row[kSB], invd[kSB];
+      const int r = lane & 31;
+#pragma unroll
+      for (int c = 0; c < kSB; ++c) row[c] = (c <= r) ? LL(c0 + r, c0 + c) : 0.0;
+      potrf32_wave(row, invd, lane, info);
+      if (lane < kSB) {
+#pragma unroll
+        for (int c = 0; c < kSB; ++c) {
+          if (c <= r) LL(c0 + r, c0 + c) = row[c];
+          if (c == lane) dinv[c0 + c] = invd[c];
+        }
       }
     }
     __syncthreads();
-    // 3. rank-w update of the trailing lower triangle
-    const int m2 = nb - r0;
-    for (int idx = t; idx < m2 * m2; idx += 256) {
-      const int c = r0 + idx / m2, i = r0 + idx % m2;
-      if (i >= c) {
-        double v = 0;
-        for (int k = c0; k < c0 + w; ++k) v += LL(i, k) * LL(c, k);
-        LL(i, c) -= v;
+    if (c0 == 0) POTRF_MARK(2);
+    const int r0 = c0 + kSB, m2 = kNB - r0;   // rows below the sub-block
+    if (m2 > 0) {
+      // 2. sub-panel solve X D^T = A by forward substitution, one lane per row (D's entries are broadcast LDS reads)
+      if (t < m2) {
+        const int i = r0 + t;
+        double v[kSB];
+#pragma unroll
+        for (int c = 0; c < kSB; ++c) {
+          double acc = LL(i, c0 + c);
+#pragma unroll
+          for (int k = 0; k < c; ++k) acc -= v[k] * LL(c0 + c, c0 + k);
+          v[c] = acc * dinv[c0 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < kSB; ++c) LL(i, c0 + c) = v[c];
       }
+      __syncthreads();
+      if (c0 == 0) POTRF_MARK(3);
+      // 3. rank-32 update of the trailing lower triangle on the matrix cores: 16 x 16 blocks (ib >= jb) dealt to the 4 waves
+      {
+        const int nbk = m2 / 16, npair = nbk * (nbk + 1) / 2;
+        const int r = lane & 15, kq = lane >> 4;
+        for (int pidx = wave; pidx < npair; pidx += 4) {
+          int ib = (int)((sqrtf(8.0f * (float)pidx + 1.0f) - 1.0f) * 0.5f);
+          while (ib * (ib + 1) / 2 > pidx) --ib;
+          while ((ib + 1) * (ib + 2) / 2 <= pidx) ++ib;
+          const int jb = pidx - ib * (ib + 1) / 2;
+          const int i0 = r0 + ib * 16, j0 = r0 + jb * 16;
+          double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int kk = 0; kk < kSB; kk += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(LL(i0 + r, c0 + kk + kq), LL(j0 + r, c0 + kk + kq), acc, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int i = i0 + kq + 4 * g, c = j0 + r;   // D: row = (lane >> 4) + 4 g, col = lane & 15
+            if (i >= c) LL(i, c) -= acc[g];
+          }
+        }
+      }
+      __syncthreads();
+      if (c0 == 0) POTRF_MARK(4);
     }
-    __syncthreads();
   }
+  POTRF_MARK(5);
+  // inverses of the four diagonal sub-blocks, one wave each, side by side (parked in the upper triangles)
+  {
+    const int c0 = wave * kSB, r = lane & 31;
+    double row[kSB], invd[kSB], x[kSB];
+#pragma unroll
+    for (int c = 0; c < kSB; ++c) { row[c] = (c <= r) ? LL(c0 + r, c0 + c) : 0.0; invd[c] = dinv[c0 + c]; }
+    trtri32_wave(row, invd, lane, x);
+    if (lane < kSB) {
+#pragma unroll
+      for (int c = 0; c < kSB; ++c)
+        if (c > lane) LL(c0 + lane, c0 + c) = x[c];    // lane = column of X, x[c] = X(c, lane), parked transposed
+    }
+  }
+  __syncthreads();
+  POTRF_MARK(6);
   // write L11 back (the factor itself is part of the result)
   for (int idx = t; idx < nb * nb; idx += 256) {
     const int i = idx % nb, j = idx / nb;
     if (i >= j) M[(long)(k0 + i) + (long)(k0 + j) * lda] = LL(i, j);
   }
-  // ---- Linv = L^-1 IN PLACE in LDS (blocked dtrtri, lower): block columns right to left ---------------------------
-  // (the first blocked version kept Linv in global memory: store-to-load round trips made it 355 us per panel)
+  // ---- Linv = L^-1 IN PLACE in LDS (blocked dtrtri, lower): block columns right to left; the diagonal blocks' inverses
+  // are parked in the upper triangles
   __syncthreads();
+  POTRF_MARK(7);
   constexpr int nB = kNB / kSB;
-  double* v = T + 96 * kSB;   // 32 doubles: column copy for the unblocked diagonal inverse
   for (int J = nB - 1; J >= 0; --J) {
     const int c0 = J * kSB, r0 = c0 + kSB, mrows = kNB - r0;
-    // (a) T = Linv[r0.., r0..] * L[r0.., c0..c0+32)    (lower-triangular times panel)
-    for (int idx = t; idx < mrows * kSB; idx += 256) {
-      const int i = idx % mrows, c = idx / mrows;
-      double acc = 0;
-      for (int k = 0; k <= i; ++k) acc += LL(r0 + i, r0 + k) * LL(r0 + k, c0 + c);
-      T[i + c * 96] = acc;
+    // (a) T = Linv[r0.., r0..] * L[r0.., c0..c0+32)    (lower-triangular times panel) -- MFMA; entries above the diagonal of
+    //     the left factor are masked (the diagonal sub-blocks' upper triangles hold parked inverses)
+    {
+      const int r = lane & 15, kq = lane >> 4;
+      const int nout = (mrows / 16) * 2;
+      for (int ob = wave; ob < nout; ob += 4) {
+        const int ib = ob >> 1, cb = ob & 1;
+        double4_t acc = {0, 0, 0, 0};
+        for (int kk = 0; kk < (ib + 1) * 16; kk += 4) {
+          const int i = ib * 16 + r, k = kk + kq;
+          const double av = (k <= i) ? LL(r0 + i, r0 + k) : 0.0;
+          const double bv = LL(r0 + k, c0 + cb * 16 + r);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) T[(ib * 16 + kq + 4 * g) + (cb * 16 + r) * 96] = acc[g];
+      }
     }
     __syncthreads();
-    // (b) diagonal block inverted in place (dtrti2, lower): columns right to left, rows in parallel
-    for (int jj = kSB - 1; jj >= 0; --jj) {
-      const int j = c0 + jj;
-      const double ajj = 1.0 / LL(j, j);
-      if (t > jj && t < kSB) v[t] = LL(c0 + t, j);
-      __syncthreads();
-      if (t > jj && t < kSB) {
-        double acc = 0;
-        for (int k = jj + 1; k <= t; ++k) acc += LL(c0 + t, c0 + k) * v[k];
-        LL(c0 + t, j) = -acc * ajj;
+    // (b) diagonal block <- its inverse
+    for (int idx = t; idx < kSB * kSB; idx += 256) { const int i = idx % kSB, c = idx / kSB; if (i > c) LL(c0 + i, c0 + c) = LL(c0 + c, c0 + i); }
+    // (c) panel = -T * Dinv  (Dinv lower: read from its parked, transposed copy)
+    {
+      const int r = lane & 15, kq = lane >> 4;
+      const int nout = (mrows / 16) * 2;
+      for (int ob = wave; ob < nout; ob += 4) {
+        const int ib = ob >> 1, cb = ob & 1;
+        double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < kSB; kk += 4) {
+          const int k = kk + kq, c = cb * 16 + r;
+          const double av = T[(ib * 16 + r) + k * 96];
+          const double bv = (k > c) ? LL(c0 + c, c0 + k) : ((k == c) ? dinv[c0 + c] : 0.0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) LL(r0 + ib * 16 + kq + 4 * g, c0 + cb * 16 + r) = -acc[g];
       }
-      if (t == 0) LL(j, j) = ajj;
-      __syncthreads();
     }
-    // (c) panel = -T * Dinv
-    for (int idx = t; idx < mrows * kSB; idx += 256) {
-      const int i = idx % mrows, c = idx / mrows;
-      double acc = 0;
-      for (int k = c; k < kSB; ++k) acc += T[i + k * 96] * LL(c0 + k, c0 + c);
-      LL(r0 + i, c0 + c) = -acc;
-    }
+    __syncthreads();
+    if (t < kSB) LL(c0 + t, c0 + t) = dinv[c0 + t];   // diagonal of the inverse (after (c) has read dinv / before the next (a))
     __syncthreads();
   }
+  POTRF_MARK(8);
   for (int idx = t; idx < kNB * kNB; idx += 256) {
     const int i = idx % kNB, j = idx / kNB;
     Linv[idx] = (i < nb && j < nb && i >= j) ? LL(i, j) : 0.0;
   }
+  POTRF_MARK(9);
+#undef DV
 #undef LL
 }
 
@@ -175,35 +271,64 @@ __device__ __forceinline__ void mfma_xyT_64x64(const double* __restrict__ X, lon
 }
 
 // ---- panel solve: P <- P * Linv^T for rows [r0, rows) of columns [k0, k0+nb) -------------------------------
-// One wave owns 64 rows x all kNB columns (two 64-column halves): it reads its rows completely before
-// writing them, so the in-place update is race-free.
-static __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ M, long lda, long rows, int k0, int nb,
+// One WORKGROUP owns 64 rows x all kNB columns; its 8 waves take 32 x 32 sub-tiles (2 row groups x 4 column groups), so a
+// wave's dependent chain is 128 MFMAs, not the 1,024 of the first version (one wave per 64 rows x 128 columns: 86 us per
+// launch whatever the height of the panel).  The rows are updated in place: every wave reads all K input columns of its
+// rows, the barrier makes sure all of the workgroup's reads are done before anybody writes.
+static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ M, long lda, long rows, int k0, int nb,
                                                     const double* __restrict__ Linv) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long r0 = (long)k0 + nb + ((long)blockIdx.x * 4 + wave) * 64;
-  if (r0 >= rows) return;
-  double4_t acc0[4][4], acc1[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { acc0[i][j] = double4_t{0, 0, 0, 0}; acc1[i][j] = double4_t{0, 0, 0, 0}; }
+  const int r = lane & 15, kq = lane >> 4;
+  const long r0 = (long)k0 + nb + (long)blockIdx.x * 64 + (wave >> 2) * 32;
+  const int cg = (wave & 3) * 32;
   const double* P = M + (long)k0 * lda;
-  mfma_xyT_64x64(P, lda, r0, rows, Linv, kNB, 0, kNB, nb, acc0);
-  mfma_xyT_64x64(P, lda, r0, rows, Linv, kNB, 64, kNB, nb, acc1);
-  // all reads of this wave's rows are done (acc depends on them); write back
-  const int c = lane & 15, rq = lane >> 4;
+  double4_t acc[2][2];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int nj = 0; nj < 4; ++nj)
+    for (int j = 0; j < 2; ++j) acc[i][j] = double4_t{0, 0, 0, 0};
+  const double* xp[2];
+  const double* yp[2];
+  bool xv[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const long xr = r0 + m * 16 + r;
+    xv[m] = xr < rows;
+    xp[m] = P + (xv[m] ? xr : 0) + (long)kq * lda;
+    yp[m] = Linv + (cg + m * 16 + r) + (long)kq * kNB;
+  }
+  // software pipeline, two k-steps deep
+  double a[2], b[2], an[2], bn[2];
+  {
+    const bool kv = kq < nb;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { a[m] = (xv[m] && kv) ? xp[m][0] : 0.0; b[m] = kv ? yp[m][0] : 0.0; }
+  }
+  for (int kk = 0; kk < nb; kk += 4) {
+    const int kn = kk + 4;
+    const bool kv = (kn + kq) < nb;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      an[m] = (xv[m] && kv) ? xp[m][(long)kn * lda] : 0.0;
+      bn[m] = kv ? yp[m][(long)kn * kNB] : 0.0;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { a[m] = an[m]; b[m] = bn[m]; }
+  }
+  __syncthreads();   // every wave of the workgroup has read its input rows
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const long row = r0 + mi * 16 + rq + 4 * g;
-        const int col0 = nj * 16 + c, col1 = 64 + nj * 16 + c;
-        if (row < rows) {
-          if (col0 < nb) M[row + (long)(k0 + col0) * lda] = acc0[mi][nj][g];
-          if (col1 < nb) M[row + (long)(k0 + col1) * lda] = acc1[mi][nj][g];
-        }
+        const long row = r0 + mi * 16 + kq + 4 * g;
+        const int col = cg + nj * 16 + r;
+        if (row < rows && col < nb) M[row + (long)(k0 + col) * lda] = acc[mi][nj][g];
       }
 }
 
@@ -395,7 +520,7 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
 inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws, double* z_ws, double* x, int* info,
                                     hipStream_t st) {
   const long rows = (long)n + 1;
-  const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kSB) * sizeof(double);
+  const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -425,7 +550,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     double* Linv1 = Linv_ws + (size_t)p * kNB * kNB;
     hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb1, Linv1, info);
     long below = rows - (k0 + nb1);
-    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 255) / 256)), dim3(256), 0, st, M, lda, rows, k0, nb1, Linv1);
+    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb1, Linv1);
     const int k1 = k0 + nb1;
     if (k1 >= n) break;
     const int nb2 = (n - k1 < kNB) ? (n - k1) : kNB;
@@ -434,7 +559,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     double* Linv2 = Linv_ws + (size_t)(p + 1) * kNB * kNB;
     hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k1, nb2, Linv2, info);
     below = rows - (k1 + nb2);
-    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 255) / 256)), dim3(256), 0, st, M, lda, rows, k1, nb2, Linv2);
+    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k1, nb2, Linv2);
     // rank-(nb1+nb2) update of everything to the right of the outer panel
     launch_update(k0, nb1 + nb2, (long)k1 + nb2, (long)n);
   }

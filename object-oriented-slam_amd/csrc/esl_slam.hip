@@ -4,6 +4,8 @@
 #include "esl_slam.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "esl_chol.hpp"
 #include "esl_kernels_slam.hpp"
@@ -188,3 +190,95 @@ int slam_try_step(esl_ctx* c, double lambda) {
 }
 
 }  // namespace esl
+
+// ---- dense-solver self test / micro-benchmark ------------------------------------------------------------------------
+// A(i,j) = h(min,max) in [-1,1) off the diagonal (a hash, so the matrix never has to be kept), A(i,i) = n: strictly
+// diagonally dominant, hence SPD.  b = A * 1 + known perturbation -> the solve must return x with A x = b.
+namespace esl {
+__device__ __forceinline__ double st_entry(long i, long j, long n) {
+  if (i == j) return (double)n;
+  const unsigned long long a = (unsigned long long)(i < j ? i : j), b = (unsigned long long)(i < j ? j : i);
+  unsigned long long h = a * 0x9E3779B97F4A7C15ull ^ (b + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  return (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+__device__ __forceinline__ double st_rhs(long i) { return 1.0 + 0.001 * (double)(i % 97); }
+static __global__ void k_selftest_fill(double* __restrict__ M, long lda, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i > n || j >= n) return;
+  double v = 0;
+  if (i == n) v = st_rhs(j);          // row n carries b^T
+  else if (i >= j) v = st_entry(i, j, n);
+  M[i + j * lda] = v;
+}
+// one workgroup per row: r_i = b_i - sum_j A(i,j) x_j ;  accumulates |r|^2 and |b|^2
+static __global__ __launch_bounds__(256) void k_selftest_resid(const double* __restrict__ x, long n, double* __restrict__ out2) {
+  __shared__ double red[256];
+  const long i = blockIdx.x;
+  double s = 0;
+  for (long j = threadIdx.x; j < n; j += 256) s += st_entry(i, j, n) * x[j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const double b = st_rhs(i), r = b - red[0];
+    atomicAdd(&out2[0], r * r);
+    atomicAdd(&out2[1], b * b);
+  }
+}
+}  // namespace esl
+
+extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, double* rel_residual_out) {
+  using namespace esl;
+  if (!c || n < 1 || !ms_out || !rel_residual_out) return ESL_ERR_INVALID;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  const long lda = (((long)n + 1 + 15) / 16) * 16;
+  double *M = nullptr, *Linv = nullptr, *z = nullptr, *x = nullptr, *out2 = nullptr;
+  int* info = nullptr;
+  const size_t np = (size_t)((n + kNB - 1) / kNB);
+  int rc = ESL_OK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() {
+    if (M) (void)hipFree(M); if (Linv) (void)hipFree(Linv); if (z) (void)hipFree(z); if (x) (void)hipFree(x);
+    if (out2) (void)hipFree(out2); if (info) (void)hipFree(info);
+    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+  };
+#define ST_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return ESL_ERR_HIP; } } while (0)
+  ST_TRY(hipMalloc((void**)&M, (size_t)lda * (size_t)n * sizeof(double)));
+  ST_TRY(hipMalloc((void**)&Linv, np * kNB * kNB * sizeof(double)));
+  ST_TRY(hipMalloc((void**)&z, kNB * sizeof(double)));
+  ST_TRY(hipMalloc((void**)&x, (size_t)n * sizeof(double)));
+  ST_TRY(hipMalloc((void**)&out2, 2 * sizeof(double)));
+  ST_TRY(hipMalloc((void**)&info, sizeof(int)));
+  ST_TRY(hipEventCreate(&e0)); ST_TRY(hipEventCreate(&e1));
+  ST_TRY(hipMemsetAsync(out2, 0, 2 * sizeof(double), c->stream));
+  ST_TRY(hipMemsetAsync(info, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_selftest_fill, dim3((unsigned)((n + 1 + 255) / 256), (unsigned)n), dim3(256), 0, c->stream, M, lda, (long)n);
+  ST_TRY(hipEventRecord(e0, c->stream));
+  ST_TRY(chol_factor_solve(M, lda, n, Linv, z, x, info, c->stream));
+  ST_TRY(hipEventRecord(e1, c->stream));
+  hipLaunchKernelGGL(k_selftest_resid, dim3((unsigned)n), dim3(256), 0, c->stream, x, (long)n, out2);
+  double h2[2] = {0, 0};
+  int hinfo = 0;
+  ST_TRY(hipMemcpyAsync(h2, out2, sizeof(h2), hipMemcpyDeviceToHost, c->stream));
+  ST_TRY(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  ST_TRY(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  ST_TRY(hipEventElapsedTime(&ms, e0, e1));
+#undef ST_TRY
+  if (std::getenv("ESL_CHOL_TIMING")) {
+    long long clk[16];
+    if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_potrf_clk), sizeof(clk)) == hipSuccess) {
+      static const char* names[9] = {"load", "factor32[0]", "subpanel[0]", "rank32[0]", "steps 1-3", "trtri x4", "store L", "inverse", "store Linv"};
+      fprintf(stderr, "[k_chol_potrf, last launch, us]");
+      for (int k = 0; k < 9; ++k) fprintf(stderr, " %s=%.1f", names[k], (double)(clk[k + 1] - clk[k]) * 0.01);
+      fprintf(stderr, "\n");
+    }
+  }
+  *ms_out = ms;
+  *rel_residual_out = h2[1] > 0 ? std::sqrt(h2[0] / h2[1]) : 0.0;
+  if (hinfo) { set_error("self test: non-positive pivot"); rc = ESL_ERR_STATE; }
+  cleanup();
+  return rc;
+}
+

@@ -20,7 +20,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_selftest_cholesky",
     "esl_init_quadric",
 ]
 
@@ -196,6 +196,12 @@ class Context:
                                           C.byref(p), ell.ctypes.data_as(_dp), prob.ctypes.data_as(_dp),
                                           st.ctypes.data_as(C.POINTER(C.c_int32)), dbg.ctypes.data_as(_dp)), "esl_fit_frame")
         return ell, prob, st, dbg
+
+    def selftest_cholesky(self, n):
+        """(ms, relative residual) of the dense FP64-MFMA Cholesky factor + solve on a generated SPD system."""
+        ms, res = C.c_double(0), C.c_double(0)
+        _check(load().esl_selftest_cholesky(self._h, C.c_int32(n), C.byref(ms), C.byref(res)), "esl_selftest_cholesky")
+        return ms.value, res.value
 
     def comm_init(self, n_ranks, rank, unique_id):
         """Join the RCCL communicator; afterwards optimize_resident() is collective over all ranks."""

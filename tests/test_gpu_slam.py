@@ -96,3 +96,12 @@ def test_c3_slam_runs_and_reduces_chi2(pkg, po, ctx):
     co, oo, ro = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=1e-6), solver=1)
     assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-3)
     assert cam_err(cg, co) < 1e-3
+
+
+@pytest.mark.parametrize("n", [1, 7, 130, 777, 3000])
+def test_dense_cholesky_selftest_residual(ctx, n):
+    """Known-answer test of the MFMA Cholesky on a generated diagonally dominant system (sizes straddle the 128-wide
+    inner panels and the 256-wide outer ones): |A x - b| / |b| at fp64 round-off."""
+    ms, res = ctx.selftest_cholesky(n)
+    assert res < 1e-12, (n, res)
+    assert ms >= 0
