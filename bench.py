@@ -58,7 +58,9 @@ def valu_issue_floor(g, avg_ms):
     floor_ms = cycles / 2.4e9 * 1e3
     return {"bbox_waves": waves_bb, "bbox_valu_instr_per_wave": v_bb, "e3d_waves": waves_e3, "e3d_valu_instr_per_wave": v_e3,
             "simds": 1024, "clock_ghz": 2.4, "floor_ms": floor_ms, "frac": floor_ms / avg_ms if avg_ms > 0 else None,
-            "note": "kernel duration includes ~4 us of dispatch; static instruction counts (both sides of branches)"}
+            "floor_ms_at_1p89_ghz": floor_ms * 2.4 / 1.89,
+            "note": "kernel duration includes ~4 us of dispatch; static instruction counts (both sides of branches); a pure "
+                    "v_fma_f64 stream pulls the shader clock down to 1.89 GHz on this part (profiles/r1_fp64_ceilings.txt)"}
 
 
 def cpu_baseline(pkg, g, c, o, params, budget_s=25.0):
