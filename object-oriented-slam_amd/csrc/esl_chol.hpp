@@ -332,50 +332,6 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
       }
 }
 
-// ---- trailing update: C <- C - P_i P_j^T over lower-triangle 128x128 tiles --------------------------------
-// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8, each XCD has its own 4 MiB L2.  Tiles are
-// grouped into 8x8 SUPER-TILES (1024 x 1024 elements; operand working set 2 x 1024 x 128 x 8 B = 2 MiB, fits one
-// L2) and a super-tile is handed to ONE XCD: workgroup b -> xcd = b % 8, q = b / 8, super-tile (q / 64) * 8 + xcd,
-// tile q % 64 inside it.  4 waves = 2x2 sub-tiles of 64x64 each.
-static __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ M, long lda, long rows, long ncols, int k0,
-                                                     int nb, int nst /* super-tile rows */) {
-  const long b = blockIdx.x;
-  const long xcd = b & 7, q = b >> 3;
-  const long sb = (q >> 6) * 8 + xcd;         // super-tile index in the lower triangle of super-tiles
-  const long nsb = (long)nst * (nst + 1) / 2;
-  if (sb >= nsb) return;
-  long SI = (long)((sqrt(8.0 * (double)sb + 1.0) - 1.0) * 0.5);
-  while (SI * (SI + 1) / 2 > sb) --SI;
-  while ((SI + 1) * (SI + 2) / 2 <= sb) ++SI;
-  const long SJ = sb - SI * (SI + 1) / 2;
-  const long ti = SI * 8 + ((q & 63) >> 3), tj = SJ * 8 + (q & 7);
-  if (tj > ti) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long base = (long)k0 + nb;
-  const long i0 = base + ti * 128 + (wave >> 1) * 64;
-  const long j0 = base + tj * 128 + (wave & 1) * 64;
-  if (i0 >= rows || j0 >= ncols) return;
-  if (j0 > i0 + 63) return;  // strictly upper 64x64 sub-tile of a diagonal tile
-  double4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0, 0, 0, 0};
-  const double* P = M + (long)k0 * lda;
-  mfma_xyT_64x64(P, lda, i0, rows, P, lda, j0, ncols, nb, acc);
-  const int c = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 4; ++nj)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const long row = i0 + mi * 16 + rq + 4 * g;
-        const long col = j0 + nj * 16 + c;
-        if (row < rows && col < ncols && row >= col) M[row + col * lda] -= acc[mi][nj][g];
-      }
-}
-
 // ---- trailing update, LDS-staged: C[base.., base..) -= P P^T with P = columns [kcol0, kcol0 + K) -------------------
 // Workgroup tile 256 (rows) x 128 (cols), 8 waves as 4 x 2 sub-tiles of 64 x 64; the K dimension is streamed
 // through LDS in chunks of 16 (double-buffered: global -> registers while the MFMAs of the previous chunk issue,
