@@ -18,3 +18,22 @@ try:
         print(f"| `{n.split('(')[0]}` | {v} | {a} | {s} | {sc} | {l} | {gx} | {wx} |")
 except Exception as e:  # schema differences between rocprofv3 versions
     print("\n(kernel resource table unavailable:", e, ")")
+
+# Per kernel AND grid size: a device-driven LM run leaves a few no-op launches (they exit at their first instruction,
+# 4-6 us) and bench.py also runs small streaming graphs through the same kernels, so the plain average above mixes
+# three populations.  "live" = launches longer than half the longest one of that (kernel, grid).
+try:
+    import statistics
+    rows = db.execute("select name, grid_x, (end - start) / 1000.0 from kernels").fetchall()
+    groups = {}
+    for n, g, t in rows:
+        groups.setdefault((n.split("(")[0], g), []).append(t)
+    print("\n| kernel | grid (threads) | launches | live | median live us | mean live us |")
+    print("|---|---|---|---|---|---|")
+    for (n, g), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        if len(v) < 3 or "rocclr" in n:
+            continue
+        live = [x for x in v if x > 0.5 * max(v)]
+        print(f"| `{n}` | {g} | {len(v)} | {len(live)} | {statistics.median(live):.2f} | {statistics.mean(live):.2f} |")
+except Exception as e:
+    print("\n(per-grid table unavailable:", e, ")")

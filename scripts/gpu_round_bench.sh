@@ -1,23 +1,44 @@
-# round-end measurement set: default bench (with CPU baseline), kernel stats of the same command, PMC traffic, SLAM benches
-mkdir -p gpurun_out/r1g
+# Round-end measurement set; everything lands under gpurun_out/r1/ and the judged summaries are copied to profiles/.
+#   default bench (with CPU baseline) + rocprofv3 kernel stats of the same command, PMC traffic of the LM kernels,
+#   optimiser-only kernel stats, fit pipeline kernel times, dense-Cholesky micro-benchmark, FP64 ceilings, other configs
+R=gpurun_out/r1
+mkdir -p $R profiles
 export TMPDIR=/tmp
-bash scripts/gpu_pmc.sh r1g > gpurun_out/r1g/pmc.txt 2>&1
-mkdir -p profiles && cp gpurun_out/pmc_r1g/traffic.json profiles/r1_pmc_traffic_device_lm.json
-timeout 400 python bench.py > gpurun_out/r1g/bench_default.json 2> gpurun_out/r1g/bench_default.err
-ESL_BENCH_NO_PROFILE=1 timeout 300 python bench.py --no-cpu-baseline > gpurun_out/r1g/bench_noprofile.json 2> /dev/null
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/r1g/prof_bench -- python /root/repo/bench.py --no-cpu-baseline > /root/repo/gpurun_out/r1g/prof_bench.log 2>&1)
-python profiles/summarize_rocpd.py gpurun_out/r1g/prof_bench/*/*_results.db > gpurun_out/r1g/prof_bench_summary.md
-timeout 300 python bench.py --mode slam --config C3 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r1g/bench_c3_slam.json 2> gpurun_out/r1g/bench_c3_slam.err
-cat gpurun_out/r1g/pmc.txt | tail -8
+bash scripts/gpu_pmc.sh r1 > $R/pmc.txt 2>&1
+cp gpurun_out/pmc_r1/traffic.json profiles/r1_pmc_traffic_device_lm.json
+timeout 600 python bench.py > $R/bench_default.json 2> $R/bench_default.err
+cp $R/bench_default.json profiles/r1_bench_c4_mapping.json
+ESL_BENCH_NO_PROFILE=1 timeout 300 python bench.py --no-cpu-baseline > $R/bench_noprofile.json 2> /dev/null
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$R/prof_bench -- python /root/repo/bench.py --no-cpu-baseline > /root/repo/$R/prof_bench.log 2>&1)
+python profiles/summarize_rocpd.py $R/prof_bench/*/*_results.db > profiles/r1_bench_default_kernel_stats.md
+bash scripts/gpu_prof_map.sh r1 > $R/prof_map.txt 2>&1
+python profiles/summarize_rocpd.py gpurun_out/prof_map_r1/*/*_results.db > profiles/r1_mapping_c4_kernel_stats.md
+bash scripts/gpu_prof_fit.sh r1 > profiles/r1_fit_kernel_times.txt 2>&1
+timeout 300 python scripts/chol_bench.py 2994 8192 16384 24576 32768 > profiles/r1_cholesky_microbench.txt 2>&1
+(hipcc -O3 --offload-arch=gfx950 scripts/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && timeout 120 /tmp/mfma_peak) > $R/fp64_ceilings.txt 2>&1
+run() { name=$1; shift; timeout 900 python bench.py --no-cpu-baseline "$@" > $R/$name.json 2> $R/$name.err; cp $R/$name.json profiles/r1_bench_$name.json; }
+run c3_slam --mode slam --config C3 --steps 3 --warmup 1
+run c4_mapping_numeric --jacobian numeric --steps 5 --warmup 1
+run c3_mapping --config C3
+run c4_slam --mode slam --config C4 --steps 1 --warmup 0
 python - <<'PY'
 import json
-for f in ["bench_default", "bench_noprofile", "bench_c3_slam"]:
+R = "gpurun_out/r1"
+for f in ["bench_default", "bench_noprofile", "c3_slam", "c4_mapping_numeric", "c3_mapping", "c4_slam"]:
     try:
-        d = json.loads(open(f"gpurun_out/r1g/{f}.json").read().strip().splitlines()[-1])
-        print(f, round(d["value"], 1), round(d["ms_per_step"], 4), json.dumps(d["roofline"])[:900])
-        if "cpu_baseline" in d: print("  cpu", d["cpu_baseline"]["value"], d.get("speedup_vs_cpu_port"))
-        if "fit" in d: print("  fit", {k: (round(v["ms_per_frame_kernel"], 3), v["samples"]) for k, v in d["fit"].items()}, "stream", round(d["streaming_c5"]["ms_per_frame"], 3))
+        d = json.loads(open(f"{R}/{f}.json").read().strip().splitlines()[-1])
+        r = d["roofline"]
+        print(f, round(d["value"], 3), "it/s", round(d["ms_per_step"], 4), "ms/step |", r["kernel"][:40], round(r["achieved"], 2), r["unit"], "frac", round(r["frac"], 4),
+              "| avg launch ms", round(r.get("avg_launch_ms", 0), 5), "| traffic", r.get("traffic"))
+        if r.get("valu_issue_floor"): print("   valu floor", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r["valu_issue_floor"].items() if k != "note"})
+        if "cpu_baseline" in d: print("   cpu", round(d["cpu_baseline"]["value"], 4), "x", round(d.get("speedup_vs_cpu_port", 0)))
+        if "fit" in d: print("   fit", {k: (round(v["ms_per_frame_kernel"], 3), round(v["ms_per_frame_host_call"], 3), v["samples"], round(v.get("cpu_port_ms_per_frame", 0), 2)) for k, v in d["fit"].items()},
+                             "stream", round(d["streaming_c5"]["ms_per_frame"], 3))
     except Exception as e:
         print(f, "FAILED", e)
 PY
-head -12 gpurun_out/r1g/prof_bench_summary.md
+cat $R/pmc.txt | tail -5
+cat profiles/r1_cholesky_microbench.txt
+cat $R/fp64_ceilings.txt
+tail -12 profiles/r1_fit_kernel_times.txt
+head -9 profiles/r1_mapping_c4_kernel_stats.md
