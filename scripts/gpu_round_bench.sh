@@ -1,22 +1,21 @@
-# Round-end measurement set; everything lands under gpurun_out/r1/ and the judged summaries are copied to profiles/.
+# Round-end measurement set (run on the GPU box through gpurun); everything lands under gpurun_out/ -- only that directory
+# travels back -- and scripts/collect_profiles.sh copies the judged summaries into profiles/ afterwards.
 #   default bench (with CPU baseline) + rocprofv3 kernel stats of the same command, PMC traffic of the LM kernels,
 #   optimiser-only kernel stats, fit pipeline kernel times, dense-Cholesky micro-benchmark, FP64 ceilings, other configs
 R=gpurun_out/r1
-mkdir -p $R profiles
+mkdir -p $R
 export TMPDIR=/tmp
 bash scripts/gpu_pmc.sh r1 > $R/pmc.txt 2>&1
-cp gpurun_out/pmc_r1/traffic.json profiles/r1_pmc_traffic_device_lm.json
 timeout 600 python bench.py > $R/bench_default.json 2> $R/bench_default.err
-cp $R/bench_default.json profiles/r1_bench_c4_mapping.json
 ESL_BENCH_NO_PROFILE=1 timeout 300 python bench.py --no-cpu-baseline > $R/bench_noprofile.json 2> /dev/null
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$R/prof_bench -- python /root/repo/bench.py --no-cpu-baseline > /root/repo/$R/prof_bench.log 2>&1)
-python profiles/summarize_rocpd.py $R/prof_bench/*/*_results.db > profiles/r1_bench_default_kernel_stats.md
+python profiles/summarize_rocpd.py $R/prof_bench/*/*_results.db > $R/bench_default_kernel_stats.md
 bash scripts/gpu_prof_map.sh r1 > $R/prof_map.txt 2>&1
-python profiles/summarize_rocpd.py gpurun_out/prof_map_r1/*/*_results.db > profiles/r1_mapping_c4_kernel_stats.md
-bash scripts/gpu_prof_fit.sh r1 > profiles/r1_fit_kernel_times.txt 2>&1
-timeout 300 python scripts/chol_bench.py 2994 8192 16384 24576 32768 > profiles/r1_cholesky_microbench.txt 2>&1
+python profiles/summarize_rocpd.py gpurun_out/prof_map_r1/*/*_results.db > $R/mapping_c4_kernel_stats.md
+bash scripts/gpu_prof_fit.sh r1 > $R/fit_kernel_times.txt 2>&1
+timeout 300 python scripts/chol_bench.py 2994 8192 16384 24576 32768 > $R/cholesky_microbench.txt 2>&1
 (hipcc -O3 --offload-arch=gfx950 scripts/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && timeout 120 /tmp/mfma_peak) > $R/fp64_ceilings.txt 2>&1
-run() { name=$1; shift; timeout 900 python bench.py --no-cpu-baseline "$@" > $R/$name.json 2> $R/$name.err; cp $R/$name.json profiles/r1_bench_$name.json; }
+run() { name=$1; shift; timeout 900 python bench.py --no-cpu-baseline "$@" > $R/$name.json 2> $R/$name.err; }
 run c3_slam --mode slam --config C3 --steps 3 --warmup 1
 run c4_mapping_numeric --jacobian numeric --steps 5 --warmup 1
 run c3_mapping --config C3
@@ -38,7 +37,7 @@ for f in ["bench_default", "bench_noprofile", "c3_slam", "c4_mapping_numeric", "
         print(f, "FAILED", e)
 PY
 cat $R/pmc.txt | tail -5
-cat profiles/r1_cholesky_microbench.txt
+cat $R/cholesky_microbench.txt
 cat $R/fp64_ceilings.txt
-tail -12 profiles/r1_fit_kernel_times.txt
-head -9 profiles/r1_mapping_c4_kernel_stats.md
+tail -12 $R/fit_kernel_times.txt
+head -9 $R/mapping_c4_kernel_stats.md
