@@ -25,7 +25,7 @@ using namespace esl;
 
 namespace esl {
 ProfScope::ProfScope(esl_ctx* ctx, int kind) : c(ctx), slot(-1) {
-  if (!c->prof_on) return;
+  if (!c || !c->prof_on) return;
   if (c->prof_level < 2 && (kind != 0 || !c->prof_gate)) return;
   if (c->prof_used + 2 > c->prof_ev.size()) {
     if (c->prof_ev.size() >= 16384) { prof_drain(c); }
@@ -225,7 +225,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (c->arena_graph) (void)hipFree(c->arena_graph);
   if (c->arena_work) (void)hipFree(c->arena_work);
   if (c->stage_host) (void)hipHostFree(c->stage_host);
-  if (c->fit_slab) (void)hipFree(c->fit_slab);
+  fit_release(c);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->host_part) (void)hipHostFree(c->host_part);
   dev_free(&c->dev_part);

@@ -78,6 +78,8 @@ struct ProfScope {
   ~ProfScope();
 };
 int prof_drain(esl_ctx* c);
+void fit_graphs_clear(esl_ctx* c);
+void fit_release(esl_ctx* c);
 // all-gather the 8-double dev_scal block of every rank into c->dev_gather (device), ordered on the context's stream
 int comm_gather_scalars_device(esl_ctx* c);
 // SLAM mode: in-place sum over ranks of a device buffer (RCCL all-reduce); no-op without a communicator
@@ -153,6 +155,9 @@ struct esl_ctx {
   char* arena_work = nullptr;  size_t arena_work_cap = 0;
   char* stage_host = nullptr;  size_t stage_host_cap = 0;   // pinned staging blob
   char* fit_slab = nullptr; size_t fit_slab_cap = 0;        // esl_fit_frame's device slab (esl_fit.hip)
+  char* fit_in = nullptr;  size_t fit_in_cap = 0;           // pinned staging of its inputs / outputs
+  char* fit_out = nullptr; size_t fit_out_cap = 0;
+  void* fit_graph_cache = nullptr;                          // captured launch sequences (std::vector<FitGraphEntry>)
   bool cams_match_snap = false;  // cameras untouched since the snapshot: esl_states_restore skips their copy
   int n_grav_edges = 0;
   void* lm_dev = nullptr;        // device-resident LM state (LmCore[2], esl_kernels_chunk.hpp)

@@ -35,12 +35,15 @@ constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kKeyOff = 1 << 20;
 #define ESL_FIX 1073741824.0  // 2^30
 
+// Per-frame values live in device memory (uploaded with the depth image), NOT in the kernel arguments: the launches of two
+// frames with the same geometry (boxes, image size, workspace capacity) are then identical, which is what lets
+// esl_fit_frame replay them from one captured hipGraph.
+struct FitFrame { double Twc[7], intr[5], ground[4]; esl_fit_params p; };
 struct FitShared;
 struct FitArgs {
   const uint16_t* depth; int w, h;
   const double* bboxes; const int* labels; int n_boxes;
-  double Twc[7], intr[5], ground[4];
-  esl_fit_params p;
+  const struct FitFrame* fr;   // everything that changes from frame to frame (pose, intrinsics, ground plane, parameters)
   // workspace (per box strides)
   long cap, H;
   unsigned long long* hk; long long* hsx; long long* hsy; long long* hsz; unsigned int* hcnt;
@@ -522,20 +525,20 @@ static __global__ __launch_bounds__(256) void k_fit_scan(FitArgs a) {
   const int b = blockIdx.y;
   const long base = (long)b * a.H;
   const double* bbox = a.bboxes + 4 * b;
-  const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
+  const double fx = a.fr->intr[0], fy = a.fr->intr[1], cx = a.fr->intr[2], cy = a.fr->intr[3], scale = a.fr->intr[4];
   if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[16 * b + 0] = (long long)wall_clock64();
   // 1 + 2. scan the box, voxel-hash at voxel_leaf
   const int x1 = (int)bbox[0], y1 = (int)bbox[1], x2 = (int)bbox[2], y2 = (int)bbox[3];
-  const int st = a.p.stride;
+  const int st = a.fr->p.stride;
   const int nsx = x2 > x1 ? (x2 - x1 + st - 1) / st : 0, nsy = y2 > y1 ? (y2 - y1 + st - 1) / st : 0;
-  const float inv = 1.0f / (float)a.p.voxel_leaf;
+  const float inv = 1.0f / (float)a.fr->p.voxel_leaf;
   int mine = 0;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)nsx * nsy; idx += (long)gridDim.x * blockDim.x) {
     const int x = x1 + (int)(idx % nsx) * st, y = y1 + (int)(idx / nsx) * st;
     if (x < 0 || y < 0 || x >= a.w || y >= a.h) continue;
     const uint16_t d = a.depth[(size_t)y * a.w + x];
     const double z = d / scale;
-    if (z <= a.p.depth_min || z > a.p.depth_max) continue;
+    if (z <= a.fr->p.depth_min || z > a.fr->p.depth_max) continue;
     const float px = (float)((x - cx) * z / fx), py = (float)((y - cy) * z / fy), pz = (float)z;
     vox_insert(a, base, vox_key(px, py, pz, inv), px, py, pz);
     ++mine;
@@ -549,9 +552,9 @@ static __global__ __launch_bounds__(256) void k_fit_plane(FitArgs a) {
   const long base = (long)b * a.H, pbase = (long)b * a.cap;
   if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[16 * b + 1] = (long long)wall_clock64();
   // 3 + 4. centroids -> world -> supporting-plane filter
-  const SE3 Twc = se3_load(a.Twc);
+  const SE3 Twc = se3_load(a.fr->Twc);
   const Mat3 Rwc = q_to_R(Twc.r);
-  const double gn = sqrt(a.ground[0] * a.ground[0] + a.ground[1] * a.ground[1] + a.ground[2] * a.ground[2]);
+  const double gn = sqrt(a.fr->ground[0] * a.fr->ground[0] + a.fr->ground[1] * a.fr->ground[1] + a.fr->ground[2] * a.fr->ground[2]);
   for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < a.H; s += (long)gridDim.x * blockDim.x) {
     const unsigned int cnt = a.hcnt[base + s];
     if (!cnt) continue;
@@ -561,8 +564,8 @@ static __global__ __launch_bounds__(256) void k_fit_plane(FitArgs a) {
                          (double)(float)((double)a.hsz[base + s] / c / ESL_FIX)};
     double q[3];
     xform(Rwc, Twc.t, p, q);
-    const double dis = (a.ground[0] * q[0] + a.ground[1] * q[1] + a.ground[2] * q[2] + a.ground[3]) / gn;
-    if (dis > a.p.plane_dist) {
+    const double dis = (a.fr->ground[0] * q[0] + a.fr->ground[1] * q[1] + a.fr->ground[2] * q[2] + a.fr->ground[3]) / gn;
+    if (dis > a.fr->p.plane_dist) {
       const int i = atomicAdd(&a.state[b].M, 1);
       a.pwx[pbase + i] = (float)q[0]; a.pwy[pbase + i] = (float)q[1]; a.pwz[pbase + i] = (float)q[2];
       a.pkey[pbase + i] = a.hk[base + s];
@@ -583,7 +586,7 @@ static __global__ __launch_bounds__(256) void k_fit_cl_init(FitArgs a) {
     else {
       // 5. GetCenter: 10 x 10 samples around the box centre
       const double* bbox = a.bboxes + 4 * b;
-      const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
+      const double fx = a.fr->intr[0], fy = a.fr->intr[1], cx = a.fr->intr[2], cy = a.fr->intr[3], scale = a.fr->intr[4];
       double v[4] = {0, 0, 0, 0};
       if (tid < 100) {
         const int x = (int)((bbox[0] + bbox[2]) / 2.0), y = (int)((bbox[1] + bbox[3]) / 2.0);
@@ -592,7 +595,7 @@ static __global__ __launch_bounds__(256) void k_fit_cl_init(FitArgs a) {
         if (x_ >= 0 && y_ >= 0 && x_ < a.w && y_ < a.h) {
           const uint16_t d = a.depth[(size_t)y_ * a.w + x_];
           const float pz = (float)(d / scale);
-          if (!(pz <= 0.1 || pz > a.p.depth_max)) {
+          if (!(pz <= 0.1 || pz > a.fr->p.depth_max)) {
             v[0] = (float)((x_ - cx) * pz / fx); v[1] = (float)((y_ - cy) * pz / fy); v[2] = pz; v[3] = 1;
           }
         }
@@ -609,7 +612,7 @@ static __global__ __launch_bounds__(256) void k_fit_cl_init(FitArgs a) {
         for (int k = 0; k < 4; ++k) t[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
         if (t[3] < 2) a.out_status[b] = 1;
         else {
-          const SE3 Twc = se3_load(a.Twc);
+          const SE3 Twc = se3_load(a.fr->Twc);
           const Mat3 Rwc = q_to_R(Twc.r);
           const double c[3] = {t[0] / t[3], t[1] / t[3], t[2] / t[3]};
           xform(Rwc, Twc.t, c, st->center);
@@ -622,13 +625,13 @@ static __global__ __launch_bounds__(256) void k_fit_cl_init(FitArgs a) {
 static __global__ __launch_bounds__(256) void k_fit_cl_insert(FitArgs a) {
   const int b = blockIdx.y;
   if (a.out_status[b] != 0) return;
-  cl_insert(a, (long)b * a.H, (long)b * a.cap, a.state[b].M, a.p.cluster_tolerance, (long)blockIdx.x * blockDim.x + threadIdx.x,
+  cl_insert(a, (long)b * a.H, (long)b * a.cap, a.state[b].M, a.fr->p.cluster_tolerance, (long)blockIdx.x * blockDim.x + threadIdx.x,
             (long)gridDim.x * blockDim.x);
 }
 static __global__ __launch_bounds__(256) void k_fit_cl_union(FitArgs a) {
   const int b = blockIdx.y;
   if (a.out_status[b] != 0) return;
-  cl_union(a, (long)b * a.H, (long)b * a.cap, a.state[b].M, a.p.cluster_tolerance, (long)blockIdx.x * blockDim.x + threadIdx.x,
+  cl_union(a, (long)b * a.H, (long)b * a.cap, a.state[b].M, a.fr->p.cluster_tolerance, (long)blockIdx.x * blockDim.x + threadIdx.x,
            (long)gridDim.x * blockDim.x);
 }
 static __global__ __launch_bounds__(256) void k_fit_cl_stats(FitArgs a) {
@@ -641,11 +644,11 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   __shared__ FitShared S;
   const int b = blockIdx.x, tid = threadIdx.x;
   const long base = (long)b * a.H, pbase = (long)b * a.cap;
-  const SE3 Twc = se3_load(a.Twc);
+  const SE3 Twc = se3_load(a.fr->Twc);
   const Mat3 Rwc = q_to_R(Twc.r);
-  const double gn = sqrt(a.ground[0] * a.ground[0] + a.ground[1] * a.ground[1] + a.ground[2] * a.ground[2]);
+  const double gn = sqrt(a.fr->ground[0] * a.fr->ground[0] + a.fr->ground[1] * a.fr->ground[1] + a.fr->ground[2] * a.fr->ground[2]);
   const double* bbox = a.bboxes + 4 * b;
-  const double fx = a.intr[0], fy = a.intr[1], cx = a.intr[2], cy = a.intr[3], scale = a.intr[4];
+  const double fx = a.fr->intr[0], fy = a.fr->intr[1], cx = a.fr->intr[2], cy = a.fr->intr[3], scale = a.fr->intr[4];
   if (tid == 0) { S.M = a.state[b].M; S.n0 = a.state[b].n0; S.n1 = a.state[b].n1; for (int k = 0; k < 3; ++k) S.center[k] = a.state[b].center[k]; S.ncl = 0; S.chosen = -1; S.maxsize = 0; S.only = -1; S.status = 0; S.ns0 = 0; S.npo = 0; S.cnt = 0; S.minkey = kEmpty; }
   __syncthreads();
   const int M = S.M;
@@ -663,7 +666,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
       if (x_ >= 0 && y_ >= 0 && x_ < a.w && y_ < a.h) {
         const uint16_t d = a.depth[(size_t)y_ * a.w + x_];
         const float pz = (float)(d / scale);
-        if (!(pz <= 0.1 || pz > a.p.depth_max)) {
+        if (!(pz <= 0.1 || pz > a.fr->p.depth_max)) {
           sx = (float)((x_ - cx) * pz / fx); sy = (float)((y_ - cy) * pz / fy); sz = pz; cn = 1;
         }
       }
@@ -674,7 +677,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   }
   ESL_FIT_MARK(3);
   // 6. Euclidean clustering: cell hash + lock-free union-find
-  const double tol = a.p.cluster_tolerance, tol2 = tol * tol;
+  const double tol = a.fr->p.cluster_tolerance, tol2 = tol * tol;
   // Same definition on two substrates: with M <= kClLds points and a cell extent that fits 10 bits per axis the cell
   // hash, the per-cell lists and the union-find forest live in LDS (the global-memory version is pointer chasing
   // through L2 at ~1 us a hop: 27 cells x probe + list walk per point made this stage 150-330 us per box).
@@ -777,25 +780,25 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   // choose the cluster: the only one, else the largest (ties: smaller voxel key) within center_dis of the centre
   for (int r = tid; r < M; r += kFitThreads) {
     const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sz >= a.p.min_cluster_size) {
+    if (sz >= a.fr->p.min_cluster_size) {
       atomicAdd(&S.ncl, 1);
       atomicMax(&S.only, r);
       const double md = __longlong_as_double((long long)__hip_atomic_load(&a.cmind[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (md < a.p.center_dis) atomicMax(&S.maxsize, sz);
+      if (md < a.fr->p.center_dis) atomicMax(&S.maxsize, sz);
     }
   }
   __syncthreads();
   for (int r = tid; r < M; r += kFitThreads) {
     const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sz >= a.p.min_cluster_size && sz == S.maxsize) {
+    if (sz >= a.fr->p.min_cluster_size && sz == S.maxsize) {
       const double md = __longlong_as_double((long long)__hip_atomic_load(&a.cmind[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (md < a.p.center_dis) atomicMin(&S.minkey, __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (md < a.fr->p.center_dis) atomicMin(&S.minkey, __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
   }
   __syncthreads();
   for (int r = tid; r < M; r += kFitThreads) {
     const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sz >= a.p.min_cluster_size && sz == S.maxsize && S.maxsize > 0 &&
+    if (sz >= a.fr->p.min_cluster_size && sz == S.maxsize && S.maxsize > 0 &&
         __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S.minkey) S.chosen = r;
   }
   __syncthreads();
@@ -832,7 +835,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
         cross3(c0, c1, c2);
         rot[2] = c2[0]; rot[5] = c2[1]; rot[8] = c2[2];
       }
-      const double nh[3] = {a.ground[0] / gn, a.ground[1] / gn, a.ground[2] / gn};
+      const double nh[3] = {a.fr->ground[0] / gn, a.fr->ground[1] / gn, a.fr->ground[2] / gn};
       {  // AlignZAxisToGravity
         double maxc = 0; int maxid = -1; bool pos = true;
         for (int i = 0; i < 3; ++i) {
@@ -846,7 +849,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
         for (int r = 0; r < 3; ++r) { rot[r * 3] = x[r]; rot[r * 3 + 1] = y[r]; rot[r * 3 + 2] = z[r]; }
       }
       {  // calibRotMatAccordingToGroundPlane
-        const double z[3] = {rot[2], rot[5], rot[8]}, nrm[3] = {a.ground[0], a.ground[1], a.ground[2]};
+        const double z[3] = {rot[2], rot[5], rot[8]}, nrm[3] = {a.fr->ground[0], a.fr->ground[1], a.fr->ground[2]};
         double ax[3];
         cross3(z, nrm, ax);
         const double an2 = ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2];
@@ -895,7 +898,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   for (long s = tid; s < ag.H; s += kFitThreads) { a.hk[base + s] = kEmpty; a.hsx[base + s] = 0; a.hsy[base + s] = 0; a.hsz[base + s] = 0; a.hcnt[base + s] = 0; }
   stage_sync();
   {
-    const float inv = 1.0f / (float)a.p.symmetry_grid;
+    const float inv = 1.0f / (float)a.fr->p.symmetry_grid;
     for (int i = tid; i < M; i += kFitThreads)
       if (a.nxt[pbase + i] == chosen) {
         const float px = a.pwx[pbase + i], py = a.pwy[pbase + i], pz = a.pwz[pbase + i];
@@ -924,14 +927,14 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   ESL_FIT_MARK(6);
   // 9. symmetry: 9 hypotheses, one wavefront each
   const int stype = symmetry_type(a.labels ? a.labels[b] : -1);
-  const bool run_sym = a.p.symmetry_open && stype > 0 && ns0 > 0;
+  const bool run_sym = a.fr->p.symmetry_open && stype > 0 && ns0 > 0;
   if (run_sym) {
     if (tid == 0) {
       SymCtx& c = S.sc;
       c.depth = a.depth; c.w = a.w; c.h = a.h;
       for (int k = 0; k < 4; ++k) c.bb[k] = (int)bbox[k];
-      c.K[0] = fx; c.K[1] = fy; c.K[2] = cx; c.K[3] = cy; c.scale = scale; c.sigma = a.p.symmetry_sigma;
-      const SE3 Toc = se3_mul(se3_load(S.Tow), se3_load(a.Twc));
+      c.K[0] = fx; c.K[1] = fy; c.K[2] = cx; c.K[3] = cy; c.scale = scale; c.sigma = a.fr->p.symmetry_sigma;
+      const SE3 Toc = se3_mul(se3_load(S.Tow), se3_load(a.fr->Twc));
       const SE3 Tco = se3_inv(Toc);
       const Mat3 Rco = q_to_R(Tco.r);
       for (int cc = 0; cc < 4; ++cc) {
@@ -977,7 +980,7 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
     for (int i = tid; i < 3 * n; i += kSymThreads) g_sym_pof[i] = sc.pof[i];
   __syncthreads();
   const bool dual = st->stype == 2;
-  const int dim = dual ? 3 : 2, iters = a.p.symmetry_lm_iters;
+  const int dim = dual ? 3 : 2, iters = a.fr->p.symmetry_lm_iters;
   const double delta = 1e-9;
   PlaneT pl;
   {
@@ -1158,7 +1161,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_post(FitArgs a) {
     SE3 I;
     I.r = Quat{0, 0, 0, 1}; I.t[0] = I.t[1] = I.t[2] = 0;
     const SE3 g = se3_mul(se3_load(S.Two), I);
-    const SE3 l = se3_mul(se3_inv(se3_load(a.Twc)), g);
+    const SE3 l = se3_mul(se3_inv(se3_load(a.fr->Twc)), g);
     double* o = a.out_ell + 10 * b;
     se3_store(l, o);
     o[7] = mx; o[8] = my; o[9] = mz;
@@ -1174,6 +1177,43 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_post(FitArgs a) {
 }  // namespace esl
 
 using namespace esl;
+
+// ---- captured launch sequences of esl_fit_frame, keyed by everything the sequence depends on -------------------------
+struct FitGraphKey {
+  int n_boxes, w, h; long cap; int sym_open; const void* slab; const void* in; const void* out;
+  bool operator==(const FitGraphKey& o) const {
+    return n_boxes == o.n_boxes && w == o.w && h == o.h && cap == o.cap && sym_open == o.sym_open && slab == o.slab && in == o.in && out == o.out;
+  }
+};
+struct FitGraphEntry { FitGraphKey key; hipGraphExec_t exec; };
+static std::vector<FitGraphEntry>& fit_graphs(esl_ctx* c) {
+  if (!c->fit_graph_cache) c->fit_graph_cache = new std::vector<FitGraphEntry>();
+  return *(std::vector<FitGraphEntry>*)c->fit_graph_cache;
+}
+static hipGraphExec_t fit_graph_find(esl_ctx* c, const FitGraphKey& k) {
+  for (auto& e : fit_graphs(c)) if (e.key == k) return e.exec;
+  return nullptr;
+}
+static void fit_graph_store(esl_ctx* c, const FitGraphKey& k, hipGraphExec_t exec) {
+  auto& v = fit_graphs(c);
+  if (v.size() >= 16) { (void)hipGraphExecDestroy(v.front().exec); v.erase(v.begin()); }   // small FIFO
+  v.push_back({k, exec});
+}
+namespace esl {
+void fit_graphs_clear(esl_ctx* c) {
+  if (!c->fit_graph_cache) return;
+  auto& v = fit_graphs(c);
+  for (auto& e : v) (void)hipGraphExecDestroy(e.exec);
+  v.clear();
+}
+void fit_release(esl_ctx* c) {   // called by esl_ctx_destroy
+  fit_graphs_clear(c);
+  delete (std::vector<FitGraphEntry>*)c->fit_graph_cache; c->fit_graph_cache = nullptr;
+  if (c->fit_slab) { (void)hipFree(c->fit_slab); c->fit_slab = nullptr; c->fit_slab_cap = 0; }
+  if (c->fit_in) { (void)hipHostFree(c->fit_in); c->fit_in = nullptr; c->fit_in_cap = 0; }
+  if (c->fit_out) { (void)hipHostFree(c->fit_out); c->fit_out = nullptr; c->fit_out_cap = 0; }
+}
+}  // namespace esl
 
 extern "C" {
 
@@ -1199,24 +1239,26 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   if (n_boxes == 0) return ESL_OK;
   ESL_HIP_TRY(hipSetDevice(c->device));
   FitArgs a{};
-  a.w = width; a.h = height; a.n_boxes = n_boxes; a.p = *p;
-  for (int i = 0; i < 7; ++i) a.Twc[i] = Twc[i];
-  for (int i = 0; i < 5; ++i) a.intr[i] = intr[i];
-  for (int i = 0; i < 4; ++i) a.ground[i] = ground[i];
+  a.w = width; a.h = height; a.n_boxes = n_boxes;
   long cap = 64;
   for (int b = 0; b < n_boxes; ++b) {
     const long w = (long)(bboxes[4 * b + 2] - bboxes[4 * b]) / p->stride + 2, h = (long)(bboxes[4 * b + 3] - bboxes[4 * b + 1]) / p->stride + 2;
     if (w > 0 && h > 0) cap = std::max(cap, w * h);
   }
-  long H = 1024;
-  while (H < 2 * cap) H <<= 1;
+  {   // workspace capacity in powers of two: consecutive frames with similar boxes then share one launch geometry
+    long q = 1024;
+    while (q < cap) q <<= 1;
+    cap = q;
+  }
+  const long H = 2 * cap;
   a.cap = cap; a.H = H;
   a.wide = cap > 4 * kClLds ? 1 : 0;   // a box may hold more voxels than the LDS clustering path takes: go grid-wide
-  // one slab for everything
+  // one slab for everything; the inputs (per-frame values | boxes | labels | depth) and the outputs are contiguous blocks
   const size_t B = (size_t)n_boxes;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_depth = take((size_t)width * height * 2), o_bb = take(B * 32), o_lab = take(B * 4);
+  const size_t o_fr = take(sizeof(FitFrame)), o_bb = take(B * 32), o_lab = take(B * 4), o_depth = take((size_t)width * height * 2);
+  const size_t in_bytes = off;
   const size_t o_hk = take(B * H * 8), o_hsx = take(B * H * 8), o_hsy = take(B * H * 8), o_hsz = take(B * H * 8), o_hcnt = take(B * H * 4);
   const size_t o_pwx = take(B * cap * 4), o_pwy = take(B * cap * 4), o_pwz = take(B * cap * 4), o_pkey = take(B * cap * 8);
   const size_t o_ck = take(B * H * 8), o_chead = take(B * H * 4), o_nxt = take(B * cap * 4), o_par = take(B * cap * 4);
@@ -1224,16 +1266,29 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   const size_t o_po = take(B * cap * 12 * 8), o_pof = take(B * cap * 3 * 4);
   const size_t o_state = take(B * sizeof(FitShared));
   const size_t o_ell = take(B * 80), o_prob = take(B * 8), o_st = take(B * 4), o_dbg = take(B * 128), o_clk = take(B * 128);
+  const size_t out_bytes = off - o_ell;
   const bool timing = std::getenv("ESL_FIT_TIMING") != nullptr;
-  // grow-only slab owned by the context: a per-frame call pays no hipMalloc / hipFree
+  // grow-only device slab and pinned staging blocks owned by the context: a per-frame call pays no allocation
   if (off > c->fit_slab_cap) {
     ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    fit_graphs_clear(c);
     if (c->fit_slab) { (void)hipFree(c->fit_slab); c->fit_slab = nullptr; c->fit_slab_cap = 0; }
     const size_t want = off + off / 4;
     ESL_HIP_TRY(hipMalloc((void**)&c->fit_slab, want));
     c->fit_slab_cap = want;
   }
+  if (in_bytes > c->fit_in_cap || out_bytes > c->fit_out_cap) {
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    fit_graphs_clear(c);
+    if (c->fit_in) { (void)hipHostFree(c->fit_in); c->fit_in = nullptr; }
+    if (c->fit_out) { (void)hipHostFree(c->fit_out); c->fit_out = nullptr; }
+    c->fit_in_cap = std::max(c->fit_in_cap, in_bytes + in_bytes / 4);
+    c->fit_out_cap = std::max(c->fit_out_cap, out_bytes + out_bytes / 4);
+    ESL_HIP_TRY(hipHostMalloc((void**)&c->fit_in, c->fit_in_cap, hipHostMallocDefault));
+    ESL_HIP_TRY(hipHostMalloc((void**)&c->fit_out, c->fit_out_cap, hipHostMallocDefault));
+  }
   char* slab = c->fit_slab;
+  a.fr = (const FitFrame*)(slab + o_fr);
   a.depth = (const uint16_t*)(slab + o_depth); a.bboxes = (const double*)(slab + o_bb); a.labels = (const int*)(slab + o_lab);
   a.hk = (unsigned long long*)(slab + o_hk); a.hsx = (long long*)(slab + o_hsx); a.hsy = (long long*)(slab + o_hsy);
   a.hsz = (long long*)(slab + o_hsz); a.hcnt = (unsigned int*)(slab + o_hcnt);
@@ -1245,53 +1300,82 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   a.clk = timing ? (long long*)(slab + o_clk) : nullptr;
   a.out_ell = (double*)(slab + o_ell); a.out_prob = (double*)(slab + o_prob); a.out_status = (int*)(slab + o_st); a.out_dbg = (double*)(slab + o_dbg);
   hipStream_t st = c->stream;
-  std::vector<int32_t> lab((size_t)n_boxes, -1);
-  if (labels) for (int b = 0; b < n_boxes; ++b) lab[b] = labels[b];
+  // stage the inputs (the previous call synchronised the stream: the staging block is free)
+  {
+    FitFrame fr;
+    for (int i = 0; i < 7; ++i) fr.Twc[i] = Twc[i];
+    for (int i = 0; i < 5; ++i) fr.intr[i] = intr[i];
+    for (int i = 0; i < 4; ++i) fr.ground[i] = ground[i];
+    fr.p = *p;
+    std::memcpy(c->fit_in + o_fr, &fr, sizeof(fr));
+    std::memcpy(c->fit_in + o_bb, bboxes, B * 32);
+    int32_t* lab = (int32_t*)(c->fit_in + o_lab);
+    for (int b = 0; b < n_boxes; ++b) lab[b] = labels ? labels[b] : -1;
+    std::memcpy(c->fit_in + o_depth, depth, (size_t)width * height * 2);
+  }
   int rc = ESL_OK;
   auto fail = [&](hipError_t e, const char* what) { set_error(std::string(what) + ": " + hipGetErrorString(e)); rc = ESL_ERR_HIP; };
   hipError_t e;
-  if ((e = hipMemcpyAsync(slab + o_depth, depth, (size_t)width * height * 2, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e, "upload depth");
-  if (!rc && (e = hipMemcpyAsync(slab + o_bb, bboxes, B * 32, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e, "upload boxes");
-  if (!rc && (e = hipMemcpyAsync(slab + o_lab, lab.data(), B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e, "upload labels");
-  if (!rc && (e = hipMemsetAsync(slab + o_hk, 0xFF, B * H * 8, st)) != hipSuccess) fail(e, "clear hash");
-  if (!rc && (e = hipMemsetAsync(slab + o_hsx, 0, (o_pwx - o_hsx), st)) != hipSuccess) fail(e, "clear sums");
-  if (!rc && (e = hipMemsetAsync(slab + o_ell, 0, off - o_ell, st)) != hipSuccess) fail(e, "clear outputs");
-  if (!rc) {
-    ProfScope ps(c, 5);
-    // five launches: box scan + voxel hash and plane filter over (tile, box) grids; per-box clustering + PCA; the 9 plane
-    // hypotheses of every box side by side; completion
-    if ((e = hipMemsetAsync(slab + o_state, 0, B * sizeof(FitShared), st)) != hipSuccess) fail(e, "clear state");
+  const int sym_open = p->symmetry_open;
+  // The frame's work as a stream of asynchronous operations.  Nothing in it depends on per-frame VALUES (those sit in the
+  // staged input block), only on the geometry (boxes, image size, capacity): it can be captured once and replayed.
+  auto enqueue = [&](bool bracket) {
+    if ((e = hipMemcpyAsync(slab, c->fit_in, in_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) { fail(e, "upload"); return; }
+    if ((e = hipMemsetAsync(slab + o_hk, 0xFF, B * H * 8, st)) != hipSuccess) { fail(e, "clear hash"); return; }
+    if ((e = hipMemsetAsync(slab + o_hsx, 0, (o_pwx - o_hsx), st)) != hipSuccess) { fail(e, "clear sums"); return; }
+    if ((e = hipMemsetAsync(slab + o_state, 0, off - o_state, st)) != hipSuccess) { fail(e, "clear state + outputs"); return; }
     {
+      ProfScope ps(bracket ? c : nullptr, 5);
+      // box scan + voxel hash and plane filter over (tile, box) grids; per-box clustering + PCA (clustering grid-wide for
+      // big boxes); the 9 plane hypotheses of every box side by side; completion
       const long tiles_scan = std::min<long>(64, std::max<long>(1, (cap + 2047) / 2048));   // ~8 samples per thread
       const long tiles_hash = std::min<long>(64, std::max<long>(1, H / 2048));
       hipLaunchKernelGGL(k_fit_scan, dim3((unsigned)tiles_scan, n_boxes), dim3(256), 0, st, a);
       hipLaunchKernelGGL(k_fit_plane, dim3((unsigned)tiles_hash, n_boxes), dim3(256), 0, st, a);
+      if (a.wide) {
+        const long tiles_pts = std::min<long>(64, std::max<long>(1, cap / 1024));
+        hipLaunchKernelGGL(k_fit_cl_init, dim3((unsigned)tiles_hash, n_boxes), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_fit_cl_insert, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_fit_cl_union, dim3((unsigned)std::min<long>(1024, tiles_pts * 27), n_boxes), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_fit_cl_stats, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
+      }
+      hipLaunchKernelGGL(k_fit_pre, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
+      if (sym_open) hipLaunchKernelGGL(k_fit_sym, dim3(n_boxes * 9), dim3(kSymThreads), 0, st, a);
+      hipLaunchKernelGGL(k_fit_post, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
+      if ((e = hipGetLastError()) != hipSuccess) { fail(e, "k_fit_*"); return; }
     }
-    if (a.wide) {   // boxes with many samples: centre + clustering over (tile, box) grids as well
-      const long tiles_pts = std::min<long>(64, std::max<long>(1, cap / 1024));
-      const long tiles_hash = std::min<long>(64, std::max<long>(1, H / 2048));
-      hipLaunchKernelGGL(k_fit_cl_init, dim3((unsigned)tiles_hash, n_boxes), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_fit_cl_insert, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_fit_cl_union, dim3((unsigned)std::min<long>(1024, tiles_pts * 27), n_boxes), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_fit_cl_stats, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
+    if ((e = hipMemcpyAsync(c->fit_out, slab + o_ell, out_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
+  };
+  // hipGraph replay unless events are wanted around the kernels (profiling / stage timing) or it is switched off
+  const bool use_graph = !c->prof_on && !timing && std::getenv("ESL_FIT_NO_GRAPH") == nullptr;
+  if (use_graph) {
+    FitGraphKey key{n_boxes, width, height, cap, sym_open, slab, c->fit_in, c->fit_out};
+    hipGraphExec_t exec = fit_graph_find(c, key);
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      if ((e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)) != hipSuccess) fail(e, "begin capture");
+      if (!rc) enqueue(false);
+      hipError_t e2 = hipStreamEndCapture(st, &graph);
+      if (!rc && e2 != hipSuccess) fail(e2, "end capture");
+      if (!rc && (e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) fail(e, "instantiate graph");
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!rc) fit_graph_store(c, key, exec);
     }
-    hipLaunchKernelGGL(k_fit_pre, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
-    if (p->symmetry_open) hipLaunchKernelGGL(k_fit_sym, dim3(n_boxes * 9), dim3(kSymThreads), 0, st, a);
-    hipLaunchKernelGGL(k_fit_post, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
-    if ((e = hipGetLastError()) != hipSuccess) fail(e, "k_fit_*");
+    if (!rc && (e = hipGraphLaunch(exec, st)) != hipSuccess) fail(e, "launch graph");
+  } else {
+    enqueue(true);
   }
-  // the four output arrays are contiguous in the slab: one D2H copy, scattered on the host
-  std::vector<char> outs(off - o_ell);
-  if (!rc && (e = hipMemcpyAsync(outs.data(), slab + o_ell, outs.size(), hipMemcpyDeviceToHost, st)) != hipSuccess) fail(e, "download");
   if ((e = hipStreamSynchronize(st)) != hipSuccess && !rc) fail(e, "sync");
+  const char* outs_data = c->fit_out;
+  // the four output arrays are contiguous in the slab: one D2H copy into the pinned block, scattered on the host
   if (!rc) {
-    std::memcpy(ellipsoids_out, outs.data(), B * 80);
-    std::memcpy(prob_out, outs.data() + (o_prob - o_ell), B * 8);
-    std::memcpy(status_out, outs.data() + (o_st - o_ell), B * 4);
-    if (debug_out) std::memcpy(debug_out, outs.data() + (o_dbg - o_ell), B * 128);
+    std::memcpy(ellipsoids_out, outs_data, B * 80);
+    std::memcpy(prob_out, outs_data + (o_prob - o_ell), B * 8);
+    std::memcpy(status_out, outs_data + (o_st - o_ell), B * 4);
+    if (debug_out) std::memcpy(debug_out, outs_data + (o_dbg - o_ell), B * 128);
     if (timing) {   // diagnostic: mean stage durations over the boxes (wall_clock64 ticks at 100 MHz)
       static const char* names[8] = {"scan+voxel", "plane filter", "centre", "cluster", "pca", "sym grid", "symmetry", "extents"};
-      const long long* clk = (const long long*)(outs.data() + (o_clk - o_ell));
+      const long long* clk = (const long long*)(outs_data + (o_clk - o_ell));
       double sum[8] = {0}; int cnt[8] = {0};
       for (size_t bx = 0; bx < B; ++bx)
         for (int k = 0; k < 8; ++k) {
