@@ -430,10 +430,19 @@ ESL_HD void e3d_hypothesis(const Mat3& R0, const double t0[3], double cy, double
 }
 
 // residual of the 3-D edge; `best` (optional) receives the chosen hypothesis' relative pose and log coefficients
-ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9], E3dHyp* best_out = nullptr) {
+// hypothesis-independent part of the 3-D edge: E_0 = (T_wc T_meas)^-1 T_est
+ESL_HD SE3 e3d_E0(const SE3& Tcw, const Ell& est, const Ell& meas) {
   const SE3 Twc = se3_inv(Tcw);
   const SE3 mw = se3_mul(Twc, meas.pose);
-  const SE3 E0 = se3_mul(se3_inv(mw), est.pose);
+  return se3_mul(se3_inv(mw), est.pose);
+}
+ESL_HD void res_e3d_from_E0(const SE3& E0, const double est_s[3], const double meas_s[3], const YawTable& yt, double r[9],
+                            E3dHyp* best_out = nullptr);
+ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTable& yt, double r[9], E3dHyp* best_out = nullptr) {
+  res_e3d_from_E0(e3d_E0(Tcw, est, meas), est.s, meas.s, yt, r, best_out);
+}
+ESL_HD void res_e3d_from_E0(const SE3& E0, const double est_s[3], const double meas_s[3], const YawTable& yt, double r[9],
+                            E3dHyp* best_out) {
   const Mat3 R0 = q_to_R(E0.r);
   double best = 0, b_cy = 1, b_sy = 0;
   LogAux b_a;
@@ -445,9 +454,9 @@ ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTa
     double e[9];
     se3_log_R(h.R, h.t, e, h.a);
     const bool swap = (k == 0 || k == 2);  // yaw = -90 or +90 degrees: a/b swapped
-    e[6] = est.s[0] - (swap ? meas.s[1] : meas.s[0]);
-    e[7] = est.s[1] - (swap ? meas.s[0] : meas.s[1]);
-    e[8] = est.s[2] - meas.s[2];
+    e[6] = est_s[0] - (swap ? meas_s[1] : meas_s[0]);
+    e[7] = est_s[1] - (swap ? meas_s[0] : meas_s[1]);
+    e[8] = est_s[2] - meas_s[2];
     double n2 = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) n2 += e[i] * e[i];
