@@ -161,6 +161,56 @@ __device__ __forceinline__ void reduce_group(const double* J, const double* r, d
   if ((lane & low_mask) == 0 && cnt >= 1) out[G * 18 + idx] = tot;   // cnt < 1: this lane ended on a padding slot
 }
 
+// ---- the same wave reductions through an LDS transpose -------------------------------------------------------------------
+// The reduce-scatter above costs 4 v_cndmask + 2 ds_bpermute + 1 add per exchange: 40 % of the analytic bbox kernel's issue
+// slots were selects and permutes.  Here every lane parks its 18 values in a wave-private LDS tile tr[18][65] (row =
+// entry, column = lane; the odd stride keeps the column sums conflict-free) and 54 lanes add up a third of a row each:
+// 18 ds_write + 22 ds_read + 22 adds per group instead of ~210 instructions.  LDS operations of one wave execute in order,
+// so no barrier is needed, only the compiler must not reorder across the hand-over.
+constexpr int kTrStride = 65, kTrDoubles = 18 * kTrStride;
+template <int D, int G>
+__device__ __forceinline__ void reduce_group_lds(const double* J, const double* r, double w, int lane, double* __restrict__ out,
+                                                 double* __restrict__ tr) {
+  double v[18];
+  fill_group<D, G>(v, J, r, w, std::make_integer_sequence<int, 18>{});
+#pragma unroll
+  for (int k = 0; k < 18; ++k) tr[k * kTrStride + lane] = v[k];
+  __builtin_amdgcn_wave_barrier();
+  const int k = lane % 18, p = lane / 18;            // lanes 0..53: third p of row k (22, 22, 20 columns)
+  double s0 = 0, s1 = 0;
+  if (lane < 54) {
+    const double* row = tr + k * kTrStride + p * 22;
+    const int n = (p == 2) ? 20 : 22;
+#pragma unroll
+    for (int i = 0; i < 22; i += 2) {
+      if (i < n) { s0 += row[i]; s1 += row[i + 1]; }
+    }
+  }
+  double s = s0 + s1;
+  const double sa = __shfl_down(s, 18, 64), sb = __shfl_down(s, 36, 64);
+  __builtin_amdgcn_wave_barrier();                   // the tile is rewritten by the next group
+  if (lane < 18) out[G * 18 + lane] = (s + sa) + sb;
+}
+// 3-D edges: two 32-lane chunks per wave; `lane64` is the lane in the wave, the chunk's columns are its own 32
+template <int G>
+__device__ __forceinline__ void reduce_group_e3d_lds(const double* Jp, const double* r, double w, int lane64, double* __restrict__ out,
+                                                     double* __restrict__ tr) {
+  double v[18];
+  fill_group_e3d<G>(v, Jp, r, w, std::make_integer_sequence<int, 18>{});
+#pragma unroll
+  for (int k = 0; k < 18; ++k) tr[k * kTrStride + lane64] = v[k];
+  __builtin_amdgcn_wave_barrier();
+  const int t = lane64 & 31, half = lane64 & 32;
+  double s0 = 0, s1 = 0;
+  if (t < 18) {
+    const double* row = tr + t * kTrStride + half;
+#pragma unroll
+    for (int i = 0; i < 32; i += 2) { s0 += row[i]; s1 += row[i + 1]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (t < 18) out[G * 18 + t] = s0 + s1;
+}
+
 // One instantiation per edge type: the bbox and the 3-D code paths have very different register needs, and a
 // kernel is allocated for the worse of its branches (the fused version spilled 304 B/lane = 69 MB of HBM
 // writes per launch at C4, profiles/r1_pmc_traffic.json).  `ids` lists the chunks of this type.
@@ -171,7 +221,9 @@ template <int JAC, int TYPE, bool VALIDATE = false>
 __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const ChunkTable& ct, const int* __restrict__ ids, int n_ids,
                                                      const double* __restrict__ cams, const double* __restrict__ objs, double delta,
                                                      double* __restrict__ chunk_out, double* __restrict__ wg_chi /* LDS, 8 slots */,
-                                                     int block, int* __restrict__ n_dropped = nullptr) {
+                                                     double* __restrict__ tr_all /* LDS, kTrDoubles per wave */, int block,
+                                                     int* __restrict__ n_dropped = nullptr) {
+  double* tr = tr_all + (threadIdx.x >> 6) * kTrDoubles;
   // bbox chunks hold <= 64 edges (one wave each); 3-D chunks hold <= 32 edges and TWO of them share a wave
   // (an ellipsoid has ~20 3-D edges: a whole wave per chunk ran at 31 % lane use).  Offsets < 32 keep the
   // shuffles of the reduce-scatter inside a half wave.
@@ -217,9 +269,9 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
 #pragma unroll
       for (int k = 0; k < 36; ++k) J[k] = 0;
     }
-    reduce_group<4, 0>(J, r, w, lane, out);
-    reduce_group<4, 1>(J, r, w, lane, out);
-    reduce_group<4, 2>(J, r, w, lane, out);
+    reduce_group_lds<4, 0>(J, r, w, lane, out, tr);
+    reduce_group_lds<4, 1>(J, r, w, lane, out, tr);
+    reduce_group_lds<4, 2>(J, r, w, lane, out, tr);
   } else {
     double r[9], Jp[36], w = 0;
     if (in) {
@@ -258,9 +310,9 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
 #pragma unroll
       for (int k = 0; k < 9; ++k) r[k] = 0;
     }
-    reduce_group_e3d<0>(Jp, r, w, lane, out, seg_on);
-    reduce_group_e3d<1>(Jp, r, w, lane, out, seg_on);
-    reduce_group_e3d<2>(Jp, r, w, lane, out, seg_on);
+    reduce_group_e3d_lds<0>(Jp, r, w, threadIdx.x & 63, out, tr);
+    reduce_group_e3d_lds<1>(Jp, r, w, threadIdx.x & 63, out, tr);
+    reduce_group_e3d_lds<2>(Jp, r, w, threadIdx.x & 63, out, tr);
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) chi += __shfl_xor(chi, off, 64);
     if (lane == 0 && seg_on) {
@@ -389,6 +441,7 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize_both(
                                                                      double* __restrict__ blk_chi, const LmCore* __restrict__ st,
                                                                      int* __restrict__ n_dropped) {
   __shared__ double wg_chi[2 * kLinWaves];
+  __shared__ double tr_all[kLinWaves * kTrDoubles];
   const double* objs = objs_a;
   double* chunk_out = chunk_a;
   if (st) {
@@ -396,8 +449,8 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize_both(
     if (st->cur == 0) { objs = objs_b; chunk_out = chunk_b; }   // trial = the pair that is NOT current
   }
   wg_chi_begin(wg_chi);
-  if ((int)blockIdx.x < nb_e3) chunk_linearize_body<JAC, 1>(g, ct, ids_e3, n_e3, cams, objs, delta, chunk_out, wg_chi, blockIdx.x);
-  else chunk_linearize_body<JAC, 0, VALIDATE>(g, ct, ids_bb, n_bb, cams, objs, delta, chunk_out, wg_chi, blockIdx.x - nb_e3, n_dropped);
+  if ((int)blockIdx.x < nb_e3) chunk_linearize_body<JAC, 1>(g, ct, ids_e3, n_e3, cams, objs, delta, chunk_out, wg_chi, tr_all, blockIdx.x);
+  else chunk_linearize_body<JAC, 0, VALIDATE>(g, ct, ids_bb, n_bb, cams, objs, delta, chunk_out, wg_chi, tr_all, blockIdx.x - nb_e3, n_dropped);
   wg_chi_end(wg_chi, blk_chi, blockIdx.x);
 }
 template <int JAC, int TYPE, bool VALIDATE = false>
@@ -408,6 +461,7 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize(DevGr
                                                                 double* __restrict__ blk_chi, int blk_offset,
                                                                 const LmCore* __restrict__ st, int* __restrict__ n_dropped) {
   __shared__ double wg_chi[2 * kLinWaves];
+  __shared__ double tr_all[kLinWaves * kTrDoubles];
   const double* objs = objs_a;
   double* chunk_out = chunk_a;
   if (st) {
@@ -415,7 +469,7 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize(DevGr
     if (st->cur == 0) { objs = objs_b; chunk_out = chunk_b; }
   }
   wg_chi_begin(wg_chi);
-  chunk_linearize_body<JAC, TYPE, VALIDATE>(g, ct, ids, n_ids, cams, objs, delta, chunk_out, wg_chi, blockIdx.x, n_dropped);
+  chunk_linearize_body<JAC, TYPE, VALIDATE>(g, ct, ids, n_ids, cams, objs, delta, chunk_out, wg_chi, tr_all, blockIdx.x, n_dropped);
   wg_chi_end(wg_chi, blk_chi, blk_offset + blockIdx.x);
 }
 
