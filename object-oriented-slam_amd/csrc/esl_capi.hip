@@ -738,7 +738,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   }
   const int max_total = p->max_iters * std::max(1, p->max_trials);
   const int depth = 2;   // trials kept in flight ahead of the device's progress counter
-  const int n_step_blocks = std::max(1, (g.n_objs + 255) / 256);
+  const int n_step_blocks = std::max(1, (g.n_objs + kStepObjs - 1) / kStepObjs);
   const int batch = 4;   // sharded: trials enqueued per round (a fixed number, so that all ranks issue the same collectives)
   const int n_lin_blocks = (c->n_ids_e3 + 2 * kLinWaves - 1) / (2 * kLinWaves) + (c->n_ids_bb + kLinWaves - 1) / kLinWaves;
   // launch k carries trial k's solve and trial k-1's decision: one launch more than there are trials

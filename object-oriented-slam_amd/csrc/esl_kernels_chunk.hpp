@@ -35,6 +35,8 @@ constexpr int kChunkOut = 56;  // 45 packed H + 9 b + chi2 + pad
 // waves per workgroup of the linearisation kernels.  Measured at C4: 1-wave workgroups make the launch 0.8 us shorter
 // (finer spreading over the 1024 SIMDs) and k_lm_step 0.8 us longer (4x the per-workgroup chi2 partials to add): a wash.
 constexpr int kLinWaves = 4;
+// k_lm_step: ellipsoids per workgroup (one lane each in the solve phase) and the row stride of their H, b sums in LDS
+constexpr int kStepObjs = 64, kHbStride = 55;
 
 // ---- reduce-scatter across the wave by recursive halving ------------------------------------------------
 // In: N values per lane.  Out: the wave-wide total of entry `idx` (returned) in the lanes whose low bits are 0.
@@ -550,7 +552,8 @@ static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, Chunk
 __device__ __forceinline__ void obj_solve_one(const DevGraph& g, const ChunkTable& ct, const double* __restrict__ chunk_out,
                                               const double* __restrict__ objs, int jac, double delta, double lambda,
                                               double* __restrict__ xo, double* __restrict__ objs_trial, double* __restrict__ part, int o,
-                                              double& cg_out, double& scale_out, double& ok_out) {
+                                              double& cg_out, double& scale_out, double& ok_out,
+                                              const double* __restrict__ hb_sum = nullptr /* 54 pre-summed entries (LDS) */) {
   const int c0 = ct.ostart[o], c1 = ct.ostart[o + 1];
   const Ell e = ell_load(objs + 10 * o);
   const int ngrav = g.gr_cnt[o];
@@ -560,12 +563,17 @@ __device__ __forceinline__ void obj_solve_one(const DevGraph& g, const ChunkTabl
     return;   // contributes cg = 0, scale = 0, ok = 1
   }
   double hb[54];
+  if (hb_sum) {
 #pragma unroll
-  for (int k = 0; k < 54; ++k) hb[k] = 0;
-  for (int ch = c0; ch < c1; ++ch) {
-    const double* p = chunk_out + (size_t)ch * kChunkOut;
+    for (int k = 0; k < 54; ++k) hb[k] = hb_sum[k];
+  } else {
 #pragma unroll
-    for (int k = 0; k < 54; ++k) hb[k] += p[k];
+    for (int k = 0; k < 54; ++k) hb[k] = 0;
+    for (int ch = c0; ch < c1; ++ch) {
+      const double* p = chunk_out + (size_t)ch * kChunkOut;
+#pragma unroll
+      for (int k = 0; k < 54; ++k) hb[k] += p[k];
+    }
   }
   const double wg = g.grav_w * ngrav;
   if (ngrav > 0) {  // the gravity prior is a unary edge on this ellipsoid: linearise it here
@@ -744,15 +752,40 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
   const double* chunk_out = s.cur ? chunk_b : chunk_a;
   const double* objs = s.cur ? objs_b : objs_a;
   double* objs_trial = s.cur ? objs_a : objs_b;
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  double cg = 0, scale = 0, okd = 1;
-  if (o < g.n_objs) obj_solve_one(g, ct, chunk_out, objs, jac, delta, s.lambda, xo, objs_trial, part, o, cg, scale, okd);
-  cg = block256_sum1(cg, sm4);
-  scale = block256_sum1(scale, sm4);
-  okd = block256_min1(okd, sm4);
-  if (threadIdx.x == 0) {
-    sp_out[blockIdx.x * 4 + 0] = cg; sp_out[blockIdx.x * 4 + 1] = 0;
-    sp_out[blockIdx.x * 4 + 2] = scale; sp_out[blockIdx.x * 4 + 3] = okd;
+  // (2) this workgroup's kStepObjs ellipsoids.  All 256 threads first add up the chunk partials, one (ellipsoid, entry) pair
+  // at a time with the loads of up to four chunks in flight together -- a lane walking its own ellipsoid's chunks one after
+  // the other sat through one L2 round trip per chunk -- then one lane per ellipsoid solves from LDS.
+  __shared__ double hbs[kStepObjs * kHbStride];
+  __shared__ int ost[kStepObjs + 1];
+  const int o0 = blockIdx.x * kStepObjs;
+  for (int j = threadIdx.x; j <= kStepObjs; j += 256) ost[j] = ct.ostart[min(o0 + j, g.n_objs)];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < kStepObjs * 54; idx += 256) {
+    const int j = idx / 54, k = idx - j * 54;
+    double acc = 0;
+    for (int ch = ost[j]; ch < ost[j + 1]; ch += 4) {
+      const int nleft = ost[j + 1] - ch;
+      const double* p = chunk_out + (size_t)ch * kChunkOut + k;
+      const double v0 = p[0];
+      const double v1 = nleft > 1 ? p[kChunkOut] : 0.0;
+      const double v2 = nleft > 2 ? p[2 * kChunkOut] : 0.0;
+      const double v3 = nleft > 3 ? p[3 * kChunkOut] : 0.0;
+      acc = (((acc + v0) + v1) + v2) + v3;   // chunk order, as the serial sum
+    }
+    hbs[j * kHbStride + k] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < kStepObjs) {   // wave 0
+    const int o = o0 + threadIdx.x;
+    double cg = 0, scale = 0, okd = 1;
+    if (o < g.n_objs)
+      obj_solve_one(g, ct, chunk_out, objs, jac, delta, s.lambda, xo, objs_trial, part, o, cg, scale, okd, hbs + threadIdx.x * kHbStride);
+    cg = wave_sum(cg); scale = wave_sum(scale);
+    okd = -wave_max(-okd);
+    if (threadIdx.x == 0) {
+      sp_out[blockIdx.x * 4 + 0] = cg; sp_out[blockIdx.x * 4 + 1] = 0;
+      sp_out[blockIdx.x * 4 + 2] = scale; sp_out[blockIdx.x * 4 + 3] = okd;
+    }
   }
 }
 
