@@ -142,3 +142,34 @@ def test_gpu_fit_c2_shape_50k_points(po, ctx, pkg):
     o = po.fit_frame(sc["depth"], [b], [28], sc["Twc"], sc["intr"], sc["ground"], Po)
     assert 45000 < o[3][0][0] < 56000
     _cmp(po, *g, *o, 1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_fit_graph_replay_and_slab_regrowth(ctx, pkg, monkeypatch):
+    """esl_fit_frame replays a captured hipGraph per launch geometry.  Alternate geometries (20 small boxes -> one 50k-sample
+    box, which regrows the slab and drops the cached graphs -> back), change the per-frame VALUES under one geometry
+    (the graph must pick them up from the staged block, not from captured arguments), and compare with direct launches."""
+    a = pkg.synth.make_depth_scene(n_objs=20, seed=7, spread=1.6, size=(0.1, 0.3))
+    b = pkg.synth.make_depth_scene(width=1280, height=960, n_objs=1, seed=11, size=(0.23, 0.28))
+    P = pkg.lib.default_fit_params(symmetry_lm_iters=0)
+    Pb = pkg.lib.default_fit_params(stride=1, symmetry_lm_iters=0)
+
+    def run_a(scene, ground=None):
+        return ctx.fit_frame(scene["depth"], scene["bboxes"], scene["labels"], scene["Twc"], scene["intr"],
+                             scene["ground"] if ground is None else ground, P)
+
+    def run_b():
+        return ctx.fit_frame(b["depth"], [b["bboxes"][0]], [28], b["Twc"], b["intr"], b["ground"], Pb)
+
+    monkeypatch.setenv("ESL_FIT_NO_GRAPH", "1")
+    ref_a, ref_b = run_a(a), run_b()
+    shifted = np.array(a["ground"], float); shifted[3] -= 0.02          # same geometry, different values
+    ref_a2 = run_a(a, shifted)
+    monkeypatch.delenv("ESL_FIT_NO_GRAPH")
+    seq = [run_a(a), run_a(a), run_b(), run_a(a), run_a(a, shifted), run_a(a), run_b()]
+    want = [ref_a, ref_a, ref_b, ref_a, ref_a2, ref_a, ref_b]
+    for got, ref in zip(seq, want):
+        np.testing.assert_array_equal(got[2], ref[2])                    # status
+        np.testing.assert_array_equal(got[3][:, :6], ref[3][:, :6])      # stage counters: exact
+        np.testing.assert_allclose(got[0], ref[0], rtol=1e-9, atol=1e-10)
+    assert not np.allclose(ref_a[0], ref_a2[0])                          # the shifted ground plane does change the result
