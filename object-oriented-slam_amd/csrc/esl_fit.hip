@@ -79,7 +79,7 @@ constexpr int kClLds = 2048, kClCells = 4096;
 constexpr unsigned int kEmpty32 = 0xFFFFFFFFu;
 __shared__ __attribute__((aligned(16))) unsigned char g_fit_lds[(kClCells * 2 + kClLds * 2) * 4];
 #define g_sym_pof ((float*)g_fit_lds)
-static_assert(sizeof(float) * 3 * kSymLds <= sizeof(g_fit_lds), "symmetry candidates must fit the shared buffer");
+static_assert(sizeof(float) * 4 * kSymLds <= sizeof(g_fit_lds), "symmetry candidates (float4) must fit the shared buffer");
 #define ESL_FIT_MARK(k) do { if (a.clk && tid == 0) a.clk[16 * b + (k)] = (long long)wall_clock64(); } while (0)
 
 // block-wide sum, result to every thread (wave shuffle + LDS)
@@ -276,12 +276,30 @@ __device__ double sym_error_wave(const SymCtx& c, const PlaneT& pl, bool dual) {
       if (!finite_pt) invalid += 1;
       else {
         double best = 1e300;
-        if (c.n <= kSymLds) {   // candidates broadcast from LDS (was: three dependent global loads per candidate)
-          for (int j = 0; j < c.n; ++j) {
-            const double dx = p[0] - (double)g_sym_pof[3 * j], dy = p[1] - (double)g_sym_pof[3 * j + 1], dz = p[2] - (double)g_sym_pof[3 * j + 2];
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < best) best = d2;
+        if (c.n <= kSymLds) {
+          // candidates broadcast from LDS as float4 (one ds_read_b128 each), four independent running minima: the plain
+          // loop (three scalar LDS reads and a compare-and-branch per candidate) cost ~0.25 us PER CANDIDATE and was the
+          // whole symmetry stage (22 us per evaluation round at 46 points)
+          const float4* cand = (const float4*)g_fit_lds;
+          double b0 = 1e300, b1 = 1e300, b2 = 1e300, b3 = 1e300;
+          int j = 0;
+          for (; j + 4 <= c.n; j += 4) {
+            const float4 q0 = cand[j], q1 = cand[j + 1], q2 = cand[j + 2], q3 = cand[j + 3];
+            const double x0 = p[0] - (double)q0.x, y0 = p[1] - (double)q0.y, z0 = p[2] - (double)q0.z;
+            const double x1 = p[0] - (double)q1.x, y1 = p[1] - (double)q1.y, z1 = p[2] - (double)q1.z;
+            const double x2 = p[0] - (double)q2.x, y2 = p[1] - (double)q2.y, z2 = p[2] - (double)q2.z;
+            const double x3 = p[0] - (double)q3.x, y3 = p[1] - (double)q3.y, z3 = p[2] - (double)q3.z;
+            b0 = fmin(b0, x0 * x0 + y0 * y0 + z0 * z0);
+            b1 = fmin(b1, x1 * x1 + y1 * y1 + z1 * z1);
+            b2 = fmin(b2, x2 * x2 + y2 * y2 + z2 * z2);
+            b3 = fmin(b3, x3 * x3 + y3 * y3 + z3 * z3);
           }
+          for (; j < c.n; ++j) {
+            const float4 q0 = cand[j];
+            const double x0 = p[0] - (double)q0.x, y0 = p[1] - (double)q0.y, z0 = p[2] - (double)q0.z;
+            b0 = fmin(b0, x0 * x0 + y0 * y0 + z0 * z0);
+          }
+          best = fmin(fmin(b0, b1), fmin(b2, b3));
         } else {
           for (int j = 0; j < c.n; ++j) {
             const double dx = p[0] - (double)c.pof[3 * j], dy = p[1] - (double)c.pof[3 * j + 1], dz = p[2] - (double)c.pof[3 * j + 2];
@@ -965,10 +983,12 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
 constexpr int kSymThreads = 512, kSymWaves = kSymThreads / 64;
 static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
   __shared__ SymCtx sc;
-  __shared__ double ev[kSymWaves];
+  __shared__ double ev[kSymWaves], s_ok[kSymWaves], s_x[kSymWaves][3], s_pl[kSymWaves][5];
   const int b = blockIdx.x / 9, h = blockIdx.x % 9, tid = threadIdx.x, wv = tid >> 6;
   FitShared* st = a.state + b;
   if (!st->pre_ok || !st->run_sym) return;
+  long long t_start = 0, t_eval = 0, t_book = 0; int n_rounds = 0;
+  if (a.clk) t_start = (long long)wall_clock64();
   {
     const unsigned long long* src = (const unsigned long long*)&st->sc;
     unsigned long long* dst = (unsigned long long*)&sc;
@@ -977,7 +997,7 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
   __syncthreads();
   const int n = sc.n;
   if (n <= kSymLds)
-    for (int i = tid; i < 3 * n; i += kSymThreads) g_sym_pof[i] = sc.pof[i];
+    for (int i = tid; i < n; i += kSymThreads) ((float4*)g_fit_lds)[i] = make_float4(sc.pof[3 * i], sc.pof[3 * i + 1], sc.pof[3 * i + 2], 0.f);
   __syncthreads();
   const bool dual = st->stype == 2;
   const int dim = dual ? 3 : 2, iters = a.fr->p.symmetry_lm_iters;
@@ -997,6 +1017,8 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
   __syncthreads();
   for (int it = 0; it < iters; ++it) {
     // linearisation: wave 0 -> E(pl), wave 1 + 2d -> E(pl + delta e_d), wave 2 + 2d -> E(pl - delta e_d)
+    ++n_rounds;
+    const long long te0 = a.clk ? (long long)wall_clock64() : 0;
     if (wv < 1 + 2 * dim) {
       PlaneT pp = pl;
       if (wv > 0) {
@@ -1008,7 +1030,9 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
       const double e = sym_error_wave(sc, pp, dual);
       if ((tid & 63) == 0) ev[wv] = e;
     }
+    if (a.clk && tid == 0) t_eval += (long long)wall_clock64() - te0;
     __syncthreads();
+    const long long tb0 = a.clk ? (long long)wall_clock64() : 0;
     const double e0 = ev[0];
     e_last = e0;
     double cur = e0 * e0;
@@ -1025,40 +1049,43 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
     double rho = 0;
     int q = 0;
     bool more = true;
+    if (a.clk && tid == 0) t_book += (long long)wall_clock64() - tb0;
     while (more) {
       // speculative batch: wave k tries the lambda reached after k further rejections
+      ++n_rounds;
       {
         double lam_k = lambda, ni_k = ni;
         for (int k = 0; k < wv; ++k) { lam_k *= ni_k; ni_k *= 2; }
         double Mx[9], x[3] = {0, 0, 0};
         for (int r = 0; r < dim * dim; ++r) Mx[r] = H[r];
         for (int r = 0; r < dim; ++r) Mx[r * dim + r] += lam_k;
-        (void)ldlt_small(Mx, dim, bvec, x);
+        const bool ok = ldlt_small(Mx, dim, bvec, x);
         PlaneT pt = pl;
         plane_update(pt, x, dual);
         const double e = sym_error_wave(sc, pt, dual);
-        if ((tid & 63) == 0) ev[wv] = e;
+        if ((tid & 63) == 0) {   // everything the sequential consumption needs from this trial
+          ev[wv] = e; s_ok[wv] = ok ? 1.0 : 0.0;
+          for (int r = 0; r < 3; ++r) s_x[wv][r] = x[r];
+          for (int r = 0; r < 4; ++r) s_pl[wv][r] = pt.p[r];
+          s_pl[wv][4] = pt.dual;
+        }
       }
       __syncthreads();
-      for (int k = 0; k < kSymWaves && more; ++k) {   // consume in the sequential order
-        const PlaneT bak = pl;
-        double Mx[9], x[3] = {0, 0, 0};
-        for (int r = 0; r < dim * dim; ++r) Mx[r] = H[r];
-        for (int r = 0; r < dim; ++r) Mx[r * dim + r] += lambda;
-        const bool ok = ldlt_small(Mx, dim, bvec, x);
-        plane_update(pl, x, dual);
+      for (int k = 0; k < kSymWaves && more; ++k) {   // consume in the sequential order (a rejected trial costs ~30 instructions)
         const double et = ev[k];
         e_last = et;
-        const double tmp = ok ? et * et : 1.7976931348623157e308;
+        const double tmp = (s_ok[k] > 0.5) ? et * et : 1.7976931348623157e308;
         double scale = 0;
-        for (int r = 0; r < dim; ++r) scale += x[r] * (lambda * x[r] + bvec[r]);
+        for (int r = 0; r < dim; ++r) scale += s_x[k][r] * (lambda * s_x[k][r] + bvec[r]);   // lambda == wave k's lam_k here
         rho = (cur - tmp) / (scale + 1e-3);
         if (rho > 0 && isfinite(tmp)) {
           double alpha = 1. - pow((2 * rho - 1), 3);
           alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
           lambda *= (1. / 3. > alpha ? 1. / 3. : alpha);
           ni = 2; cur = tmp;
-        } else { lambda *= ni; ni *= 2; pl = bak; }
+          for (int r = 0; r < 4; ++r) pl.p[r] = s_pl[k][r];
+          pl.dual = s_pl[k][4];
+        } else { lambda *= ni; ni *= 2; }
         q++;
         more = (rho < 0 && q < 10);
       }
@@ -1069,6 +1096,14 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
     if (nbad >= 3) break;
   }
   if (tid == 0) { st->prob[h] = exp(-e_last); st->planes[h] = pl; }
+  if (a.clk && tid == 0) {   // diagnostic: the slowest hypothesis of the box (duration in ticks, rounds)
+    const long long dur = (long long)wall_clock64() - t_start;
+    atomicMax((unsigned long long*)&a.clk[16 * b + 10], (unsigned long long)dur);
+    atomicMax((unsigned long long*)&a.clk[16 * b + 11], (unsigned long long)n_rounds);
+    atomicMax((unsigned long long*)&a.clk[16 * b + 12], (unsigned long long)n);
+    atomicMax((unsigned long long*)&a.clk[16 * b + 13], (unsigned long long)t_eval);
+    atomicMax((unsigned long long*)&a.clk[16 * b + 14], (unsigned long long)t_book);
+  }
 }
 
 // ---- completion: best hypothesis, mirrored points, extents, ellipsoid (one workgroup per box) ----------------
@@ -1390,6 +1425,13 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
         for (int k = 1; k <= 8; ++k) if (clk[16 * bx + k] > last) last = clk[16 * bx + k];
         const double t = (double)(last - clk[16 * bx]) * 0.01;
         if (t > slow_t) { slow_t = t; slow = bx; }
+      }
+      {
+        double md = 0; long long mr = 0, mn = 0;
+        double me = 0, mb = 0;
+        for (size_t bx = 0; bx < B; ++bx) { md = std::max(md, (double)clk[16 * bx + 10] * 0.01); mr = std::max(mr, clk[16 * bx + 11]); mn = std::max(mn, clk[16 * bx + 12]);
+          me = std::max(me, (double)clk[16 * bx + 13] * 0.01); mb = std::max(mb, (double)clk[16 * bx + 14] * 0.01); }
+        fprintf(stderr, "\n[esl_fit timing] symmetry kernel: slowest hypothesis %.1f us, max evaluation rounds %lld, max points %lld; linearisation evaluations (wave 0) %.1f us, bookkeeping %.1f us", md, mr, mn, me, mb);
       }
       fprintf(stderr, "\n[esl_fit timing] slowest box %zu: %.1f us:", slow, slow_t);
       for (int k = 0; k < 8; ++k) {
