@@ -93,6 +93,27 @@ __device__ double block_sum(double v, double* red) {
   for (int i = 0; i < kFitThreads / 64; ++i) s += red[i];
   return s;
 }
+// N sums at once with ONE barrier pair (red: N x 16 doubles); same per-value summation order as block_sum
+template <int N>
+__device__ void block_sum_n(double (&v)[N], double* red) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[k * (kFitThreads / 64) + (threadIdx.x >> 6)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double s = 0;
+    for (int i = 0; i < kFitThreads / 64; ++i) s += red[k * (kFitThreads / 64) + i];
+    v[k] = s;
+  }
+}
 __device__ double block_max(double v, double* red) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -429,7 +450,7 @@ __device__ __forceinline__ int symmetry_type(int label) {  // EllipsoidExtractor
 }
 
 struct FitShared {
-  double red[kFitThreads / 64];
+  double red[6 * (kFitThreads / 64)];
   int M, n0, n1, ncl, chosen, maxsize, only, status, ns0, npo, cnt;
   int cmin[3], cmax[3];   // cell-coordinate extent of the box's points (LDS clustering path)
   int nc, pre_ok, run_sym, stype;   // carried from the first kernel to the later ones
@@ -701,12 +722,20 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   // through L2 at ~1 us a hop: 27 cells x probe + list walk per point made this stage 150-330 us per box).
   if (tid == 0) { for (int k = 0; k < 3; ++k) { S.cmin[k] = INT_MAX; S.cmax[k] = INT_MIN; } }
   __syncthreads();
-  for (int i = tid; i < M; i += kFitThreads) {
-    const int cx_ = (int)(long long)floor((double)a.pwx[pbase + i] / tol), cy_ = (int)(long long)floor((double)a.pwy[pbase + i] / tol),
-              cz_ = (int)(long long)floor((double)a.pwz[pbase + i] / tol);
-    atomicMin(&S.cmin[0], cx_); atomicMax(&S.cmax[0], cx_);
-    atomicMin(&S.cmin[1], cy_); atomicMax(&S.cmax[1], cy_);
-    atomicMin(&S.cmin[2], cz_); atomicMax(&S.cmax[2], cz_);
+  {
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (int i = tid; i < M; i += kFitThreads) {
+      const int cc[3] = {(int)(long long)floor((double)a.pwx[pbase + i] / tol), (int)(long long)floor((double)a.pwy[pbase + i] / tol),
+                         (int)(long long)floor((double)a.pwz[pbase + i] / tol)};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], cc[k]); hi[k] = max(hi[k], cc[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // one LDS atomic per wave and axis instead of six per point
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { lo[k] = min(lo[k], __shfl_xor(lo[k], off, 64)); hi[k] = max(hi[k], __shfl_xor(hi[k], off, 64)); }
+      if ((tid & 63) == 0) { atomicMin(&S.cmin[k], lo[k]); atomicMax(&S.cmax[k], hi[k]); }
+    }
   }
   __syncthreads();
   const bool lds_path = M <= kClLds && (long)S.cmax[0] - S.cmin[0] < 1020 && (long)S.cmax[1] - S.cmin[1] < 1020 &&
@@ -834,7 +863,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
     double sx = 0, sy = 0, sz = 0;
     for (int i = tid; i < M; i += kFitThreads)
       if (a.nxt[pbase + i] == chosen) { sx += a.pwx[pbase + i]; sy += a.pwy[pbase + i]; sz += a.pwz[pbase + i]; }
-    sx = block_sum(sx, S.red); sy = block_sum(sy, S.red); sz = block_sum(sz, S.red);
+    { double v3[3] = {sx, sy, sz}; block_sum_n<3>(v3, S.red); sx = v3[0]; sy = v3[1]; sz = v3[2]; }
     const double cen[3] = {sx / nc, sy / nc, sz / nc};
     double cv[6] = {0, 0, 0, 0, 0, 0};
     for (int i = tid; i < M; i += kFitThreads)
@@ -842,7 +871,8 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
         const double d0 = a.pwx[pbase + i] - cen[0], d1 = a.pwy[pbase + i] - cen[1], d2 = a.pwz[pbase + i] - cen[2];
         cv[0] += d0 * d0; cv[1] += d0 * d1; cv[2] += d0 * d2; cv[3] += d1 * d1; cv[4] += d1 * d2; cv[5] += d2 * d2;
       }
-    for (int k = 0; k < 6; ++k) cv[k] = block_sum(cv[k], S.red);
+    __syncthreads();   // S.red is reused
+    block_sum_n<6>(cv, S.red);
     if (tid == 0) {
       const double cov[9] = {cv[0] / nc, cv[1] / nc, cv[2] / nc, cv[1] / nc, cv[3] / nc, cv[4] / nc, cv[2] / nc, cv[4] / nc, cv[5] / nc};
       double ev[3], rot[9];
