@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -394,7 +396,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     wk.add(&c->chunk_out2, (size_t)c->n_chunks * kChunkOut);
     wk.add(&c->chunk_chi, (size_t)c->n_chunks);
     wk.add(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2);
-    wk.add(&c->solve_part, (size_t)((N + 63) / 64 + 1) * 4 * 2);   // x2: ping-pong of k_lm_step
+    wk.add(&c->solve_part, (size_t)((N + kStepObjs - 1) / kStepObjs + (N + 63) / 64 + 2) * 4 * 2);   // k_obj_solve / k_lm_step (x2: ping-pong)
     wk.add(&c->blk_chi, (size_t)(c->n_chunks + 2));                 // <= one workgroup per chunk
   }
   // cameras + odometry
@@ -792,6 +794,12 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   // `done` was stored with release semantics after the results: they are visible without draining the stream (the
   // one or two no-op launches still queued touch nothing the caller can see)
   if (sharded) ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // leave no collective in flight behind the caller's back
+  if (std::getenv("ESL_LM_TIMING")) {
+    (void)hipStreamSynchronize(c->stream);
+    fprintf(stderr, "[k_lm_step, workgroup 0, last live launch, us] decision=%.2f gather=%.2f solve=%.2f\n",
+            (double)(hv->dbg_clk[1] - hv->dbg_clk[0]) * 0.01, (double)(hv->dbg_clk[2] - hv->dbg_clk[1]) * 0.01,
+            (double)(hv->dbg_clk[3] - hv->dbg_clk[2]) * 0.01);
+  }
   const LmCore& r = hv->core;
   out->n_bbox_dropped = hv->n_dropped;
   out->n_bbox_valid = g.n_bbox - hv->n_dropped;

@@ -36,7 +36,7 @@ constexpr int kChunkOut = 56;  // 45 packed H + 9 b + chi2 + pad
 // (finer spreading over the 1024 SIMDs) and k_lm_step 0.8 us longer (4x the per-workgroup chi2 partials to add): a wash.
 constexpr int kLinWaves = 4;
 // k_lm_step: ellipsoids per workgroup (one lane each in the solve phase) and the row stride of their H, b sums in LDS
-constexpr int kStepObjs = 64, kHbStride = 55;
+constexpr int kStepObjs = 16, kHbStride = 55;   // 16: the gather is 864 sums per workgroup = 3.4 per thread, all loads in flight
 
 // ---- reduce-scatter across the wave by recursive halving ------------------------------------------------
 // In: N values per lane.  Out: the wave-wide total of entry `idx` (returned) in the lanes whose low bits are 0.
@@ -365,6 +365,7 @@ struct LmHostView {   // mapped host memory, written by the device only: progres
   double trace_chi2[ESL_MAX_TRACE], trace_lambda[ESL_MAX_TRACE];
   int trace_trials[ESL_MAX_TRACE];
   int trace_len, pad;
+  long long dbg_clk[8];   // diagnostic (ESL_LM_TIMING): wall_clock64 marks of workgroup 0 in the last live k_lm_step
 };
 
 __device__ __forceinline__ void lm_core_init(LmCore& s, double chi2, double max_diag, double tau) {
@@ -701,8 +702,10 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
   // Sharded run (n_ranks > 0): `gathered` holds every rank's 8-double block {chi2_lin, max_diag, chi2_trial, scale, ok,
   // has_edges, -, -} (all-gathered on this stream); the decision adds them in rank order, so every rank decides alike.
   // first: 1 = state in `in` is initialised (single GPU), 2 = initialise it here from the gathered linearisation scalars.
-  __shared__ double sm4[4];
+  __shared__ double sm12[12];
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+  long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+  if (writer) tk0 = (long long)wall_clock64();
   // all loads of the decision go out together (each is an HBM / fabric round trip: the producers ran on other XCDs)
   double c = 0, sc = 0, okv = 1;
   if (!first && n_ranks == 0) {
@@ -734,9 +737,13 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
     if (n_ranks > 0) {
       for (int r = 0; r < n_ranks; ++r) { c += gathered[r * 8 + 2]; sc += gathered[r * 8 + 3]; okv = fmin(okv, gathered[r * 8 + 4]); }
     } else {
-      c = block256_sum1(c, sm4);
-      sc = block256_sum1(sc, sm4);
-      okv = block256_min1(okv, sm4);
+      // three block reductions behind one barrier pair
+      c = wave_sum(c); sc = wave_sum(sc); okv = -wave_max(-okv);
+      if ((threadIdx.x & 63) == 0) { sm12[threadIdx.x >> 6] = c; sm12[4 + (threadIdx.x >> 6)] = sc; sm12[8 + (threadIdx.x >> 6)] = okv; }
+      __syncthreads();
+      c = ((sm12[0] + sm12[1]) + sm12[2]) + sm12[3];
+      sc = ((sm12[4] + sm12[5]) + sm12[6]) + sm12[7];
+      okv = fmin(fmin(sm12[8], sm12[9]), fmin(sm12[10], sm12[11]));
     }
     lm_decide(s, c, sc, okv, max_iters, max_trials, writer, host);
     if (writer) {
@@ -749,6 +756,7 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
   }
   if (writer) *out = s;
   if (s.done) return;
+  if (writer) tk1 = (long long)wall_clock64();
   const double* chunk_out = s.cur ? chunk_b : chunk_a;
   const double* objs = s.cur ? objs_b : objs_a;
   double* objs_trial = s.cur ? objs_a : objs_b;
@@ -760,31 +768,47 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
   const int o0 = blockIdx.x * kStepObjs;
   for (int j = threadIdx.x; j <= kStepObjs; j += 256) ost[j] = ct.ostart[min(o0 + j, g.n_objs)];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < kStepObjs * 54; idx += 256) {
-    const int j = idx / 54, k = idx - j * 54;
-    double acc = 0;
-    for (int ch = ost[j]; ch < ost[j + 1]; ch += 4) {
-      const int nleft = ost[j + 1] - ch;
-      const double* p = chunk_out + (size_t)ch * kChunkOut + k;
-      const double v0 = p[0];
-      const double v1 = nleft > 1 ? p[kChunkOut] : 0.0;
-      const double v2 = nleft > 2 ? p[2 * kChunkOut] : 0.0;
-      const double v3 = nleft > 3 ? p[3 * kChunkOut] : 0.0;
-      acc = (((acc + v0) + v1) + v2) + v3;   // chunk order, as the serial sum
+  {
+    constexpr int kIt = (kStepObjs * 54 + 255) / 256;
+    double v[kIt][4];
+    int jj[kIt], kk[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {   // issue every load of the first four chunks of every pair before using any
+      const int idx = threadIdx.x + 256 * it;
+      const bool on = idx < kStepObjs * 54;
+      const int j = on ? idx / 54 : 0, k = on ? idx - j * 54 : 0;
+      jj[it] = on ? j : -1; kk[it] = k;
+      const int c0 = ost[j], nleft = on ? ost[j + 1] - c0 : 0;
+      const double* p = chunk_out + (size_t)c0 * kChunkOut + k;
+      v[it][0] = nleft > 0 ? p[0] : 0.0;
+      v[it][1] = nleft > 1 ? p[kChunkOut] : 0.0;
+      v[it][2] = nleft > 2 ? p[2 * kChunkOut] : 0.0;
+      v[it][3] = nleft > 3 ? p[3 * kChunkOut] : 0.0;
     }
-    hbs[j * kHbStride + k] = acc;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      if (jj[it] < 0) continue;
+      double acc = (((0.0 + v[it][0]) + v[it][1]) + v[it][2]) + v[it][3];   // chunk order, as the serial sum
+      for (int ch = ost[jj[it]] + 4; ch < ost[jj[it] + 1]; ++ch) acc += chunk_out[(size_t)ch * kChunkOut + kk[it]];   // > 4 chunks: rare
+      hbs[jj[it] * kHbStride + kk[it]] = acc;
+    }
   }
   __syncthreads();
-  if (threadIdx.x < kStepObjs) {   // wave 0
+  if (writer) tk2 = (long long)wall_clock64();
+  if (threadIdx.x < 64) {   // wave 0, all 64 lanes stay in for the shuffles; the first kStepObjs lanes own an ellipsoid
     const int o = o0 + threadIdx.x;
     double cg = 0, scale = 0, okd = 1;
-    if (o < g.n_objs)
+    if (threadIdx.x < kStepObjs && o < g.n_objs)
       obj_solve_one(g, ct, chunk_out, objs, jac, delta, s.lambda, xo, objs_trial, part, o, cg, scale, okd, hbs + threadIdx.x * kHbStride);
     cg = wave_sum(cg); scale = wave_sum(scale);
     okd = -wave_max(-okd);
     if (threadIdx.x == 0) {
       sp_out[blockIdx.x * 4 + 0] = cg; sp_out[blockIdx.x * 4 + 1] = 0;
       sp_out[blockIdx.x * 4 + 2] = scale; sp_out[blockIdx.x * 4 + 3] = okd;
+    }
+    if (writer) {
+      tk3 = (long long)wall_clock64();
+      host->dbg_clk[0] = tk0; host->dbg_clk[1] = tk1; host->dbg_clk[2] = tk2; host->dbg_clk[3] = tk3;
     }
   }
 }
