@@ -655,7 +655,8 @@ __device__ __forceinline__ void lm_decide(LmCore& s, double chi, double sc, doub
   const double tempChi = (okv > 0.5) ? chi : DBL_MAX;
   const double rho = (s.currentChi - tempChi) / (sc + 1e-3);
   if (rho > 0 && isfinite(tempChi)) {
-    double alpha = 1. - pow((2 * rho - 1), 3.0);
+    const double t3 = 2 * rho - 1;
+    double alpha = 1. - t3 * t3 * t3;   // g2o: pow(2 rho - 1, 3); the library pow() is ~200 dependent instructions here
     alpha = fmin(alpha, 2. / 3.);
     s.lambda *= fmax(1. / 3., alpha);
     s.ni = 2;
@@ -747,11 +748,13 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
     }
     lm_decide(s, c, sc, okv, max_iters, max_trials, writer, host);
     if (writer) {
-      if (s.done) {   // results first, then the flag with release semantics: the host reads them as soon as it sees it
+      if (s.done) {   // results first, then the flags with release semantics: the host reads them as soon as it sees `done`
         host->core = s;
         __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {        // progress counter only (it throttles the host's enqueueing): no system-scope release fence per trial
+        __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   if (writer) *out = s;
