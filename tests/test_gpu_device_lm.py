@@ -5,7 +5,7 @@ sharded run in which one shard is empty."""
 import numpy as np
 import pytest
 
-from test_gpu_optimizer import assert_traces_match
+from test_gpu_optimizer import assert_traces_match, group_rel_err
 from test_gpu_sharded import ThreadAllreduce
 
 pytestmark = pytest.mark.gpu
@@ -109,3 +109,23 @@ def test_sharded_run_with_an_empty_shard(pkg, ctx):
         assert rep["iterations"] == ref["iterations"] and rep["trace_trials"] == ref["trace_trials"]
         np.testing.assert_allclose(rep["trace_chi2"], ref["trace_chi2"], rtol=1e-12)
     np.testing.assert_allclose(out, ro, rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_graph_sweep_matches_oracle(pkg, po, ctx, seed):
+    """A sweep over graph shapes (3-80 cameras, 1-12 ellipsoids, with / without 3-D and gravity edges, both Jacobian modes):
+    same LM trajectory as the CPU restatement and final ellipsoids within the north-star tolerance."""
+    rng = np.random.default_rng(1000 + seed)
+    n_cams, n_objs = int(rng.integers(3, 80)), int(rng.integers(1, 13))
+    n_edges = int(rng.integers(n_objs * 3, n_objs * 60))
+    g, c, o, _ = pkg.synth.make_graph(n_cams, n_objs, n_edges, seed=seed, gravity=bool(seed % 3))
+    if seed % 4 == 0:   # bbox edges only
+        g = pkg.Graph(g.K, g.n_cams, g.n_objs, None, g.bbox_cam, g.bbox_obj, g.bbox_meas, g.bbox_weight,
+                      grav_obj=g.grav_obj, grav_normal=g.grav_normal, grav_weight=g.grav_weight)
+    jac = seed % 2
+    p = pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6)
+    _, oo, ro = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=1e-6), solver=1)
+    _, og, rg = ctx.optimize(g, c, o, p)
+    assert rg["n_bbox_dropped"] == ro["n_bbox_dropped"]
+    assert_traces_match(rg, ro, rtol=1e-5)
+    assert group_rel_err(og, oo) < 1e-4   # |dt| / |t|, |dq|, |ds| / |s| per ellipsoid
