@@ -173,3 +173,17 @@ def test_gpu_fit_graph_replay_and_slab_regrowth(ctx, pkg, monkeypatch):
         np.testing.assert_array_equal(got[3][:, :6], ref[3][:, :6])      # stage counters: exact
         np.testing.assert_allclose(got[0], ref[0], rtol=1e-9, atol=1e-10)
     assert not np.allclose(ref_a[0], ref_a2[0])                          # the shifted ground plane does change the result
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10, 18))
+def test_gpu_fit_scene_sweep_matches_oracle(po, ctx, pkg, seed):
+    """More scenes (3-14 boxes, sizes, spreads), alternately without and with the symmetry LM (whose delta = 1e-9
+    differences set the looser tolerance)."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 15))
+    sc = pkg.synth.make_depth_scene(n_objs=n, seed=seed, spread=float(rng.uniform(1.0, 1.8)), size=(0.1, float(rng.uniform(0.25, 0.5))))
+    iters, tol = ((0, 1e-7), (5, 1e-4))[seed % 2]
+    o = po.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], po.default_fit_params(symmetry_lm_iters=iters))
+    g = ctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], pkg.lib.default_fit_params(symmetry_lm_iters=iters))
+    _cmp(po, *g, *o, tol)
