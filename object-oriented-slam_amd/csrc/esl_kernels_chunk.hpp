@@ -245,6 +245,19 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
   if (type == 0) {
     double r[4] = {0, 0, 0, 0}, J[36], w = 0;
     const bool act = in && (VALIDATE || g.bb_valid[i]);
+    if (JAC == ESL_JAC_NUMERIC) {
+      // g2o perturbs the ELLIPSOID: the 18 states ell_oplus(e, +-delta e_d) are the same for every edge of the chunk, so
+      // 18 lanes compute one each (same code, same values) and park them in the wave's LDS tile; every lane used to
+      // redo all 18 retractions (exp, quaternion products, normalisations: half of the kernel's 10k instructions)
+      const int l64 = threadIdx.x & 63;
+      if (l64 < 18) {
+        double u[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 9; ++q) u[q] = (q == (l64 >> 1)) ? ((l64 & 1) ? -delta : delta) : 0.0;
+        ell_store(ell_oplus(e, u), tr + 10 * l64);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     if (act) {
       const SE3 T = se3_load(cams + 7 * g.bb_cam[i]);
       double meas[4] = {g.bb_meas[4 * i], g.bb_meas[4 * i + 1], g.bb_meas[4 * i + 2], g.bb_meas[4 * i + 3]};
@@ -252,7 +265,17 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
       if (JAC == ESL_JAC_ANALYTIC) jac_bbox_t<true, false>(T, e, g.K, meas, r, J, nullptr);
       else {
         res_bbox(T, e, g.K, meas, r);
-        numeric_jac_obj(e, delta, 4, J, [&](const Ell& ep, double* o4) { res_bbox(T, ep, g.K, meas, o4); });
+        const double scalar = 1.0 / (2 * delta);
+        for (int d = 0; d < 9; ++d) {   // not unrolled: one body, 9 trips
+          double rp[4], rm[4];
+          res_bbox(T, ell_load(tr + 20 * d), g.K, meas, rp);
+          res_bbox(T, ell_load(tr + 20 * d + 10), g.K, meas, rm);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) if (q == d) J[k * 9 + q] = scalar * (rp[k] - rm[k]);
+          }
+        }
       }
       chi = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
       if (VALIDATE) {
@@ -271,6 +294,7 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
 #pragma unroll
       for (int k = 0; k < 36; ++k) J[k] = 0;
     }
+    if (JAC == ESL_JAC_NUMERIC) __builtin_amdgcn_wave_barrier();   // the perturbed states have been read; the tile is reused
     reduce_group_lds<4, 0>(J, r, w, lane, out, tr);
     reduce_group_lds<4, 1>(J, r, w, lane, out, tr);
     reduce_group_lds<4, 2>(J, r, w, lane, out, tr);
