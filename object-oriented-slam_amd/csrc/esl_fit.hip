@@ -147,16 +147,18 @@ __device__ __forceinline__ unsigned long long cell_key(float x, float y, float z
                   cz = (long long)floor((double)z / tol) + dz;
   return ((unsigned long long)(cz + kKeyOff) << 42) | ((unsigned long long)(cy + kKeyOff) << 21) | (unsigned long long)(cx + kKeyOff);
 }
-// find with path halving: a node is re-pointed at its grandparent (CAS, so a concurrent link is never undone; an
-// ancestor stays an ancestor).  Linking by index (larger root under smaller) alone grows chains hundreds of hops long
-// inside a 4.5k-point cluster, and every hop is an L2 round trip.
+// find with path halving: a node is re-pointed at its grandparent.  Linking by index (larger root under smaller) alone
+// grows chains hundreds of hops long inside a 4.5k-point cluster, and every hop is an L2 round trip.  The re-pointing is
+// a plain (relaxed atomic) STORE: only roots are ever targets of the linking CAS and a non-root never becomes a root
+// again, so the only concurrent writers of parent[i] are other halvings, all of them writing ancestors of i -- and a
+// same-address read-modify-write costs ~10 ns of serialisation on this part where a store does not.
 __device__ __forceinline__ int uf_find(int* parent, int i) {
   for (;;) {
     const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == i) return i;
     const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gp == p) return p;
-    (void)atomicCAS(&parent[i], p, gp);
+    __hip_atomic_store(&parent[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     i = gp;
   }
 }
@@ -594,18 +596,40 @@ static __global__ __launch_bounds__(256) void k_fit_plane(FitArgs a) {
   const SE3 Twc = se3_load(a.fr->Twc);
   const Mat3 Rwc = q_to_R(Twc.r);
   const double gn = sqrt(a.fr->ground[0] * a.fr->ground[0] + a.fr->ground[1] * a.fr->ground[1] + a.fr->ground[2] * a.fr->ground[2]);
-  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < a.H; s += (long)gridDim.x * blockDim.x) {
-    const unsigned int cnt = a.hcnt[base + s];
-    if (!cnt) continue;
-    atomicAdd(&a.state[b].n1, 1);
-    const double c = (double)cnt;
-    const double p[3] = {(double)(float)((double)a.hsx[base + s] / c / ESL_FIX), (double)(float)((double)a.hsy[base + s] / c / ESL_FIX),
-                         (double)(float)((double)a.hsz[base + s] / c / ESL_FIX)};
-    double q[3];
-    xform(Rwc, Twc.t, p, q);
-    const double dis = (a.fr->ground[0] * q[0] + a.fr->ground[1] * q[1] + a.fr->ground[2] * q[2] + a.fr->ground[3]) / gn;
-    if (dis > a.fr->p.plane_dist) {
-      const int i = atomicAdd(&a.state[b].M, 1);
+  // whole waves walk the table together (H and the strides are multiples of 64), so the two counters take ONE atomic per
+  // wave and round instead of one per voxel (8.5k same-address atomics for a 50k-sample box)
+  __shared__ int s_cnt[12];
+  const int lane = threadIdx.x & 63;
+  for (long s0 = (long)blockIdx.x * blockDim.x + threadIdx.x - lane; s0 < a.H; s0 += (long)gridDim.x * blockDim.x) {
+    const long s = s0 + lane;
+    const unsigned int cnt = s < a.H ? a.hcnt[base + s] : 0u;
+    const bool occ = cnt != 0;
+    bool keep = false;
+    double q[3] = {0, 0, 0};
+    if (occ) {
+      const double c = (double)cnt;
+      const double p[3] = {(double)(float)((double)a.hsx[base + s] / c / ESL_FIX), (double)(float)((double)a.hsy[base + s] / c / ESL_FIX),
+                           (double)(float)((double)a.hsz[base + s] / c / ESL_FIX)};
+      xform(Rwc, Twc.t, p, q);
+      const double dis = (a.fr->ground[0] * q[0] + a.fr->ground[1] * q[1] + a.fr->ground[2] * q[2] + a.fr->ground[3]) / gn;
+      keep = dis > a.fr->p.plane_dist;
+    }
+    // same-address device atomics cost ~10 ns each however they are issued: one pair per WORKGROUP and round
+    const unsigned long long m_occ = __ballot(occ), m_keep = __ballot(keep);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();   // (previous round's readers of s_cnt are done)
+    if (lane == 0) { s_cnt[wv] = __popcll(m_occ); s_cnt[4 + wv] = __popcll(m_keep); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t_occ = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], t_keep = s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7];
+      if (t_occ) atomicAdd(&a.state[b].n1, t_occ);
+      s_cnt[8] = t_keep ? atomicAdd(&a.state[b].M, t_keep) : 0;
+    }
+    __syncthreads();
+    int base_i = s_cnt[8];
+    for (int k = 0; k < wv; ++k) base_i += s_cnt[4 + k];
+    if (keep) {
+      const int i = base_i + __popcll(m_keep & ((1ull << lane) - 1ull));
       a.pwx[pbase + i] = (float)q[0]; a.pwy[pbase + i] = (float)q[1]; a.pwz[pbase + i] = (float)q[2];
       a.pkey[pbase + i] = a.hk[base + s];
     }
@@ -1393,8 +1417,9 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
       ProfScope ps(bracket ? c : nullptr, 5);
       // box scan + voxel hash and plane filter over (tile, box) grids; per-box clustering + PCA (clustering grid-wide for
       // big boxes); the 9 plane hypotheses of every box side by side; completion
-      const long tiles_scan = std::min<long>(64, std::max<long>(1, (cap + 2047) / 2048));   // ~8 samples per thread
-      const long tiles_hash = std::min<long>(64, std::max<long>(1, H / 2048));
+      // latency-bound walks (a sample / slot is a chain of 2-3 dependent loads and a few atomics): go wide rather than deep
+      const long tiles_scan = std::min<long>(512, std::max<long>(1, (cap + 511) / 512));    // ~2 samples per thread
+      const long tiles_hash = std::min<long>(512, std::max<long>(1, H / 512));              // ~2 slots per thread
       hipLaunchKernelGGL(k_fit_scan, dim3((unsigned)tiles_scan, n_boxes), dim3(256), 0, st, a);
       hipLaunchKernelGGL(k_fit_plane, dim3((unsigned)tiles_hash, n_boxes), dim3(256), 0, st, a);
       if (a.wide) {
