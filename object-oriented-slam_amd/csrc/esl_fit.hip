@@ -1,5 +1,11 @@
-// esl_fit.hip — esl_fit_frame: the single-frame ellipsoid fit, ONE WORKGROUP PER BOUNDING BOX, one launch
-// per frame for all boxes (the boxes of a frame are independent: no collective, replicas only).
+// esl_fit.hip — esl_fit_frame: the single-frame ellipsoid fit for all boxes of a frame (the boxes are independent: no
+// collective, replicas only), a short pipeline of launches replayed from a captured hipGraph:
+//   k_fit_scan / k_fit_plane          (tile, box) grids: depth samples -> voxel hash -> world frame -> supporting-plane filter
+//   k_fit_cl_*                        boxes with many samples: centre + Euclidean clustering over (tile, box) grids
+//   k_fit_pre                         one workgroup per box: (clustering in LDS for small boxes,) cluster choice, PCA +
+//                                     gravity alignment, 10 cm grid, symmetry context
+//   k_fit_sym                         one workgroup per (box, plane hypothesis): the 1-edge symmetry LM
+//   k_fit_post                        one workgroup per box: mirrored completion, extents, ellipsoid
 //
 // Replaces EllipsoidSLAM::EllipsoidExtractor::EstimateLocalEllipsoid (reference
 // src/pca/EllipsoidExtractor.cpp:292-493) with its helpers: getPointCloudInRect
@@ -15,9 +21,8 @@
 // integer atomics for the centroids; Euclidean clusters = connected components by lock-free union-find
 // over a 2 cm cell hash; 1-NN = brute force over the <= few hundred 10 cm voxels.
 //
-// Stages run back to back inside the workgroup (1024 threads = 16 waves on one CU), separated by
-// agent-scope fence + barrier; reductions are wave shuffles + one LDS hop.  The 9 symmetry hypotheses
-// each get their own wavefront (lanes over mirrored points).
+// Inside a kernel the stages of a box are separated by a barrier + agent-scope acquire (stage_sync); reductions are wave
+// shuffles + one LDS hop.  ESL_FIT_TIMING=1 prints a per-stage breakdown, ESL_FIT_NO_GRAPH=1 forces direct launches.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -78,7 +83,6 @@ constexpr int kSymLds = 1024;
 constexpr int kClLds = 2048, kClCells = 4096;
 constexpr unsigned int kEmpty32 = 0xFFFFFFFFu;
 __shared__ __attribute__((aligned(16))) unsigned char g_fit_lds[(kClCells * 2 + kClLds * 2) * 4];
-#define g_sym_pof ((float*)g_fit_lds)
 static_assert(sizeof(float) * 4 * kSymLds <= sizeof(g_fit_lds), "symmetry candidates (float4) must fit the shared buffer");
 #define ESL_FIT_MARK(k) do { if (a.clk && tid == 0) a.clk[16 * b + (k)] = (long long)wall_clock64(); } while (0)
 

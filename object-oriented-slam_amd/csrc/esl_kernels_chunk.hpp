@@ -1,19 +1,25 @@
-// esl_kernels_chunk.hpp — mapping-mode kernels, second generation (the ones the LM driver launches).
+// esl_kernels_chunk.hpp — mapping-mode kernels and the device-resident Levenberg-Marquardt control.
 //
-// Why: the first cut (esl_kernels_map.hpp: one wave per ellipsoid, 54 accumulators per lane carried across
-// rounds) ran at 1 wave/SIMD with scratch spills and a tail set by the ellipsoid with the most edges.
-// Here the unit of work is a CHUNK = up to 64 edges of one type hanging on one ellipsoid (table built at
-// upload, edges are already sorted by ellipsoid so a chunk is a contiguous, coalesced slice):
-//   k_chunk_linearize   one wave per chunk: lane = edge; residual + Jacobian in registers, then the 45+9
-//                       entries of J^T W J / -J^T W r are reduced across the wave with a transpose-reduce
-//                       (reduce-scatter by recursive halving: ~21 exchanges per 18 values instead of 108),
-//                       so nothing has to live across rounds -> ~4x the occupancy, uniform task size
-//   k_chunk_finalize    (first LM iteration only) per-ellipsoid diagonal of H -> max diag (lambda_0), chi2
-//   k_obj_solve         one wave per ellipsoid: sum its chunk partials in fixed order (deterministic),
-//                       row-parallel LDL^T of the 9x9, retraction, trial state
-//   k_chunk_chi2        one wave per chunk: chi2 of the trial state; the last workgroup to finish reduces
-//                       everything in fixed order and writes the LM scalars straight into mapped host memory
-// Reference pieces replaced: see esl_kernels_map.hpp.
+// The unit of work is a CHUNK = up to 64 bbox edges (or 32 3-D edges) hanging on one ellipsoid (table built at upload;
+// edges are sorted by ellipsoid, so a chunk is a contiguous, coalesced slice).  The first cut (one wave per ellipsoid, 54
+// accumulators per lane carried across rounds) ran at 1 wave/SIMD with scratch spills and a tail set by the ellipsoid with
+// the most edges.
+//   k_chunk_linearize_both  one wave per chunk (two 3-D chunks per wave), both edge types in one launch: lane = edge;
+//                           residual + Jacobian in registers, the 45+9 entries of J^T W J / -J^T W r summed over the wave
+//                           through a wave-private LDS transpose, written as a chunk partial; per-workgroup chi2 partial.
+//                           The first linearisation of a run also performs the NaN pre-check of the bbox edges.
+//   k_chunk_finalize        once per run: per-ellipsoid diagonal of H -> max diag (lambda_0), chi2, LM state initialisation
+//   k_lm_step               one LM trial's head: every workgroup decides the previous trial (accept / reject, lambda, stop
+//                           rule -- lm_decide), then solves its 16 ellipsoids for the new lambda -> trial state.
+//                           A trial is linearised AT its trial state, so its chi2 is the sum of the chunk chi2 and its
+//                           H, b are the next iteration's system if it is accepted: no residual-only pass.
+//   k_lm_partials           sharded runs: this rank's share of a trial's scalars -> send buffer of the all-gather
+//   k_chunk_linearize / k_obj_solve / k_chunk_chi2 / k_chunk_combine
+//                           per-type numeric-Jacobian kernels and the pieces behind the step API (esl_lm_*)
+// Reference pieces replaced: BlockSolver::buildSystem (core/block_solver.hpp:502-560), BlockSolver::solve +
+// LinearSolverDense (:356-365, solvers/linear_solver_dense.h:65-113), SparseOptimizer::update / computeActiveErrors /
+// activeRobustChi2 (core/sparse_optimizer.cpp:61-114, 422-435), OptimizationAlgorithmLevenberg::solve
+// (core/optimization_algorithm_levenberg.cpp:61-164).
 #pragma once
 #include <cfloat>
 #include <utility>
