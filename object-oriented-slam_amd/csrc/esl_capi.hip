@@ -1,9 +1,11 @@
-// esl_capi.hip — C-ABI of libesl_hip.so (include/esl.h): context, graph upload, LM driver.
+// esl_capi.hip — C-ABI of libesl_hip.so (include/esl.h): context, graph upload (grow-only arenas), LM drivers.
 //
-// Host-side control mirrors OptimizationAlgorithmLevenberg::solve
-// (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164) and
-// SparseOptimizer::optimize (core/sparse_optimizer.cpp:354-419); all arithmetic on states, residuals,
-// Jacobians and normal equations runs in the HIP kernels of esl_kernels_*.hpp.  There is no CPU
+// Mapping mode (cameras fixed, the shipped setting): esl_optimize_resident enqueues the whole Levenberg-Marquardt run
+// ahead of the device; the control flow of OptimizationAlgorithmLevenberg::solve
+// (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164) and SparseOptimizer::optimize
+// (core/sparse_optimizer.cpp:354-419) runs in k_lm_step (esl_kernels_chunk.hpp), the host only watches a progress
+// counter in mapped memory.  SLAM mode and the step API (esl_lm_*) keep the same statements on the host.  All arithmetic
+// on states, residuals, Jacobians and normal equations runs in the HIP kernels of esl_kernels_*.hpp.  There is no CPU
 // fallback: without a HIP device every compute entry point fails with ESL_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cfloat>
