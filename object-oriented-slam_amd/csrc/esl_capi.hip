@@ -94,29 +94,36 @@ static int arena_reserve(char** dev, size_t* cap, size_t need) {
   *cap = want;
   return ESL_OK;
 }
-struct UploadStage {
+struct UploadStage {   // arrays are packed straight into the context's pinned staging block (grown on demand, kept)
   struct Fix { void** dst; size_t off; };
-  std::vector<char> blob;
+  esl_ctx* c;
+  size_t used = 0;
+  int err = ESL_OK;
   std::vector<Fix> fixes;
+  explicit UploadStage(esl_ctx* ctx) : c(ctx) {}
+  bool reserve(size_t need) {
+    if (need <= c->stage_host_cap) return true;
+    const size_t want = std::max(need + need / 2 + 4096, 2 * c->stage_host_cap);
+    char* nb = nullptr;
+    if (hipHostMalloc((void**)&nb, want, hipHostMallocDefault) != hipSuccess) { esl::set_error("hipHostMalloc (upload staging) failed"); err = ESL_ERR_HIP; return false; }
+    if (c->stage_host) { std::memcpy(nb, c->stage_host, used); (void)hipHostFree(c->stage_host); }
+    c->stage_host = nb; c->stage_host_cap = want;
+    return true;
+  }
   template <class T>
   void add(T** dst, const T* src, size_t n) {
-    const size_t off = align_up(blob.size(), 256);
-    blob.resize(off + std::max<size_t>(n, 1) * sizeof(T));
-    if (n) std::memcpy(blob.data() + off, src, n * sizeof(T));
+    const size_t off = align_up(used, 256), bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (err || !reserve(off + bytes)) return;
+    if (n) std::memcpy(c->stage_host + off, src, n * sizeof(T));
+    used = off + bytes;
     fixes.push_back({(void**)dst, off});
   }
-  int commit(esl_ctx* c) {
-    const size_t need = std::max<size_t>(blob.size(), 256);
+  int commit() {
+    if (err) return err;
+    const size_t need = std::max<size_t>(used, 256);
     int rc = arena_reserve(&c->arena_graph, &c->arena_graph_cap, need);
     if (rc) return rc;
-    if (need > c->stage_host_cap) {
-      if (c->stage_host) { (void)hipHostFree(c->stage_host); c->stage_host = nullptr; c->stage_host_cap = 0; }
-      const size_t want = need + need / 2 + 4096;
-      ESL_HIP_TRY(hipHostMalloc((void**)&c->stage_host, want, hipHostMallocDefault));
-      c->stage_host_cap = want;
-    }
-    std::memcpy(c->stage_host, blob.data(), blob.size());
-    ESL_HIP_TRY(hipMemcpyAsync(c->arena_graph, c->stage_host, blob.size(), hipMemcpyHostToDevice, c->stream));
+    if (used) ESL_HIP_TRY(hipMemcpyAsync(c->arena_graph, c->stage_host, used, hipMemcpyHostToDevice, c->stream));
     for (const Fix& f : fixes) *f.dst = c->arena_graph + f.off;
     return ESL_OK;
   }
@@ -304,7 +311,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   hipStream_t st = c->stream;
   // every array of the device-resident graph goes into ONE staging blob -> one H2D copy into a grow-only arena;
   // work buffers come from a second arena (a per-frame esl_optimize used to pay ~45 hipMalloc/hipFree pairs here)
-  UploadStage up;
+  UploadStage up(c);
   WorkStage wk;
   d.n_cams = g->n_cams; d.n_objs = g->n_objs; d.n_bbox = g->n_bbox; d.n_e3d = g->n_e3d; d.n_odom = g->n_odom;
   d.K[0] = g->fx; d.K[1] = g->fy; d.K[2] = g->cx; d.K[3] = g->cy;
@@ -442,7 +449,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   wk.add(&c->bo, (size_t)N * 9);
   wk.add(&c->xo, (size_t)N * 9);
   wk.add(&c->obj_part, (size_t)N * 4);
-  if ((rc = up.commit(c))) return rc;
+  if ((rc = up.commit())) return rc;
   if ((rc = wk.commit(c))) return rc;
   ESL_HIP_TRY(hipMemsetAsync(c->obj_part, 0, std::max<size_t>(N, 1) * 4 * sizeof(double), st));
   if (d.n_free_cams > 0) {
