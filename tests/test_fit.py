@@ -187,3 +187,21 @@ def test_gpu_fit_scene_sweep_matches_oracle(po, ctx, pkg, seed):
     o = po.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], po.default_fit_params(symmetry_lm_iters=iters))
     g = ctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], pkg.lib.default_fit_params(symmetry_lm_iters=iters))
     _cmp(po, *g, *o, tol)
+
+
+@pytest.mark.gpu
+def test_gpu_fit_extreme_geometries(po, ctx, pkg):
+    """A box covering a whole 1280x960 frame at stride 1 (1.2 M samples: grid-wide path, 2^21-slot tables) and 60 small
+    boxes in one frame; compared with the CPU restatement."""
+    sc = pkg.synth.make_depth_scene(width=1280, height=960, n_objs=1, seed=3, size=(0.3, 0.35))
+    full = np.array([[0.0, 0.0, 1279.0, 959.0]])
+    Pg = pkg.lib.default_fit_params(stride=1, symmetry_lm_iters=0); Po = po.default_fit_params(stride=1, symmetry_lm_iters=0)
+    g = ctx.fit_frame(sc["depth"], full, [0], sc["Twc"], sc["intr"], sc["ground"], Pg)
+    o = po.fit_frame(sc["depth"], full, [0], sc["Twc"], sc["intr"], sc["ground"], Po)
+    assert o[3][0][0] > 500000
+    _cmp(po, *g, *o, 1e-7)
+    many = pkg.synth.make_depth_scene(n_objs=60, seed=5, spread=2.2, size=(0.08, 0.2))
+    P2 = pkg.lib.default_fit_params(symmetry_lm_iters=0)
+    g2 = ctx.fit_frame(many["depth"], many["bboxes"], many["labels"], many["Twc"], many["intr"], many["ground"], P2)
+    o2 = po.fit_frame(many["depth"], many["bboxes"], many["labels"], many["Twc"], many["intr"], many["ground"], po.default_fit_params(symmetry_lm_iters=0))
+    _cmp(po, *g2, *o2, 1e-7)

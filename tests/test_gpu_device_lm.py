@@ -129,3 +129,16 @@ def test_random_graph_sweep_matches_oracle(pkg, po, ctx, seed):
     assert rg["n_bbox_dropped"] == ro["n_bbox_dropped"]
     assert_traces_match(rg, ro, rtol=1e-5)
     assert group_rel_err(og, oo) < 1e-4   # |dt| / |t|, |dq|, |ds| / |s| per ellipsoid
+
+
+def test_one_ellipsoid_with_many_chunks(pkg, po, ctx):
+    """An ellipsoid seen 1,500 times: 24 bbox chunks + dozens of 3-D chunks on ONE vertex (k_lm_step's gather walks more than
+    its four batched chunks, the chunk partials of one 9x9 system span many workgroups)."""
+    g, c, o, _ = pkg.synth.make_graph(1500, 1, 3000, seed=41)
+    assert np.bincount(g.bbox_obj).max() > 64 * 4
+    for jac in (1, 0):
+        p = pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6)
+        _, oo, ro = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=1e-6), solver=1)
+        _, og, rg = ctx.optimize(g, c, o, p)
+        assert_traces_match(rg, ro, rtol=1e-5)
+        assert group_rel_err(og, oo) < 1e-4
