@@ -249,6 +249,28 @@ int esl_fit_frame_debug(esl_ctx* ctx, const uint16_t* depth, int32_t width, int3
                         const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
                         int32_t* status_out, double* debug_out);
 
+/* SymmetryOutputData (reference src/symmetry/Symmetry.h:16-32) as EstimateLocalEllipsoid fills it
+ * (src/pca/EllipsoidExtractor.cpp:376-393, 415-423) and Tracking consumes it (src/core/Tracking.cpp:351-372):
+ * result = 0 when no symmetry estimation ran for the box (symmetry closed, label without a symmetry type, fit failed);
+ * planes are in the WORLD frame (A B C D of A x + B y + C z + D = 0, not normalised further), plane2 only for
+ * symmetry_type 2 (dual reflection), prob = exp(-cost) of the winning hypothesis, center = centre of the completed
+ * (mirrored) cloud in the world frame.  The point-cloud pointers of the reference struct stay on the device. */
+typedef struct {
+  int32_t result;
+  int32_t symmetry_type;   /* 1 reflection, 2 dual reflection (EllipsoidExtractor::LoadSymmetryPrior, :52-79); -1 when result == 0 */
+  double plane[4];
+  double plane2[4];
+  double prob;
+  double center[3];
+} esl_fit_symmetry;
+
+/* esl_fit_frame + the symmetry outputs (what EllipsoidExtractor::GetSymmetryOutputData() returns, EllipsoidExtractor.h:61);
+ * symmetry_out: n_boxes entries or NULL; debug_out as in esl_fit_frame_debug or NULL */
+int esl_fit_frame_ex(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes,
+                     const int32_t* labels, int32_t n_boxes, const double Twc[7], const double intr[5],
+                     const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
+                     int32_t* status_out, esl_fit_symmetry* symmetry_out, double* debug_out);
+
 /* ---- SVD quadric initialisation -----------------------------------------------------------------*/
 int esl_init_quadric(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const double* bboxes /* n x 4 */,
                      int32_t n, const double K[4], int32_t rows, int32_t cols, int32_t faithful,

@@ -74,6 +74,12 @@ class EslFitParams(C.Structure):
     ]
 
 
+class EslFitSymmetry(C.Structure):
+    """SymmetryOutputData (reference src/symmetry/Symmetry.h:16-32) as esl_fit_frame_ex returns it."""
+    _fields_ = [("result", C.c_int32), ("symmetry_type", C.c_int32), ("plane", C.c_double * 4),
+                ("plane2", C.c_double * 4), ("prob", C.c_double), ("center", C.c_double * 3)]
+
+
 def default_lm_params(**kw):
     """Reference settings: optimize(10) (Optimizer.cpp:291), tau 1e-5, 10 trials
     (optimization_algorithm_levenberg.cpp:45-49), delta 1e-9 (base_binary_edge.hpp:147)."""

@@ -57,6 +57,7 @@ struct FitArgs {
   int* csize; unsigned long long* cminkey; unsigned long long* cmind;
   double* po; float* pof;
   double* out_ell; double* out_prob; int* out_status; double* out_dbg;
+  double* out_sym;   // 16 per box: SymmetryOutputData (src/symmetry/Symmetry.h:16-32), see include/esl.h
   int wide;   // != 0: centre + clustering already ran as grid-wide kernels (boxes with many samples)
   struct FitShared* state;   // per box: the first kernel's shared block, read by the symmetry and the completion kernels
   long long* clk;   // optional (ESL_FIT_TIMING=1): 16 wall_clock64() marks per box written by thread 0 at the stage boundaries
@@ -1216,6 +1217,21 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_post(FitArgs a) {
     sx = block_sum(sx, S.red); sy = block_sum(sy, S.red); sz = block_sum(sz, S.red);
     if (tid == 0) {
       const double cc[3] = {sx / (double)npo, sy / (double)npo, sz / (double)npo};
+      {   // SymmetryOutputData (EllipsoidExtractor.cpp:376-393, 415-423): planes via plane::transform(*pSE3Two) =
+          // (Two^T)^-1 pi  ->  n' = R n, d' = d - t . n'; centre of the completed cloud in the world frame
+        double* so = a.out_sym + 16 * b;
+        const SE3 Two = se3_load(S.Two);
+        const Mat3 Rwo = q_to_R(Two.r);
+        for (int pl = 0; pl < (stype == 2 ? 2 : 1); ++pl) {
+          const double* q = pl ? p2 : best.p;
+          double n[3];
+          for (int r = 0; r < 3; ++r) n[r] = Rwo.m[3 * r] * q[0] + Rwo.m[3 * r + 1] * q[1] + Rwo.m[3 * r + 2] * q[2];
+          so[4 * pl] = n[0]; so[4 * pl + 1] = n[1]; so[4 * pl + 2] = n[2];
+          so[4 * pl + 3] = q[3] - (Two.t[0] * n[0] + Two.t[1] * n[1] + Two.t[2] * n[2]);
+        }
+        so[8] = prob_sym; so[9] = (double)stype; so[10] = 1.0;
+        for (int r = 0; r < 3; ++r) so[11 + r] = Rwo.m[3 * r] * cc[0] + Rwo.m[3 * r + 1] * cc[1] + Rwo.m[3 * r + 2] * cc[2] + Two.t[r];
+      }
       const double nn = sqrt(best.p[0] * best.p[0] + best.p[1] * best.p[1] + best.p[2] * best.p[2]);
       const double x[3] = {best.p[0] / nn, best.p[1] / nn, best.p[2] / nn}, z[3] = {0, 0, 1};
       double y[3];
@@ -1316,10 +1332,10 @@ void esl_fit_params_default(esl_fit_params* p) {
   p->symmetry_open = 1; p->symmetry_grid = 0.1; p->symmetry_sigma = 0.1; p->symmetry_lm_iters = 5;
 }
 
-int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes,
-                        const int32_t* labels, int32_t n_boxes, const double Twc[7], const double intr[5],
-                        const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
-                        int32_t* status_out, double* debug_out) {
+static int fit_frame_impl(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes,
+                          const int32_t* labels, int32_t n_boxes, const double Twc[7], const double intr[5],
+                          const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
+                          int32_t* status_out, double* debug_out, esl_fit_symmetry* sym_out) {
   if (!c || !depth || !bboxes || !Twc || !intr || !ground || !p || !ellipsoids_out || !prob_out || !status_out || width <= 0 ||
       height <= 0 || n_boxes < 0) {
     set_error("esl_fit_frame: bad argument");
@@ -1358,7 +1374,7 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   const size_t o_cs = take(B * cap * 4), o_cmk = take(B * cap * 8), o_cmd = take(B * cap * 8);
   const size_t o_po = take(B * cap * 12 * 8), o_pof = take(B * cap * 3 * 4);
   const size_t o_state = take(B * sizeof(FitShared));
-  const size_t o_ell = take(B * 80), o_prob = take(B * 8), o_st = take(B * 4), o_dbg = take(B * 128), o_clk = take(B * 128);
+  const size_t o_ell = take(B * 80), o_prob = take(B * 8), o_st = take(B * 4), o_dbg = take(B * 128), o_clk = take(B * 128), o_sym = take(B * 128);
   const size_t out_bytes = off - o_ell;
   const bool timing = std::getenv("ESL_FIT_TIMING") != nullptr;
   // grow-only device slab and pinned staging blocks owned by the context: a per-frame call pays no allocation
@@ -1392,6 +1408,7 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   a.state = (FitShared*)(slab + o_state);
   a.clk = timing ? (long long*)(slab + o_clk) : nullptr;
   a.out_ell = (double*)(slab + o_ell); a.out_prob = (double*)(slab + o_prob); a.out_status = (int*)(slab + o_st); a.out_dbg = (double*)(slab + o_dbg);
+  a.out_sym = (double*)(slab + o_sym);
   hipStream_t st = c->stream;
   // stage the inputs (the previous call synchronised the stream: the staging block is free)
   {
@@ -1467,6 +1484,17 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
     std::memcpy(prob_out, outs_data + (o_prob - o_ell), B * 8);
     std::memcpy(status_out, outs_data + (o_st - o_ell), B * 4);
     if (debug_out) std::memcpy(debug_out, outs_data + (o_dbg - o_ell), B * 128);
+    if (sym_out) {
+      const double* so = (const double*)(outs_data + (o_sym - o_ell));
+      for (size_t bx = 0; bx < B; ++bx) {
+        esl_fit_symmetry& o = sym_out[bx];
+        for (int k = 0; k < 4; ++k) { o.plane[k] = so[16 * bx + k]; o.plane2[k] = so[16 * bx + 4 + k]; }
+        o.prob = so[16 * bx + 8];
+        o.result = so[16 * bx + 10] > 0.5 ? 1 : 0;
+        o.symmetry_type = o.result ? (int32_t)so[16 * bx + 9] : -1;
+        for (int k = 0; k < 3; ++k) o.center[k] = so[16 * bx + 11 + k];
+      }
+    }
     if (timing) {   // diagnostic: mean stage durations over the boxes (wall_clock64 ticks at 100 MHz)
       static const char* names[8] = {"scan+voxel", "plane filter", "centre", "cluster", "pca", "sym grid", "symmetry", "extents"};
       const long long* clk = (const long long*)(outs_data + (o_clk - o_ell));
@@ -1503,11 +1531,27 @@ int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_
   return rc;
 }
 
+int esl_fit_frame_debug(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes,
+                        const int32_t* labels, int32_t n_boxes, const double Twc[7], const double intr[5],
+                        const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
+                        int32_t* status_out, double* debug_out) {
+  return fit_frame_impl(c, depth, width, height, bboxes, labels, n_boxes, Twc, intr, ground, p, ellipsoids_out, prob_out, status_out,
+                        debug_out, nullptr);
+}
+
 int esl_fit_frame(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
                   int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4], const esl_fit_params* p,
                   double* ellipsoids_out, double* prob_out, int32_t* status_out) {
-  return esl_fit_frame_debug(c, depth, width, height, bboxes, labels, n_boxes, Twc, intr, ground, p, ellipsoids_out, prob_out,
-                             status_out, nullptr);
+  return fit_frame_impl(c, depth, width, height, bboxes, labels, n_boxes, Twc, intr, ground, p, ellipsoids_out, prob_out, status_out,
+                        nullptr, nullptr);
+}
+
+int esl_fit_frame_ex(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
+                     int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4], const esl_fit_params* p,
+                     double* ellipsoids_out, double* prob_out, int32_t* status_out, esl_fit_symmetry* symmetry_out,
+                     double* debug_out) {
+  return fit_frame_impl(c, depth, width, height, bboxes, labels, n_boxes, Twc, intr, ground, p, ellipsoids_out, prob_out, status_out,
+                        debug_out, symmetry_out);
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_selftest_cholesky",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
     "esl_init_quadric",
 ]
 
@@ -196,6 +196,33 @@ class Context:
                                           C.byref(p), ell.ctypes.data_as(_dp), prob.ctypes.data_as(_dp),
                                           st.ctypes.data_as(C.POINTER(C.c_int32)), dbg.ctypes.data_as(_dp)), "esl_fit_frame")
         return ell, prob, st, dbg
+
+    def fit_frame_ex(self, depth, bboxes, labels, Twc, intr, ground, params=None):
+        """fit_frame + SymmetryOutputData per box (EllipsoidExtractor::GetSymmetryOutputData): returns
+        (ellipsoids, prob, status, debug, sym) with sym a dict of arrays result (B,), symmetry_type (B,), plane (B,4),
+        plane2 (B,4), prob (B,), center (B,3)."""
+        p = params if params is not None else default_fit_params()
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        h, w = depth.shape
+        boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
+        B = len(boxes)
+        lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float64); intr = np.ascontiguousarray(intr, dtype=np.float64)
+        ground = np.ascontiguousarray(ground, dtype=np.float64)
+        ell = np.zeros((B, 10)); prob = np.zeros(B); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 16))
+        sym = (abi.EslFitSymmetry * max(B, 1))()
+        _check(load().esl_fit_frame_ex(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                                       boxes.ctypes.data_as(_dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(B),
+                                       Twc.ctypes.data_as(_dp), intr.ctypes.data_as(_dp), ground.ctypes.data_as(_dp),
+                                       C.byref(p), ell.ctypes.data_as(_dp), prob.ctypes.data_as(_dp),
+                                       st.ctypes.data_as(C.POINTER(C.c_int32)), sym, dbg.ctypes.data_as(_dp)), "esl_fit_frame_ex")
+        out = dict(result=np.array([sym[b].result for b in range(B)], dtype=np.int32),
+                   symmetry_type=np.array([sym[b].symmetry_type for b in range(B)], dtype=np.int32),
+                   plane=np.array([list(sym[b].plane) for b in range(B)]).reshape(B, 4),
+                   plane2=np.array([list(sym[b].plane2) for b in range(B)]).reshape(B, 4),
+                   prob=np.array([sym[b].prob for b in range(B)]),
+                   center=np.array([list(sym[b].center) for b in range(B)]).reshape(B, 3))
+        return ell, prob, st, dbg, out
 
     def selftest_cholesky(self, n):
         """(ms, relative residual) of the dense FP64-MFMA Cholesky factor + solve on a generated SPD system."""

@@ -78,6 +78,12 @@ int esl_oracle_fit_frame(const uint16_t* depth, int32_t width, int32_t height, c
                          int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4],
                          const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
                          double* debug_out);
+/* same + SymmetryOutputData (src/symmetry/Symmetry.h:16-32) per box, 16 doubles: plane (world) [0..3], plane2 [4..7],
+ * prob [8], symmetry type [9], result flag [10], centre of the completed cloud (world) [11..13] */
+int esl_oracle_fit_frame_ex(const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
+                            int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4],
+                            const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
+                            double* debug_out, double* sym_out);
 
 /* timing helper for bench.py's cpu_baseline: seconds spent in linearise / solve / error evaluation
  * of the last esl_oracle_optimize call */

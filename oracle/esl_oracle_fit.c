@@ -314,8 +314,9 @@ static int symmetry_type(int label) { /* EllipsoidExtractor::LoadSymmetryPrior (
 
 static int fit_one(const uint16_t* depth, int w, int h, const double bbox[4], int label, const double Twc[7],
                    const double intr[5], const double ground[4], const esl_fit_params* P, double ell[10], double* prob,
-                   double dbg[16]) {
+                   double dbg[16], double sym[16]) {
   for (int i = 0; i < 10; ++i) ell[i] = 0;
+  if (sym) for (int i = 0; i < 16; ++i) sym[i] = 0;
   *prob = 0;
   const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3], scale = intr[4];
   /* 1. getPointCloudInRect (PointCloudFilter.cpp:21-56) */
@@ -555,6 +556,20 @@ static int fit_one(const uint16_t* depth, int w, int h, const double bbox[4], in
     double cc[3] = {0, 0, 0};
     for (int i = 0; i < npo; ++i) { cc[0] += po[i].x; cc[1] += po[i].y; cc[2] += po[i].z; }
     for (int r = 0; r < 3; ++r) cc[r] /= (double)npo;
+    if (sym) { /* SymmetryOutputData (:376-393, 415-423): plane::transform(*pSE3Two) = (Two^T)^-1 pi (Plane.cpp:117-122) */
+      double Rwo[9], p2[4];
+      quat_to_R(&Two7[3], Rwo);
+      plane_another(&best, p2);
+      for (int pl = 0; pl < (stype == 2 ? 2 : 1); ++pl) {
+        const double* q = pl ? p2 : best.p;
+        double n[3];
+        for (int r = 0; r < 3; ++r) n[r] = Rwo[r * 3] * q[0] + Rwo[r * 3 + 1] * q[1] + Rwo[r * 3 + 2] * q[2];
+        sym[4 * pl] = n[0]; sym[4 * pl + 1] = n[1]; sym[4 * pl + 2] = n[2];
+        sym[4 * pl + 3] = q[3] - (Two7[0] * n[0] + Two7[1] * n[1] + Two7[2] * n[2]);
+      }
+      sym[8] = bestp; sym[9] = stype; sym[10] = 1;
+      for (int r = 0; r < 3; ++r) sym[11 + r] = Rwo[r * 3] * cc[0] + Rwo[r * 3 + 1] * cc[1] + Rwo[r * 3 + 2] * cc[2] + Two7[r];
+    }
     double nn = sqrt(best.p[0] * best.p[0] + best.p[1] * best.p[1] + best.p[2] * best.p[2]);
     double x[3] = {best.p[0] / nn, best.p[1] / nn, best.p[2] / nn}, z[3] = {0, 0, 1}, y[3];
     cross3(z, x, y);
@@ -588,12 +603,27 @@ static int fit_one(const uint16_t* depth, int w, int h, const double bbox[4], in
   return 0;
 }
 
+int esl_oracle_fit_frame_ex(const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
+                            int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4],
+                            const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
+                            double* debug_out, double* sym_out);
+
 int esl_oracle_fit_frame(const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
                          int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4],
                          const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
                          double* debug_out /* n_boxes x 16 or NULL */) {
+  return esl_oracle_fit_frame_ex(depth, width, height, bboxes, labels, n_boxes, Twc, intr, ground, p, ellipsoids_out, prob_out,
+                                 status_out, debug_out, NULL);
+}
+
+/* same + SymmetryOutputData per box: 16 doubles = plane (world, 4) | plane2 (4) | prob | type | result | centre (3) | pad */
+int esl_oracle_fit_frame_ex(const uint16_t* depth, int32_t width, int32_t height, const double* bboxes, const int32_t* labels,
+                            int32_t n_boxes, const double Twc[7], const double intr[5], const double ground[4],
+                            const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
+                            double* debug_out, double* sym_out /* n_boxes x 16 or NULL */) {
   for (int b = 0; b < n_boxes; ++b)
     status_out[b] = fit_one(depth, width, height, &bboxes[4 * b], labels ? labels[b] : -1, Twc, intr, ground, p,
-                            &ellipsoids_out[10 * b], &prob_out[b], debug_out ? &debug_out[16 * b] : NULL);
+                            &ellipsoids_out[10 * b], &prob_out[b], debug_out ? &debug_out[16 * b] : NULL,
+                            sym_out ? &sym_out[16 * b] : NULL);
   return 0;
 }

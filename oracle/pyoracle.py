@@ -189,6 +189,29 @@ def fit_frame(depth, bboxes, labels, Twc, intr, ground, params=None):
     return ell, prob, st, dbg
 
 
+def fit_frame_ex(depth, bboxes, labels, Twc, intr, ground, params=None):
+    """fit_frame + SymmetryOutputData: returns (ell, prob, status, debug, sym dict as lib.Context.fit_frame_ex)."""
+    p = params if params is not None else default_fit_params()
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    h, w = depth.shape
+    boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
+    B = len(boxes)
+    lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+    Twc = np.ascontiguousarray(Twc, dtype=np.float64); intr = np.ascontiguousarray(intr, dtype=np.float64)
+    ground = np.ascontiguousarray(ground, dtype=np.float64)
+    ell = np.zeros((B, 10)); prob = np.zeros(B); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 16)); sym = np.zeros((B, 16))
+    dp = C.POINTER(C.c_double)
+    lib().esl_oracle_fit_frame_ex(depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                                  boxes.ctypes.data_as(dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(B),
+                                  Twc.ctypes.data_as(dp), intr.ctypes.data_as(dp), ground.ctypes.data_as(dp), C.byref(p),
+                                  ell.ctypes.data_as(dp), prob.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  dbg.ctypes.data_as(dp), sym.ctypes.data_as(dp))
+    res = sym[:, 10] > 0.5
+    out = dict(result=res.astype(np.int32), symmetry_type=np.where(res, sym[:, 9], -1).astype(np.int32), plane=sym[:, 0:4].copy(),
+               plane2=sym[:, 4:8].copy(), prob=sym[:, 8].copy(), center=sym[:, 11:14].copy())
+    return ell, prob, st, dbg, out
+
+
 def last_timing():
     t = (C.c_double * 3)()
     lib().esl_oracle_last_timing(t)
