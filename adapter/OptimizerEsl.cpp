@@ -1,10 +1,11 @@
 // OptimizerEsl.cpp — drop-in body for EllipsoidSLAM::Optimizer that routes
 // GlobalObjectGraphOptimization through the C-ABI of libesl_hip.so (include/esl.h).
 //
-// Compile this file INSIDE the reference tree INSTEAD OF src/core/Optimizer.cpp (it needs the
-// reference's own headers: Eigen, Frame.h, Map.h, Config.h).  It cannot be compiled in the
-// development container (no Eigen there); tests/test_adapter_flatten.py compile-checks the
-// flattening logic through the template below with tiny stand-in types.
+// Compile this file INSIDE the reference tree INSTEAD OF src/core/Optimizer.cpp with
+// -DESL_BUILD_IN_REFERENCE_TREE (it needs the reference's own headers: Eigen, Frame.h, Map.h, Config.h).
+// No Eigen in the development container: tests/test_adapter_flatten.py runs the flattening logic through the
+// template below with tiny stand-in types, tests/test_adapter_link.py compiles and LINKS all three adapters against
+// compile-only stand-ins of the reference headers (tests/adapter_stubs/) together with Tracking's call sites.
 //
 // What it mirrors (reference src/core/Optimizer.cpp):
 //   :88-90   config keys Optimizer.Edges.3DEllipsoid.Scale / GravityPrior.Open / GravityPrior.Scale
@@ -103,15 +104,18 @@ inline esl_graph MakeGraph(const FlatGraph& f, const double K[4], const double g
 #ifdef ESL_BUILD_IN_REFERENCE_TREE
 #include <src/config/Config.h>
 
+#include <fstream>
+
+#include "EslAdapterCtx.hpp"
 #include "include/core/Optimizer.h"
 
 namespace EllipsoidSLAM {
 
-static esl_ctx* g_ctx = nullptr;
-
 Optimizer::Optimizer() { mbGroundPlaneSet = false; }
 void Optimizer::SetGroundPlane(Vector4d& normal) { mbGroundPlaneSet = true; mGroundPlaneNormal = normal; }
 
+// rows, cols, save_graph, withAssociation are unused by the reference unless check_visibility is set, and Tracking never
+// sets it (Tracking.cpp:226; the visibility check of Optimizer.cpp:35-81 is dead code there)
 void Optimizer::GlobalObjectGraphOptimization(std::vector<Frame*>& pFrames, Map* pMap, int, int, Matrix3d& mCalib,
                                               std::map<int, Observations>& objectObservations, bool, bool, bool) {
   const double scale3d = Config::Get<double>("Optimizer.Edges.3DEllipsoid.Scale");
@@ -120,20 +124,40 @@ void Optimizer::GlobalObjectGraphOptimization(std::vector<Frame*>& pFrames, Map*
   std::map<int, g2o::ellipsoid*> ells = pMap->GetAllEllipsoidsMap();
   esl_adapter::FlatGraph f = esl_adapter::Flatten(pFrames, ells, objectObservations, scale3d, grav);
   const double K[4] = {mCalib(0, 0), mCalib(1, 1), mCalib(0, 2), mCalib(1, 2)};
-  const double ground[4] = {mGroundPlaneNormal[0], mGroundPlaneNormal[1], mGroundPlaneNormal[2], mGroundPlaneNormal[3]};
-  esl_graph g = esl_adapter::MakeGraph(f, K, ground, grav_scale);
-  if (!g_ctx && esl_ctx_create(0, &g_ctx) != ESL_OK) { std::cerr << "esl: " << esl_last_error() << std::endl; return; }
+  double ground[4] = {0, 0, 0, 0};
+  if (mbGroundPlaneSet)
+    for (int k = 0; k < 4; ++k) ground[k] = mGroundPlaneNormal[k];
+  esl_graph g = esl_adapter::MakeGraph(f, K, mbGroundPlaneSet ? ground : nullptr, grav_scale);
   esl_lm_params p; esl_lm_params_default(&p);
   esl_lm_report rep;
-  if (esl_optimize(g_ctx, &g, f.cams.data(), f.objs.data(), &p, &rep) != ESL_OK) {
-    std::cerr << "esl_optimize: " << esl_last_error() << std::endl;  // the reference never throws here
-    return;
+  {
+    std::lock_guard<std::mutex> lock(esl_adapter::CtxMutex());
+    esl_ctx* ctx = esl_adapter::SharedCtx();
+    if (!ctx) return;
+    if (esl_optimize(ctx, &g, f.cams.data(), f.objs.data(), &p, &rep) != ESL_OK) {
+      std::cerr << "esl_optimize: " << esl_last_error() << std::endl;  // the reference never throws here
+      return;
+    }
   }
+  // graph summary the reference prints before optimising (Optimizer.cpp:281-288)
+  std::cout << " -- GRAPH INFORMATION : " << std::endl;
+  std::cout << " * Object Num : " << g.n_objs << std::endl;
+  std::cout << " * Vertices: " << g.n_cams + g.n_objs << std::endl;
+  std::cout << " * 2d Edges [Valid/Invalid] : " << g.n_bbox << " [" << rep.n_bbox_valid << "/" << rep.n_bbox_dropped << "]" << std::endl;
+  std::cout << " * 3d Edges : " << g.n_e3d << std::endl;
+  std::cout << " * Gravity edges: " << g.n_grav << std::endl << std::endl;
   for (size_t o = 0; o < f.instance_of_obj.size(); ++o) {      // Optimizer.cpp:294-306: in-place write-back
     g2o::ellipsoid* e = ells[f.instance_of_obj[o]];
     Vector10d v; for (int k = 0; k < 10; ++k) v[k] = f.objs[o * 10 + k];
     e->fromVector(v);                                           // keeps label / colour / instance / prob
   }
+  // object list (Optimizer.cpp:308-316): instance, minimal vector, label of every optimised ellipsoid, ascending instance
+  std::ofstream out_obj("./object_list.txt");
+  for (size_t o = 0; o < f.instance_of_obj.size(); ++o) {
+    const g2o::ellipsoid* e = ells[f.instance_of_obj[o]];
+    out_obj << f.instance_of_obj[o] << "\t" << e->toMinimalVector().transpose() << "\t" << e->miLabel << std::endl;
+  }
+  out_obj.close();
 }
 
 }  // namespace EllipsoidSLAM

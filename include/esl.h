@@ -276,6 +276,15 @@ int esl_init_quadric(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const do
                      int32_t n, const double K[4], int32_t rows, int32_t cols, int32_t faithful,
                      double ellipsoid_out[10], double qstar_out[16], int32_t* ok);
 
+/* Initializer::getEllipsoidFromQStar (reference include/core/Initializer.h:53, src/core/Initializer.cpp:186-248): pose and
+ * half-axes from a dual quadric Q* (row-major 4x4).  faithful != 0 reproduces the reference's decomposition (4x4
+ * eigenvalues for the half-axes), 0 the exact one through Q_33. */
+int esl_init_from_qstar(esl_ctx* ctx, const double qstar[16], int32_t faithful, double ellipsoid_out[10], int32_t* ok);
+/* Initializer::quadricErrorWithPlanes (include/core/Initializer.h:50, src/core/Initializer.cpp:271-284): sum over the
+ * bbox tangent planes pi of (pi^T Q* pi)^2 for the given ellipsoid (10-vector, world frame). */
+int esl_init_plane_error(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const double* bboxes /* n x 4 */, int32_t n,
+                         const double K[4], int32_t rows, int32_t cols, const double ellipsoid[10], double* error_out);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------*/
 /* Dense FP64-MFMA Cholesky factor + solve (the reduced-camera solver of SLAM mode) on a procedurally generated,
  * strictly diagonally dominant n x n system; returns the time of factor + solve (HIP events) and |A x - b| / |b|.

@@ -179,23 +179,28 @@ int esl_ctx_create(int device_id, esl_ctx** out) {
   ESL_HIP_TRY(hipSetDevice(device_id));
   esl_ctx* c = new esl_ctx();
   c->device = device_id;
-  ESL_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  ESL_HIP_TRY(hipHostMalloc((void**)&c->host_part, 16 * sizeof(double), hipHostMallocDefault));
-  ESL_HIP_TRY(hipMalloc((void**)&c->dev_part, 16 * sizeof(double)));
-  ESL_HIP_TRY(hipMalloc((void**)&c->chol_info, 4 * sizeof(int)));
-  ESL_HIP_TRY(hipMemset(c->chol_info, 0, 4 * sizeof(int)));
-  ESL_HIP_TRY(hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)));
-  ESL_HIP_TRY(hipMemset(c->tickets, 0, 4 * sizeof(unsigned int)));
-  ESL_HIP_TRY(hipMalloc((void**)&c->dev_scal, 8 * sizeof(double)));
-  ESL_HIP_TRY(hipEventCreateWithFlags(&c->ev_try, hipEventDisableTiming));
-  ESL_HIP_TRY(hipHostMalloc(&c->host_scal, sizeof(LmScalars), hipHostMallocMapped));
-  ESL_HIP_TRY(hipHostGetDevicePointer(&c->host_scal_dev, c->host_scal, 0));
-  std::memset(c->host_scal, 0, sizeof(LmScalars));
-  ESL_HIP_TRY(hipMalloc(&c->lm_dev, 2 * sizeof(LmCore)));   // ping-pong pair
-  ESL_HIP_TRY(hipMemset(c->lm_dev, 0, 2 * sizeof(LmCore)));
-  ESL_HIP_TRY(hipHostMalloc(&c->lm_host, sizeof(LmHostView), hipHostMallocMapped));
-  ESL_HIP_TRY(hipHostGetDevicePointer(&c->lm_host_dev, c->lm_host, 0));
-  std::memset(c->lm_host, 0, sizeof(LmHostView));
+  auto init = [&]() -> int {
+    ESL_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    ESL_HIP_TRY(hipHostMalloc((void**)&c->host_part, 16 * sizeof(double), hipHostMallocDefault));
+    ESL_HIP_TRY(hipMalloc((void**)&c->dev_part, 16 * sizeof(double)));
+    ESL_HIP_TRY(hipMalloc((void**)&c->chol_info, 4 * sizeof(int)));
+    ESL_HIP_TRY(hipMemset(c->chol_info, 0, 4 * sizeof(int)));
+    ESL_HIP_TRY(hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)));
+    ESL_HIP_TRY(hipMemset(c->tickets, 0, 4 * sizeof(unsigned int)));
+    ESL_HIP_TRY(hipMalloc((void**)&c->dev_scal, 8 * sizeof(double)));
+    ESL_HIP_TRY(hipEventCreateWithFlags(&c->ev_try, hipEventDisableTiming));
+    ESL_HIP_TRY(hipHostMalloc(&c->host_scal, sizeof(LmScalars), hipHostMallocMapped));
+    ESL_HIP_TRY(hipHostGetDevicePointer(&c->host_scal_dev, c->host_scal, 0));
+    std::memset(c->host_scal, 0, sizeof(LmScalars));
+    ESL_HIP_TRY(hipMalloc(&c->lm_dev, 2 * sizeof(LmCore)));   // ping-pong pair
+    ESL_HIP_TRY(hipMemset(c->lm_dev, 0, 2 * sizeof(LmCore)));
+    ESL_HIP_TRY(hipHostMalloc(&c->lm_host, sizeof(LmHostView), hipHostMallocMapped));
+    ESL_HIP_TRY(hipHostGetDevicePointer(&c->lm_host_dev, c->lm_host, 0));
+    std::memset(c->lm_host, 0, sizeof(LmHostView));
+    return ESL_OK;
+  };
+  const int rc = init();
+  if (rc) { const std::string msg = g_err; esl_ctx_destroy(c); set_error(msg); return rc; }   // a half-built context is released
   *out = c;
   return ESL_OK;
 }
@@ -606,7 +611,7 @@ static int lm_begin_enqueue(esl_ctx* c, const esl_lm_params* p, bool validate_in
   c->lm.slam = c->g.n_free_cams > 0;
   c->lm.have_trial = false;
   int* cnt = c->chol_info + 2;
-  if (validate_in_linearize && c->g.n_bbox && p->drop_nan_bbox) {   // counter is zero (context creation / k_chunk_finalize)
+  if (validate_in_linearize && c->g.n_bbox && p->drop_nan_bbox) {   // counter is zero: context creation, k_chunk_finalize, or esl_lm_begin's read-back
     c->lm.begun = true;
     return ESL_OK;
   }
@@ -630,6 +635,8 @@ int esl_lm_begin(esl_ctx* c, const esl_lm_params* p, int32_t* n_valid, int32_t* 
   int dropped = 0;
   if (c->g.n_bbox && p->drop_nan_bbox) {
     ESL_HIP_TRY(hipMemcpyAsync(&dropped, c->chol_info + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // leave the counter at zero: a device-driven mapping run on this context counts into it without clearing it first
+    ESL_HIP_TRY(hipMemsetAsync(c->chol_info + 2, 0, sizeof(int), c->stream));
     ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   }
   if (n_valid) *n_valid = c->g.n_bbox - dropped;

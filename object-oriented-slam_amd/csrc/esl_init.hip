@@ -93,15 +93,28 @@ __device__ double inv_det(const double* Ain, double* inv) {
   return det;
 }
 
-struct InitArgs { double K[4]; int n, rows, cols, faithful; };
+// mode 0: initializeQuadric; 1: getEllipsoidFromQStar of a given Q* (extra[0..15]); 2: quadricErrorWithPlanes of a given
+// ellipsoid (extra[0..9]).  a_glob != null: the plane matrix lives in global memory (more observations than LDS holds).
+struct InitArgs { double K[4]; int n, rows, cols, faithful, mode; double extra[16]; double* a_glob; };
 
-// out: [0..9] ellipsoid 10-vector, [10..25] Q* row-major, [26] ok
+__device__ void decompose_qstar(const double* Qs, int faithful, double* __restrict__ out);
+
+// out: [0..9] ellipsoid 10-vector, [10..25] Q* row-major, [26] ok, [27] plane error (mode 2)
 static __global__ __launch_bounds__(64) void k_init_quadric(const double* __restrict__ poses, const double* __restrict__ boxes,
                                                             InitArgs a, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* A = sm;                       // m x 10
-  double* V = sm + (size_t)a.n * 40;    // 10 x 10
+  double* V = sm;                                   // 10 x 10
+  double* A = a.a_glob ? a.a_glob : sm + 100;       // m x 10
   const int lane = threadIdx.x;
+  if (a.mode == 1) {
+    if (lane == 0) {
+      for (int i = 0; i < 16; ++i) out[10 + i] = a.extra[i];
+      for (int i = 0; i < 10; ++i) out[i] = 0;
+      out[26] = 0; out[27] = 0;
+      decompose_qstar(a.extra, a.faithful, out);
+    }
+    return;
+  }
   int m = 0;  // rows so far (wave-uniform)
   for (int base = 0; base < a.n; base += 64) {
     const int i = base + lane;
@@ -149,8 +162,29 @@ static __global__ __launch_bounds__(64) void k_init_quadric(const double* __rest
   }
   for (int idx = lane; idx < 100; idx += 64) V[idx] = (idx / 10 == idx % 10) ? 1.0 : 0.0;
   __syncthreads();
-  if (m < 9) {  // at least 9 planes are needed (Initializer.cpp:38)
+  if (a.mode == 2) {   // quadricErrorWithPlanes (Initializer.cpp:271-284): sum over the planes of (v(pi) . q_hat)^2
+    SE3 T = se3_load(a.extra);
+    const Mat3 R = q_to_R(T.r);
+    const double d[4] = {a.extra[7] * a.extra[7], a.extra[8] * a.extra[8], a.extra[9] * a.extra[9], -1.0};
+    double Z[16], Qs[16];   // Q* = Z diag(a^2, b^2, c^2, -1) Z^T (Ellipsoid.cpp:290-300)
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Z[i * 4 + j] = R.m[i * 3 + j]; Z[i * 4 + 3] = T.t[i]; Z[12 + i] = 0; }
+    Z[15] = 1;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { double v = 0; for (int k = 0; k < 4; ++k) v += Z[i * 4 + k] * d[k] * Z[j * 4 + k]; Qs[i * 4 + j] = v; }
+    const double qh[10] = {Qs[0], Qs[1], Qs[2], Qs[3], Qs[5], Qs[6], Qs[7], Qs[10], Qs[11], Qs[15]};
+    double err = 0;
+    for (int r = lane; r < m; r += 64) {
+      double v = 0;
+      for (int k = 0; k < 10; ++k) v += A[(size_t)r * 10 + k] * qh[k];
+      err += v * v;
+    }
+    err = wave_allsum(err);
     if (lane < 27) out[lane] = 0.0;
+    if (lane == 0) { out[27] = err; out[26] = 1.0; }
+    return;
+  }
+  if (m < 9) {  // at least 9 planes are needed (Initializer.cpp:38)
+    if (lane < 28) out[lane] = 0.0;
     return;
   }
   // one-sided Jacobi SVD on the columns of A
@@ -199,10 +233,15 @@ static __global__ __launch_bounds__(64) void k_init_quadric(const double* __rest
   const double Qs[16] = {q[0], q[1], q[2], q[3], q[1], q[4], q[5], q[6], q[2], q[5], q[7], q[8], q[3], q[6], q[8], q[9]};
   for (int i = 0; i < 16; ++i) out[10 + i] = Qs[i];
   for (int i = 0; i < 10; ++i) out[i] = 0;
-  out[26] = 0;
+  out[26] = 0; out[27] = 0;
+  decompose_qstar(Qs, a.faithful, out);
+}
+
+// getEllipsoidFromQStar (Initializer.cpp:186-248); faithful = 0: the exact decomposition through Q_33
+__device__ void decompose_qstar(const double* Qs, int faithful, double* __restrict__ out) {
   const double t[3] = {Qs[3] / Qs[15], Qs[7] / Qs[15], Qs[11] / Qs[15]};
   double s[3], Rm[9];
-  if (a.faithful) {
+  if (faithful) {
     double Qi[16], Q[16], w4[4], V4[16], tmp[16];
     const double cb = cbrt(inv_det<4>(Qs, Qi));
     for (int i = 0; i < 16; ++i) Q[i] = Qi[i] * cb;
@@ -259,35 +298,79 @@ static __global__ __launch_bounds__(64) void k_init_quadric(const double* __rest
 
 using namespace esl;
 
+namespace {
+struct DevBuf {   // released on every exit path
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { ESL_HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return ESL_OK; }
+};
+constexpr int kInitLdsObs = 480;   // plane matrix of up to 480 observations fits the 160 KB of LDS; beyond that it goes to HBM
+
+int init_launch(esl_ctx* c, const double* poses_Twc, const double* bboxes, int32_t n, const double K[4], int32_t rows, int32_t cols,
+                int32_t faithful, int mode, const double* extra, int n_extra, double h[28]) {
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  DevBuf dp, db, dout, dA;
+  int rc;
+  if ((rc = dp.alloc((size_t)n * 7 * sizeof(double))) || (rc = db.alloc((size_t)n * 4 * sizeof(double))) || (rc = dout.alloc(28 * sizeof(double))))
+    return rc;
+  if (n) {
+    ESL_HIP_TRY(hipMemcpyAsync(dp.p, poses_Twc, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ESL_HIP_TRY(hipMemcpyAsync(db.p, bboxes, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  InitArgs a{};
+  a.K[0] = K[0]; a.K[1] = K[1]; a.K[2] = K[2]; a.K[3] = K[3];
+  a.n = n; a.rows = rows; a.cols = cols; a.faithful = faithful; a.mode = mode;
+  for (int i = 0; i < n_extra; ++i) a.extra[i] = extra[i];
+  size_t lds = 100 * sizeof(double);
+  if (n > kInitLdsObs) {
+    if ((rc = dA.alloc((size_t)n * 40 * sizeof(double)))) return rc;
+    a.a_glob = (double*)dA.p;
+  } else {
+    lds += (size_t)n * 40 * sizeof(double);
+  }
+  ESL_HIP_TRY(hipFuncSetAttribute((const void*)k_init_quadric, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_init_quadric, dim3(1), dim3(64), lds, c->stream, (const double*)dp.p, (const double*)db.p, a, (double*)dout.p);
+  ESL_HIP_TRY(hipGetLastError());
+  ESL_HIP_TRY(hipMemcpyAsync(h, dout.p, 28 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+}  // namespace
+
 extern "C" int esl_init_quadric(esl_ctx* c, const double* poses_Twc, const double* bboxes, int32_t n, const double K[4],
                                 int32_t rows, int32_t cols, int32_t faithful, double ellipsoid_out[10], double qstar_out[16],
                                 int32_t* ok) {
   if (!c || !poses_Twc || !bboxes || !K || !ellipsoid_out || !qstar_out || !ok || n < 0) return ESL_ERR_INVALID;
-  if (n > 480) { set_error("esl_init_quadric: at most 480 observations per object (LDS-resident plane matrix)"); return ESL_ERR_INVALID; }
-  ESL_HIP_TRY(hipSetDevice(c->device));
   *ok = 0;
   for (int i = 0; i < 10; ++i) ellipsoid_out[i] = 0;
   for (int i = 0; i < 16; ++i) qstar_out[i] = 0;
   if (n < 3) return ESL_OK;  // < 9 planes possible only
-  double *dp = nullptr, *db = nullptr, *dout = nullptr;
-  ESL_HIP_TRY(hipMalloc((void**)&dp, (size_t)n * 7 * sizeof(double)));
-  ESL_HIP_TRY(hipMalloc((void**)&db, (size_t)n * 4 * sizeof(double)));
-  ESL_HIP_TRY(hipMalloc((void**)&dout, 27 * sizeof(double)));
-  ESL_HIP_TRY(hipMemcpyAsync(dp, poses_Twc, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  ESL_HIP_TRY(hipMemcpyAsync(db, bboxes, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  InitArgs a;
-  a.K[0] = K[0]; a.K[1] = K[1]; a.K[2] = K[2]; a.K[3] = K[3];
-  a.n = n; a.rows = rows; a.cols = cols; a.faithful = faithful;
-  const size_t lds = ((size_t)n * 40 + 100) * sizeof(double);
-  ESL_HIP_TRY(hipFuncSetAttribute((const void*)k_init_quadric, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_init_quadric, dim3(1), dim3(64), lds, c->stream, dp, db, a, dout);
-  ESL_HIP_TRY(hipGetLastError());
-  double h[27];
-  ESL_HIP_TRY(hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
-  (void)hipFree(dp); (void)hipFree(db); (void)hipFree(dout);
+  double h[28];
+  const int rc = init_launch(c, poses_Twc, bboxes, n, K, rows, cols, faithful, 0, nullptr, 0, h);
+  if (rc) return rc;
   for (int i = 0; i < 10; ++i) ellipsoid_out[i] = h[i];
   for (int i = 0; i < 16; ++i) qstar_out[i] = h[10 + i];
   *ok = h[26] > 0.5 ? 1 : 0;
+  return ESL_OK;
+}
+
+extern "C" int esl_init_from_qstar(esl_ctx* c, const double qstar[16], int32_t faithful, double ellipsoid_out[10], int32_t* ok) {
+  if (!c || !qstar || !ellipsoid_out || !ok) return ESL_ERR_INVALID;
+  const double K[4] = {1, 1, 0, 0};
+  double h[28];
+  const int rc = init_launch(c, nullptr, nullptr, 0, K, 0, 0, faithful, 1, qstar, 16, h);
+  if (rc) return rc;
+  for (int i = 0; i < 10; ++i) ellipsoid_out[i] = h[i];
+  *ok = h[26] > 0.5 ? 1 : 0;
+  return ESL_OK;
+}
+
+extern "C" int esl_init_plane_error(esl_ctx* c, const double* poses_Twc, const double* bboxes, int32_t n, const double K[4],
+                                    int32_t rows, int32_t cols, const double ellipsoid[10], double* error_out) {
+  if (!c || !K || !ellipsoid || !error_out || n < 0 || (n && (!poses_Twc || !bboxes))) return ESL_ERR_INVALID;
+  double h[28];
+  const int rc = init_launch(c, poses_Twc, bboxes, n, K, rows, cols, 1, 2, ellipsoid, 10, h);
+  if (rc) return rc;
+  *error_out = h[27];
   return ESL_OK;
 }

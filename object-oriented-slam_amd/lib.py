@@ -21,7 +21,7 @@ EXPORTS = [
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
     "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
-    "esl_init_quadric",
+    "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error",
 ]
 
 
@@ -177,6 +177,25 @@ class Context:
                                        Kd.ctypes.data_as(_dp), C.c_int32(rows), C.c_int32(cols), C.c_int32(faithful),
                                        e.ctypes.data_as(_dp), Q.ctypes.data_as(_dp), C.byref(ok)), "esl_init_quadric")
         return e, Q.reshape(4, 4), bool(ok.value)
+
+    def init_from_qstar(self, qstar, faithful=1):
+        """Initializer::getEllipsoidFromQStar: (ellipsoid 10-vector, ok)."""
+        Q = np.ascontiguousarray(qstar, dtype=np.float64).reshape(16)
+        e = np.zeros(10); ok = C.c_int32(0)
+        _check(load().esl_init_from_qstar(self._h, Q.ctypes.data_as(_dp), C.c_int32(faithful), e.ctypes.data_as(_dp), C.byref(ok)),
+               "esl_init_from_qstar")
+        return e, bool(ok.value)
+
+    def init_plane_error(self, poses_Twc, bboxes, K, ellipsoid, rows=480, cols=640):
+        """Initializer::quadricErrorWithPlanes."""
+        poses = np.ascontiguousarray(poses_Twc, dtype=np.float64).reshape(-1, 7)
+        boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
+        Kd = np.ascontiguousarray(K, dtype=np.float64); e = np.ascontiguousarray(ellipsoid, dtype=np.float64)
+        err = C.c_double(0)
+        _check(load().esl_init_plane_error(self._h, poses.ctypes.data_as(_dp), boxes.ctypes.data_as(_dp), C.c_int32(len(poses)),
+                                           Kd.ctypes.data_as(_dp), C.c_int32(rows), C.c_int32(cols), e.ctypes.data_as(_dp),
+                                           C.byref(err)), "esl_init_plane_error")
+        return err.value
 
     def fit_frame(self, depth, bboxes, labels, Twc, intr, ground, params=None):
         """EllipsoidExtractor::EstimateLocalEllipsoid for every box of one frame.
