@@ -178,6 +178,9 @@ int esl_lm_linearize(esl_ctx* ctx, esl_lm_partials* out);
  * triangle of S = Hcc + lambda I - sum_o W_o (Hoo + lambda I)^-1 W_o^T, row n holds b_s^T.
  * A multi-GPU caller may sum the lda*n doubles across shards in place (SURVEY.md §8 e). */
 int esl_lm_reduced_system(esl_ctx* ctx, double lambda, void** dev_ptr, int64_t* n, int64_t* lda);
+/* SLAM mode diagnostic (tests at sizes no CPU checker reaches): re-builds the reduced camera system for the lambda of
+ * the last esl_lm_try_step (the factorisation overwrote it) and returns |S x_c - b_s| / |b_s| for the x_c that step solved. */
+int esl_lm_reduced_residual(esl_ctx* ctx, double* rel_residual_out);
 /* backup states, solve (H + lambda I) x = b, apply x, recompute chi2; states stay updated */
 int esl_lm_try_step(esl_ctx* ctx, double lambda, esl_lm_partials* out);
 /* accept != 0: discard backup; accept == 0: restore states from backup */

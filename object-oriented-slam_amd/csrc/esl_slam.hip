@@ -189,7 +189,69 @@ int slam_try_step(esl_ctx* c, double lambda) {
   return ESL_OK;
 }
 
+// ---- diagnostic: residual of the reduced camera system ------------------------------------------------------------------
+// y += S x for the LOWER-triangle storage of S (column-major, lda): workgroup = (row tile of 256, column panel of 64) with
+// row tile >= column panel; loads run down the columns (coalesced); an entry S_ij (i > j) serves y_i and y_j.
+static __global__ __launch_bounds__(256) void k_symv_lower(const double* __restrict__ M, long lda, long n, const double* __restrict__ x,
+                                                           double* __restrict__ y) {
+  __shared__ double ycol[64];
+  __shared__ double xcol[64];
+  const long j0 = (long)blockIdx.y * 64, i0 = (long)blockIdx.x * 256;
+  if (i0 + 255 < j0) return;                         // tile entirely above the diagonal
+  const long i = i0 + threadIdx.x;
+  if (threadIdx.x < 64) { ycol[threadIdx.x] = 0; xcol[threadIdx.x] = (j0 + threadIdx.x < n) ? x[j0 + threadIdx.x] : 0.0; }
+  __syncthreads();
+  const double xi = i < n ? x[i] : 0.0;
+  double acc = 0;
+  if (i < n) {
+    for (int jj = 0; jj < 64; ++jj) {
+      const long j = j0 + jj;
+      if (j >= n || j > i) break;
+      const double a = M[i + j * lda];
+      acc += a * xcol[jj];
+      if (i > j) atomicAdd(&ycol[jj], a * xi);
+    }
+    if (acc != 0) atomicAdd(&y[i], acc);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && j0 + threadIdx.x < n && ycol[threadIdx.x] != 0) atomicAdd(&y[j0 + threadIdx.x], ycol[threadIdx.x]);
+}
+static __global__ __launch_bounds__(256) void k_resid_norms(const double* __restrict__ M, long lda, long n, const double* __restrict__ y,
+                                                            double* __restrict__ out2) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  double r2 = 0, b2 = 0;
+  if (j < n) { const double b = M[n + j * lda], r = y[j] - b; r2 = r * r; b2 = b * b; }
+  r2 = wave_sum(r2); b2 = wave_sum(b2);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&out2[0], r2); atomicAdd(&out2[1], b2); }
+}
+
 }  // namespace esl
+
+extern "C" int esl_lm_reduced_residual(esl_ctx* c, double* rel_residual_out) {
+  using namespace esl;
+  if (!c || !rel_residual_out) return ESL_ERR_INVALID;
+  if (!c->lm.begun || !c->lm.slam || !c->xc || c->S_n <= 0) { set_error("esl_lm_reduced_residual: needs a SLAM-mode trial step"); return ESL_ERR_STATE; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  const long n = (long)c->S_n, lda = (long)c->S_lda;
+  int rc = slam_build_reduced(c, c->lm.lambda_used, nullptr, nullptr);   // the factorisation overwrote S and b_s
+  if (rc) return rc;
+  double* y = nullptr;
+  ESL_HIP_TRY(hipMalloc((void**)&y, ((size_t)n + 2) * sizeof(double)));
+  hipError_t e = hipMemsetAsync(y, 0, ((size_t)n + 2) * sizeof(double), c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_symv_lower, dim3((unsigned)((n + 255) / 256), (unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, c->S, lda, n,
+                       c->xc, y);
+    hipLaunchKernelGGL(k_resid_norms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S, lda, n, y, y + n);
+    e = hipGetLastError();
+  }
+  double h2[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(h2, y + n, sizeof(h2), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(y);
+  if (e != hipSuccess) { set_error(std::string("esl_lm_reduced_residual: ") + hipGetErrorString(e)); return ESL_ERR_HIP; }
+  *rel_residual_out = h2[1] > 0 ? std::sqrt(h2[0] / h2[1]) : 0.0;
+  return ESL_OK;
+}
 
 // ---- dense-solver self test / micro-benchmark ------------------------------------------------------------------------
 // A(i,j) = h(min,max) in [-1,1) off the diagonal (a hash, so the matrix never has to be kept), A(i,i) = n: strictly

@@ -19,7 +19,7 @@ _lib = None
 EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
-    "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system",
+    "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
     "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
     "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error",
 ]
@@ -142,6 +142,12 @@ class Context:
         _check(load().esl_lm_reduced_system(self._h, C.c_double(lam), C.byref(ptr), C.byref(n), C.byref(lda)),
                "esl_lm_reduced_system")
         return ptr.value, n.value, lda.value
+
+    def lm_reduced_residual(self):
+        """|S x_c - b_s| / |b_s| of the last SLAM-mode trial step (the reduced system is re-built for it)."""
+        r = C.c_double(0)
+        _check(load().esl_lm_reduced_residual(self._h, C.byref(r)), "esl_lm_reduced_residual")
+        return r.value
 
     def lm_download(self, which, count):
         out = np.zeros(int(count))
