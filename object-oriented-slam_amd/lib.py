@@ -13,7 +13,8 @@ import numpy as np
 from . import abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libesl_hip.so")
+# ESL_HIP_LIB: load another build of the SAME library (kernel tuning variants side by side); never a fallback
+LIB_PATH = os.environ.get("ESL_HIP_LIB") or os.path.join(_CSRC, "libesl_hip.so")
 _lib = None
 
 EXPORTS = [

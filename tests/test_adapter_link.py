@@ -106,9 +106,11 @@ def test_adapters_replay_tracking_sequence_on_gpu(pkg, ctx, tmp_path):
     e, p, st, _, sym = ctx.fit_frame_ex(sc["depth"], [b], [28], sc["Twc"], intr, ground, pkg.lib.default_fit_params())
     ok, sres, stype, eprob, sprob = rec["FITFLAGS"][0]
     assert int(ok) == int(st[0] == 0) == 1 and int(sres) == sym["result"][0] == 1 and int(stype) == sym["symmetry_type"][0] == 2
-    np.testing.assert_allclose([float(v) for v in rec["FIT"][0][1:]], e[0], rtol=0, atol=1e-12)
-    assert abs(float(eprob) - p[0]) < 1e-12 and abs(float(sprob) - sym["prob"][0]) < 1e-12
-    np.testing.assert_allclose([float(v) for v in rec["SYM"][0]], np.concatenate([sym["plane"][0], sym["plane2"][0], sym["center"][0]]), atol=1e-12)
+    # two runs of the fit agree to ~1e-9, not bit for bit: the compaction order of the voxels after the plane filter depends on
+    # atomics timing, the sums over them differ in the last bit, and the symmetry LM's delta = 1e-9 differences amplify that
+    np.testing.assert_allclose([float(v) for v in rec["FIT"][0][1:]], e[0], rtol=0, atol=1e-7)
+    assert abs(float(eprob) - p[0]) < 1e-7 and abs(float(sprob) - sym["prob"][0]) < 1e-7
+    np.testing.assert_allclose([float(v) for v in rec["SYM"][0]], np.concatenate([sym["plane"][0], sym["plane2"][0], sym["center"][0]]), atol=1e-7)
 
     # --- SVD initialisation of every instance with >= 3 observations, then the global optimisation
     objs, inst_of = [], []

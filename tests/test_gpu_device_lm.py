@@ -142,3 +142,67 @@ def test_one_ellipsoid_with_many_chunks(pkg, po, ctx):
         _, og, rg = ctx.optimize(g, c, o, p)
         assert_traces_match(rg, ro, rtol=1e-5)
         assert group_rel_err(og, oo) < 1e-4
+
+
+def _fused_cases(pkg):
+    K = pkg.synth.TUM3_K
+    out = {}
+    g, c, o, _ = pkg.synth.make_graph(60, 10, 700, seed=7)
+    out["plain"] = (g, c, o, {})
+    out["one_iteration"] = (g, c, o, dict(max_iters=1))
+    out["one_trial_per_iteration"] = (g, c, o, dict(max_trials=1))
+    out["no_nan_precheck"] = (g, c, o, dict(drop_nan_bbox=0))
+    g2, c2, o2, _ = pkg.synth.make_graph(10, 5, 0, seed=2)
+    out["gravity_only"] = (pkg.Graph(g2.K, g2.n_cams, g2.n_objs, None, grav_obj=np.arange(g2.n_objs), grav_normal=g2.grav_normal,
+                                     grav_weight=g2.grav_weight), c2, o2, {})
+    # ellipsoid 3 has no edge at all (inactive vertex, never touched); ellipsoid 1 has no gravity prior
+    g3, c3, o3, _ = pkg.synth.make_graph(50, 6, 400, seed=9)
+    mb, me = g3.bbox_obj != 3, g3.e3d_obj != 3
+    out["inactive_vertex"] = (pkg.Graph(g3.K, g3.n_cams, g3.n_objs, None, g3.bbox_cam[mb], g3.bbox_obj[mb], g3.bbox_meas.reshape(-1, 4)[mb],
+                                        g3.bbox_weight[mb], g3.e3d_cam[me], g3.e3d_obj[me], g3.e3d_meas.reshape(-1, 10)[me], g3.e3d_weight[me],
+                                        np.array([0, 2, 4, 5]), g3.grav_normal, g3.grav_weight), c3, o3, {})
+    # some bbox edges are NaN at the start state (camera inside the ellipsoid) and must be dropped, the others stay
+    g4, c4, o4, _ = pkg.synth.make_graph(40, 5, 300, seed=11)
+    c4 = c4.copy()
+    bad_cam = int(g4.bbox_cam[g4.bbox_obj == 2][0])
+    from oracle import np_fit
+    Twc = np_fit.se3_inv(c4[bad_cam]); Twc[:3] = o4[2][:3]; c4[bad_cam] = np_fit.se3_inv(Twc)    # camera centre = ellipsoid centre
+    out["some_nan_edges"] = (g4, c4, o4, {})
+    g5, c5, o5, _ = pkg.synth.make_graph(1500, 1, 3000, seed=41)
+    out["one_ellipsoid_many_items"] = (g5, c5, o5, {})
+    g6, c6, o6, _ = pkg.synth.make_config("C3", seed=0)
+    out["C3"] = (g6, c6, o6, {})
+    return out
+
+
+@pytest.mark.parametrize("case", ["plain", "one_iteration", "one_trial_per_iteration", "no_nan_precheck", "gravity_only", "inactive_vertex",
+                                  "some_nan_edges", "one_ellipsoid_many_items", "C3"])
+def test_fused_trial_equals_two_launch_trial(pkg, ctx, monkeypatch, case):
+    """The one-launch LM trial (esl_kernels_fused.hpp) against the two-launch trial it replaced (k_lm_step +
+    k_chunk_linearize_both, forced with ESL_LM_UNFUSED=1): same arithmetic per edge, same LM control, only the order in
+    which an ellipsoid's partial sums are added differs (per wave instead of per 64-edge chunk) -> identical accept /
+    reject sequence, chi2 trace to 1e-11, states to 1e-10."""
+    g, c, o, kw = _fused_cases(pkg)[case]
+    p = pkg.default_lm_params(jacobian_mode=1, **kw)
+    monkeypatch.setenv("ESL_LM_UNFUSED", "1")
+    _, o_ref, r_ref = ctx.optimize(g, c, o, p)
+    monkeypatch.delenv("ESL_LM_UNFUSED")
+    _, o_fz, r_fz = ctx.optimize(g, c, o, p)
+    for k in ("iterations", "total_trials", "stop_reason", "n_bbox_valid", "n_bbox_dropped", "trace_trials"):
+        assert r_fz[k] == r_ref[k], (k, r_fz[k], r_ref[k])
+    if case == "some_nan_edges":
+        assert r_fz["n_bbox_dropped"] >= 1
+    assert r_fz["chi2_initial"] == pytest.approx(r_ref["chi2_initial"], rel=1e-12)
+    np.testing.assert_allclose(r_fz["trace_chi2"], r_ref["trace_chi2"], rtol=1e-11)
+    np.testing.assert_allclose(r_fz["trace_lambda"], r_ref["trace_lambda"], rtol=1e-9)
+    np.testing.assert_allclose(o_fz, o_ref, rtol=0, atol=1e-10)
+    if case == "inactive_vertex":
+        np.testing.assert_array_equal(o_fz[3], o[3])
+    # a second fused run on the same context reproduces the first bit for bit (fixed-order reductions)
+    _, o_fz2, r_fz2 = ctx.optimize(g, c, o, p)
+    assert np.array_equal(o_fz2, o_fz) and r_fz2["trace_chi2"] == r_fz["trace_chi2"]
+    if kw.get("max_iters", 10) == 10 and case != "gravity_only":
+        # max_iters = 0: the start state is reported, nothing moves
+        _, o0, r0 = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1, max_iters=0, **{k: v for k, v in kw.items() if k != "max_iters"}))
+        assert r0["iterations"] == 0 and r0["chi2_initial"] == pytest.approx(r_ref["chi2_initial"], rel=1e-12)
+        np.testing.assert_array_equal(o0, o)
