@@ -9,9 +9,14 @@ same initial estimate every step (device-side state restore, no PCIe in the time
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode mapping|slam] [--config C4|C3]
 
 N > 1 is launched by the driver through torch.distributed.run, one rank per GPU (RCCL).  The path
-shards by ellipsoid (SURVEY.md §8 e): every rank owns one graph-sized shard (weak scaling), the only
-exchange in mapping mode is the all-reduce of the LM scalars (chi2, max diag, scale, ok) per trial.
-value = LM iterations x shards / max-over-ranks wall time.
+shards by ellipsoid (SURVEY.md §8 e): the ellipsoids of the ONE named graph are partitioned over the ranks
+(strong scaling, cameras replicated); the exchange in mapping mode is one 64-byte all-gather of the LM scalars per
+trial, in SLAM mode additionally the all-reduce of the camera blocks and of the reduced camera system.
+value = LM iterations of that one global optimisation / max-over-ranks wall time.
+
+The default single-GPU line also carries: `repeat_blocks` (the K-step block repeated 10 times: median / min / max),
+`slam` (the Schur half of the metric: C3 and C4 with free cameras, FP64-MFMA roofline, CPU baseline), `fit`
+(per-frame ellipsoid fit with its own roofline record), `streaming_c5`, `cpu_baseline` and `host`.
 """
 import argparse
 import importlib
@@ -63,9 +68,48 @@ def valu_issue_floor(g, avg_ms):
                     "v_fma_f64 stream pulls the shader clock down to 1.89 GHz on this part (profiles/r1_fp64_ceilings.txt)"}
 
 
+def host_info():
+    """CPU model and core count of the box the CPU legs run on."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cores_usable": len(os.sched_getaffinity(0))}
+
+
+class pinned_to_one_core:
+    """taskset -c <core> for the CPU legs: the single-threaded restatement must not migrate while it is timed."""
+
+    def __enter__(self):
+        self.old = os.sched_getaffinity(0)
+        self.core = min(self.old)
+        try:
+            os.sched_setaffinity(0, {self.core})
+        except OSError:
+            self.core = None
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            os.sched_setaffinity(0, self.old)
+        except OSError:
+            pass
+
+
 def cpu_baseline(pkg, g, c, o, params, budget_s=25.0):
-    """The CPU restatement (oracle/, single thread) timed on a bounded sample of the same workload."""
+    """The CPU restatement (oracle/, single thread, pinned to one core) timed on a bounded sample of the same workload."""
     from oracle import pyoracle as po
+    with pinned_to_one_core() as pin:
+        out = _cpu_baseline_pinned(pkg, po, g, c, o, params)
+    out["pinned_to_core"] = pin.core
+    return out
+
+
+def _cpu_baseline_pinned(pkg, po, g, c, o, params):
     # sample: the first n_s ellipsoids with all their edges, sized so the run takes ~10-30 s
     n_s = min(g.n_objs, 400)
     sub = g.subset_objects(np.arange(n_s))
@@ -86,8 +130,9 @@ def cpu_baseline(pkg, g, c, o, params, budget_s=25.0):
     dense_solve_full = td["solve_s"] * (g.n_objs / n_d) ** 3
     return {
         "value": block_it_s, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-        "sample": (f"oracle/esl_oracle.c (CPU restatement, numeric Jacobians, per-ellipsoid LDLT = 'improved over "
-                   f"reference' solver), first {n_s} of {g.n_objs} ellipsoids with all their edges, {its} LM iterations in "
+        "sample": (f"oracle/esl_oracle.c (CPU restatement, g2o's numeric Jacobians at delta = 1e-9 -- the GPU side of this "
+                   f"line runs analytic ones, see speedup note --, per-ellipsoid LDLT = 'improved over reference' solver), "
+                   f"first {n_s} of {g.n_objs} ellipsoids with all their edges, {its} LM iterations in "
                    f"{dt:.1f} s, scaled linearly by {scale:.1f}x"),
         "split_s": tm,
         "faithful_dense_ldlt": {
@@ -124,17 +169,105 @@ def fit_bench(pkg, ctx, with_cpu=True):
             res = ctx.fit_frame(*args)
         prof = ctx.profile_get().get("k5", dict(count=1, total_ms=0.0))
         ctx.profile_enable(False)
-        entry = {"ms_per_frame_host_call": 1e3 * dt, "ms_per_frame_kernel": prof["total_ms"] / max(prof["count"], 1),
+        k_ms = prof["total_ms"] / max(prof["count"], 1)
+        # SURVEY.md §8 d: 2 B per depth sample scanned + 32 B per occupied 1 cm voxel written and read once
+        abytes = 2.0 * float(res[3][:, 0].sum()) + 32.0 * float(res[3][:, 1].sum())
+        ach = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        entry = {"ms_per_frame_host_call": 1e3 * dt, "ms_per_frame_kernel": k_ms,
+                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": None, "algorithmic_bytes_per_frame": abytes,
+                              "note": "latency-bound pointer chasing (hash inserts, union-find, 1-edge LM): a few hundred KB per frame, "
+                                      "nowhere near a bandwidth roof; the lever is launch structure, not bytes (DESIGN.md §4)"},
                  "boxes": len(lab), "ok_boxes": int((res[2] == 0).sum()), "samples": int(res[3][:, 0].sum()),
                  "note": "host call = staging + H2D of the depth image + kernels + D2H, replayed from a captured hipGraph (PCIe-inclusive); kernel = HIP events around direct launches"}
         if with_cpu:
             from oracle import pyoracle as po
             Po = po.default_fit_params(**kw)
-            t0 = time.perf_counter()
-            m = 5
-            for _ in range(m):
-                po.fit_frame(sc["depth"], boxes, lab, sc["Twc"], sc["intr"], sc["ground"], Po)
-            entry["cpu_port_ms_per_frame"] = 1e3 * (time.perf_counter() - t0) / m
+            with pinned_to_one_core():
+                t0 = time.perf_counter()
+                m = 5
+                for _ in range(m):
+                    po.fit_frame(sc["depth"], boxes, lab, sc["Twc"], sc["intr"], sc["ground"], Po)
+                entry["cpu_port_ms_per_frame"] = 1e3 * (time.perf_counter() - t0) / m
+        out[name] = entry
+    return out
+
+
+def slam_bench(pkg, ctx, with_cpu=True):
+    """The Schur half of BASELINE.json's metric: free cameras (cam 0 fixed), odometry edges, ellipsoids eliminated by the
+    Schur complement, dense FP64-MFMA Cholesky of the reduced camera system every LM trial.  C3 (n = 2,994) = several full
+    optimize(10) steps; C4 (n = 59,994, S = 28.8 GB) = ONE optimize(10).  Roofline: the factor + solve launches against
+    the FP64 matrix peak.  CPU: the restatement with its block-Schur solver ("improved over reference": g2o as shipped
+    would factor the whole system densely) measured on C3 on one pinned core, extrapolated to C4 from the LDLT flop rate
+    it reached there."""
+    out = {}
+    params = pkg.default_lm_params(jacobian_mode=1)
+    cpu = {}
+    for name, steps in (("C3", 5), ("C4", 1)):
+        g, c, o, _ = pkg.synth.make_config(name, seed=0, slam=True)
+        n = 6 * int((~g.cam_fixed.astype(bool)).sum())
+        ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
+        if name == "C3":
+            ctx.restore_states(); ctx.optimize_resident(params)          # warm-up
+        ctx.profile_enable(2)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        its = trials = 0
+        for _ in range(steps):
+            ctx.restore_states()
+            rep = ctx.optimize_resident(params)
+            its += rep["iterations"]; trials += rep["total_trials"]
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        prof = ctx.profile_get()
+        ctx.profile_enable(False)
+        ch = prof.get("cholesky_solve", dict(count=1, total_ms=0.0))
+        avg_ms = ch["total_ms"] / max(ch["count"], 1)
+        flops = n ** 3 / 3.0 + 2.0 * n * n
+        ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        lda = (n + 1 + 15) // 16 * 16
+        entry = {
+            "value": its / dt, "unit": "LM iterations/s", "ms_per_optimize": 1e3 * dt / steps, "steps": steps,
+            "lm_iterations_per_step": its / steps, "lm_trials_per_step": trials / steps,
+            "workload": f"{name} SLAM mode: {g.n_cams} cams ({n // 6} free), {g.n_objs} ellipsoids, {len(g.bbox_cam)} bbox + {len(g.e3d_cam)} 3-D + "
+                        f"{len(g.grav_obj)} gravity + {len(g.odom_i)} odometry edges; analytic Jacobians; optimize(10)",
+            "reduced_system": {"n": n, "bytes": lda * n * 8},
+            "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]},
+            "kernel_ms": prof,
+            "roofline": {"kernel": "dense_cholesky_f64 (k_chol_potrf + k_chol_panel + k_chol_update_lds + triangular solves)", "bound": "mfma",
+                         "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
+                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": ch["count"],
+                         "measured_ceiling": {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_MEASURED_TF,
+                                              "note": "register-only v_mfma_f64_16x16x4_f64 stream on this part (scripts/mfma_peak.hip, "
+                                                      "profiles/r1_fp64_ceilings.txt): half the spec-sheet figure"}},
+        }
+        if with_cpu:
+            from oracle import pyoracle as po
+            if name == "C3":
+                with pinned_to_one_core() as pin:
+                    t0 = time.perf_counter()
+                    _, _, ro = po.optimize(g, c, o, pkg.default_lm_params(), solver=po.ORACLE_BLOCK)
+                    dtc = time.perf_counter() - t0
+                tm = po.last_timing()
+                nt = max(ro["total_trials"], 1)
+                cpu = {"n": n, "edges": len(g.bbox_cam) + len(g.e3d_cam), "lin_s_per_it": tm["linearize_s"] / max(ro["iterations"], 1),
+                       "err_s_per_trial": tm["errors_s"] / nt, "ldlt_flops_per_s": (n ** 3 / 3.0) * nt / max(tm["solve_s"], 1e-9)}
+                entry["cpu_baseline"] = {
+                    "value": ro["iterations"] / dtc, "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_to_core": pin.core,
+                    "sample": f"oracle/esl_oracle.c, whole {name} SLAM graph, numeric Jacobians (delta 1e-9), block-Schur solver with a dense "
+                              f"pivoted LDLT of the {n} x {n} reduced system ('improved over reference'): {ro['iterations']} LM iterations / "
+                              f"{ro['total_trials']} trials in {dtc:.1f} s", "split_s": tm}
+            elif cpu:
+                e4 = len(g.bbox_cam) + len(g.e3d_cam)
+                per_trial = (n ** 3 / 3.0) / cpu["ldlt_flops_per_s"] + cpu["err_s_per_trial"] * e4 / cpu["edges"]
+                per_it = cpu["lin_s_per_it"] * e4 / cpu["edges"] + per_trial * (trials / max(its, 1))
+                entry["cpu_baseline"] = {
+                    "value": 1.0 / per_it, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                    "sample": f"EXTRAPOLATED, not run ({n}^3/3 = {n ** 3 / 3.0:.2e} flop per trial): linearisation and error evaluation of the "
+                              f"C3 run scaled by the edge count, the reduced solve from the LDLT flop rate measured there "
+                              f"({cpu['ldlt_flops_per_s'] / 1e9:.2f} GFLOP/s on one core) -> {per_it:.0f} s per LM iteration"}
+        if "cpu_baseline" in entry:
+            entry["speedup_vs_cpu_port"] = entry["value"] / entry["cpu_baseline"]["value"]
         out[name] = entry
     return out
 
@@ -183,6 +316,7 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-slam", action="store_true", help="skip the C3 / C4 SLAM-mode record of the default run (C4 allocates 28.8 GB)")
     a = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON).  Libraries (RCCL prints a banner at exit) write to fd 1 too,
@@ -207,16 +341,14 @@ def main():
 
     pkg = importlib.import_module("object-oriented-slam_amd")
     slam = a.mode == "slam"
-    # every rank owns one graph-sized shard (same camera trajectory, its own ellipsoids: different seed)
+    # ONE graph of the named shape; N > 1: its ellipsoids (with all their edges) partitioned over the ranks, cameras (and
+    # odometry) replicated -> strong scaling of one global LM in both modes
     sharded = world > 1 or force_dist
-    if slam and sharded:
-        # SLAM mode couples all ellipsoids through the cameras: ONE graph, its ellipsoids partitioned over the
-        # ranks (cameras + odometry replicated), the reduced camera system all-reduced -> strong scaling
-        g, c, o, _ = pkg.synth.make_config(a.config, seed=0, slam=True)
-        mine = np.nonzero(pkg.lib.partition_objects(g, world) == rank)[0]
-        g, o = g.subset_objects(mine), o[mine]
-    else:
-        g, c, o, _ = pkg.synth.make_config(a.config, seed=rank, slam=slam)
+    g_full, c, o_full, _ = pkg.synth.make_config(a.config, seed=0, slam=slam)
+    g, o = g_full, o_full
+    if sharded:
+        mine = np.nonzero(pkg.lib.partition_objects(g_full, world) == rank)[0]
+        g, o = g_full.subset_objects(mine), o_full[mine]
     params = pkg.default_lm_params(jacobian_mode=1 if a.jacobian == "analytic" else 0)
     ctx = pkg.Context(local_rank)
     ctx.upload_graph(g)
@@ -269,6 +401,17 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_get()
     ctx.profile_enable(False)
+    # the same K-step block ten more times, events off: how much one scheduler hiccup moves a 5 ms timed region
+    blocks = []
+    if not slam:
+        for _ in range(10):
+            barrier()
+            tb = time.perf_counter()
+            ib = 0
+            for _ in range(a.steps):
+                ib += one_step()["iterations"]
+            barrier()
+            blocks.append(ib / (time.perf_counter() - tb))
     if not slam:   # per-class breakdown from a short extra pass outside the timed region
         ctx.profile_enable(2)
         for _ in range(3):
@@ -321,15 +464,15 @@ def main():
                                                  "of the spec sheet; v_fma_f64 tops out at 55 TFLOP/s (clock drops to 1.9 GHz)"}}
         out = {
             "metric": "LM iterations/sec (cams+ellipsoids)",
-            "value": world * iters / dt,
-            "unit": "LM iterations/s (one graph-sized shard per GPU, summed over GPUs)",
+            "value": iters / dt,
+            "unit": "LM iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "strong" if (slam and sharded) else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.config} synthetic graph per GPU: {g.n_cams} cams, {g.n_objs} ellipsoids, "
-                                   f"{len(g.bbox_cam)} bbox + {len(g.e3d_cam)} 3-D + {len(g.grav_obj)} gravity"
-                                   f"{' + %d odometry' % len(g.odom_i) if slam else ''} edges; "
+            "config": {"workload": f"{a.config} synthetic graph: {g_full.n_cams} cams, {g_full.n_objs} ellipsoids, "
+                                   f"{len(g_full.bbox_cam)} bbox + {len(g_full.e3d_cam)} 3-D + {len(g_full.grav_obj)} gravity"
+                                   f"{' + %d odometry' % len(g_full.odom_i) if slam else ''} edges; "
                                    f"{'SLAM mode (free cameras, Schur)' if slam else 'mapping mode (cameras fixed, as shipped)'}; "
                                    f"{a.jacobian} Jacobians; optimize(10) per step",
                        "lm_iterations_per_step": iters / a.steps, "lm_trials_per_step": trials / a.steps,
@@ -338,13 +481,22 @@ def main():
             "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]},
             "roofline": roof,
         }
+        if blocks:
+            out["repeat_blocks"] = {"blocks": len(blocks), "steps_per_block": a.steps, "median": float(np.median(blocks)),
+                                    "min": float(np.min(blocks)), "max": float(np.max(blocks)),
+                                    "note": "LM iterations/s of 10 further K-step blocks (HIP events off); `value` is the first, timed block"}
+        out["host"] = host_info()
         if world == 1:
             out["fit"] = fit_bench(pkg, ctx, with_cpu=not a.no_cpu_baseline)
             out["streaming_c5"] = streaming_bench(pkg, ctx)
+            if not slam and not a.no_slam:
+                out["slam"] = slam_bench(pkg, ctx, with_cpu=not a.no_cpu_baseline)
             ctx.upload_graph(g); ctx.upload_states(c, o)   # leave the context as the timed section found it
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, g, c, o, pkg.default_lm_params())
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            out["speedup_note"] = ("GPU: analytic Jacobians; CPU port: g2o's numeric Jacobians with the restatement's per-ellipsoid solver; "
+                                   "a reported baseline, not a kernel-quality figure (that is roofline.frac)")
         final_line = json.dumps(out)
     else:
         final_line = None

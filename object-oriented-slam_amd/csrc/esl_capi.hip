@@ -18,7 +18,6 @@
 #include "esl_ctx.hpp"
 #include "esl_kernels_map.hpp"
 #include "esl_kernels_chunk.hpp"
-#include "esl_kernels_fused.hpp"
 #include "esl_slam.hpp"
 
 namespace esl {
@@ -219,8 +218,6 @@ static void free_graph(esl_ctx* c) {
   forget(&c->ck_obj); forget(&c->ck_type); forget(&c->ck_begin); forget(&c->ck_end); forget(&c->ck_ostart);
   forget(&c->chunk_out); forget(&c->chunk_out2); forget(&c->chunk_chi); forget(&c->blk_part); forget(&c->solve_part); forget(&c->blk_chi);
   forget(&c->ck_ids_bb); forget(&c->ck_ids_e3);
-  forget(&c->fz_wave_start); forget(&c->fz_items); forget(&c->fz_wg_obj); forget(&c->fz_slot_obj); forget(&c->sys_a); forget(&c->sys_b); forget(&c->fz_part); forget(&c->fz_sp);
-  c->fz_n_wg = 0;
   c->n_chunks = 0;
   forget(&c->cams); forget(&c->cams_trial); forget(&c->objs); forget(&c->objs_trial);
   forget(&c->Hoo); forget(&c->bo); forget(&c->xo); forget(&c->obj_part);
@@ -413,88 +410,8 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     wk.add(&c->chunk_out2, (size_t)c->n_chunks * kChunkOut);
     wk.add(&c->chunk_chi, (size_t)c->n_chunks);
     wk.add(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2);
-    wk.add(&c->solve_part, (size_t)((N + kStepObjs - 1) / kStepObjs + (N + 63) / 64 + 2) * 4 * 2);   // k_obj_solve / k_lm_step (x2: ping-pong)
+    wk.add(&c->solve_part, (size_t)((N + kStepWaves - 1) / kStepWaves + (N + 63) / 64 + 2) * 4 * 2);   // k_obj_solve / k_lm_step* (x2: ping-pong)
     wk.add(&c->blk_chi, (size_t)(c->n_chunks + 2));                 // <= one workgroup per chunk
-    // schedule of the fused LM-trial kernel: every workgroup owns up to kFzObjs consecutive ellipsoids; their edges are cut
-    // into items (<= 64 bbox edges | two <= 32-edge 3-D slices) which are spread over the workgroup's waves longest-first;
-    // every (wave, ellipsoid) pair that occurs gets an accumulator slot (<= kFzSlots per workgroup)
-    {
-      constexpr int kCostBbox = 1143, kCostE3d = 1918;   // VALU instructions per wave-item (profiles/r1_isa_counts.md)
-      std::vector<int> wg_obj{0}, wstart, slot_obj;
-      std::vector<FzItem> items;
-      std::vector<std::pair<int, FzItem>> tmp;   // (cost, item)
-      std::vector<FzItem> per_wave[kFzWaves];
-      auto n_items_of = [&](int o) { return (h_bb_start[o + 1] - h_bb_start[o] + 63) / 64 + (h_e3_start[o + 1] - h_e3_start[o] + 31) / 32; };
-      int o_next = 0;
-      while (o_next < N) {
-        // ellipsoids of this workgroup: as many as the slot budget certainly holds (pairs <= items, pairs <= waves x ellipsoids)
-        int n_e = 1, cnt = n_items_of(o_next);
-        while (n_e < kFzObjs && o_next + n_e < N) {
-          const int cnt2 = cnt + n_items_of(o_next + n_e);
-          if (std::min(cnt2, kFzWaves * (n_e + 1)) > kFzSlots) break;
-          cnt = cnt2; ++n_e;
-        }
-        const int wg = (int)wg_obj.size() - 1, ob = o_next;
-        o_next += n_e;
-        wg_obj.push_back(o_next);
-        tmp.clear();
-        std::vector<FzItem> halves;
-        for (int e = 0; e < n_e; ++e)
-          for (int b0 = h_e3_start[ob + e]; b0 < h_e3_start[ob + e + 1]; b0 += 32)
-            halves.push_back(FzItem{1, e, b0, std::min(b0 + 32, h_e3_start[ob + e + 1]), 0, 0, 0, 0});
-        for (size_t k = 0; k < halves.size(); k += 2) {
-          FzItem it = halves[k];
-          if (k + 1 < halves.size()) { it.ob = halves[k + 1].oa; it.bb = halves[k + 1].ba; it.eb = halves[k + 1].ea; }
-          tmp.push_back({kCostE3d, it});
-        }
-        for (int e = 0; e < n_e; ++e)
-          for (int b0 = h_bb_start[ob + e]; b0 < h_bb_start[ob + e + 1]; b0 += 64)
-            tmp.push_back({kCostBbox, FzItem{0, e, b0, std::min(b0 + 64, h_bb_start[ob + e + 1]), 0, 0, 0, 0}});
-        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, FzItem>& a, const std::pair<int, FzItem>& b) { return a.first > b.first; });
-        int load[kFzWaves] = {0};
-        for (auto& pw : per_wave) pw.clear();
-        for (const auto& ci : tmp) {
-          int w = 0;
-          for (int q = 1; q < kFzWaves; ++q) if (load[q] < load[w]) w = q;
-          load[w] += ci.first;
-          per_wave[w].push_back(ci.second);
-        }
-        slot_obj.resize((size_t)(wg + 1) * kFzSlots, -1);
-        int n_slots = 0;
-        for (int w = 0; w < kFzWaves; ++w) {
-          wstart.push_back((int)items.size());
-          int slot_of[kFzObjs];
-          for (int e = 0; e < kFzObjs; ++e) slot_of[e] = -1;
-          auto slot = [&](int e) {
-            if (slot_of[e] < 0) { slot_of[e] = n_slots; slot_obj[(size_t)wg * kFzSlots + n_slots] = e; ++n_slots; }
-            return slot_of[e];
-          };
-          for (FzItem it : per_wave[w]) {
-            const int sa = slot(it.oa);
-            const int sb = (it.type == 1 && it.eb > it.bb) ? slot(it.ob) : sa;
-            it.slots = sa | (sb << 16);
-            items.push_back(it);
-          }
-        }
-        if (n_slots > kFzSlots) { set_error("internal: fused schedule ran out of accumulator slots"); return ESL_ERR_STATE; }
-      }
-      const int n_wg = (int)wg_obj.size() - 1;
-      if (n_wg == 0) {   // no ellipsoid: one idle workgroup
-        wg_obj.push_back(0);
-        for (int w = 0; w < kFzWaves; ++w) wstart.push_back(0);
-        slot_obj.assign(kFzSlots, -1);
-      }
-      wstart.push_back((int)items.size());
-      c->fz_n_wg = n_wg;
-      up.add(&c->fz_wg_obj, wg_obj.data(), wg_obj.size());
-      up.add(&c->fz_wave_start, wstart.data(), wstart.size());
-      up.add(&c->fz_items, (const int*)items.data(), items.size() * (sizeof(FzItem) / sizeof(int)));
-      up.add(&c->fz_slot_obj, slot_obj.data(), slot_obj.size());
-      wk.add(&c->sys_a, (size_t)N * kSysStride);
-      wk.add(&c->sys_b, (size_t)N * kSysStride);
-      wk.add(&c->fz_part, (size_t)std::max(n_wg, 1) * kFzPart);
-      wk.add(&c->fz_sp, (size_t)std::max(1, (N + kStepWaves - 1) / kStepWaves) * 2 * 2);
-    }
   }
   // cameras + odometry
   {
@@ -839,7 +756,9 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   }
   const int max_total = p->max_iters * std::max(1, p->max_trials);
   const int depth = 2;   // trials kept in flight ahead of the device's progress counter
-  const int n_step_blocks = std::max(1, (g.n_objs + kStepObjs - 1) / kStepObjs);
+  // ESL_LM_STEP_OLD=1: round 1's step kernel (16 ellipsoids per workgroup, one lane each) for A/B measurements
+  const bool step_rows = std::getenv("ESL_LM_STEP_OLD") == nullptr;
+  const int n_step_blocks = std::max(1, step_rows ? (g.n_objs + kStepWaves - 1) / kStepWaves : (g.n_objs + kStepObjs - 1) / kStepObjs);
   const int batch = 4;   // sharded: trials enqueued per round (a fixed number, so that all ranks issue the same collectives)
   const int n_lin_blocks = (c->n_ids_e3 + 2 * kLinWaves - 1) / (2 * kLinWaves) + (c->n_ids_bb + kLinWaves - 1) / kLinWaves;
   // launch k carries trial k's solve and trial k-1's decision: one launch more than there are trials
@@ -853,7 +772,14 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
       LmCore* nxt = core + ((enq + 1) & 1);
       {
         ProfScope ps(c, 1);
-        hipLaunchKernelGGL(k_lm_step, dim3(n_step_blocks), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out, c->chunk_out2,
+        if (step_rows)
+          hipLaunchKernelGGL(k_lm_step_rows, dim3(n_step_blocks), dim3(64 * kStepWaves), 0, c->stream, g, chunk_table(c), c->chunk_out,
+                             c->chunk_out2, c->objs, c->objs_trial, in, nxt, c->blk_chi, n_lin_blocks, c->solve_part + 4 * n_step_blocks * (enq & 1),
+                             c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? (sharded ? 2 : 1) : 0, p->max_iters, p->max_trials,
+                             (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo,
+                             sharded ? c->dev_gather : (const double*)nullptr, sharded ? c->comm_ranks : 0, p->tau);
+        else
+          hipLaunchKernelGGL(k_lm_step, dim3(n_step_blocks), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out, c->chunk_out2,
                            c->objs, c->objs_trial, in, nxt, c->blk_chi, n_lin_blocks, c->solve_part + 4 * n_step_blocks * (enq & 1),
                            c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? (sharded ? 2 : 1) : 0, p->max_iters,
                            p->max_trials, (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo, c->obj_part,
@@ -921,152 +847,13 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   return ESL_OK;
 }
 
-// The same run on the grouped pipeline (esl_kernels_fused.hpp): an ellipsoid's sums never leave its workgroup, the step
-// kernel solves row-parallel.  Launch sequence and host protocol are those of optimize_mapping_device: the start state's
-// linearisation (+ NaN pre-check), then per trial k_group_step (decide trial k-1, solve trial k) and k_group_linearize at
-// trial k's state; a few trials kept in flight ahead of the progress counter in mapped memory.
-static int optimize_mapping_grouped(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
-  int rc;
-  const DevGraph& g = c->g;
-  LmHostView* hv = (LmHostView*)c->lm_host;
-  LmCore* core = (LmCore*)c->lm_dev;   // [2]
-  const bool sharded = c->comm != nullptr;
-  if (!sharded && (g.n_objs == 0 || (g.n_bbox == 0 && g.n_e3d == 0 && c->n_grav_edges == 0))) {   // empty graph
-    out->stop_reason = 3;
-    return ESL_OK;
-  }
-  hv->trace_len = 0;
-  hv->n_dropped = 0;
-  __atomic_store_n(&hv->seq, 0, __ATOMIC_RELAXED);
-  __atomic_store_n(&hv->done, 0, __ATOMIC_RELEASE);
-  if (!p->drop_nan_bbox && g.n_bbox) ESL_HIP_TRY(hipMemsetAsync(g.bb_valid, 1, (size_t)g.n_bbox, c->stream));
-  FusedSched sc;
-  sc.n_wg = c->fz_n_wg; sc.wg_obj = c->fz_wg_obj; sc.wave_start = c->fz_wave_start; sc.items = (const FzItem*)c->fz_items;
-  sc.slot_obj = c->fz_slot_obj;
-  const int n_lin = std::max(1, c->fz_n_wg), n_step = std::max(1, (g.n_objs + kStepWaves - 1) / kStepWaves);
-  double* sp[2] = {c->fz_sp, c->fz_sp + (size_t)n_step * 2};
-  LmHostView* hvd = (LmHostView*)c->lm_host_dev;
-  auto linearize = [&](const LmCore* st, bool validate) {
-    if (validate)
-      hipLaunchKernelGGL((k_group_linearize<ESL_JAC_ANALYTIC, true>), dim3(n_lin), dim3(kFzThreads), 0, c->stream, g, sc, c->cams, c->objs,
-                         c->objs_trial, c->sys_a, c->sys_b, st, c->fz_part, p->numeric_delta);
-    else
-      hipLaunchKernelGGL((k_group_linearize<ESL_JAC_ANALYTIC, false>), dim3(n_lin), dim3(kFzThreads), 0, c->stream, g, sc, c->cams, c->objs,
-                         c->objs_trial, c->sys_a, c->sys_b, st, c->fz_part, p->numeric_delta);
-  };
-  {
-    c->prof_gate = false;
-    ProfScope ps(c, 0);
-    linearize(nullptr, p->drop_nan_bbox != 0 && g.n_bbox > 0);
-    ESL_HIP_TRY(hipGetLastError());
-  }
-  c->prof_gate = true;
-  if (sharded) {
-    hipLaunchKernelGGL(k_fz_partials, dim3(1), dim3(256), 0, c->stream, c->fz_part, n_lin, (const double*)nullptr, 0, 1, g.n_bbox, g.n_e3d,
-                       c->n_grav_edges, c->dev_scal, hvd);
-    ESL_HIP_TRY(hipGetLastError());
-    if ((rc = comm_gather_scalars_device(c))) return rc;
-  }
-  if (p->max_iters <= 0) {   // nothing to iterate: report the start state
-    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<double> hp((size_t)n_lin * kFzPart);
-    ESL_HIP_TRY(hipMemcpy(hp.data(), c->fz_part, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
-    double chi = 0, nd = 0;
-    for (int b = 0; b < n_lin; ++b) { chi += hp[(size_t)b * kFzPart]; nd += hp[(size_t)b * kFzPart + 3]; }
-    out->chi2_initial = out->chi2_final = chi;
-    out->n_bbox_dropped = (int)nd;
-    out->n_bbox_valid = g.n_bbox - (int)nd;
-    if (!((g.n_bbox - (int)nd > 0) || g.n_e3d > 0 || c->n_grav_edges > 0)) out->stop_reason = 3;
-    return ESL_OK;
-  }
-  const int max_total = p->max_iters * std::max(1, p->max_trials);
-  const int depth = 2;   // trials kept in flight ahead of the device's progress counter
-  const int batch = 4;   // sharded: trials enqueued per round (a fixed number, so that all ranks issue the same collectives)
-  int enq = 0, seen = 0;
-  bool done = false;
-  while (!done) {
-    const int enq_limit = sharded ? enq + batch : max_total + 1;
-    if (sharded && enq > max_total + batch) { set_error("device-side LM did not terminate"); return ESL_ERR_STATE; }
-    while (enq < enq_limit && (sharded || enq - seen < depth)) {
-      const LmCore* in = core + (enq & 1);
-      LmCore* nxt = core + ((enq + 1) & 1);
-      {
-        ProfScope ps(c, 1);
-        hipLaunchKernelGGL(k_group_step, dim3(n_step), dim3(64 * kStepWaves), 0, c->stream, g, c->sys_a, c->sys_b, c->objs, c->objs_trial, in, nxt,
-                           c->fz_part, n_lin, sp[enq & 1], sp[(enq + 1) & 1], enq == 0 ? (sharded ? 2 : 1) : 0, p->max_iters, p->max_trials,
-                           hvd, c->xo, sharded ? c->dev_gather : (const double*)nullptr, sharded ? c->comm_ranks : 0, p->tau, c->n_grav_edges);
-        ESL_HIP_TRY(hipGetLastError());
-      }
-      {
-        c->prof_gate = (enq == 1);   // the second trial's linearisation is the sampled one (always a live launch when it exists)
-        ProfScope ps(c, 0);
-        linearize(nxt, false);
-        ESL_HIP_TRY(hipGetLastError());
-      }
-      c->prof_gate = true;
-      if (sharded) {   // this rank's share of the trial's scalars, then everybody's (one small all-gather on the stream)
-        hipLaunchKernelGGL(k_fz_partials, dim3(1), dim3(256), 0, c->stream, c->fz_part, n_lin, sp[(enq + 1) & 1], n_step, 0, 0, 0, 0, c->dev_scal, hvd);
-        ESL_HIP_TRY(hipGetLastError());
-        ProfScope ps(c, 6);
-        if ((rc = comm_gather_scalars_device(c))) return rc;
-      }
-      ++enq;
-    }
-    const int want = sharded ? enq - 1 : seen + 1;
-    int s = seen;
-    for (int spin = 0; spin < 400000; ++spin) {
-      s = __atomic_load_n(&hv->seq, __ATOMIC_ACQUIRE);
-      if (s >= want || __atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) break;
-    }
-    if (s < want && !__atomic_load_n(&hv->done, __ATOMIC_ACQUIRE)) {
-      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
-      s = __atomic_load_n(&hv->seq, __ATOMIC_ACQUIRE);
-      if (s < want && !hv->done) { set_error("device-side LM made no progress"); return ESL_ERR_STATE; }
-    }
-    seen = s;
-    done = __atomic_load_n(&hv->done, __ATOMIC_ACQUIRE) != 0;
-  }
-  if (sharded) ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // leave no collective in flight behind the caller's back
-  const LmCore& r = hv->core;
-  out->n_bbox_dropped = hv->n_dropped;
-  out->n_bbox_valid = g.n_bbox - hv->n_dropped;
-  if (r.cur) {   // the current estimate (and its system) live in the second pair
-    std::swap(c->objs, c->objs_trial);
-    std::swap(c->sys_a, c->sys_b);
-  }
-  c->sys_combined = false;
-  c->lm.have_trial = false;
-  c->lm.begun = false;   // the step API's chunk partials do not describe this state
-  out->iterations = r.it;
-  out->total_trials = r.total_trials;
-  out->stop_reason = r.stop_reason;
-  out->chi2_initial = r.chi2_initial;
-  out->chi2_final = r.currentChi;
-  out->lambda_final = r.lambda;
-  out->trace_len = hv->trace_len;
-  for (int k = 0; k < hv->trace_len && k < ESL_MAX_TRACE; ++k) {
-    out->trace_chi2[k] = hv->trace_chi2[k]; out->trace_lambda[k] = hv->trace_lambda[k]; out->trace_trials[k] = hv->trace_trials[k];
-  }
-  return ESL_OK;
-}
-
 int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
   if (!c || !p || !out) return ESL_ERR_INVALID;
   std::memset(out, 0, sizeof(*out));
   if (c->graph_loaded && c->g.n_free_cams == 0) {   // mapping mode: the LM runs on the device, nothing waits on the host
-    // numeric Jacobians (g2o's scheme, for step-for-step debugging) keep the chunked pipeline: one kernel per edge type, each
-    // with its own register budget (a kernel holding the bbox AND the 3-D central differences spills 0.5 KB per lane);
-    // ESL_LM_UNFUSED=1 forces that path for analytic Jacobians too (A/B measurements, grouped-vs-chunked parity test)
-    if (p->jacobian_mode != ESL_JAC_ANALYTIC || std::getenv("ESL_LM_UNFUSED")) {
-      int rc0 = lm_begin_enqueue(c, p, true);
-      if (rc0) return rc0;
-      return optimize_mapping_device(c, p, out);
-    }
-    if (!c->states_loaded) { set_error("esl_optimize_resident: upload graph and states first"); return ESL_ERR_STATE; }
-    ESL_HIP_TRY(hipSetDevice(c->device));
-    c->lm.p = *p;
-    c->lm.slam = false;
-    return optimize_mapping_grouped(c, p, out);
+    int rc0 = lm_begin_enqueue(c, p, true);
+    if (rc0) return rc0;
+    return optimize_mapping_device(c, p, out);
   }
   int32_t nv = 0, nd = 0;
   int rc = esl_lm_begin(c, p, &nv, &nd);

@@ -150,11 +150,6 @@ struct esl_ctx {
   double* blk_chi = nullptr;     // per-workgroup chi2 of the last linearisation
   unsigned int* tickets = nullptr;  // 2 arrival counters
   double* dev_scal = nullptr;    // {chi2_lin, max_diag}
-  // fused mapping-mode LM trial (esl_kernels_fused.hpp): work schedule built at upload, per-ellipsoid systems of the two
-  // state pairs, per-workgroup partials (ping-pong)
-  int fz_n_wg = 0;
-  int* fz_wave_start = nullptr; int* fz_items = nullptr; int* fz_wg_obj = nullptr; int* fz_slot_obj = nullptr;
-  double *sys_a = nullptr, *sys_b = nullptr, *fz_part = nullptr, *fz_sp = nullptr;
   // grow-only arenas behind esl_graph_upload (esl_capi.hip)
   char* arena_graph = nullptr; size_t arena_graph_cap = 0;
   char* arena_work = nullptr;  size_t arena_work_cap = 0;

@@ -846,6 +846,220 @@ static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable c
   }
 }
 
+__device__ __forceinline__ double lm_readlane(double v, int src) {   // src: compile-time constant after unrolling
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// (H + lambda I) x = b for one 9x9 block, ROW-PARALLEL: lane i (< 9) of the calling wave owns row i.  Right-looking LDL^T
+// without pivoting, pivots / rows broadcast with v_readlane; the triangular solves run on the same 9 lanes (the factor is
+// transposed once through LDS so that lane i also owns column i).  One lane with the whole matrix in registers
+// (ldlt_solve_packed, esl_math.hpp) needs ~250 VGPRs and a 400-deep dependent chain; this needs 9 + 9 doubles and ~100 steps.
+// hb: 45 packed upper + 9 rhs (LDS); tl: 81 doubles of LDS scratch of this wave; returns x[0..8] in every lane and
+// `ok` = all pivots positive (Eigen's LDLT::isPositive, solvers/linear_solver_dense.h:107-112).
+__device__ __forceinline__ bool lm_solve9_rows(const double* __restrict__ hb, double lambda, int lane, double* __restrict__ tl, double x[9]) {
+  const int i = lane < 9 ? lane : 8;   // lanes >= 9 shadow row 8
+  double a[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int r = i < j ? i : j, c = i < j ? j : i;
+    a[j] = hb[r * 9 - (r * (r - 1)) / 2 + (c - r)] + ((i == j) ? lambda : 0.0);
+  }
+  double y = hb[45 + i], d = 0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double dk = lm_readlane(a[k], k);
+    ok = ok && (dk > 0);
+    if (i == k) d = dk;
+    const double lik = a[k] * (1.0 / dk);
+#pragma unroll
+    for (int j = k + 1; j < 9; ++j) {
+      const double rkj = lm_readlane(a[j], k);
+      if (i > k) a[j] -= lik * rkj;
+    }
+    if (i > k) a[k] = lik;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {   // L y = b
+    const double yk = lm_readlane(y, k);
+    if (i > k) y -= a[k] * yk;
+  }
+  double z = y / d;                 // D z = y
+  if (lane < 9) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) tl[lane * 9 + j] = a[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  double c[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) c[j] = tl[j * 9 + i];   // c[j] = L[j][i]: column i of L
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 8; k >= 1; --k) {    // L^T x = z
+    const double xk = lm_readlane(z, k);
+    if (i < k) z -= c[k] * xk;
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) x[j] = lm_readlane(z, j);
+  return ok;
+}
+
+// k_lm_step with the per-ellipsoid part on a WAVE per ellipsoid (round 2).  k_lm_step gathered the chunk partials of 16
+// ellipsoids with all 256 threads ((ellipsoid, entry) pairs, 3.4 us of scattered loads) and then solved on 16 lanes with the
+// whole 9x9 system in registers (254 VGPRs, 3.9 us).  Here lane k < 54 of the wave adds entry k over the ellipsoid's chunks
+// (one coalesced 432-byte row per chunk, the rows of BOTH state pairs already in flight while the decision is taken), the
+// gravity prior is linearised uniformly by the wave, and the system is solved row-parallel on lanes 0..8 (lm_solve9_rows).
+constexpr int kStepWaves = 4;
+static __global__ __launch_bounds__(64 * kStepWaves) void k_lm_step_rows(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_a,
+                                                                          const double* __restrict__ chunk_b, double* __restrict__ objs_a,
+                                                                          double* __restrict__ objs_b, const LmCore* __restrict__ in,
+                                                                          LmCore* __restrict__ out, const double* __restrict__ blk_chi, int n_lin_blocks,
+                                                                          const double* __restrict__ sp_in, double* __restrict__ sp_out, int first,
+                                                                          int max_iters, int max_trials, LmHostView* __restrict__ host, int jac,
+                                                                          double delta, double* __restrict__ xo, const double* __restrict__ gathered,
+                                                                          int n_ranks, double tau) {
+  __shared__ double sm12[3 * kStepWaves];
+  __shared__ double hbs[kStepWaves][56];
+  __shared__ double tls[kStepWaves][81];
+  __shared__ double jgs[kStepWaves][12];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool writer = blockIdx.x == 0 && tid == 0;
+  const int o = blockIdx.x * kStepWaves + wave;
+  const bool own = o < g.n_objs;
+  // the first four chunk rows of this wave's ellipsoid from BOTH pairs: which one is current is only known after the decision
+  const int c0 = own ? ct.ostart[o] : 0, c1 = own ? ct.ostart[o + 1] : 0;
+  double va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
+  if (lane < 54) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (c0 + q < c1) { va[q] = chunk_a[(size_t)(c0 + q) * kChunkOut + lane]; vb[q] = chunk_b[(size_t)(c0 + q) * kChunkOut + lane]; }
+  }
+  // ... and its state from both pairs (one value per lane; broadcast after the decision)
+  double ea = 0, eb = 0;
+  int ngrav = 0;
+  if (own) {
+    if (lane < 10) { ea = objs_a[10 * (size_t)o + lane]; eb = objs_b[10 * (size_t)o + lane]; }
+    ngrav = g.gr_cnt[o];
+  }
+  double c = 0, sc = 0, okv = 1;
+  if (!first && n_ranks == 0) {
+#pragma unroll 8
+    for (int k = tid; k < n_lin_blocks; k += 64 * kStepWaves) c += blk_chi[k];
+    for (int b = tid; b < (int)gridDim.x; b += 64 * kStepWaves) { c += sp_in[b * 4 + 0]; sc += sp_in[b * 4 + 2]; okv = fmin(okv, sp_in[b * 4 + 3]); }
+  }
+  LmCore s;
+  if (first == 2) {
+    double chi = 0, md = 0, any = 0;
+    for (int r = 0; r < n_ranks; ++r) { chi += gathered[r * 8 + 0]; md = fmax(md, gathered[r * 8 + 1]); any = fmax(any, gathered[r * 8 + 5]); }
+    lm_core_init(s, chi, md, tau);
+    if (any < 0.5) {   // no rank has an active edge
+      s.done = 1; s.stop_reason = 3;
+      if (writer) {
+        host->core = s;
+        host->trace_len = 0;
+        __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  } else {
+    s = *in;
+  }
+  if (s.done) {   // queued behind a finished run: pass the state on and leave
+    if (writer) *out = s;
+    return;
+  }
+  if (!first) {
+    if (n_ranks > 0) {
+      for (int r = 0; r < n_ranks; ++r) { c += gathered[r * 8 + 2]; sc += gathered[r * 8 + 3]; okv = fmin(okv, gathered[r * 8 + 4]); }
+    } else {   // three block reductions behind one barrier pair
+      c = wave_sum(c); sc = wave_sum(sc); okv = -wave_max(-okv);
+      if (lane == 0) { sm12[wave] = c; sm12[kStepWaves + wave] = sc; sm12[2 * kStepWaves + wave] = okv; }
+      __syncthreads();
+      c = sm12[0]; sc = sm12[kStepWaves]; okv = sm12[2 * kStepWaves];
+#pragma unroll
+      for (int k = 1; k < kStepWaves; ++k) { c += sm12[k]; sc += sm12[kStepWaves + k]; okv = fmin(okv, sm12[2 * kStepWaves + k]); }
+    }
+    lm_decide(s, c, sc, okv, max_iters, max_trials, writer, host);
+    if (writer) {
+      if (s.done) {   // results first, then the flags with release semantics: the host reads them as soon as it sees `done`
+        host->core = s;
+        __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {        // progress counter only (it throttles the host's enqueueing): no system-scope release fence per trial
+        __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  if (writer) *out = s;
+  if (s.done) return;
+  const double* chunk_out = s.cur ? chunk_b : chunk_a;
+  double* objs_trial = s.cur ? objs_a : objs_b;
+  const double lambda = s.lambda;
+  double cg = 0, scale = 0, okd = 1;
+  if (own) {
+    const double ev = s.cur ? eb : ea;
+    double e10[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) e10[k] = lm_readlane(ev, k);
+    Ell e = ell_load(e10);
+    if (c0 < c1 || ngrav > 0) {   // an inactive vertex is never touched (sparse_optimizer.cpp:236-257)
+      const double wg = g.grav_w * ngrav;
+      if (ngrav > 0) {   // the gravity prior is a unary edge on this ellipsoid: linearised here (uniformly by the wave)
+        double Jg[9], rg;
+        if (jac == ESL_JAC_ANALYTIC) rg = jac_grav(e, g.grav_n, Jg);
+        else {
+          rg = res_grav(e, g.grav_n);
+          numeric_jac_obj(e, delta, 1, Jg, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) jgs[wave][k] = Jg[k];
+          jgs[wave][9] = rg;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane < 54) {
+        double v = 0;   // chunk order, as the serial sum
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v += s.cur ? vb[q] : va[q];
+        for (int ch = c0 + 4; ch < c1; ++ch) v += chunk_out[(size_t)ch * kChunkOut + lane];   // > 4 chunks: rare
+        if (ngrav > 0) {
+          const double* jg = jgs[wave];
+          if (lane < 45) v += (wg * jg[tri_a(lane)]) * jg[tri_c(lane)];
+          else v -= jg[lane - 45] * (wg * jg[9]);
+        }
+        hbs[wave][lane] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double* hb = hbs[wave];
+      double x[9];
+      const bool ok = lm_solve9_rows(hb, lambda, lane, tls[wave], x);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) scale += x[i] * (lambda * x[i] + hb[45 + i]);
+      if (lane < 9) {
+        double xl = x[0];
+#pragma unroll
+        for (int i = 1; i < 9; ++i) if (lane == i) xl = x[i];
+        xo[(size_t)o * 9 + lane] = xl;
+      }
+      okd = ok ? 1.0 : 0.0;
+      e = ell_oplus(e, x);
+      if (ngrav > 0) { const double rg = res_grav(e, g.grav_n); cg = wg * rg * rg; }   // chi2 of the gravity prior at the trial state
+    }
+    if (lane == 0) ell_store(e, objs_trial + 10 * (size_t)o);
+  }
+  // this workgroup's share of the trial scalars, ellipsoids in order
+  __syncthreads();
+  if (lane == 0) { sm12[wave] = cg; sm12[kStepWaves + wave] = scale; sm12[2 * kStepWaves + wave] = okd; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0, b = 0, m = 1;
+#pragma unroll
+    for (int k = 0; k < kStepWaves; ++k) { a += sm12[k]; b += sm12[kStepWaves + k]; m = fmin(m, sm12[2 * kStepWaves + k]); }
+    sp_out[blockIdx.x * 4 + 0] = a; sp_out[blockIdx.x * 4 + 1] = 0;
+    sp_out[blockIdx.x * 4 + 2] = b; sp_out[blockIdx.x * 4 + 3] = m;
+  }
+}
+
 // Sharded run: this rank's share of a trial's scalars -> dev_scal[2..4], the send buffer of the all-gather
 static __global__ __launch_bounds__(256) void k_lm_partials(const double* __restrict__ blk_chi, int n_lin_blocks,
                                                             const double* __restrict__ sp, int n_step_blocks,
