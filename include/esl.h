@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ESL_ABI_VERSION 1
+#define ESL_ABI_VERSION 2   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append */
 #define ESL_MAX_TRACE 32
 
 typedef enum {
@@ -97,9 +97,19 @@ typedef enum {
 } esl_jacobian_mode;
 
 typedef enum {
-  ESL_SOLVER_AUTO = 0,        /* all cameras fixed: batched 9x9 blocks; else Schur on ellipsoids + dense Cholesky */
-  ESL_SOLVER_DENSE_FULL = 1   /* one dense factorisation of the whole free system (what g2o LinearSolverDense does) */
+  ESL_SOLVER_AUTO = 0         /* all cameras fixed: 9x9 blocks per ellipsoid; else Schur complement on the ellipsoids + dense
+                               * FP64-MFMA Cholesky of the reduced camera system.  Mathematically the solve of g2o's
+                               * LinearSolverDense (one pivoted LDLT of the whole free system, solvers/linear_solver_dense.h:65-113);
+                               * that literal form exists only in the CPU checker (oracle/, ORACLE_DENSE), which the tests compare
+                               * against.  Any other value is rejected with ESL_ERR_INVALID. */
 } esl_linear_solver;
+
+typedef enum {
+  ESL_BBOX_REPROJECTION = 0,  /* r = bbox(Q*, P) - z, the reference's EdgeSE3EllipsoidProj (BasicEllipsoidEdges.cpp:90-112) */
+  ESL_BBOX_TANGENCY = 1       /* OPTIONAL EXTRA, off for parity: r_k = pi_k^T Q* pi_k for the four planes pi_k = P^T l_k through the
+                               * camera centre and the bbox lines (unit normals): the tangency constraint the reference only uses in
+                               * its SVD initialiser (Initializer.cpp:147-164, 271-284) as an edge; same weight, same < 5 px rule */
+} esl_bbox_residual;
 
 typedef struct {
   int32_t max_iters;        /* 10  (Optimizer.cpp:291) */
@@ -107,8 +117,9 @@ typedef struct {
   double tau;               /* 1e-5 (optimization_algorithm_levenberg.cpp:45) */
   int32_t jacobian_mode;    /* esl_jacobian_mode */
   double numeric_delta;     /* 1e-9 */
-  int32_t linear_solver;    /* esl_linear_solver */
+  int32_t linear_solver;    /* esl_linear_solver: must be ESL_SOLVER_AUTO */
   int32_t drop_nan_bbox;    /* 1: pre-evaluate bbox edges and drop those with NaN chi2 (Optimizer.cpp:234-243) */
+  int32_t bbox_residual;    /* esl_bbox_residual; 0 = the reference */
 } esl_lm_params;
 
 typedef struct {

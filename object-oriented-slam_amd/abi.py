@@ -35,7 +35,7 @@ class EslLmParams(C.Structure):
     _fields_ = [
         ("max_iters", C.c_int32), ("max_trials", C.c_int32), ("tau", C.c_double),
         ("jacobian_mode", C.c_int32), ("numeric_delta", C.c_double),
-        ("linear_solver", C.c_int32), ("drop_nan_bbox", C.c_int32),
+        ("linear_solver", C.c_int32), ("drop_nan_bbox", C.c_int32), ("bbox_residual", C.c_int32),
     ]
 
 
@@ -84,7 +84,7 @@ def default_lm_params(**kw):
     """Reference settings: optimize(10) (Optimizer.cpp:291), tau 1e-5, 10 trials
     (optimization_algorithm_levenberg.cpp:45-49), delta 1e-9 (base_binary_edge.hpp:147)."""
     p = EslLmParams(max_iters=10, max_trials=10, tau=1e-5, jacobian_mode=0, numeric_delta=1e-9,
-                    linear_solver=0, drop_nan_bbox=1)
+                    linear_solver=0, drop_nan_bbox=1, bbox_residual=0)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

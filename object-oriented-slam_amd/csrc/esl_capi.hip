@@ -165,6 +165,7 @@ void esl_lm_params_default(esl_lm_params* p) {
   p->numeric_delta = 1e-9;
   p->linear_solver = ESL_SOLVER_AUTO;
   p->drop_nan_bbox = 1;
+  p->bbox_residual = ESL_BBOX_REPROJECTION;
 }
 
 int esl_ctx_create(int device_id, esl_ctx** out) {
@@ -516,7 +517,17 @@ static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_obj
     ProfScope ps(c, 0);
     const dim3 block(64 * kLinWaves);
     int* cnt = c->chol_info + 2;
-    if (an) {   // both edge types in one launch, 3-D workgroups first
+    if (an && g.bbox_mode) {   // plane-tangency rows instead of the reprojection residual (never NaN: nothing to validate, but the
+                               // flags are (re)set to valid by the VALIDATE instantiation)
+      if (validate)
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, true, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+                           c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
+                           chunk_b, c->blk_chi, st, cnt);
+      else
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, false, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+                           c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
+                           chunk_b, c->blk_chi, st, cnt);
+    } else if (an) {   // both edge types in one launch, 3-D workgroups first
       if (validate)
         hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
                            c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
@@ -608,6 +619,7 @@ static int lm_begin_enqueue(esl_ctx* c, const esl_lm_params* p, bool validate_in
   if (!c->graph_loaded || !c->states_loaded) { set_error("esl_lm_begin: upload graph and states first"); return ESL_ERR_STATE; }
   ESL_HIP_TRY(hipSetDevice(c->device));
   c->lm.p = *p;
+  c->g.bbox_mode = p->bbox_residual == ESL_BBOX_TANGENCY ? 1 : 0;
   c->lm.slam = c->g.n_free_cams > 0;
   c->lm.have_trial = false;
   int* cnt = c->chol_info + 2;
@@ -849,6 +861,8 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
 
 int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
   if (!c || !p || !out) return ESL_ERR_INVALID;
+  if (p->linear_solver != ESL_SOLVER_AUTO) { set_error("esl_lm_params::linear_solver: only ESL_SOLVER_AUTO exists"); return ESL_ERR_INVALID; }
+  if (p->bbox_residual != ESL_BBOX_REPROJECTION && p->bbox_residual != ESL_BBOX_TANGENCY) { set_error("esl_lm_params::bbox_residual: unknown mode"); return ESL_ERR_INVALID; }
   std::memset(out, 0, sizeof(*out));
   if (c->graph_loaded && c->g.n_free_cams == 0) {   // mapping mode: the LM runs on the device, nothing waits on the host
     int rc0 = lm_begin_enqueue(c, p, true);

@@ -28,6 +28,7 @@ struct DevGraph {
   double K[4];
   double grav_n[3];
   double grav_w = 0;
+  int bbox_mode = 0;   // esl_lm_params::bbox_residual of the current run (0 reprojection, 1 plane tangency)
   YawTable yt;
   // per ellipsoid
   int* bb_start = nullptr;   // n_objs + 1

@@ -44,39 +44,6 @@ constexpr int kLinWaves = 4;
 // k_lm_step: ellipsoids per workgroup (one lane each in the solve phase) and the row stride of their H, b sums in LDS
 constexpr int kStepObjs = 16, kHbStride = 55;   // 16: the gather is 864 sums per workgroup = 3.4 per thread, all loads in flight
 
-// ---- reduce-scatter across the wave by recursive halving ------------------------------------------------
-// In: N values per lane.  Out: the wave-wide total of entry `idx` (returned) in the lanes whose low bits are 0.
-template <int N>
-struct WaveRS {
-  // cnt = number of REAL (non-padding) entries among the N this lane currently holds
-  static __device__ __forceinline__ double run(const double* v, int lane, int& idx, int& cnt, int off) {
-    constexpr int H = (N + 1) / 2;
-    const bool hi = (lane & off) != 0;
-    double nv[H];
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-      const double lo_v = v[i];
-      const double hi_v = (i + H < N) ? v[i + H] : 0.0;
-      const double send = hi ? lo_v : hi_v;
-      const double keep = hi ? hi_v : lo_v;
-      nv[i] = keep + __shfl_xor(send, off, 64);
-    }
-    if (hi) { idx += H; cnt -= H; }
-    else cnt = cnt < H ? cnt : H;
-    return WaveRS<H>::run(nv, lane, idx, cnt, off >> 1);
-  }
-};
-template <>
-struct WaveRS<1> {
-  static __device__ __forceinline__ double run(const double* v, int, int&, int&, int off) {
-    double s = v[0];
-    for (; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    return s;
-  }
-};
-// number of halving steps that distribute entries for N values (the remaining steps are plain adds)
-constexpr int rs_steps(int n) { return n <= 1 ? 0 : 1 + rs_steps((n + 1) / 2); }
-
 // packed upper-triangle index -> (a, c)
 __device__ __forceinline__ constexpr int tri_a(int p) {
   int a = 0, base = 0;
@@ -145,33 +112,9 @@ template <int G, int... T>
 __device__ __forceinline__ void fill_group_e3d(double* v, const double* Jp, const double* r, double w, std::integer_sequence<int, T...>) {
   ((v[T] = hb_entry_e3d<G * 18 + T>(Jp, r, w)), ...);
 }
-// half-wave version: `lane` is the lane inside the 32-lane segment; 18 -> 9 -> 5 -> 3 -> 2 -> 1 uses exactly the
-// five offsets 16..1, so every lane of the segment ends up owning (at most) one entry
-template <int G>
-__device__ __forceinline__ void reduce_group_e3d(const double* Jp, const double* r, double w, int lane, double* __restrict__ out,
-                                                 bool seg_on) {
-  double v[18];
-  fill_group_e3d<G>(v, Jp, r, w, std::make_integer_sequence<int, 18>{});
-  int idx = 0, cnt = 18;
-  const double tot = WaveRS<18>::run(v, lane, idx, cnt, 16);
-  if (seg_on && cnt >= 1) out[G * 18 + idx] = tot;
-}
-
-// entries [G*18, G*18+18) reduced over the wave; the owning lanes write the totals
-template <int D, int G>
-__device__ __forceinline__ void reduce_group(const double* J, const double* r, double w, int lane, double* __restrict__ out) {
-  double v[18];
-  fill_group<D, G>(v, J, r, w, std::make_integer_sequence<int, 18>{});
-  int idx = 0, cnt = 18;
-  const double tot = WaveRS<18>::run(v, lane, idx, cnt, 32);
-  constexpr int used = rs_steps(18);               // 5 distributing steps: offsets 32..2
-  const int low_mask = (64 >> used) - 1;           // remaining low bits (here: bit 0)
-  if ((lane & low_mask) == 0 && cnt >= 1) out[G * 18 + idx] = tot;   // cnt < 1: this lane ended on a padding slot
-}
-
-// ---- the same wave reductions through an LDS transpose -------------------------------------------------------------------
-// The reduce-scatter above costs 4 v_cndmask + 2 ds_bpermute + 1 add per exchange: 40 % of the analytic bbox kernel's issue
-// slots were selects and permutes.  Here every lane parks its 18 values in a wave-private LDS tile tr[18][65] (row =
+// ---- wave reductions through an LDS transpose -----------------------------------------------------------------------------
+// (A shuffle-based reduce-scatter -- recursive halving, 4 v_cndmask + 2 ds_bpermute + 1 add per exchange -- was tried first: 40 %
+// of the analytic bbox kernel's issue slots were selects and permutes.)  Every lane parks its 18 values in a wave-private LDS tile tr[18][65] (row =
 // entry, column = lane; the odd stride keeps the column sums conflict-free) and 54 lanes add up a third of a row each:
 // 18 ds_write + 22 ds_read + 22 adds per group instead of ~210 instructions.  LDS operations of one wave execute in order,
 // so no barrier is needed, only the compiler must not reorder across the hand-over.
@@ -225,7 +168,7 @@ __device__ __forceinline__ void reduce_group_e3d_lds(const double* Jp, const dou
 // VALIDATE (bbox only): this is the first linearisation of a run and doubles as the reference's NaN pre-check of the
 // bbox edges (Optimizer.cpp:234-243): an edge whose residual is NaN at the start state is marked invalid for the
 // whole run and counted in *n_dropped (same residual code as k_bbox_validate, which the synchronous API still uses).
-template <int JAC, int TYPE, bool VALIDATE = false>
+template <int JAC, int TYPE, bool VALIDATE = false, bool TANG = false>
 __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const ChunkTable& ct, const int* __restrict__ ids, int n_ids,
                                                      const double* __restrict__ cams, const double* __restrict__ objs, double delta,
                                                      double* __restrict__ chunk_out, double* __restrict__ wg_chi /* LDS, 8 slots */,
@@ -268,14 +211,16 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
       const SE3 T = se3_load(cams + 7 * g.bb_cam[i]);
       double meas[4] = {g.bb_meas[4 * i], g.bb_meas[4 * i + 1], g.bb_meas[4 * i + 2], g.bb_meas[4 * i + 3]};
       w = g.bb_w[i];
-      if (JAC == ESL_JAC_ANALYTIC) jac_bbox_t<true, false>(T, e, g.K, meas, r, J, nullptr);
-      else {
-        res_bbox(T, e, g.K, meas, r);
+      if (JAC == ESL_JAC_ANALYTIC) {
+        if (TANG) jac_tangency_t<true, false>(T, e, g.K, meas, r, J, nullptr);
+        else jac_bbox_t<true, false>(T, e, g.K, meas, r, J, nullptr);
+      } else {
+        res_box_edge(g.bbox_mode, T, e, g.K, meas, r);
         const double scalar = 1.0 / (2 * delta);
         for (int d = 0; d < 9; ++d) {   // not unrolled: one body, 9 trips
           double rp[4], rm[4];
-          res_bbox(T, ell_load(tr + 20 * d), g.K, meas, rp);
-          res_bbox(T, ell_load(tr + 20 * d + 10), g.K, meas, rm);
+          res_box_edge(g.bbox_mode, T, ell_load(tr + 20 * d), g.K, meas, rp);
+          res_box_edge(g.bbox_mode, T, ell_load(tr + 20 * d + 10), g.K, meas, rm);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -465,7 +410,7 @@ __device__ double block256_max(double v, double* sm) {
 // the rest the bbox chunks.  Launched back to back the two kernels ran 18 + 17.5 us at C4 although neither fills the
 // chip for long (3-D: ~0.7 waves per SIMD on a 4.8k-instruction stream; bbox: 3 waves per SIMD, 1.7k instructions);
 // together they take 27 us.
-template <int JAC, bool VALIDATE = false>
+template <int JAC, bool VALIDATE = false, bool TANG = false>
 static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize_both(DevGraph g, ChunkTable ct, const int* __restrict__ ids_e3, int n_e3,
                                                                      int nb_e3, const int* __restrict__ ids_bb, int n_bb,
                                                                      const double* __restrict__ cams,
@@ -483,7 +428,7 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize_both(
   }
   wg_chi_begin(wg_chi);
   if ((int)blockIdx.x < nb_e3) chunk_linearize_body<JAC, 1>(g, ct, ids_e3, n_e3, cams, objs, delta, chunk_out, wg_chi, tr_all, blockIdx.x);
-  else chunk_linearize_body<JAC, 0, VALIDATE>(g, ct, ids_bb, n_bb, cams, objs, delta, chunk_out, wg_chi, tr_all, blockIdx.x - nb_e3, n_dropped);
+  else chunk_linearize_body<JAC, 0, VALIDATE, TANG>(g, ct, ids_bb, n_bb, cams, objs, delta, chunk_out, wg_chi, tr_all, blockIdx.x - nb_e3, n_dropped);
   wg_chi_end(wg_chi, blk_chi, blockIdx.x);
 }
 template <int JAC, int TYPE, bool VALIDATE = false>
@@ -1099,7 +1044,7 @@ static __global__ __launch_bounds__(256) void k_chunk_chi2(DevGraph g, ChunkTabl
     if (TYPE == 0) {
       if (in && g.bb_valid[i]) {
         double r[4];
-        res_bbox(se3_load(cams + 7 * g.bb_cam[i]), e, g.K, g.bb_meas + 4 * i, r);
+        res_box_edge(g.bbox_mode, se3_load(cams + 7 * g.bb_cam[i]), e, g.K, g.bb_meas + 4 * i, r);
         chi = g.bb_w[i] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
       }
     } else if (in) {

@@ -66,7 +66,7 @@ static __global__ void k_bbox_validate(DevGraph g, const double* __restrict__ ca
   const SE3 T = se3_load(cams + 7 * g.bb_cam[i]);
   const Ell e = ell_load(objs + 10 * g.bb_obj[i]);
   double r[4];
-  res_bbox(T, e, g.K, g.bb_meas + 4 * i, r);
+  res_box_edge(g.bbox_mode, T, e, g.K, g.bb_meas + 4 * i, r);
   const double w = g.bb_w[i];
   const double c = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
   const bool bad = (c != c);
@@ -82,7 +82,7 @@ __device__ __forceinline__ double obj_chi2(const DevGraph& g, const double* __re
     if (!g.bb_valid[i]) continue;
     const SE3 T = se3_load(cams + 7 * g.bb_cam[i]);
     double r[4];
-    res_bbox(T, e, g.K, g.bb_meas + 4 * i, r);
+    res_box_edge(g.bbox_mode, T, e, g.K, g.bb_meas + 4 * i, r);
     chi += g.bb_w[i] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
   }
   for (int i = g.e3_start[o] + lane; i < g.e3_start[o + 1]; i += 64) {

@@ -96,11 +96,11 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_linearize
     const double w = g.bb_w[i];
     double r[4], Jo[36], Jc[24];
     if (JAC == ESL_JAC_ANALYTIC) {
-      jac_bbox(T, e, g.K, meas, r, Jo, cam_free ? Jc : nullptr);
+      jac_box_edge(g.bbox_mode, T, e, g.K, meas, r, Jo, cam_free ? Jc : nullptr);
     } else {
-      res_bbox(T, e, g.K, meas, r);
-      numeric_jac_obj(e, delta, 4, Jo, [&](const Ell& ep, double* out) { res_bbox(T, ep, g.K, meas, out); });
-      if (cam_free) numeric_jac_cam(T, delta, 4, Jc, [&](const SE3& Tp, double* out) { res_bbox(Tp, e, g.K, meas, out); });
+      res_box_edge(g.bbox_mode, T, e, g.K, meas, r);
+      numeric_jac_obj(e, delta, 4, Jo, [&](const Ell& ep, double* out) { res_box_edge(g.bbox_mode, T, ep, g.K, meas, out); });
+      if (cam_free) numeric_jac_cam(T, delta, 4, Jc, [&](const SE3& Tp, double* out) { res_box_edge(g.bbox_mode, Tp, e, g.K, meas, out); });
     }
     chi += w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
     accum_obj<4>(Jo, r, w, acc);

@@ -388,6 +388,72 @@ ESL_HD void jac_bbox_t(const SE3& Tcw, const Ell& e, const double K[4], const do
 #undef ESL_SYM5
 }
 
+// ------------------------------------------------------------------------------------------------
+// Plane-tangency residual (esl_lm_params::bbox_residual = ESL_BBOX_TANGENCY; NOT a reference edge type: the reference
+// uses the constraint pi^T Q* pi = 0 only in its SVD initialiser, src/core/Initializer.cpp:147-164, 271-284).
+// Row k of a bbox observation is the plane through the camera centre and the image line l_k (l_0: x = x1, l_1: y = y1,
+// l_2: x = x2, l_3: y = y2; Initializer.cpp:115-142), pi = P^T l with the normal scaled to unit length; the residual is
+// pi^T Q* pi, evaluated in the camera frame:  r_k = sum_j s_j^2 (Rco_j . n)^2 - (tco . n)^2  (m^2; 0 = tangent).
+// Entries whose measurement is < 5 are skipped like in the reprojection residual (BasicEllipsoidEdges.cpp:109).
+// ------------------------------------------------------------------------------------------------
+ESL_HD void tangency_normal(const double K[4], const double meas[4], int k, double n[3]) {
+  // K^T l_k : l = (1, 0, -x) for k even, (0, 1, -y) for k odd
+  if ((k & 1) == 0) { n[0] = K[0]; n[1] = 0; n[2] = K[2] - meas[k]; }
+  else { n[0] = 0; n[1] = K[1]; n[2] = K[3] - meas[k]; }
+  const double inv = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  n[0] *= inv; n[1] *= inv; n[2] *= inv;
+}
+template <bool WITH_JO, bool WITH_JC>
+ESL_HD void jac_tangency_t(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4], double* Jo, double* Jc) {
+  BoxGeom g;
+  box_geom(Tcw, e, K, g);   // g.n[j] = column j of R_co (j < 3), g.n[3] = t_co
+  (void)Jo; (void)Jc;
+  const double d[3] = {e.s[0] * e.s[0], e.s[1] * e.s[1], e.s[2] * e.s[2]};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool on = meas[k] >= 5;
+    double n[3];
+    tangency_normal(K, meas, k, n);
+    double m[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m[j] = g.n[j][0] * n[0] + g.n[j][1] * n[1] + g.n[j][2] * n[2];
+    const double q = g.n[3][0] * n[0] + g.n[3][1] * n[1] + g.n[3][2] * n[2];
+    r[k] = on ? d[0] * m[0] * m[0] + d[1] * m[1] * m[1] + d[2] * m[2] * m[2] - q * q : 0.0;
+    if constexpr (WITH_JO) {   // pose * exp([w, v]), s + ds
+      double* J = Jo + 9 * k;
+      J[0] = on ? 2 * m[1] * m[2] * (d[1] - d[2]) : 0.0;
+      J[1] = on ? 2 * m[0] * m[2] * (d[2] - d[0]) : 0.0;
+      J[2] = on ? 2 * m[0] * m[1] * (d[0] - d[1]) : 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { J[3 + j] = on ? -2 * q * m[j] : 0.0; J[6 + j] = on ? 2 * e.s[j] * m[j] * m[j] : 0.0; }
+    }
+    if constexpr (WITH_JC) {   // exp([w, v]) * Tcw
+      double* J = Jc + 6 * k;
+      double a[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double f = 2 * d[j] * m[j];
+        a[0] += f * (g.n[j][1] * n[2] - g.n[j][2] * n[1]);
+        a[1] += f * (g.n[j][2] * n[0] - g.n[j][0] * n[2]);
+        a[2] += f * (g.n[j][0] * n[1] - g.n[j][1] * n[0]);
+      }
+      a[0] -= 2 * q * (g.n[3][1] * n[2] - g.n[3][2] * n[1]);
+      a[1] -= 2 * q * (g.n[3][2] * n[0] - g.n[3][0] * n[2]);
+      a[2] -= 2 * q * (g.n[3][0] * n[1] - g.n[3][1] * n[0]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { J[j] = on ? a[j] : 0.0; J[3 + j] = on ? -2 * q * n[j] : 0.0; }
+    }
+  }
+}
+ESL_HD void res_tangency(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4]) {
+  jac_tangency_t<false, false>(Tcw, e, K, meas, r, nullptr, nullptr);
+}
+// the residual of a bbox observation in the mode the run asks for (0 = reprojection, the reference's edge; 1 = tangency)
+ESL_HD void res_box_edge(int mode, const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4]) {
+  if (mode) res_tangency(Tcw, e, K, meas, r);
+  else res_bbox(Tcw, e, K, meas, r);
+}
+
 // runtime-pointer front end (either Jacobian may be null)
 ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4],
                      double* Jo, double* Jc) {
@@ -395,6 +461,13 @@ ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
   else if (Jo) jac_bbox_t<true, false>(Tcw, e, K, meas, r, Jo, nullptr);
   else if (Jc) jac_bbox_t<false, true>(Tcw, e, K, meas, r, nullptr, Jc);
   else res_bbox(Tcw, e, K, meas, r);
+}
+ESL_HD void jac_box_edge(int mode, const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4], double* Jo, double* Jc) {
+  if (!mode) { jac_bbox(Tcw, e, K, meas, r, Jo, Jc); return; }
+  if (Jo && Jc) jac_tangency_t<true, true>(Tcw, e, K, meas, r, Jo, Jc);
+  else if (Jo) jac_tangency_t<true, false>(Tcw, e, K, meas, r, Jo, nullptr);
+  else if (Jc) jac_tangency_t<false, true>(Tcw, e, K, meas, r, nullptr, Jc);
+  else res_tangency(Tcw, e, K, meas, r);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -341,8 +341,36 @@ static void ell_min_log_error(ell self, ell newone, double res[9]) {
 /* ------------------------------------------------------------------------------------------------
  * residuals
  * ----------------------------------------------------------------------------------------------*/
+/* Plane-tangency rows (esl_lm_params::bbox_residual = 1; an optional extra of the product, NOT a reference edge): the
+ * constraint of Initializer.cpp:147-164, 271-284 written literally -- P = K [I|0] Tcw (3 x 4), the four bbox lines
+ * l (Initializer.cpp:115-142), planes pi = P^T l scaled to a unit normal, r_k = pi^T Q* pi with the 4 x 4 dual quadric. */
+static int g_bbox_residual = 0;
+void esl_oracle_set_bbox_residual(int mode) { g_bbox_residual = mode; }
+static void res_tangency(se3 Tcw, ell e, const double K[4], const double meas[4], double r[4]) {
+  double Q[16], Mc[16], P[12];
+  ell_quadric(e, Q);
+  se3_to_M(Tcw, Mc);
+  double Kf[9] = {K[0], 0, K[2], 0, K[1], K[3], 0, 0, 1};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += Kf[i * 3 + k] * Mc[k * 4 + j];
+      P[i * 4 + j] = s;
+    }
+  const double lines[4][3] = {{1, 0, -meas[0]}, {0, 1, -meas[1]}, {1, 0, -meas[2]}, {0, 1, -meas[3]}};
+  for (int k = 0; k < 4; ++k) {
+    double pi[4];
+    for (int j = 0; j < 4; ++j) pi[j] = P[j] * lines[k][0] + P[4 + j] * lines[k][1] + P[8 + j] * lines[k][2];
+    double nn = sqrt(pi[0] * pi[0] + pi[1] * pi[1] + pi[2] * pi[2]);
+    for (int j = 0; j < 4; ++j) pi[j] /= nn;
+    double v = 0;
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) v += pi[a] * Q[a * 4 + b] * pi[b];
+    r[k] = (meas[k] >= 5) ? v : 0.0;
+  }
+}
 /* EdgeSE3EllipsoidProj::computeError (BasicEllipsoidEdges.cpp:102-112) */
 static void res_bbox(se3 Tcw, ell e, const double K[4], const double meas[4], double r[4]) {
+  if (g_bbox_residual == 1) { res_tangency(Tcw, e, K, meas, r); return; }
   double proj[4];
   ell_project_bbox(e, Tcw, K, proj);
   for (int i = 0; i < 4; ++i) r[i] = (meas[i] >= 5) ? proj[i] - meas[i] : 0.0;
@@ -899,6 +927,7 @@ static int solve_schur(const ograph* G, const double* H, const double* b, double
 int esl_oracle_optimize(const esl_graph* g, double* cams_io, double* objs_io, const esl_lm_params* p,
                         int solver, esl_lm_report* out) {
   ograph G;
+  g_bbox_residual = p->bbox_residual;   /* stays set: esl_oracle_res_bbox / jac_bbox / build_system follow the last run's mode */
   ograph_build(&G, g, cams_io, objs_io, p->drop_nan_bbox);
   memset(out, 0, sizeof(*out));
   g_timing[0] = g_timing[1] = g_timing[2] = 0;

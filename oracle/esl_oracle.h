@@ -85,6 +85,10 @@ int esl_oracle_fit_frame_ex(const uint16_t* depth, int32_t width, int32_t height
                             const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
                             double* debug_out, double* sym_out);
 
+/* 0: the reference's reprojection residual (default); 1: plane-tangency rows (esl_lm_params::bbox_residual).  Applies to
+ * esl_oracle_res_bbox / jac_bbox / build_system; esl_oracle_optimize sets it from its params. */
+void esl_oracle_set_bbox_residual(int mode);
+
 /* timing helper for bench.py's cpu_baseline: seconds spent in linearise / solve / error evaluation
  * of the last esl_oracle_optimize call */
 void esl_oracle_last_timing(double t[3]);

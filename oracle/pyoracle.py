@@ -212,6 +212,10 @@ def fit_frame_ex(depth, bboxes, labels, Twc, intr, ground, params=None):
     return ell, prob, st, dbg, out
 
 
+def set_bbox_residual(mode):
+    lib().esl_oracle_set_bbox_residual(C.c_int(mode))
+
+
 def last_timing():
     t = (C.c_double * 3)()
     lib().esl_oracle_last_timing(t)
