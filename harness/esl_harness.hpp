@@ -17,8 +17,8 @@
 //   border filter                        src/utils/dataprocess_utils.cpp:150-190 (calibrateMeasurement)
 //   graph assembly                       adapter/OptimizerEsl.cpp (esl_adapter::Flatten = src/core/Optimizer.cpp:127-279)
 //   outputs                              src/core/System.cpp:75-91 (objects.txt), src/core/Optimizer.cpp:281-288 (graph summary)
-// Not restated: the viewer, the dense builder, automatic data association (the clip carries instance ids, rgbd.cpp:73 runs
-// withAssociation = true) and the PCL ground-plane extraction (src/plane/PlaneExtractor.cpp: the supporting plane is an
+//   data association                   src/core/DataAssociation.cpp:16-135 (used when the clip carries no instance ids)
+// Not restated: the viewer, the dense builder and the PCL ground-plane extraction (src/plane/PlaneExtractor.cpp: the supporting plane is an
 // input of the run until SURVEY.md §8 f-3 is built).
 #pragma once
 #include <dirent.h>
@@ -292,6 +292,55 @@ struct Observation3D { Ell* pObj; Frame* pFrame; };
 
 struct GraphInfo { int frame, objects, vertices, edges_2d, valid_2d, invalid_2d, edges_3d, gravity, lm_iterations; double chi2_initial, chi2_final; };
 
+// DataAssociationSolver (src/core/DataAssociation.cpp:16-135): only the 3-D mode exists.  Cost = distance between the centre
+// of a map ellipsoid and the centre of the frame's single-frame ellipsoid (moved to the world); rows are served in turn, each
+// takes its cheapest column if that is below 1 m and blocks it for the later rows, otherwise a new instance id is created.
+// As in the reference the value returned for a match is the COLUMN of the map ellipsoid in ascending-instance order.
+class DataAssociationSolver {
+ public:
+  std::vector<int> Solve(const Frame* f, const std::map<int, Ell*>& map_ells) {
+    const size_t n = f->mmObservations.size();
+    std::vector<int> assoc(n, 0), rows;
+    for (size_t i = 0; i < n; ++i) {
+      if (i < f->mpLocalObjects.size() && f->mpLocalObjects[i] != nullptr) rows.push_back((int)i);
+      else assoc[i] = -1;
+    }
+    if (rows.empty()) return assoc;
+    std::vector<std::vector<double>> cost;
+    for (int i : rows) {
+      Vec7 pose;
+      for (int k = 0; k < 7; ++k) pose[k] = f->mpLocalObjects[i]->v[k];
+      const Vec7 w = se3_mul(f->cam_pose_Twc.v, pose);   // transform_from(campose_wc)
+      std::vector<double> row;
+      for (const auto& kv : map_ells) {
+        const double dx = kv.second->v[0] - w[0], dy = kv.second->v[1] - w[1], dz = kv.second->v[2] - w[2];
+        row.push_back(std::sqrt(dx * dx + dy * dy + dz * dz));
+      }
+      cost.push_back(row);
+    }
+    const std::vector<int> m = SolveCostMat(cost);
+    for (size_t r = 0; r < rows.size(); ++r) assoc[rows[r]] = m[r];
+    return assoc;
+  }
+  std::vector<int> SolveCostMat(std::vector<std::vector<double>> cost) {
+    const double kDisThresh = 1.0;
+    std::vector<int> out(cost.size());
+    for (size_t i = 0; i < cost.size(); ++i) {
+      if (cost[i].empty()) { out[i] = next_instance_++; continue; }
+      size_t best = 0;
+      for (size_t c = 1; c < cost[i].size(); ++c) if (cost[i][c] < cost[i][best]) best = c;
+      if (cost[i][best] < kDisThresh) {
+        out[i] = (int)best;
+        for (auto& row : cost) row[best] = 999;
+      } else out[i] = next_instance_++;
+    }
+    return out;
+  }
+
+ private:
+  int next_instance_ = 0;
+};
+
 template <class Backend>
 class Tracker {
  public:
@@ -372,9 +421,10 @@ class Tracker {
         f->mpLocalObjects.push_back(extracted);
       }
     }
-    // 1.3 data association: the clip carries the instance id (GetMannualAssociation)
+    // 1.3 data association: the instance column of the clip (GetMannualAssociation) or the nearest-centre solver
     std::vector<int> assoc;
-    for (const Detection& d : f->mmObservations) assoc.push_back((int)std::lround(d.instance));
+    if (s_.with_association) for (const Detection& d : f->mmObservations) assoc.push_back((int)std::lround(d.instance));
+    else assoc = da_.Solve(f, map_);
     const std::vector<bool> key = CheckKeyObservations(f, assoc);
     // Update3DObservationDataAssociation
     if (s_.depth_ellipsoid)
@@ -482,6 +532,7 @@ class Tracker {
 
   Backend& be_;
   Settings s_;
+  DataAssociationSolver da_;
   double ground_[4] = {0, 0, 1, 0};
   bool ground_set_ = false;
   std::vector<Frame*> frames_;

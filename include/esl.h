@@ -89,6 +89,13 @@ typedef struct {
   const int32_t* odom_j;          /* vertex 1 */
   const double* odom_meas;        /* n_odom x 7 */
   const double* odom_info;        /* n_odom x 6 ; NULL = identity */
+
+  /* the optional visibility test of the bbox edges (checkVisibility, Optimizer.cpp:35-81; argument check_visibility of
+   * GlobalObjectGraphOptimization, false at the reference's only call site): an edge also needs the ellipsoid in front of its
+   * camera, the camera outside the ellipsoid and the projected centre or a corner of the projected box inside the image.
+   * Evaluated once at the start state together with the NaN test; failing edges count as dropped. */
+  int32_t check_visibility;       /* 0 = off (as shipped) */
+  int32_t image_rows, image_cols; /* Optimizer.h:20-23 rows, cols; only read when check_visibility != 0 */
 } esl_graph;
 
 typedef enum {

@@ -28,6 +28,7 @@ class EslGraph(C.Structure):
         ("grav_normal", C.c_double * 4), ("grav_weight", C.c_double),
         ("n_odom", C.c_int32), ("odom_i", c_int32_p), ("odom_j", c_int32_p),
         ("odom_meas", c_double_p), ("odom_info", c_double_p),
+        ("check_visibility", C.c_int32), ("image_rows", C.c_int32), ("image_cols", C.c_int32),
     ]
 
 
@@ -106,7 +107,7 @@ class Graph:
                  bbox_cam=(), bbox_obj=(), bbox_meas=(), bbox_weight=(),
                  e3d_cam=(), e3d_obj=(), e3d_meas=(), e3d_weight=(),
                  grav_obj=(), grav_normal=(0, 0, 1, 0), grav_weight=0.0,
-                 odom_i=(), odom_j=(), odom_meas=(), odom_info=None):
+                 odom_i=(), odom_j=(), odom_meas=(), odom_info=None, check_visibility=0, image_rows=480, image_cols=640):
         self.K = tuple(float(k) for k in K)
         self.n_cams, self.n_objs = int(n_cams), int(n_objs)
         self.cam_fixed = None if cam_fixed is None else _arr(cam_fixed, np.uint8)
@@ -119,6 +120,7 @@ class Graph:
         self.odom_i = _arr(odom_i, np.int32); self.odom_j = _arr(odom_j, np.int32)
         self.odom_meas = _arr(odom_meas, np.float64, (7,))
         self.odom_info = None if odom_info is None else _arr(odom_info, np.float64, (6,))
+        self.check_visibility, self.image_rows, self.image_cols = int(check_visibility), int(image_rows), int(image_cols)
         assert len(self.bbox_cam) == len(self.bbox_obj) == len(self.bbox_weight) == len(self.bbox_meas.reshape(-1, 4))
         assert len(self.e3d_cam) == len(self.e3d_obj) == len(self.e3d_weight) == len(self.e3d_meas.reshape(-1, 10))
         assert len(self.odom_i) == len(self.odom_j) == len(self.odom_meas.reshape(-1, 7))
@@ -144,6 +146,7 @@ class Graph:
         g.n_odom = len(self.odom_i)
         g.odom_i = self._p(self.odom_i, c_int32_p); g.odom_j = self._p(self.odom_j, c_int32_p)
         g.odom_meas = self._p(self.odom_meas, c_double_p); g.odom_info = self._p(self.odom_info, c_double_p)
+        g.check_visibility, g.image_rows, g.image_cols = self.check_visibility, self.image_rows, self.image_cols
         return g
 
     def subset_objects(self, keep):
@@ -161,4 +164,4 @@ class Graph:
                      self.e3d_cam[me], remap[self.e3d_obj[me]] if me.any() else (),
                      self.e3d_meas.reshape(-1, 10)[me], self.e3d_weight[me],
                      remap[self.grav_obj[mg]] if mg.any() else (), self.grav_normal, self.grav_weight,
-                     self.odom_i, self.odom_j, self.odom_meas, self.odom_info)
+                     self.odom_i, self.odom_j, self.odom_meas, self.odom_info, self.check_visibility, self.image_rows, self.image_cols)

@@ -323,6 +323,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   d.K[0] = g->fx; d.K[1] = g->fy; d.K[2] = g->cx; d.K[3] = g->cy;
   d.grav_n[0] = g->grav_normal[0]; d.grav_n[1] = g->grav_normal[1]; d.grav_n[2] = g->grav_normal[2];
   d.grav_w = g->grav_weight;
+  d.check_vis = g->check_visibility ? 1 : 0; d.img_rows = g->image_rows; d.img_cols = g->image_cols;
   {  // rotate_ellipsoid's yaw table (src/core/Ellipsoid.cpp:78, 100): yaw = k*pi/2, k = -1,0,1,2
     const double ang[4] = {-1, 0, 1, 2};
     double hs[4], hc[4];
@@ -623,13 +624,14 @@ static int lm_begin_enqueue(esl_ctx* c, const esl_lm_params* p, bool validate_in
   c->lm.slam = c->g.n_free_cams > 0;
   c->lm.have_trial = false;
   int* cnt = c->chol_info + 2;
-  if (validate_in_linearize && c->g.n_bbox && p->drop_nan_bbox) {   // counter is zero: context creation, k_chunk_finalize, or esl_lm_begin's read-back
+  const bool validate = p->drop_nan_bbox != 0 || c->g.check_vis != 0;   // the visibility test rides on the NaN pre-check's pass
+  if (validate_in_linearize && c->g.n_bbox && validate) {   // counter is zero: context creation, k_chunk_finalize, or esl_lm_begin's read-back
     c->lm.begun = true;
     return ESL_OK;
   }
   ESL_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), c->stream));
   if (c->g.n_bbox) {
-    if (p->drop_nan_bbox) {
+    if (validate) {
       hipLaunchKernelGGL(k_bbox_validate, dim3((c->g.n_bbox + 255) / 256), dim3(256), 0, c->stream, c->g, c->cams, c->objs, cnt);
       ESL_HIP_TRY(hipGetLastError());
     } else {
@@ -645,7 +647,7 @@ int esl_lm_begin(esl_ctx* c, const esl_lm_params* p, int32_t* n_valid, int32_t* 
   int rc = lm_begin_enqueue(c, p);
   if (rc) return rc;
   int dropped = 0;
-  if (c->g.n_bbox && p->drop_nan_bbox) {
+  if (c->g.n_bbox && (p->drop_nan_bbox || c->g.check_vis)) {
     ESL_HIP_TRY(hipMemcpyAsync(&dropped, c->chol_info + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // leave the counter at zero: a device-driven mapping run on this context counts into it without clearing it first
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info + 2, 0, sizeof(int), c->stream));
@@ -745,7 +747,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   __atomic_store_n(&hv->done, 0, __ATOMIC_RELEASE);
   // linearisation of the start state + chi2, max diag, LM state initialisation (computeLambdaInit) into core[0]
   c->prof_gate = false;
-  rc = map_launch_linearize(c, false, nullptr, nullptr, nullptr, g.n_bbox > 0 && p->drop_nan_bbox != 0);
+  rc = map_launch_linearize(c, false, nullptr, nullptr, nullptr, g.n_bbox > 0 && (p->drop_nan_bbox != 0 || g.check_vis != 0));
   c->prof_gate = true;
   if (rc) return rc;
   {

@@ -28,6 +28,7 @@ struct DevGraph {
   double K[4];
   double grav_n[3];
   double grav_w = 0;
+  int check_vis = 0, img_rows = 0, img_cols = 0;   // esl_graph::check_visibility / image_rows / image_cols
   int bbox_mode = 0;   // esl_lm_params::bbox_residual of the current run (0 reprojection, 1 plane tangency)
   YawTable yt;
   // per ellipsoid

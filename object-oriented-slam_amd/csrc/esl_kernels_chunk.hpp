@@ -230,7 +230,7 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
       }
       chi = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
       if (VALIDATE) {
-        const bool bad = (chi != chi);
+        const bool bad = (chi != chi) || (g.check_vis && !bbox_edge_visible(T, e, g.K, g.img_rows, g.img_cols));
         g.bb_valid[i] = bad ? 0 : 1;
         if (bad) {   // dropped: contributes nothing (its J / r may hold NaN)
           atomicAdd(n_dropped, 1);

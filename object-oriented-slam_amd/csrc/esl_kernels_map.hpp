@@ -69,7 +69,7 @@ static __global__ void k_bbox_validate(DevGraph g, const double* __restrict__ ca
   res_box_edge(g.bbox_mode, T, e, g.K, g.bb_meas + 4 * i, r);
   const double w = g.bb_w[i];
   const double c = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-  const bool bad = (c != c);
+  const bool bad = (c != c) || (g.check_vis && !bbox_edge_visible(T, e, g.K, g.img_rows, g.img_cols));
   g.bb_valid[i] = bad ? 0 : 1;
   if (bad) atomicAdd(n_dropped, 1);
 }

@@ -388,6 +388,35 @@ ESL_HD void jac_bbox_t(const SE3& Tcw, const Ell& e, const double K[4], const do
 #undef ESL_SYM5
 }
 
+// checkVisibility (src/core/Optimizer.cpp:35-81): ellipsoid centre in front of the camera, camera centre outside the
+// ellipsoid, and the projected centre -- or the top-left / bottom-right corner of the projected box -- inside the image
+ESL_HD bool bbox_edge_visible(const SE3& Tcw, const Ell& e, const double K[4], int rows, int cols) {
+  const Mat3 Rc = q_to_R(Tcw.r);
+  double pc[3];
+  m3_vec(Rc, e.pose.t, pc);
+  pc[0] += Tcw.t[0]; pc[1] += Tcw.t[1]; pc[2] += Tcw.t[2];
+  if (pc[2] < 0) return false;
+  // camera centre in the world: -Rc^T tc; in the object frame: Ro^T (X - to)
+  double xw[3], d[3], xo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) xw[k] = -(Rc.m[k] * Tcw.t[0] + Rc.m[3 + k] * Tcw.t[1] + Rc.m[6 + k] * Tcw.t[2]);
+  const Mat3 Ro = q_to_R(e.pose.r);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = xw[k] - e.pose.t[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) xo[k] = (Ro.m[k] * d[0] + Ro.m[3 + k] * d[1] + Ro.m[6 + k] * d[2]) / e.s[k];
+  if (xo[0] * xo[0] + xo[1] * xo[1] + xo[2] * xo[2] - 1.0 < 0) return false;
+  const double u = (K[0] * pc[0] + K[2] * pc[2]) / pc[2], v = (K[1] * pc[1] + K[3] * pc[2]) / pc[2];
+  if (u > 0 && u < cols && v > 0 && v < rows) return true;
+  BoxGeom g;
+  box_geom(Tcw, e, K, g);
+  double bb[4], sq[2];
+  box_from_conic(g, bb, sq);
+  if (bb[0] > 0 && bb[0] < cols && bb[1] > 0 && bb[1] < rows) return true;
+  if (bb[2] > 0 && bb[2] < cols && bb[3] > 0 && bb[3] < rows) return true;
+  return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Plane-tangency residual (esl_lm_params::bbox_residual = ESL_BBOX_TANGENCY; NOT a reference edge type: the reference
 // uses the constraint pi^T Q* pi = 0 only in its SVD initialiser, src/core/Initializer.cpp:147-164, 271-284).

@@ -375,6 +375,36 @@ static void res_bbox(se3 Tcw, ell e, const double K[4], const double meas[4], do
   ell_project_bbox(e, Tcw, K, proj);
   for (int i = 0; i < 4; ++i) r[i] = (meas[i] >= 5) ? proj[i] - meas[i] : 0.0;
 }
+/* checkVisibility (Optimizer.cpp:35-81), statement by statement */
+static int in_image(double u, double v, int rows, int cols) { return (u > 0 && u < cols) && (v > 0 && v < rows); }
+static int check_visibility(se3 Tcw, ell e, const double K[4], int rows, int cols) {
+  double Mc[16], Q[16];
+  se3_to_M(Tcw, Mc);
+  double ch[4] = {e.pose.t[0], e.pose.t[1], e.pose.t[2], 1.0}, pc[4];
+  for (int i = 0; i < 4; ++i) { pc[i] = 0; for (int k = 0; k < 4; ++k) pc[i] += Mc[i * 4 + k] * ch[k]; }
+  if (pc[2] < 0) return 0;                                  /* behind the camera */
+  se3 Twc = se3_inv(Tcw);
+  double X[4] = {Twc.t[0], Twc.t[1], Twc.t[2], 1.0};
+  ell_quadric(e, Q);
+  /* point_in_Q = X^T (Q*)^-1 X: solve Q* y = X by Gaussian elimination with partial pivoting */
+  double A[4][5];
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) A[i][j] = Q[i * 4 + j]; A[i][4] = X[i]; }
+  for (int c = 0; c < 4; ++c) {
+    int p = c;
+    for (int r2 = c + 1; r2 < 4; ++r2) if (fabs(A[r2][c]) > fabs(A[p][c])) p = r2;
+    for (int k = 0; k < 5; ++k) { double t = A[c][k]; A[c][k] = A[p][k]; A[p][k] = t; }
+    for (int r2 = 0; r2 < 4; ++r2) if (r2 != c) { double f = A[r2][c] / A[c][c]; for (int k = 0; k < 5; ++k) A[r2][k] -= f * A[c][k]; }
+  }
+  double piq = 0;
+  for (int i = 0; i < 4; ++i) piq += X[i] * (A[i][4] / A[i][i]);
+  if (piq < 0) return 0;                                    /* the camera centre is inside the ellipsoid */
+  double u = (K[0] * pc[0] + K[2] * pc[2]) / pc[2], v = (K[1] * pc[1] + K[3] * pc[2]) / pc[2];
+  if (in_image(u, v, rows, cols)) return 1;
+  double bb[4];
+  ell_project_bbox(e, Tcw, K, bb);
+  if (in_image(bb[0], bb[1], rows, cols) || in_image(bb[2], bb[3], rows, cols)) return 1;
+  return 0;
+}
 /* EdgeSE3Ellipsoid9DOF::computeError (BasicEllipsoidEdges.cpp:68-77) */
 static void res_e3d(se3 Tcw, ell e, ell meas, double r[9]) {
   se3 Twc = se3_inv(Tcw);
@@ -696,10 +726,11 @@ static int ograph_build(ograph* G, const esl_graph* g, const double* cams, const
       oedge tmp; memset(&tmp, 0, sizeof(tmp));
       tmp.type = 0; tmp.src = i; tmp.v0 = g->bbox_cam[i]; tmp.v1 = F + o; tmp.D = 4;
       for (int k = 0; k < 4; ++k) tmp.w[k] = g->bbox_weight[i];
-      if (drop_nan) { /* NaN check at graph build (Optimizer.cpp:234-243) */
+      if (drop_nan || g->check_visibility) { /* NaN check at graph build (Optimizer.cpp:234-243) + optional visibility test (:35-81) */
         res_bbox(G->cams[tmp.v0], G->objs[o], K, &g->bbox_meas[4 * i], tmp.r);
         double c = oedge_chi2(&tmp);
         if (isnan(c)) { G->n_dropped++; continue; }
+        if (g->check_visibility && !check_visibility(G->cams[tmp.v0], G->objs[o], K, g->image_rows, g->image_cols)) { G->n_dropped++; continue; }
       }
       G->edges[ne++] = tmp;
     }

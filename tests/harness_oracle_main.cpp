@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     if (a == "--ground" && i + 4 < argc) { for (int k = 0; k < 4; ++k) ground[k] = std::atof(argv[i + 1 + k]); i += 4; }
     else if (a == "--delta" && i + 1 < argc) be.lm.numeric_delta = std::atof(argv[++i]);
     else if (a == "--no-symmetry") s.symmetry = false;
+    else if (a == "--auto-association") s.with_association = false;
     else if (a == "--sym-iters" && i + 1 < argc) s.fit.symmetry_lm_iters = std::atoi(argv[++i]);
     else if (a == "--jacobian" && i + 1 < argc) ++i;   // the checker only has g2o's numeric scheme
     else return 1;

@@ -136,3 +136,40 @@ def test_cabinet_clip_end_to_end_on_gpu(oracle_exe, clip_dir, tmp_path):
         rel = np.linalg.norm(o_g[0, 1:] - o_ref9[0, 1:]) / np.linalg.norm(o_ref9[0, 1:])
         print("cabinet clip, GPU %s vs checker (reference settings): relative difference of the final ellipsoid %.2e" % (extra or ["numeric"], rel))
         assert rel < 1e-4
+
+
+def test_data_association_solver(tmp_path):
+    """DataAssociationSolver (src/core/DataAssociation.cpp:16-135) on hand-made ellipsoids: nearest centre below 1 m wins and is
+    blocked for later rows, anything else opens a new instance, rows without a single-frame ellipsoid get -1."""
+    src = os.path.join(str(tmp_path), "da_probe.cpp")
+    open(src, "w").write('''#include "%s/harness/esl_harness.hpp"
+using namespace esl_harness;
+int main() {
+  DataAssociationSolver da;
+  Frame f; f.cam_pose_Twc.v = {1, 0, 0, 0, 0, 0, 1};                 // camera at x = 1, no rotation
+  std::map<int, Ell*> map;
+  auto ell = [](double x, double y, double z) { Ell* e = new Ell(); e->v = {x, y, z, 0, 0, 0, 1, .1, .1, .1}; return e; };
+  f.mmObservations.resize(4);
+  f.mpLocalObjects = {ell(0, 0, 2), nullptr, ell(0.2, 0, 2), ell(5, 5, 5)};   // camera frame
+  std::vector<int> a = da.Solve(&f, map);                            // empty map: every valid row opens an instance
+  std::printf("%%d %%d %%d %%d\\n", a[0], a[1], a[2], a[3]);
+  map[0] = ell(1.05, 0, 2); map[1] = ell(1.2, 0, 2.1); map[2] = ell(9, 9, 9);
+  a = da.Solve(&f, map);                                             // row 0 -> column 0 (0.05 m), row 2 -> column 1, row 3 -> new (3)
+  std::printf("%%d %%d %%d %%d\\n", a[0], a[1], a[2], a[3]);
+  map.erase(1);
+  a = da.Solve(&f, map);                                             // row 0 takes column 0; row 2 finds it blocked -> new instance
+  std::printf("%%d %%d %%d %%d\\n", a[0], a[1], a[2], a[3]);
+}
+''' % ROOT)
+    exe = os.path.join(str(tmp_path), "da_probe")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-lz", "-o", exe])
+    out = subprocess.check_output([exe]).decode().split("\n")
+    assert out[0] == "0 -1 1 2" and out[1] == "0 -1 1 3" and out[2] == "0 -1 4 5"
+
+
+def test_cabinet_clip_with_automatic_association(oracle_exe, clip_dir, tmp_path):
+    """the clip without its instance column: one object throughout (every single-frame ellipsoid lands within 1 m of it)"""
+    txt, objs, log, hist = run(oracle_exe, clip_dir, str(tmp_path / "auto"), "--auto-association")
+    assert "objects 1" in txt and len(log) == 58
+    R = np.load(GOLD_RUN)
+    np.testing.assert_allclose(objs, R["ref_objects"], rtol=0, atol=1e-9)
