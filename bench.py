@@ -274,37 +274,68 @@ def slam_bench(pkg, ctx, with_cpu=True):
 
 def streaming_bench(pkg, ctx, n_frames=120):
     """BASELINE.json configs[4]: streaming RGB-D at 30 fps, 20 boxes per frame: per frame = single-frame fit of the
-    20 boxes + re-optimisation of the whole accumulated graph (the reference rebuilds and re-optimises the full
-    graph every frame, Optimizer.cpp:127,166,250).  Reports sustained ms/frame."""
+    20 boxes + re-optimisation of the whole accumulated graph.  Two ways of keeping the graph: "rebuild" = what the
+    reference does every frame (Optimizer.cpp:127,166,250: every vertex and edge again; here: sort + pack + one H2D of the
+    whole graph), "append" = esl_graph_append (the frame's edges into the slack of the device-resident arrays).  Reports
+    sustained ms/frame of both; `ms_per_frame` is the append path."""
     sc = pkg.synth.make_depth_scene(n_objs=20, seed=7, spread=1.6, size=(0.1, 0.3))
     P = pkg.lib.default_fit_params()
     g, c, o, _ = pkg.synth.make_graph(n_frames, 20, 20 * n_frames, seed=3)
     params = pkg.default_lm_params(jacobian_mode=1)
-    order_b = np.argsort(g.bbox_cam, kind="stable"); order_e = np.argsort(g.e3d_cam, kind="stable")
-    t_fit = t_opt = 0.0
-    n_edges = 0
-    objs = o.copy()
-    ctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], P)  # warm-up
-    t0 = time.perf_counter()
+    meas, e3m = g.bbox_meas.reshape(-1, 4), g.e3d_meas.reshape(-1, 10)
+    # per-frame edge sets, prepared outside the timed loops (the tracker would hand them over as they arrive)
+    full, delta = [], []
+    cnt_prev = np.zeros(g.n_objs, int)
     for f in range(n_frames):
-        ta = time.perf_counter()
-        ctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], P)
-        tb = time.perf_counter()
-        mb = g.bbox_cam <= f; me = g.e3d_cam <= f
+        mb = g.bbox_cam <= f
         cnt = np.bincount(g.bbox_obj[mb], minlength=g.n_objs)
-        mb &= cnt[g.bbox_obj] > 2                      # 2-D edges only for objects with > 2 observations (Optimizer.cpp:201)
-        gf = pkg.Graph(g.K, f + 1, g.n_objs, None, g.bbox_cam[mb], g.bbox_obj[mb], g.bbox_meas.reshape(-1, 4)[mb], g.bbox_weight[mb],
-                       g.e3d_cam[me], g.e3d_obj[me], g.e3d_meas.reshape(-1, 10)[me], g.e3d_weight[me], g.grav_obj, g.grav_normal,
-                       g.grav_weight)
-        _, objs, rep = ctx.optimize(gf, c[:f + 1], objs, params)
-        tc = time.perf_counter()
-        t_fit += tb - ta; t_opt += tc - tb
-        n_edges = int(mb.sum() + me.sum())
-    dt = time.perf_counter() - t0
-    return {"frames": n_frames, "boxes_per_frame": 20, "ms_per_frame": 1e3 * dt / n_frames, "fps": n_frames / dt,
-            "fit_ms_per_frame": 1e3 * t_fit / n_frames, "reoptimize_ms_per_frame": 1e3 * t_opt / n_frames,
-            "final_graph_edges": n_edges,
-            "note": "host-call times incl. PCIe (depth upload, full graph re-upload every frame); the fit replays a captured hipGraph, the LM loop is device-driven (no host in the loop, nothing to capture)"}
+        mbf = mb & (cnt[g.bbox_obj] > 2)                  # 2-D edges only for objects with > 2 observations (Optimizer.cpp:201)
+        me = g.e3d_cam <= f
+        full.append((mbf, me))
+        new = mbf & ((g.bbox_cam == f) | (cnt_prev[g.bbox_obj] <= 2))
+        delta.append((new, g.e3d_cam == f))
+        cnt_prev = cnt
+    out = {"frames": n_frames, "boxes_per_frame": 20}
+    ctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], P)  # warm-up
+    for mode in ("rebuild", "append"):
+        t_fit = t_opt = 0.0
+        objs = o.copy()
+        its = 0
+        t0 = time.perf_counter()
+        for f in range(n_frames):
+            ta = time.perf_counter()
+            ctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], P)
+            tb = time.perf_counter()
+            if mode == "rebuild" or f == 0:
+                mb, me = full[f]
+                gf = pkg.Graph(g.K, f + 1, g.n_objs, None, g.bbox_cam[mb], g.bbox_obj[mb], meas[mb], g.bbox_weight[mb],
+                               g.e3d_cam[me], g.e3d_obj[me], e3m[me], g.e3d_weight[me], g.grav_obj, g.grav_normal, g.grav_weight)
+                if mode == "rebuild":
+                    _, objs, rep = ctx.optimize(gf, c[:f + 1], objs, params)
+                else:
+                    ctx.upload_graph(gf); ctx.upload_states(c[:1], objs)
+                    rep = ctx.optimize_resident(params)
+            else:
+                mb, me = delta[f]
+                ctx.append_graph(new_cams=c[f:f + 1], bbox=(g.bbox_cam[mb], g.bbox_obj[mb], meas[mb], g.bbox_weight[mb]),
+                                 e3d=(g.e3d_cam[me], g.e3d_obj[me], e3m[me], g.e3d_weight[me]))
+                rep = ctx.optimize_resident(params)
+            if mode == "append":
+                _, objs = ctx.download_states()       # the tracker reads the ellipsoids back every frame
+            its += rep["iterations"]
+            tc = time.perf_counter()
+            t_fit += tb - ta; t_opt += tc - tb
+        dt = time.perf_counter() - t0
+        out[mode] = {"ms_per_frame": 1e3 * dt / n_frames, "fps": n_frames / dt, "fit_ms_per_frame": 1e3 * t_fit / n_frames,
+                     "reoptimize_ms_per_frame": 1e3 * t_opt / n_frames, "lm_iterations_per_frame": its / n_frames}
+        if mode == "append":
+            out[mode]["relayouts"] = ctx.graph_sizes()["relayouts"]
+    out["ms_per_frame"] = out["append"]["ms_per_frame"]
+    out["fps"] = out["append"]["fps"]
+    out["final_graph_edges"] = int(full[-1][0].sum() + full[-1][1].sum())
+    out["note"] = ("host-call times incl. PCIe (depth upload every frame; rebuild: the whole graph every frame, append: the frame's edges); "
+                   "the fit replays a captured hipGraph, the LM loop is device-driven (no host in the loop, nothing to capture)")
+    return out
 
 
 def main():

@@ -177,6 +177,26 @@ int esl_optimize_resident(esl_ctx* ctx, const esl_lm_params* p, esl_lm_report* o
 int esl_states_snapshot(esl_ctx* ctx);
 int esl_states_restore(esl_ctx* ctx);
 
+/* ---- streaming: extend the device-resident graph instead of rebuilding it (BASELINE configs[4]) --------------------------
+ * The reference rebuilds every g2o vertex and edge for every frame (Optimizer.cpp:127, 166, 250).  esl_graph_append adds the
+ * observations of a new frame to the graph that is already in HBM: new cameras get the indices n_cams.., new ellipsoids
+ * n_objs.. (their states are given; the states of the existing vertices -- e.g. the ellipsoids the previous frame's run
+ * optimised -- stay where they are), edge indices refer to the extended numbering.  The result is indistinguishable from
+ * esl_graph_upload of the concatenated graph (edges of an ellipsoid keep their arrival order).  Edges are stored sorted by
+ * ellipsoid with slack behind every ellipsoid's slice: an append writes the new edges into free slots (one staged copy + two
+ * small launches, independent of the size of the graph) and re-lays the arrays out, with doubled slack, only when a slice or an
+ * array is full.  Mapping-mode graphs only (all cameras fixed, no odometry edges: the shipped setting). */
+typedef struct {
+  int32_t n_new_cams; const double* new_cams;   /* n_new_cams x 7 (Tcw) */
+  int32_t n_new_objs; const double* new_objs;   /* n_new_objs x 10 */
+  int32_t n_bbox; const int32_t* bbox_cam; const int32_t* bbox_obj; const double* bbox_meas; const double* bbox_weight;
+  int32_t n_e3d; const int32_t* e3d_cam; const int32_t* e3d_obj; const double* e3d_meas; const double* e3d_weight;
+  int32_t n_grav; const int32_t* grav_obj;      /* gravity priors on (new or old) ellipsoids */
+} esl_graph_delta;
+int esl_graph_append(esl_ctx* ctx, const esl_graph_delta* d);
+/* sizes of the resident graph (after uploads / appends) */
+int esl_graph_sizes(esl_ctx* ctx, int32_t* n_cams, int32_t* n_objs, int32_t* n_bbox, int32_t* n_e3d, int32_t* relayouts);
+
 /* per-kernel timing with HIP events recorded on the context's own stream.
  * kernel ids: 0 linearise, 1 LM trial (solve + retract + chi2), 2 reduced-system build (Schur),
  *             3 dense Cholesky + solves, 4 reductions / misc, 6 RCCL all-reduce of the reduced system (sharded SLAM).

@@ -32,6 +32,16 @@ class EslGraph(C.Structure):
     ]
 
 
+class EslGraphDelta(C.Structure):
+    """esl_graph_delta: what one new frame adds to the resident graph (esl_graph_append)."""
+    _fields_ = [
+        ("n_new_cams", C.c_int32), ("new_cams", c_double_p), ("n_new_objs", C.c_int32), ("new_objs", c_double_p),
+        ("n_bbox", C.c_int32), ("bbox_cam", c_int32_p), ("bbox_obj", c_int32_p), ("bbox_meas", c_double_p), ("bbox_weight", c_double_p),
+        ("n_e3d", C.c_int32), ("e3d_cam", c_int32_p), ("e3d_obj", c_int32_p), ("e3d_meas", c_double_p), ("e3d_weight", c_double_p),
+        ("n_grav", C.c_int32), ("grav_obj", c_int32_p),
+    ]
+
+
 class EslLmParams(C.Structure):
     _fields_ = [
         ("max_iters", C.c_int32), ("max_trials", C.c_int32), ("tau", C.c_double),

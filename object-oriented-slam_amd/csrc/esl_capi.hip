@@ -206,8 +206,10 @@ int esl_ctx_create(int device_id, esl_ctx** out) {
   return ESL_OK;
 }
 
+static void image_release(esl_ctx* c);
 static void free_graph(esl_ctx* c) {
   DevGraph& g = c->g;
+  image_release(c);   // the appendable host image describes the graph that goes away
   (void)hipStreamSynchronize(c->stream);   // nothing may still read the arenas that are about to be rewritten
   forget(&g.bb_start); forget(&g.e3_start); forget(&g.gr_cnt);
   forget(&g.bb_cam); forget(&g.bb_obj); forget(&g.bb_meas); forget(&g.bb_w); forget(&g.bb_valid);
@@ -242,6 +244,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (c->arena_graph) (void)hipFree(c->arena_graph);
   if (c->arena_work) (void)hipFree(c->arena_work);
   if (c->stage_host) (void)hipHostFree(c->stage_host);
+  if (c->append_dev) (void)hipFree(c->append_dev);
   fit_release(c);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->host_part) (void)hipHostFree(c->host_part);
@@ -320,6 +323,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   UploadStage up(c);
   WorkStage wk;
   d.n_cams = g->n_cams; d.n_objs = g->n_objs; d.n_bbox = g->n_bbox; d.n_e3d = g->n_e3d; d.n_odom = g->n_odom;
+  d.n_bbox_edges = g->n_bbox;
   d.K[0] = g->fx; d.K[1] = g->fy; d.K[2] = g->cx; d.K[3] = g->cy;
   d.grav_n[0] = g->grav_normal[0]; d.grav_n[1] = g->grav_normal[1]; d.grav_n[2] = g->grav_normal[2];
   d.grav_w = g->grav_weight;
@@ -464,6 +468,332 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   }
   ESL_HIP_TRY(hipStreamSynchronize(st));
   c->graph_loaded = true;
+  return ESL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// esl_graph_append: the appendable layout (mapping mode).  HostImage is the exact host copy of the device arrays: edges
+// sorted by ellipsoid, every ellipsoid owning a slice [begin, begin + cap) of which cnt entries are used.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct HostImage {
+  bool appendable = false;          // the device arrays have this image's capacities
+  int n_cams = 0, n_objs = 0, cap_cams = 0, cap_objs = 0, n_grav = 0, relayouts = 0;
+  size_t cap_bb = 0, cap_e3 = 0, used_bb = 0, used_e3 = 0;
+  std::vector<int> bb_begin, bb_cnt, bb_cap, e3_begin, e3_cnt, e3_cap, gr_cnt;
+  std::vector<int> bb_cam, bb_obj, e3_cam, e3_obj;
+  std::vector<double> bb_meas, bb_w, e3_meas, e3_w;
+};
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// chunk table of an image: per ellipsoid its bbox chunks (<= 64 edges) then its 3-D chunks (<= 32), as esl_graph_upload
+void image_chunks(const HostImage& im, std::vector<int>& co, std::vector<int>& cty, std::vector<int>& cb, std::vector<int>& ce,
+                  std::vector<int>& cos, std::vector<int>& ib, std::vector<int>& ie) {
+  co.clear(); cty.clear(); cb.clear(); ce.clear(); ib.clear(); ie.clear();
+  cos.assign((size_t)im.n_objs + 1, 0);
+  for (int o = 0; o < im.n_objs; ++o) {
+    cos[o] = (int)co.size();
+    const int b0 = im.bb_begin[o], b1 = b0 + im.bb_cnt[o], e0 = im.e3_begin[o], e1 = e0 + im.e3_cnt[o];
+    for (int b = b0; b < b1; b += 64) { ib.push_back((int)co.size()); co.push_back(o); cty.push_back(0); cb.push_back(b); ce.push_back(std::min(b + 64, b1)); }
+    for (int b = e0; b < e1; b += 32) { ie.push_back((int)co.size()); co.push_back(o); cty.push_back(1); cb.push_back(b); ce.push_back(std::min(b + 32, e1)); }
+  }
+  cos[im.n_objs] = (int)co.size();
+}
+}  // namespace
+
+static void image_release(esl_ctx* c) {
+  delete (HostImage*)c->append_img;
+  c->append_img = nullptr;
+}
+
+// the image of the graph that is resident now (compact layout of esl_graph_upload), read back from the device
+static int image_from_device(esl_ctx* c, HostImage& im) {
+  const DevGraph& g = c->g;
+  const int N = g.n_objs;
+  im = HostImage();
+  im.n_cams = g.n_cams; im.n_objs = N; im.n_grav = c->n_grav_edges;
+  std::vector<int> bs((size_t)N + 1), es((size_t)N + 1);
+  im.gr_cnt.assign((size_t)N, 0);
+  im.bb_cam.resize(g.n_bbox); im.bb_obj.resize(g.n_bbox); im.bb_meas.resize((size_t)g.n_bbox * 4); im.bb_w.resize(g.n_bbox);
+  im.e3_cam.resize(g.n_e3d); im.e3_obj.resize(g.n_e3d); im.e3_meas.resize((size_t)g.n_e3d * 10); im.e3_w.resize(g.n_e3d);
+  auto dl = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (bytes) ESL_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return ESL_OK;
+  };
+  int rc;
+  if ((rc = dl(bs.data(), g.bb_start, bs.size() * 4)) || (rc = dl(es.data(), g.e3_start, es.size() * 4)) || (rc = dl(im.gr_cnt.data(), g.gr_cnt, (size_t)N * 4)) ||
+      (rc = dl(im.bb_cam.data(), g.bb_cam, (size_t)g.n_bbox * 4)) || (rc = dl(im.bb_obj.data(), g.bb_obj, (size_t)g.n_bbox * 4)) ||
+      (rc = dl(im.bb_meas.data(), g.bb_meas, (size_t)g.n_bbox * 32)) || (rc = dl(im.bb_w.data(), g.bb_w, (size_t)g.n_bbox * 8)) ||
+      (rc = dl(im.e3_cam.data(), g.e3_cam, (size_t)g.n_e3d * 4)) || (rc = dl(im.e3_obj.data(), g.e3_obj, (size_t)g.n_e3d * 4)) ||
+      (rc = dl(im.e3_meas.data(), g.e3_meas, (size_t)g.n_e3d * 80)) || (rc = dl(im.e3_w.data(), g.e3_w, (size_t)g.n_e3d * 8)))
+    return rc;
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  im.bb_begin.assign(bs.begin(), bs.end() - 1); im.e3_begin.assign(es.begin(), es.end() - 1);
+  im.bb_cnt.resize(N); im.e3_cnt.resize(N);
+  for (int o = 0; o < N; ++o) { im.bb_cnt[o] = bs[o + 1] - bs[o]; im.e3_cnt[o] = es[o + 1] - es[o]; }
+  im.bb_cap = im.bb_cnt; im.e3_cap = im.e3_cnt;
+  im.used_bb = im.cap_bb = (size_t)g.n_bbox; im.used_e3 = im.cap_e3 = (size_t)g.n_e3d;
+  im.cap_cams = im.n_cams; im.cap_objs = N;
+  return ESL_OK;
+}
+
+// a fresh image with slack: every slice doubled (+ 64 / 32), arrays and vertex counts with room for as much again
+static void image_relayout(const HostImage& old, HostImage& im, const std::vector<int>& add_bb, const std::vector<int>& add_e3, int n_cams, int n_objs) {
+  im = HostImage();
+  im.appendable = true;
+  im.relayouts = old.relayouts + 1;
+  im.n_cams = n_cams; im.n_objs = n_objs; im.n_grav = old.n_grav;
+  im.cap_cams = n_cams * 2 + 64; im.cap_objs = n_objs * 2 + 16;
+  im.bb_begin.resize(n_objs); im.bb_cnt.assign(n_objs, 0); im.bb_cap.resize(n_objs);
+  im.e3_begin.resize(n_objs); im.e3_cnt.assign(n_objs, 0); im.e3_cap.resize(n_objs);
+  im.gr_cnt.assign(n_objs, 0);
+  size_t pb = 0, pe = 0;
+  for (int o = 0; o < n_objs; ++o) {
+    const int cb = (o < old.n_objs ? old.bb_cnt[o] : 0) + add_bb[o], ce = (o < old.n_objs ? old.e3_cnt[o] : 0) + add_e3[o];
+    im.bb_begin[o] = (int)pb; im.bb_cap[o] = (int)round_up((size_t)2 * cb + 64, 64); pb += im.bb_cap[o];
+    im.e3_begin[o] = (int)pe; im.e3_cap[o] = (int)round_up((size_t)2 * ce + 32, 32); pe += im.e3_cap[o];
+    if (o < old.n_objs) im.gr_cnt[o] = old.gr_cnt[o];
+  }
+  im.used_bb = pb; im.used_e3 = pe;
+  im.cap_bb = pb + pb / 2 + 64 * 64; im.cap_e3 = pe + pe / 2 + 32 * 64;     // room for ellipsoids that do not exist yet
+  im.bb_cam.assign(im.cap_bb, 0); im.bb_obj.assign(im.cap_bb, -1); im.bb_meas.assign(im.cap_bb * 4, 0.0); im.bb_w.assign(im.cap_bb, 0.0);
+  im.e3_cam.assign(im.cap_e3, 0); im.e3_obj.assign(im.cap_e3, -1); im.e3_meas.assign(im.cap_e3 * 10, 0.0); im.e3_w.assign(im.cap_e3, 0.0);
+  for (int o = 0; o < old.n_objs; ++o) {
+    for (int k = 0; k < old.bb_cnt[o]; ++k) {
+      const size_t s0 = (size_t)old.bb_begin[o] + k, s1 = (size_t)im.bb_begin[o] + k;
+      im.bb_cam[s1] = old.bb_cam[s0]; im.bb_obj[s1] = old.bb_obj[s0]; im.bb_w[s1] = old.bb_w[s0];
+      for (int q = 0; q < 4; ++q) im.bb_meas[s1 * 4 + q] = old.bb_meas[s0 * 4 + q];
+    }
+    im.bb_cnt[o] = old.bb_cnt[o];
+    for (int k = 0; k < old.e3_cnt[o]; ++k) {
+      const size_t s0 = (size_t)old.e3_begin[o] + k, s1 = (size_t)im.e3_begin[o] + k;
+      im.e3_cam[s1] = old.e3_cam[s0]; im.e3_obj[s1] = old.e3_obj[s0]; im.e3_w[s1] = old.e3_w[s0];
+      for (int q = 0; q < 10; ++q) im.e3_meas[s1 * 10 + q] = old.e3_meas[s0 * 10 + q];
+    }
+    im.e3_cnt[o] = old.e3_cnt[o];
+  }
+}
+
+// the whole image to the device (capacities included) + the states; replaces what esl_graph_upload laid out
+static int image_upload(esl_ctx* c, const HostImage& im, const double* cams, const double* objs, const double K[4], const double grav_n[3], double grav_w,
+                        const YawTable& yt, int check_vis, int rows, int cols) {
+  free_graph(c);
+  DevGraph& d = c->g;
+  UploadStage up(c);
+  WorkStage wk;
+  d = DevGraph();
+  d.n_cams = im.n_cams; d.n_objs = im.n_objs; d.n_bbox = (int)im.used_bb; d.n_e3d = (int)im.used_e3; d.n_odom = 0;
+  int nb = 0;
+  for (int o = 0; o < im.n_objs; ++o) nb += im.bb_cnt[o];
+  d.n_bbox_edges = nb;
+  for (int k = 0; k < 4; ++k) d.K[k] = K[k];
+  for (int k = 0; k < 3; ++k) d.grav_n[k] = grav_n[k];
+  d.grav_w = grav_w; d.yt = yt; d.check_vis = check_vis; d.img_rows = rows; d.img_cols = cols;
+  const size_t cN = (size_t)im.cap_objs, cF = (size_t)im.cap_cams;
+  std::vector<int> start((size_t)im.cap_objs + 1, 0), gr((size_t)im.cap_objs, 0);
+  for (int o = 0; o < im.n_objs; ++o) { start[o] = im.bb_begin[o]; gr[o] = im.gr_cnt[o]; }
+  up.add(&d.bb_start, start.data(), start.size());
+  for (int o = 0; o < im.n_objs; ++o) start[o] = im.e3_begin[o];
+  up.add(&d.e3_start, start.data(), start.size());
+  up.add(&d.gr_cnt, gr.data(), gr.size());
+  up.add(&d.bb_cam, im.bb_cam.data(), im.cap_bb); up.add(&d.bb_obj, im.bb_obj.data(), im.cap_bb);
+  up.add(&d.bb_meas, im.bb_meas.data(), im.cap_bb * 4); up.add(&d.bb_w, im.bb_w.data(), im.cap_bb);
+  std::vector<unsigned char> valid(im.cap_bb, 1);
+  up.add(&d.bb_valid, valid.data(), valid.size());
+  up.add(&d.e3_cam, im.e3_cam.data(), im.cap_e3); up.add(&d.e3_obj, im.e3_obj.data(), im.cap_e3);
+  up.add(&d.e3_meas, im.e3_meas.data(), im.cap_e3 * 10); up.add(&d.e3_w, im.e3_w.data(), im.cap_e3);
+  std::vector<int> co, cty, cb, ce, cos, ib, ie;
+  image_chunks(im, co, cty, cb, ce, cos, ib, ie);
+  const size_t cap_chunks = im.cap_bb / 64 + im.cap_e3 / 32 + 2 * cN + 2;
+  c->n_chunks = (int)co.size(); c->n_ids_bb = (int)ib.size(); c->n_ids_e3 = (int)ie.size();
+  auto padded = [&](std::vector<int> v, size_t n) { v.resize(n, 0); return v; };
+  { auto v = padded(co, cap_chunks); up.add(&c->ck_obj, v.data(), v.size()); }
+  { auto v = padded(cty, cap_chunks); up.add(&c->ck_type, v.data(), v.size()); }
+  { auto v = padded(cb, cap_chunks); up.add(&c->ck_begin, v.data(), v.size()); }
+  { auto v = padded(ce, cap_chunks); up.add(&c->ck_end, v.data(), v.size()); }
+  { auto v = padded(cos, cN + 1); up.add(&c->ck_ostart, v.data(), v.size()); }
+  { auto v = padded(ib, cap_chunks); up.add(&c->ck_ids_bb, v.data(), v.size()); }
+  { auto v = padded(ie, cap_chunks); up.add(&c->ck_ids_e3, v.data(), v.size()); }
+  std::vector<unsigned char> fixed(cF, 1);
+  std::vector<int> slot(cF, -1), one(2, 0);
+  up.add(&d.cam_fixed, fixed.data(), fixed.size());
+  up.add(&d.cam_slot, slot.data(), slot.size());
+  d.n_free_cams = 0;
+  c->h_cam_slot.assign(cF, -1); c->h_bb_cam.clear(); c->h_bb_obj.clear(); c->h_e3_cam.clear(); c->h_e3_obj.clear();
+  const double dz[8] = {0};
+  up.add(&d.od_i, one.data(), 1); up.add(&d.od_j, one.data(), 1); up.add(&d.od_meas, dz, 7); up.add(&d.od_info, dz, 6);
+  up.add(&d.cbb_start, one.data(), 2); up.add(&d.cbb_edge, one.data(), 1); up.add(&d.ce3_start, one.data(), 2); up.add(&d.ce3_edge, one.data(), 1);
+  up.add(&d.cod_start, one.data(), 2); up.add(&d.cod_edge, one.data(), 1);
+  wk.add(&c->chunk_out, cap_chunks * kChunkOut); wk.add(&c->chunk_out2, cap_chunks * kChunkOut);
+  wk.add(&c->chunk_chi, cap_chunks);
+  wk.add(&c->blk_part, (size_t)((cN + 255) / 256 + 1) * 2);
+  wk.add(&c->solve_part, (size_t)((cN + kStepWaves - 1) / kStepWaves + (cN + 63) / 64 + 2) * 4 * 2);
+  wk.add(&c->blk_chi, cap_chunks + 2);
+  wk.add(&c->cams, cF * 7); wk.add(&c->cams_trial, cF * 7);
+  wk.add(&c->objs, cN * 10); wk.add(&c->objs_trial, cN * 10);
+  wk.add(&c->Hoo, cN * 45); wk.add(&c->bo, cN * 9); wk.add(&c->xo, cN * 9); wk.add(&c->obj_part, cN * 4);
+  int rc;
+  if ((rc = up.commit())) return rc;
+  if ((rc = wk.commit(c))) return rc;
+  ESL_HIP_TRY(hipMemsetAsync(c->obj_part, 0, std::max<size_t>(cN, 1) * 4 * sizeof(double), c->stream));
+  if (im.n_cams) ESL_HIP_TRY(hipMemcpyAsync(c->cams, cams, (size_t)im.n_cams * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (im.n_objs) ESL_HIP_TRY(hipMemcpyAsync(c->objs, objs, (size_t)im.n_objs * 10 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n_grav_edges = im.n_grav;
+  c->graph_loaded = true; c->states_loaded = true; c->cams_match_snap = false; c->lm.begun = false;
+  return ESL_OK;
+}
+
+int esl_graph_sizes(esl_ctx* c, int32_t* n_cams, int32_t* n_objs, int32_t* n_bbox, int32_t* n_e3d, int32_t* relayouts) {
+  if (!c || !c->graph_loaded) return ESL_ERR_STATE;
+  const HostImage* im = (const HostImage*)c->append_img;
+  int ne = c->g.n_e3d;
+  if (im) { ne = 0; for (int o = 0; o < im->n_objs; ++o) ne += im->e3_cnt[o]; }
+  if (n_cams) *n_cams = c->g.n_cams;
+  if (n_objs) *n_objs = c->g.n_objs;
+  if (n_bbox) *n_bbox = c->g.n_bbox_edges;
+  if (n_e3d) *n_e3d = ne;
+  if (relayouts) *relayouts = im ? im->relayouts : 0;
+  return ESL_OK;
+}
+
+int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
+  if (!c || !dl) return ESL_ERR_INVALID;
+  if (!c->graph_loaded || !c->states_loaded) { set_error("esl_graph_append: upload a graph and its states first"); return ESL_ERR_STATE; }
+  if (c->g.n_free_cams > 0 || c->g.n_odom > 0 || c->comm) { set_error("esl_graph_append: mapping-mode graphs on one GPU only (all cameras fixed, no odometry)"); return ESL_ERR_STATE; }
+  if (dl->n_new_cams < 0 || dl->n_new_objs < 0 || dl->n_bbox < 0 || dl->n_e3d < 0 || dl->n_grav < 0 || (dl->n_new_cams && !dl->new_cams) ||
+      (dl->n_new_objs && !dl->new_objs) || (dl->n_bbox && (!dl->bbox_cam || !dl->bbox_obj || !dl->bbox_meas || !dl->bbox_weight)) ||
+      (dl->n_e3d && (!dl->e3d_cam || !dl->e3d_obj || !dl->e3d_meas || !dl->e3d_weight)) || (dl->n_grav && !dl->grav_obj)) {
+    set_error("esl_graph_delta: null array or negative size");
+    return ESL_ERR_INVALID;
+  }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if (!c->append_img) {
+    HostImage* im0 = new HostImage();
+    if ((rc = image_from_device(c, *im0))) { delete im0; return rc; }
+    c->append_img = im0;
+  }
+  HostImage& im = *(HostImage*)c->append_img;
+  const int F = im.n_cams + dl->n_new_cams, N = im.n_objs + dl->n_new_objs;
+  for (int i = 0; i < dl->n_bbox; ++i)
+    if (dl->bbox_cam[i] < 0 || dl->bbox_cam[i] >= F || dl->bbox_obj[i] < 0 || dl->bbox_obj[i] >= N) { set_error("esl_graph_delta: bbox edge index out of range"); return ESL_ERR_INVALID; }
+  for (int i = 0; i < dl->n_e3d; ++i)
+    if (dl->e3d_cam[i] < 0 || dl->e3d_cam[i] >= F || dl->e3d_obj[i] < 0 || dl->e3d_obj[i] >= N) { set_error("esl_graph_delta: 3-D edge index out of range"); return ESL_ERR_INVALID; }
+  for (int i = 0; i < dl->n_grav; ++i)
+    if (dl->grav_obj[i] < 0 || dl->grav_obj[i] >= N) { set_error("esl_graph_delta: gravity edge index out of range"); return ESL_ERR_INVALID; }
+  std::vector<int> add_bb((size_t)N, 0), add_e3((size_t)N, 0), add_gr((size_t)N, 0);
+  for (int i = 0; i < dl->n_bbox; ++i) add_bb[dl->bbox_obj[i]]++;
+  for (int i = 0; i < dl->n_e3d; ++i) add_e3[dl->e3d_obj[i]]++;
+  for (int i = 0; i < dl->n_grav; ++i) add_gr[dl->grav_obj[i]]++;
+  for (int o = 0; o < N; ++o)
+    if ((o < im.n_objs ? im.gr_cnt[o] : 0) + add_gr[o] > 64) { set_error("more than 64 gravity edges on one ellipsoid"); return ESL_ERR_INVALID; }
+  // does everything fit the slack of the resident layout?
+  bool fits = im.appendable && F <= im.cap_cams && N <= im.cap_objs;
+  size_t ub = im.used_bb, ue = im.used_e3;
+  if (fits) {
+    for (int o = 0; o < im.n_objs && fits; ++o) fits = im.bb_cnt[o] + add_bb[o] <= im.bb_cap[o] && im.e3_cnt[o] + add_e3[o] <= im.e3_cap[o];
+    for (int o = im.n_objs; o < N; ++o) { ub += round_up((size_t)2 * add_bb[o] + 64, 64); ue += round_up((size_t)2 * add_e3[o] + 32, 32); }
+    fits = fits && ub <= im.cap_bb && ue <= im.cap_e3;
+  }
+  const DevGraph gd = c->g;   // K, gravity, yaw table, visibility settings survive a re-layout
+  std::vector<AppendBb> rb;
+  std::vector<AppendE3> re;
+  auto place = [&](HostImage& I, bool record) {   // the new edges into the free slots of I (arrival order inside an ellipsoid)
+    for (int i = 0; i < dl->n_bbox; ++i) {
+      const int o = dl->bbox_obj[i];
+      const size_t s = (size_t)I.bb_begin[o] + I.bb_cnt[o]++;
+      I.bb_cam[s] = dl->bbox_cam[i]; I.bb_obj[s] = o; I.bb_w[s] = dl->bbox_weight[i];
+      for (int q = 0; q < 4; ++q) I.bb_meas[s * 4 + q] = dl->bbox_meas[(size_t)i * 4 + q];
+      if (record) {
+        AppendBb r{(int)s, dl->bbox_cam[i], o, 0, {0, 0, 0, 0}, dl->bbox_weight[i]};
+        for (int q = 0; q < 4; ++q) r.meas[q] = dl->bbox_meas[(size_t)i * 4 + q];
+        rb.push_back(r);
+      }
+    }
+    for (int i = 0; i < dl->n_e3d; ++i) {
+      const int o = dl->e3d_obj[i];
+      const size_t s = (size_t)I.e3_begin[o] + I.e3_cnt[o]++;
+      I.e3_cam[s] = dl->e3d_cam[i]; I.e3_obj[s] = o; I.e3_w[s] = dl->e3d_weight[i];
+      for (int q = 0; q < 10; ++q) I.e3_meas[s * 10 + q] = dl->e3d_meas[(size_t)i * 10 + q];
+      if (record) {
+        AppendE3 r{(int)s, dl->e3d_cam[i], o, 0, {0}, dl->e3d_weight[i]};
+        for (int q = 0; q < 10; ++q) r.meas[q] = dl->e3d_meas[(size_t)i * 10 + q];
+        re.push_back(r);
+      }
+    }
+    for (int o = 0; o < N; ++o) I.gr_cnt[o] += add_gr[o];
+    I.n_grav += dl->n_grav;
+  };
+  if (!fits) {
+    // full re-layout with doubled slack: the states that live on the device come back first
+    std::vector<double> cams((size_t)F * 7), objs((size_t)N * 10);
+    if (im.n_cams) ESL_HIP_TRY(hipMemcpyAsync(cams.data(), c->cams, (size_t)im.n_cams * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (im.n_objs) ESL_HIP_TRY(hipMemcpyAsync(objs.data(), c->objs, (size_t)im.n_objs * 10 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < (size_t)dl->n_new_cams * 7; ++k) cams[(size_t)im.n_cams * 7 + k] = dl->new_cams[k];
+    for (size_t k = 0; k < (size_t)dl->n_new_objs * 10; ++k) objs[(size_t)im.n_objs * 10 + k] = dl->new_objs[k];
+    HostImage* ni = new HostImage();
+    image_relayout(im, *ni, add_bb, add_e3, F, N);
+    place(*ni, false);
+    c->append_img = nullptr;   // free_graph (inside image_upload) must not drop the image under construction
+    rc = image_upload(c, *ni, cams.data(), objs.data(), gd.K, gd.grav_n, gd.grav_w, gd.yt, gd.check_vis, gd.img_rows, gd.img_cols);
+    delete &im;
+    if (rc) { delete ni; return rc; }
+    c->append_img = ni;
+    dev_free(&c->cams_snap); dev_free(&c->objs_snap);
+    return ESL_OK;
+  }
+  // incremental: slices of the new ellipsoids at the end of the arrays, edges into free slots, tables rebuilt on the host
+  im.bb_begin.resize(N); im.bb_cnt.resize(N, 0); im.bb_cap.resize(N); im.e3_begin.resize(N); im.e3_cnt.resize(N, 0); im.e3_cap.resize(N);
+  im.gr_cnt.resize(N, 0);
+  for (int o = im.n_objs; o < N; ++o) {
+    im.bb_begin[o] = (int)im.used_bb; im.bb_cap[o] = (int)round_up((size_t)2 * add_bb[o] + 64, 64); im.used_bb += im.bb_cap[o];
+    im.e3_begin[o] = (int)im.used_e3; im.e3_cap[o] = (int)round_up((size_t)2 * add_e3[o] + 32, 32); im.used_e3 += im.e3_cap[o];
+  }
+  const int F0 = im.n_cams, N0 = im.n_objs;
+  im.n_cams = F; im.n_objs = N;
+  place(im, true);
+  std::vector<int> co, cty, cb, ce, cos, ib, ie, bbs((size_t)N + 1, 0), e3s((size_t)N + 1, 0);
+  image_chunks(im, co, cty, cb, ce, cos, ib, ie);
+  for (int o = 0; o < N; ++o) { bbs[o] = im.bb_begin[o]; e3s[o] = im.e3_begin[o]; }
+  // one staged blob: tables | bbox records | 3-D records
+  UploadStage st(c);   // (re)uses the context's pinned staging block; `fixes` is not used here
+  struct Part { size_t off, bytes; };
+  auto put = [&](const void* src, size_t bytes) {
+    const size_t off = align_up(st.used, 256);
+    if (!st.reserve(off + std::max<size_t>(bytes, 8))) return Part{0, 0};
+    if (bytes) std::memcpy(c->stage_host + off, src, bytes);
+    st.used = off + std::max<size_t>(bytes, 8);
+    return Part{off, bytes};
+  };
+  const Part p_co = put(co.data(), co.size() * 4), p_ty = put(cty.data(), cty.size() * 4), p_cb = put(cb.data(), cb.size() * 4), p_ce = put(ce.data(), ce.size() * 4),
+             p_os = put(cos.data(), cos.size() * 4), p_ib = put(ib.data(), ib.size() * 4), p_ie = put(ie.data(), ie.size() * 4),
+             p_gr = put(im.gr_cnt.data(), im.gr_cnt.size() * 4), p_bs = put(bbs.data(), bbs.size() * 4), p_es = put(e3s.data(), e3s.size() * 4),
+             p_rb = put(rb.data(), rb.size() * sizeof(AppendBb)), p_re = put(re.data(), re.size() * sizeof(AppendE3));
+  if (st.err) return st.err;
+  if ((rc = arena_reserve(&c->append_dev, &c->append_dev_cap, st.used))) return rc;
+  ESL_HIP_TRY(hipMemcpyAsync(c->append_dev, c->stage_host, st.used, hipMemcpyHostToDevice, c->stream));
+  DevGraph& g = c->g;
+  g.n_cams = F; g.n_objs = N; g.n_bbox = (int)im.used_bb; g.n_e3d = (int)im.used_e3; g.n_bbox_edges += dl->n_bbox;
+  c->n_chunks = (int)co.size(); c->n_ids_bb = (int)ib.size(); c->n_ids_e3 = (int)ie.size();
+  c->n_grav_edges = im.n_grav;
+  AppendCopies cp{};
+  auto tab = [&](const Part& p, int* dst) { cp.src[cp.n] = (const int*)(c->append_dev + p.off); cp.dst[cp.n] = dst; cp.count[cp.n] = (int)(p.bytes / 4); ++cp.n; };
+  tab(p_co, c->ck_obj); tab(p_ty, c->ck_type); tab(p_cb, c->ck_begin); tab(p_ce, c->ck_end); tab(p_os, c->ck_ostart); tab(p_ib, c->ck_ids_bb);
+  tab(p_ie, c->ck_ids_e3); tab(p_gr, g.gr_cnt); tab(p_bs, g.bb_start); tab(p_es, g.e3_start);
+  hipLaunchKernelGGL(k_append_tables, dim3(16), dim3(256), 0, c->stream, cp);
+  const int n_rec = (int)(rb.size() + re.size());
+  if (n_rec)
+    hipLaunchKernelGGL(k_append_scatter, dim3((n_rec + 127) / 128), dim3(128), 0, c->stream, g, (const AppendBb*)(c->append_dev + p_rb.off), (int)rb.size(),
+                       (const AppendE3*)(c->append_dev + p_re.off), (int)re.size());
+  ESL_HIP_TRY(hipGetLastError());
+  if (dl->n_new_cams) ESL_HIP_TRY(hipMemcpyAsync(c->cams + (size_t)F0 * 7, dl->new_cams, (size_t)dl->n_new_cams * 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (dl->n_new_objs) ESL_HIP_TRY(hipMemcpyAsync(c->objs + (size_t)N0 * 10, dl->new_objs, (size_t)dl->n_new_objs * 10 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's buffers and the staging block are free again
+  dev_free(&c->cams_snap); dev_free(&c->objs_snap);
+  c->cams_match_snap = false;
+  c->lm.begun = false;
   return ESL_OK;
 }
 
@@ -653,7 +983,7 @@ int esl_lm_begin(esl_ctx* c, const esl_lm_params* p, int32_t* n_valid, int32_t* 
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info + 2, 0, sizeof(int), c->stream));
     ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   }
-  if (n_valid) *n_valid = c->g.n_bbox - dropped;
+  if (n_valid) *n_valid = c->g.n_bbox_edges - dropped;
   if (n_dropped) *n_dropped = dropped;
   return ESL_OK;
 }
@@ -764,7 +1094,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
     const LmScalars* h = (const LmScalars*)c->host_scal;
     out->chi2_initial = out->chi2_final = h->chi2_lin;
     out->n_bbox_dropped = hv->n_dropped;
-    out->n_bbox_valid = g.n_bbox - hv->n_dropped;
+    out->n_bbox_valid = g.n_bbox_edges - hv->n_dropped;
     if (hv->done) out->stop_reason = hv->core.stop_reason;
     return ESL_OK;
   }
@@ -841,7 +1171,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   }
   const LmCore& r = hv->core;
   out->n_bbox_dropped = hv->n_dropped;
-  out->n_bbox_valid = g.n_bbox - hv->n_dropped;
+  out->n_bbox_valid = g.n_bbox_edges - hv->n_dropped;
   if (r.cur) {   // the current estimate (and its system, for the inspection API) live in the second pair
     std::swap(c->objs, c->objs_trial);
     std::swap(c->chunk_out, c->chunk_out2);

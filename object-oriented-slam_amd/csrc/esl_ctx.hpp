@@ -24,7 +24,8 @@ void set_error(const std::string& s);
 // Device-resident graph: edges sorted by ellipsoid (CSR), camera-side CSR for the SLAM-mode gather.
 struct DevGraph {
   int n_cams = 0, n_objs = 0;
-  int n_bbox = 0, n_e3d = 0, n_odom = 0;
+  int n_bbox = 0, n_e3d = 0, n_odom = 0;   // extents of the edge arrays (appendable layout: including the slack behind the slices)
+  int n_bbox_edges = 0;                    // bbox edges that exist (= n_bbox unless the layout has slack)
   double K[4];
   double grav_n[3];
   double grav_w = 0;
@@ -152,6 +153,8 @@ struct esl_ctx {
   double* blk_chi = nullptr;     // per-workgroup chi2 of the last linearisation
   unsigned int* tickets = nullptr;  // 2 arrival counters
   double* dev_scal = nullptr;    // {chi2_lin, max_diag}
+  void* append_img = nullptr;    // host image of the appendable layout (esl_graph_append, esl_capi.hip)
+  char* append_dev = nullptr; size_t append_dev_cap = 0;   // device scratch of an append's staged blob
   // grow-only arenas behind esl_graph_upload (esl_capi.hip)
   char* arena_graph = nullptr; size_t arena_graph_cap = 0;
   char* arena_work = nullptr;  size_t arena_work_cap = 0;

@@ -506,7 +506,7 @@ static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, Chunk
         const int nd = *n_dropped;
         hv->n_dropped = nd;
         *n_dropped = 0;   // ready for the next run (the first linearisation of a run counts into it)
-        const bool any_edge = (g.n_bbox - nd > 0) || g.n_e3d > 0 || n_grav > 0;
+        const bool any_edge = (g.n_bbox_edges - nd > 0) || g.n_e3d > 0 || n_grav > 0;
         dev_scal[5] = any_edge ? 1.0 : 0.0;   // sharded run: the ranks' flags are gathered, k_lm_step initialises
         if (st) {   // single GPU: computeLambdaInit and the bookkeeping of iteration 0 right here
           LmCore s;

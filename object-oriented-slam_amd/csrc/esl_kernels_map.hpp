@@ -63,6 +63,7 @@ static __global__ void k_bbox_validate(DevGraph g, const double* __restrict__ ca
                                 int* __restrict__ n_dropped) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.n_bbox) return;
+  if (g.bb_obj[i] < 0) return;   // slack slot of an appendable layout
   const SE3 T = se3_load(cams + 7 * g.bb_cam[i]);
   const Ell e = ell_load(objs + 10 * g.bb_obj[i]);
   double r[4];
@@ -100,6 +101,31 @@ __device__ __forceinline__ double obj_chi2(const DevGraph& g, const double* __re
     chi += g.grav_w * r * r;
   }
   return wave_sum(chi);
+}
+
+// ---- esl_graph_append: new edges into their slots of the ellipsoid-sorted arrays ----------------------------------------
+struct AppendBb { int slot, cam, obj, pad; double meas[4], w; };      // 56 B
+struct AppendE3 { int slot, cam, obj, pad; double meas[10], w; };     // 104 B
+static __global__ void k_append_scatter(DevGraph g, const AppendBb* __restrict__ rb, int nb, const AppendE3* __restrict__ re, int ne) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nb) {
+    const AppendBb r = rb[t];
+    g.bb_cam[r.slot] = r.cam; g.bb_obj[r.slot] = r.obj; g.bb_w[r.slot] = r.w; g.bb_valid[r.slot] = 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.bb_meas[4 * (size_t)r.slot + k] = r.meas[k];
+  } else if (t - nb < ne) {
+    const AppendE3 r = re[t - nb];
+    g.e3_cam[r.slot] = r.cam; g.e3_obj[r.slot] = r.obj; g.e3_w[r.slot] = r.w;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) g.e3_meas[10 * (size_t)r.slot + k] = r.meas[k];
+  }
+}
+// small tables (chunk table, id lists, per-ellipsoid counters) from the staged blob to their places: one launch instead of
+// a dozen tiny copies
+struct AppendCopies { int n; const int* src[12]; int* dst[12]; int count[12]; };
+static __global__ void k_append_tables(AppendCopies cp) {
+  for (int k = 0; k < cp.n; ++k)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cp.count[k]; i += gridDim.x * blockDim.x) cp.dst[k][i] = cp.src[k][i];
 }
 
 // ---- deterministic reduction of the per-vertex partials: out = {sum chi2, max maxdiag, sum scale, min ok}

@@ -19,7 +19,7 @@ _lib = None
 
 EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
-    "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_states_upload",
+    "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
     "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
     "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error",
@@ -101,6 +101,42 @@ class Context:
         self._graph = graph
         g = graph.c_struct()
         _check(load().esl_graph_upload(self._h, C.byref(g)), "esl_graph_upload")
+
+    def append_graph(self, new_cams=(), new_objs=(), bbox=None, e3d=None, grav_obj=()):
+        """esl_graph_append: bbox = (cam, obj, meas (n,4), weight), e3d = (cam, obj, meas (n,10), weight); indices in the extended
+        numbering (new cameras / ellipsoids follow the existing ones)."""
+        keep = []
+
+        def arr(a, dt, tail=None):
+            a = np.ascontiguousarray(a, dtype=dt)
+            if tail is not None and a.size:
+                a = a.reshape((-1,) + tail)
+            keep.append(a)
+            return a
+        d = abi.EslGraphDelta()
+        nc, no = arr(new_cams, np.float64, (7,)), arr(new_objs, np.float64, (10,))
+        d.n_new_cams, d.n_new_objs = (len(nc) if nc.size else 0), (len(no) if no.size else 0)
+        d.new_cams = nc.ctypes.data_as(_dp) if nc.size else _dp(); d.new_objs = no.ctypes.data_as(_dp) if no.size else _dp()
+        ip = C.POINTER(C.c_int32)
+        if bbox is not None and len(bbox[0]):
+            bc, bo, bm, bw = arr(bbox[0], np.int32), arr(bbox[1], np.int32), arr(bbox[2], np.float64, (4,)), arr(bbox[3], np.float64)
+            d.n_bbox = len(bc); d.bbox_cam = bc.ctypes.data_as(ip); d.bbox_obj = bo.ctypes.data_as(ip)
+            d.bbox_meas = bm.ctypes.data_as(_dp); d.bbox_weight = bw.ctypes.data_as(_dp)
+        if e3d is not None and len(e3d[0]):
+            ec, eo, em, ew = arr(e3d[0], np.int32), arr(e3d[1], np.int32), arr(e3d[2], np.float64, (10,)), arr(e3d[3], np.float64)
+            d.n_e3d = len(ec); d.e3d_cam = ec.ctypes.data_as(ip); d.e3d_obj = eo.ctypes.data_as(ip)
+            d.e3d_meas = em.ctypes.data_as(_dp); d.e3d_weight = ew.ctypes.data_as(_dp)
+        go = arr(grav_obj, np.int32)
+        if go.size:
+            d.n_grav = len(go); d.grav_obj = go.ctypes.data_as(ip)
+        _check(load().esl_graph_append(self._h, C.byref(d)), "esl_graph_append")
+        if self._graph is not None:
+            self._graph = _Sizes(self._graph.n_cams + d.n_new_cams, self._graph.n_objs + d.n_new_objs)
+
+    def graph_sizes(self):
+        v = [C.c_int32(0) for _ in range(5)]
+        _check(load().esl_graph_sizes(self._h, *[C.byref(x) for x in v]), "esl_graph_sizes")
+        return dict(zip(("n_cams", "n_objs", "n_bbox", "n_e3d", "relayouts"), [x.value for x in v]))
 
     def upload_states(self, cams, objs):
         cams = np.ascontiguousarray(cams, dtype=np.float64)
@@ -278,6 +314,13 @@ class Context:
 
     def synchronize(self):
         _check(load().esl_ctx_synchronize(self._h), "esl_ctx_synchronize")
+
+
+class _Sizes:
+    """vertex counts of a resident graph that has been extended by append_graph (download_states needs them)"""
+
+    def __init__(self, n_cams, n_objs):
+        self.n_cams, self.n_objs = n_cams, n_objs
 
 
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
