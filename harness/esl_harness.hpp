@@ -18,8 +18,8 @@
 //   graph assembly                       adapter/OptimizerEsl.cpp (esl_adapter::Flatten = src/core/Optimizer.cpp:127-279)
 //   outputs                              src/core/System.cpp:75-91 (objects.txt), src/core/Optimizer.cpp:281-288 (graph summary)
 //   data association                   src/core/DataAssociation.cpp:16-135 (used when the clip carries no instance ids)
-// Not restated: the viewer, the dense builder and the PCL ground-plane extraction (src/plane/PlaneExtractor.cpp: the supporting plane is an
-// input of the run until SURVEY.md §8 f-3 is built).
+//   ground plane                       src/core/Tracking.cpp:690-799, src/core/System.cpp:46 (backend: esl_extract_ground_plane)
+// Not restated: the viewer and the dense builder.
 #pragma once
 #include <dirent.h>
 #include <zlib.h>
@@ -254,6 +254,7 @@ struct Settings {   // Example/param/TUM3.yaml + src/config/Config.cpp:29-30
   double scale_3d = 10000, gravity_scale = 100;      // Optimizer.Edges.*
   bool gravity_open = true, depth_ellipsoid = true, optimization = true, symmetry = true;
   esl_fit_params fit;                                // filled by the backend's defaults, then overridden from here
+  esl_plane_params plane = {200, 5.0, 0.1, 10, 0.05, 100};   // Plane.MinSize / AngleThreshold / DistanceThreshold + PlaneExtractor.cpp:57-58, 74
   bool with_association = true;                      // rgbd.cpp:73
 };
 
@@ -346,7 +347,13 @@ class Tracker {
  public:
   Tracker(Backend& be, const Settings& s) : be_(be), s_(s) {}
   // Tracking::ProcessGroundPlaneEstimation's outcome (world frame); until then no ellipsoid is extracted (Tracking.cpp:316)
-  void SetGroundPlane(const double plane[4]) { for (int k = 0; k < 4; ++k) ground_[k] = plane[k]; ground_set_ = true; }
+  void SetGroundPlane(const double plane[4]) { for (int k = 0; k < 4; ++k) ground_[k] = plane[k]; ground_set_ = true; ground_state_ = 2; }
+  // Tracking::OpenGroundPlaneEstimation (Tracking.cpp:690-702): the supporting plane is extracted from the depth image of the
+  // first frame on which the extraction succeeds
+  void OpenGroundPlaneEstimation() { ground_state_ = 1; ground_set_ = false; }
+  int GetGroundPlaneEstimationState() const { return ground_state_; }
+  const double* ground_plane() const { return ground_; }
+  int ground_frame() const { return ground_frame_; }
 
   // Tracking::GrabPoseAndObjects
   bool Grab(double timestamp, const Vec7& pose_Twc, const std::vector<Detection>& dets, const uint16_t* depth, int w, int h) {
@@ -393,7 +400,25 @@ class Tracker {
   int fits_attempted = 0, fits_ok = 0;
 
  private:
+  // Tracking::ProcessGroundPlaneEstimation (Tracking.cpp:716-799) without the viewer and the manual check
+  bool ProcessGroundPlaneEstimation(Frame* f, const uint16_t* depth, int w, int h) {
+    const double intr[5] = {s_.fx, s_.fy, s_.cx, s_.cy, s_.scale};
+    double pc[4];
+    int ok = 0;
+    if (be_.ground_plane(depth, w, h, intr, &s_.plane, pc, &ok) != 0) return false;
+    if (!ok) return true;                                   // " * Estimate Ground Plane Fails ": tried again on the next frame
+    // g2o::plane::transform(Twc) (src/core/Plane.cpp:117-122: pi' = Twc^-T pi): n' = R n, d' = d - t . n'
+    const Vec7& T = f->cam_pose_Twc.v;
+    double n[3];
+    q_rot(&T[3], pc, n);
+    ground_[0] = n[0]; ground_[1] = n[1]; ground_[2] = n[2];
+    ground_[3] = pc[3] - (T[0] * n[0] + T[1] * n[1] + T[2] * n[2]);
+    ground_set_ = true; ground_state_ = 2; ground_frame_ = f->frame_seq_id;
+    return true;
+  }
   bool UpdateObjectObservation(Frame* f, const uint16_t* depth, int w, int h) {
+    // 1.1 ground-plane estimation (Tracking.cpp:498-499)
+    if (ground_state_ == 1 && !ProcessGroundPlaneEstimation(f, depth, w, h)) return false;
     // 1.2 single-frame ellipsoid estimation (UpdateDepthEllipsoidEstimation)
     if (s_.depth_ellipsoid) {
       for (const Detection& d : f->mmObservations) {
@@ -535,6 +560,7 @@ class Tracker {
   DataAssociationSolver da_;
   double ground_[4] = {0, 0, 1, 0};
   bool ground_set_ = false;
+  int ground_state_ = 0, ground_frame_ = -1;
   std::vector<Frame*> frames_;
   std::map<int, Observations> obs_;
   std::map<int, std::vector<Observation3D>> obs3d_;
@@ -551,7 +577,7 @@ int run_clip(Backend& be, const std::string& dataset_dir, const std::string& out
   Dataset ds;
   if (!ds.load(dataset_dir)) { std::fprintf(stderr, "cannot read dataset %s\n", dataset_dir.c_str()); return 2; }
   Tracker<Backend> tr(be, s);
-  if (ground) tr.SetGroundPlane(ground);
+  if (ground) tr.SetGroundPlane(ground); else tr.OpenGroundPlaneEstimation();   // System.cpp:46
   std::vector<uint16_t> depth;
   int n_valid = 0;
   for (int i = 0; i < ds.size(); ++i) {
@@ -570,6 +596,10 @@ int run_clip(Backend& be, const std::string& dataset_dir, const std::string& out
     rows.push_back({(double)gi.frame, (double)gi.objects, (double)gi.vertices, (double)gi.edges_2d, (double)gi.valid_2d, (double)gi.invalid_2d,
                     (double)gi.edges_3d, (double)gi.gravity, (double)gi.lm_iterations, gi.chi2_initial, gi.chi2_final});
   save_number_table(rows, od + "graph_log.txt");
+  if (tr.GetGroundPlaneEstimationState() == 2) {
+    const double* gp = tr.ground_plane();
+    save_number_table({{(double)tr.ground_frame(), gp[0], gp[1], gp[2], gp[3]}}, od + "ground_plane.txt");
+  }
   std::printf("frames %d (valid %d), fits %d / %d ok, objects %zu, optimisations %zu\n", ds.size(), n_valid, tr.fits_ok, tr.fits_attempted,
               tr.map_ellipsoids().size(), tr.graph_log().size());
   return 0;

@@ -6,8 +6,8 @@
 //
 // Writes objects.txt (System::SaveObjectsToFile), object_history.txt (Tracking::SaveObjectHistory) and graph_log.txt (one
 // row per GlobalObjectGraphOptimization call: frame, objects, vertices, 2-D edges, valid, invalid, 3-D edges, gravity edges,
-// LM iterations, chi2 before / after).  The supporting plane defaults to z = 0 of the mocap world (the reference estimates it
-// from the first frame with PCL, src/plane/PlaneExtractor.cpp).  There is no CPU fallback: without a HIP device this fails.
+// LM iterations, chi2 before / after).  The supporting plane is estimated from the depth images (esl_extract_ground_plane; the reference does the same
+// with PCL, src/plane/PlaneExtractor.cpp) unless --ground gives it in the world frame.  There is no CPU fallback: without a HIP device this fails.
 #include "esl_harness.hpp"
 
 struct HipBackend {
@@ -19,6 +19,13 @@ struct HipBackend {
     const int rc = esl_fit_frame(ctx, depth, w, h, box, &lab, 1, Twc, intr, ground, p, e10, prob, &st);
     *state = st;
     if (rc) std::fprintf(stderr, "esl_fit_frame: %s\n", esl_last_error());
+    return rc;
+  }
+  int ground_plane(const uint16_t* depth, int w, int h, const double intr[5], const esl_plane_params* p, double plane[4], int* ok) {
+    int32_t k = 0;
+    const int rc = esl_extract_ground_plane(ctx, depth, w, h, intr, p, plane, &k, nullptr, nullptr);
+    *ok = k;
+    if (rc) std::fprintf(stderr, "esl_extract_ground_plane: %s\n", esl_last_error());
     return rc;
   }
   int init_quadric(const double* poses, const double* boxes, int n, const double K[4], int rows, int cols, double e10[10], int* ok) {
@@ -43,9 +50,10 @@ int main(int argc, char** argv) {
   esl_harness::Settings s;
   esl_fit_params_default(&s.fit);
   double ground[4] = {0, 0, 1, 0};
+  bool have_ground = false;   // default: estimated from the depth images as the reference does (System.cpp:46)
   for (int i = 3; i < argc; ++i) {
     const std::string a = argv[i];
-    if (a == "--ground" && i + 4 < argc) { for (int k = 0; k < 4; ++k) ground[k] = std::atof(argv[i + 1 + k]); i += 4; }
+    if (a == "--ground" && i + 4 < argc) { for (int k = 0; k < 4; ++k) ground[k] = std::atof(argv[i + 1 + k]); i += 4; have_ground = true; }
     else if (a == "--jacobian" && i + 1 < argc) { be.lm.jacobian_mode = std::string(argv[++i]) == "analytic" ? ESL_JAC_ANALYTIC : ESL_JAC_NUMERIC; }
     else if (a == "--delta" && i + 1 < argc) be.lm.numeric_delta = std::atof(argv[++i]);
     else if (a == "--no-symmetry") s.symmetry = false;
@@ -54,7 +62,7 @@ int main(int argc, char** argv) {
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
   }
   if (esl_ctx_create(0, &be.ctx) != ESL_OK) { std::fprintf(stderr, "esl: %s\n", esl_last_error()); return 4; }
-  const int rc = esl_harness::run_clip(be, argv[1], argv[2], ground, s);
+  const int rc = esl_harness::run_clip(be, argv[1], argv[2], have_ground ? ground : nullptr, s);
   esl_ctx_destroy(be.ctx);
   return rc;
 }

@@ -312,6 +312,26 @@ int esl_fit_frame_ex(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t
                      const double ground[4], const esl_fit_params* p, double* ellipsoids_out, double* prob_out,
                      int32_t* status_out, esl_fit_symmetry* symmetry_out, double* debug_out);
 
+/* ---- ground plane -------------------------------------------------------------------------------*/
+/* Replaces EllipsoidSLAM::PlaneExtractor (reference include/src/plane/PlaneExtractor.h:34-77, src/plane/PlaneExtractor.cpp):
+ * SetParam's fields + the two constants extractPlanes passes to PCL's normal estimation (:57-58, :74). */
+typedef struct esl_plane_params {
+  int32_t min_size;               /* Plane.MinSize: smallest segment kept as a plane (PlaneExtractor.cpp:87) */
+  double angle_threshold_deg;     /* Plane.AngleThreshold */
+  double distance_threshold;      /* Plane.DistanceThreshold */
+  int32_t normal_smoothing;       /* setNormalSmoothingSize(10) */
+  double max_depth_change_factor; /* setMaxDepthChangeFactor(0.05) */
+  int32_t min_inliers;            /* setMinInliers(100) */
+} esl_plane_params;
+void esl_plane_params_default(esl_plane_params* p);
+/* PlaneExtractor::extractGroundPlane(depth, plane) (PlaneExtractor.cpp:107-183): the largest plane segment of the depth image
+ * whose normal is within 45 degrees of the camera's y axis, in the camera frame, normalised, camera centre on the positive
+ * side.  *ok = 0 when no segment qualifies (the reference returns false).  n_planes (segments of >= min_size pixels) and
+ * n_pixels (pixels of the returned segment) may be NULL.  The caller moves the plane to the world with the frame's pose as
+ * Tracking::ProcessGroundPlaneEstimation does (src/core/Tracking.cpp:741-744). */
+int esl_extract_ground_plane(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
+                             const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels);
+
 /* ---- SVD quadric initialisation -----------------------------------------------------------------*/
 int esl_init_quadric(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const double* bboxes /* n x 4 */,
                      int32_t n, const double K[4], int32_t rows, int32_t cols, int32_t faithful,

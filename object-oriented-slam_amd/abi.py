@@ -91,6 +91,23 @@ class EslFitSymmetry(C.Structure):
                 ("plane2", C.c_double * 4), ("prob", C.c_double), ("center", C.c_double * 3)]
 
 
+class EslPlaneParams(C.Structure):
+    """esl_plane_params (PlaneExtractorParam + the PCL constants of PlaneExtractor.cpp:57-58, 74)."""
+    _fields_ = [("min_size", C.c_int32), ("angle_threshold_deg", C.c_double), ("distance_threshold", C.c_double),
+                ("normal_smoothing", C.c_int32), ("max_depth_change_factor", C.c_double), ("min_inliers", C.c_int32)]
+
+
+def default_plane_params(**kw):
+    """Example/param/TUM3.yaml:36-38 + PlaneExtractor.cpp:57-58, 74."""
+    p = EslPlaneParams(min_size=200, angle_threshold_deg=5.0, distance_threshold=0.1, normal_smoothing=10,
+                       max_depth_change_factor=0.05, min_inliers=100)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
 def default_lm_params(**kw):
     """Reference settings: optimize(10) (Optimizer.cpp:291), tau 1e-5, 10 trials
     (optimization_algorithm_levenberg.cpp:45-49), delta 1e-9 (base_binary_edge.hpp:147)."""

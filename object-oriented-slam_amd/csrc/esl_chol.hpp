@@ -43,7 +43,12 @@ __device__ __forceinline__ void potrf32_wave(double (&row)[kSB], double (&invd)[
   for (int j = 0; j < kSB; ++j) {
     const double d = readlane_f64(row[j], j);
     if (!(d > 0) && lane == 0) atomicOr(info, 1);
-    const double s = sqrt(d), is = 1.0 / s;
+    // 1/sqrt(d) from the hardware estimate + two Newton steps, L(j,j) = d * that: the sqrt + divide pair of the first version was
+    // ~500 of the ~1,000 cycles of a column step (each is a 20-30 instruction sequence in fp64)
+    double is = __builtin_amdgcn_rsq(d);
+    is = is * (1.5 - 0.5 * d * is * is);
+    is = is * (1.5 - 0.5 * d * is * is);
+    const double s = d * is;
     invd[j] = is;
     const double lij = (lane == j) ? s : row[j] * is;   // lanes above the diagonal carry unused values
     row[j] = lij;

@@ -1,0 +1,258 @@
+// esl_plane.hip — esl_extract_ground_plane: the supporting plane of the scene from one depth image.
+// Replaces EllipsoidSLAM::PlaneExtractor::extractGroundPlane / extractPlanes (reference src/plane/PlaneExtractor.cpp:22-183),
+// the step in front of the per-frame fit (Tracking::ProcessGroundPlaneEstimation, src/core/Tracking.cpp:712-790).
+//
+// The reference delegates the two heavy steps to PCL (unpinned, not vendored): IntegralImageNormalEstimation
+// (AVERAGE_3D_GRADIENT, smoothing size 10, depth-change factor 0.05; PlaneExtractor.cpp:54-61) and
+// OrganizedMultiPlaneSegmentation::segmentAndRefine (min 100 inliers, angular threshold Plane.AngleThreshold degrees, distance
+// threshold Plane.DistanceThreshold; :68-83).  As for the PCL steps of the fit (esl_fit.hip), they are restated as
+// deterministic, order-independent definitions, which the CPU checker and an independent numpy / scipy version used by the
+// tests restate as well:
+//   points      every pixel: z = depth / scale as float, x = (u - cx) z / fx, y = (v - cy) z / fy (float, :38-42); depth 0 = no point
+//   normals     average 3-D gradient over the (2R+1)^2 window, R = smoothing / 2: dh = sum_W (P(v, u+1) - P(v, u-1)),
+//               dv = sum_W (P(v+1, u) - P(v-1, u)), n = dv x dh normalised and turned towards the camera; no normal where the
+//               (2R+3)^2 neighbourhood holds a missing depth or two adjacent depths that differ by more than factor * z
+//   segments    connected components (4-neighbourhood) of pixels with normals whose plane offsets d = -n.p differ by less than
+//               the distance threshold and whose normals differ by less than the angular threshold (PCL's
+//               PlaneCoefficientComparator); a lock-free union-find over the pixel grid
+//   planes      per component of >= max(100, Plane.MinSize) pixels the least-squares plane of its points (centroid + smallest
+//               eigenvector of the covariance, moments accumulated exactly in fixed point), d >= 0 (:95-96)
+//   ground      among the planes whose normal is within 45 degrees of the camera's y axis (either sign, :139-146) the one with
+//               the most pixels (:160-162; ties: the component with the smaller root pixel); sign such that the camera
+//               centre is on the positive side (:165-167)
+// Runs once per sequence (until it succeeds): nothing here is tuned for throughput, everything for determinism.
+#include <cmath>
+
+#include "esl_ctx.hpp"
+
+namespace esl {
+
+struct PlaneArgs {
+  const uint16_t* depth; int w, h;
+  double fx, fy, cx, cy, scale;
+  int R; double depth_factor, cos_ang, dist_th; int min_size;
+  float* nrm;            // 4 per pixel: nx ny nz d ; nx = NaN: no normal
+  int* parent;           // union-find forest over the pixels
+  int* cnt;              // pixels per root
+  long long* mom;        // per root: 9 fixed-point sums  x y z xx xy xz yy yz zz
+  double* out;           // [0..3] plane, [4] ok, [5] planes >= min size, [6] pixels of the chosen plane, [7] components with normals
+};
+constexpr double kFix1 = 1048576.0;        // 2^20: first moments in 2^-20 m
+constexpr double kFix2 = 1048576.0;        // second moments in 2^-20 m^2
+
+__device__ __forceinline__ bool px_point(const PlaneArgs& a, int u, int v, float p[3]) {
+  const uint16_t d = a.depth[(size_t)v * a.w + u];
+  const float z = (float)((double)d / a.scale);
+  p[2] = z;
+  p[0] = (float)(((double)u - a.cx) * (double)z / a.fx);
+  p[1] = (float)(((double)v - a.cy) * (double)z / a.fy);
+  return d != 0;
+}
+
+static __global__ __launch_bounds__(256) void k_plane_normals(PlaneArgs a) {
+  const int u = blockIdx.x * 16 + (threadIdx.x & 15), v = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (u >= a.w || v >= a.h) return;
+  float* o = a.nrm + 4 * ((size_t)v * a.w + u);
+  const float qnan = __builtin_nanf("");
+  o[0] = qnan; o[1] = o[2] = o[3] = 0;
+  const int R = a.R;
+  if (u - R - 1 < 0 || v - R - 1 < 0 || u + R + 1 >= a.w || v + R + 1 >= a.h) return;
+  // validity of the (2R+3)^2 neighbourhood: every depth present, no jump between horizontal / vertical neighbours
+  for (int y = v - R - 1; y <= v + R + 1; ++y)
+    for (int x = u - R - 1; x <= u + R + 1; ++x) {
+      const uint16_t d = a.depth[(size_t)y * a.w + x];
+      if (d == 0) return;
+      const double z = (double)d / a.scale;
+      if (x + 1 <= u + R + 1) { const double z2 = (double)a.depth[(size_t)y * a.w + x + 1] / a.scale; if (fabs(z2 - z) > a.depth_factor * z) return; }
+      if (y + 1 <= v + R + 1) { const double z2 = (double)a.depth[(size_t)(y + 1) * a.w + x] / a.scale; if (fabs(z2 - z) > a.depth_factor * z) return; }
+    }
+  double dh[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+  for (int y = v - R; y <= v + R; ++y)
+    for (int x = u - R; x <= u + R; ++x) {
+      float pr[3], pl[3], pd[3], pu[3];
+      px_point(a, x + 1, y, pr); px_point(a, x - 1, y, pl); px_point(a, x, y + 1, pd); px_point(a, x, y - 1, pu);
+      for (int k = 0; k < 3; ++k) { dh[k] += (double)pr[k] - (double)pl[k]; dv[k] += (double)pd[k] - (double)pu[k]; }
+    }
+  double n[3] = {dv[1] * dh[2] - dv[2] * dh[1], dv[2] * dh[0] - dv[0] * dh[2], dv[0] * dh[1] - dv[1] * dh[0]};
+  const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  if (!(nn > 0)) return;
+  float p[3];
+  px_point(a, u, v, p);
+  double s = 1.0 / nn;
+  if ((n[0] * p[0] + n[1] * p[1] + n[2] * p[2]) * s > 0) s = -s;   // towards the camera at the origin
+  const float nx = (float)(n[0] * s), ny = (float)(n[1] * s), nz = (float)(n[2] * s);
+  o[0] = nx; o[1] = ny; o[2] = nz;
+  o[3] = -(nx * p[0] + ny * p[1] + nz * p[2]);
+}
+
+__device__ __forceinline__ int uf_find(int* parent, int i) {
+  while (true) {
+    const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == i) return i;
+    const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp != p) (void)atomicCAS(&parent[i], p, gp);   // path halving
+    i = p;
+  }
+}
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+  while (true) {
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }      // the smaller index becomes the root
+    if (atomicCAS(&parent[a], a, b) == a) return;
+  }
+}
+__device__ __forceinline__ bool same_plane(const PlaneArgs& a, const float* ni, const float* nj) {
+  if (ni[0] != ni[0] || nj[0] != nj[0]) return false;
+  const float dot = ni[0] * nj[0] + ni[1] * nj[1] + ni[2] * nj[2];
+  return fabsf(ni[3] - nj[3]) < (float)a.dist_th && dot > (float)a.cos_ang;
+}
+static __global__ __launch_bounds__(256) void k_plane_init(PlaneArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  a.parent[i] = i; a.cnt[i] = 0;
+  for (int k = 0; k < 9; ++k) a.mom[(size_t)i * 9 + k] = 0;
+}
+static __global__ __launch_bounds__(256) void k_plane_union(PlaneArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  const int u = i % a.w, v = i / a.w;
+  const float* ni = a.nrm + 4 * (size_t)i;
+  if (ni[0] != ni[0]) return;
+  if (u + 1 < a.w && same_plane(a, ni, a.nrm + 4 * (size_t)(i + 1))) uf_union(a.parent, i, i + 1);
+  if (v + 1 < a.h && same_plane(a, ni, a.nrm + 4 * (size_t)(i + a.w))) uf_union(a.parent, i, i + a.w);
+}
+static __global__ __launch_bounds__(256) void k_plane_moments(PlaneArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  const float* ni = a.nrm + 4 * (size_t)i;
+  if (ni[0] != ni[0]) return;
+  const int r = uf_find(a.parent, i);
+  float p[3];
+  px_point(a, i % a.w, i / a.w, p);
+  atomicAdd(&a.cnt[r], 1);
+  unsigned long long* m = (unsigned long long*)(a.mom + (size_t)r * 9);
+  const double x = p[0], y = p[1], z = p[2];
+  const double v9[9] = {x * kFix1, y * kFix1, z * kFix1, x * x * kFix2, x * y * kFix2, x * z * kFix2, y * y * kFix2, y * z * kFix2, z * z * kFix2};
+  for (int k = 0; k < 9; ++k) atomicAdd(&m[k], (unsigned long long)llrint(v9[k]));
+}
+
+// symmetric 3x3 eigen-decomposition by cyclic Jacobi; returns the eigenvector of the smallest eigenvalue
+__device__ void smallest_eigvec3(const double C[9], double n[3]) {
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) A[i] = C[i];
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        const double c = 1 / sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < 3; ++k) { const double x = A[k * 3 + p], y = A[k * 3 + q]; A[k * 3 + p] = c * x - s * y; A[k * 3 + q] = s * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = A[p * 3 + k], y = A[q * 3 + k]; A[p * 3 + k] = c * x - s * y; A[q * 3 + k] = s * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = V[k * 3 + p], y = V[k * 3 + q]; V[k * 3 + p] = c * x - s * y; V[k * 3 + q] = s * x + c * y; }
+      }
+  }
+  int m = 0;
+  for (int j = 1; j < 3; ++j) if (A[j * 4] < A[m * 4]) m = j;
+  for (int k = 0; k < 3; ++k) n[k] = V[k * 3 + m];
+}
+
+// one workgroup: every component of >= min_size pixels -> its plane; the ground-plane candidate with the most pixels wins
+static __global__ __launch_bounds__(256) void k_plane_select(PlaneArgs a) {
+  __shared__ int s_cnt[256], s_root[256], s_np[256], s_nc[256];
+  int best_cnt = 0, best_root = -1, n_planes = 0, n_comp = 0;
+  const int N = a.w * a.h;
+  for (int r = threadIdx.x; r < N; r += 256) {
+    const int c = a.cnt[r];
+    if (c <= 0) continue;
+    ++n_comp;
+    if (c < a.min_size) continue;
+    ++n_planes;
+    const long long* m = a.mom + (size_t)r * 9;
+    const double inv = 1.0 / (double)c;
+    const double cx = (double)m[0] / kFix1 * inv, cy = (double)m[1] / kFix1 * inv, cz = (double)m[2] / kFix1 * inv;
+    const double C[9] = {(double)m[3] / kFix2 * inv - cx * cx, (double)m[4] / kFix2 * inv - cx * cy, (double)m[5] / kFix2 * inv - cx * cz,
+                         (double)m[4] / kFix2 * inv - cx * cy, (double)m[6] / kFix2 * inv - cy * cy, (double)m[7] / kFix2 * inv - cy * cz,
+                         (double)m[5] / kFix2 * inv - cx * cz, (double)m[7] / kFix2 * inv - cy * cz, (double)m[8] / kFix2 * inv - cz * cz};
+    double n[3];
+    smallest_eigvec3(C, n);
+    // wall filter: the angle between the normal and the camera's y axis must not lie in (pi/4, 3 pi/4)
+    const double th = acos(n[1] / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]));
+    if (th > M_PI / 4 && th < 3 * M_PI / 4) continue;
+    if (c > best_cnt || (c == best_cnt && (best_root < 0 || r < best_root))) { best_cnt = c; best_root = r; }
+  }
+  s_cnt[threadIdx.x] = best_cnt; s_root[threadIdx.x] = best_root; s_np[threadIdx.x] = n_planes; s_nc[threadIdx.x] = n_comp;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int k = 1; k < 256; ++k) {
+    n_planes += s_np[k]; n_comp += s_nc[k];
+    if (s_root[k] >= 0 && (s_cnt[k] > best_cnt || (s_cnt[k] == best_cnt && (best_root < 0 || s_root[k] < best_root)))) { best_cnt = s_cnt[k]; best_root = s_root[k]; }
+  }
+  for (int k = 0; k < 8; ++k) a.out[k] = 0;
+  a.out[5] = n_planes; a.out[7] = n_comp;
+  if (best_root < 0) return;
+  const long long* m = a.mom + (size_t)best_root * 9;
+  const double inv = 1.0 / (double)best_cnt;
+  const double cx = (double)m[0] / kFix1 * inv, cy = (double)m[1] / kFix1 * inv, cz = (double)m[2] / kFix1 * inv;
+  const double C[9] = {(double)m[3] / kFix2 * inv - cx * cx, (double)m[4] / kFix2 * inv - cx * cy, (double)m[5] / kFix2 * inv - cx * cz,
+                       (double)m[4] / kFix2 * inv - cx * cy, (double)m[6] / kFix2 * inv - cy * cy, (double)m[7] / kFix2 * inv - cy * cz,
+                       (double)m[5] / kFix2 * inv - cx * cz, (double)m[7] / kFix2 * inv - cy * cz, (double)m[8] / kFix2 * inv - cz * cz};
+  double n[3];
+  smallest_eigvec3(C, n);
+  const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  double pl[4] = {n[0] / nn, n[1] / nn, n[2] / nn, 0};
+  pl[3] = -(pl[0] * cx + pl[1] * cy + pl[2] * cz);
+  if (pl[3] < 0) for (int k = 0; k < 4; ++k) pl[k] = -pl[k];   // camera centre on the positive side (PlaneExtractor.cpp:95-96, 165-167)
+  for (int k = 0; k < 4; ++k) a.out[k] = pl[k];
+  a.out[4] = 1; a.out[6] = best_cnt;
+}
+
+}  // namespace esl
+
+using namespace esl;
+
+extern "C" void esl_plane_params_default(esl_plane_params* p) {
+  p->min_size = 200; p->angle_threshold_deg = 5; p->distance_threshold = 0.1;   // Example/param/TUM3.yaml:36-38
+  p->normal_smoothing = 10; p->max_depth_change_factor = 0.05;                   // PlaneExtractor.cpp:57-58
+  p->min_inliers = 100;                                                           // PlaneExtractor.cpp:74
+}
+
+extern "C" int esl_extract_ground_plane(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
+                                        const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels) {
+  if (!c || !depth || !intr || !p || !plane_out || !ok || width <= 0 || height <= 0) { set_error("esl_extract_ground_plane: bad argument"); return ESL_ERR_INVALID; }
+  if (p->normal_smoothing < 2 || p->distance_threshold <= 0 || p->angle_threshold_deg <= 0) { set_error("esl_extract_ground_plane: bad parameters"); return ESL_ERR_INVALID; }
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  *ok = 0;
+  for (int k = 0; k < 4; ++k) plane_out[k] = 0;
+  const size_t npx = (size_t)width * height;
+  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_depth, d_nrm, d_par, d_cnt, d_mom, d_out;
+  ESL_HIP_TRY(hipMalloc(&d_depth.p, npx * 2)); ESL_HIP_TRY(hipMalloc(&d_nrm.p, npx * 16)); ESL_HIP_TRY(hipMalloc(&d_par.p, npx * 4));
+  ESL_HIP_TRY(hipMalloc(&d_cnt.p, npx * 4)); ESL_HIP_TRY(hipMalloc(&d_mom.p, npx * 72)); ESL_HIP_TRY(hipMalloc(&d_out.p, 8 * sizeof(double)));
+  ESL_HIP_TRY(hipMemcpyAsync(d_depth.p, depth, npx * 2, hipMemcpyHostToDevice, c->stream));
+  PlaneArgs a;
+  a.depth = (const uint16_t*)d_depth.p; a.w = width; a.h = height;
+  a.fx = intr[0]; a.fy = intr[1]; a.cx = intr[2]; a.cy = intr[3]; a.scale = intr[4];
+  a.R = p->normal_smoothing / 2; a.depth_factor = p->max_depth_change_factor;
+  a.cos_ang = std::cos(p->angle_threshold_deg * 0.017453);   // the reference's degree-to-radian constant (PlaneExtractor.cpp:75)
+  a.dist_th = p->distance_threshold; a.min_size = std::max(p->min_size, p->min_inliers);
+  a.nrm = (float*)d_nrm.p; a.parent = (int*)d_par.p; a.cnt = (int*)d_cnt.p; a.mom = (long long*)d_mom.p; a.out = (double*)d_out.p;
+  const unsigned nb = (unsigned)((npx + 255) / 256);
+  hipLaunchKernelGGL(k_plane_normals, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_plane_init, dim3(nb), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_plane_union, dim3(nb), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_plane_moments, dim3(nb), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_plane_select, dim3(1), dim3(256), 0, c->stream, a);
+  ESL_HIP_TRY(hipGetLastError());
+  double h[8];
+  ESL_HIP_TRY(hipMemcpyAsync(h, d_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  *ok = h[4] > 0.5 ? 1 : 0;
+  if (*ok) for (int k = 0; k < 4; ++k) plane_out[k] = h[k];
+  if (n_planes) *n_planes = (int32_t)h[5];
+  if (n_pixels) *n_pixels = (int32_t)h[6];
+  return ESL_OK;
+}

@@ -22,7 +22,7 @@ EXPORTS = [
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
     "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
-    "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error",
+    "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane",
 ]
 
 
@@ -285,6 +285,18 @@ class Context:
                    prob=np.array([sym[b].prob for b in range(B)]),
                    center=np.array([list(sym[b].center) for b in range(B)]).reshape(B, 3))
         return ell, prob, st, dbg, out
+
+    def extract_ground_plane(self, depth, intr, params=None):
+        """PlaneExtractor::extractGroundPlane: dict(ok, plane (camera frame, 4), n_planes, n_pixels)."""
+        p = params if params is not None else abi.default_plane_params()
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        h, w = depth.shape
+        intr = np.ascontiguousarray(intr, dtype=np.float64)
+        plane = np.zeros(4); ok = C.c_int32(0); npl = C.c_int32(0); npx = C.c_int32(0)
+        _check(load().esl_extract_ground_plane(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                                               intr.ctypes.data_as(_dp), C.byref(p), plane.ctypes.data_as(_dp), C.byref(ok),
+                                               C.byref(npl), C.byref(npx)), "esl_extract_ground_plane")
+        return dict(ok=bool(ok.value), plane=plane, n_planes=npl.value, n_pixels=npx.value)
 
     def selftest_cholesky(self, n):
         """(ms, relative residual) of the dense FP64-MFMA Cholesky factor + solve on a generated SPD system."""

@@ -85,6 +85,12 @@ int esl_oracle_fit_frame_ex(const uint16_t* depth, int32_t width, int32_t height
                             const esl_fit_params* p, double* ellipsoids_out, double* prob_out, int32_t* status_out,
                             double* debug_out, double* sym_out);
 
+/* Ground plane of one depth image (esl_oracle_plane.c; esl_extract_ground_plane of include/esl.h).  normals_out (optional):
+ * 4 floats per pixel, nx ny nz d, nx = NaN where no normal exists. */
+int esl_oracle_extract_ground_plane(const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
+                                    const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes,
+                                    int32_t* n_pixels, float* normals_out);
+
 /* 0: the reference's reprojection residual (default); 1: plane-tangency rows (esl_lm_params::bbox_residual).  Applies to
  * esl_oracle_res_bbox / jac_bbox / build_system; esl_oracle_optimize sets it from its params. */
 void esl_oracle_set_bbox_residual(int mode);

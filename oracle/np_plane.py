@@ -1,0 +1,129 @@
+"""np_plane.py — INDEPENDENT numpy / scipy version of the ground-plane extraction.  TEST INFRASTRUCTURE ONLY.
+
+Written from the definitions at the top of object-oriented-slam_amd/csrc/esl_plane.hip and from the reference's
+PlaneExtractor (src/plane/PlaneExtractor.cpp:22-183), with none of the machinery the C restatement
+(oracle/esl_oracle_plane.c) or the HIP kernels use: window sums through integral images, connected components through
+scipy.sparse.csgraph, the plane through numpy.linalg.eigh on floating-point moments.  Agreement between the three is the
+pin of this step (PCL itself is not available: parity with PCL's own normal estimation / segmentation is unpinned)."""
+import numpy as np
+from scipy.sparse import coo_matrix
+from scipy.sparse.csgraph import connected_components
+
+
+def _box(a, r):
+    """sum of a over the (2r+1)^2 window centred on every pixel (zero where the window leaves the image)"""
+    h, w = a.shape[:2]
+    s = np.zeros((h + 1, w + 1) + a.shape[2:], dtype=np.float64)
+    s[1:, 1:] = np.cumsum(np.cumsum(a.astype(np.float64), axis=0), axis=1)
+    out = np.zeros(a.shape, dtype=np.float64)
+    k = 2 * r + 1
+    if h >= k and w >= k:
+        out[r:h - r, r:w - r] = s[k:, k:] - s[:-k, k:] - s[k:, :-k] + s[:-k, :-k]
+    return out
+
+
+def points(depth, intr):
+    fx, fy, cx, cy, scale = intr
+    h, w = depth.shape
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    z = (depth.astype(np.float64) / scale).astype(np.float32)
+    x = ((u - cx) * z.astype(np.float64) / fx).astype(np.float32)
+    y = ((v - cy) * z.astype(np.float64) / fy).astype(np.float32)
+    return np.stack([x, y, z], axis=-1)
+
+
+def normals(depth, intr, smoothing=10, factor=0.05):
+    """(h, w, 4) float32: unit normal towards the camera + plane offset d = -n.p; NaN where undefined"""
+    h, w = depth.shape
+    R = smoothing // 2
+    P = points(depth, intr).astype(np.float64)
+    z = depth.astype(np.float64) / intr[4]
+    # pixels that break a window: missing depth, or a jump to the right / lower neighbour
+    miss = (depth == 0).astype(np.float64)
+    jr = np.zeros((h, w)); jd = np.zeros((h, w))
+    jr[:, :-1] = np.abs(z[:, 1:] - z[:, :-1]) > factor * z[:, :-1]
+    jd[:-1, :] = np.abs(z[1:, :] - z[:-1, :]) > factor * z[:-1, :]
+    Rn = R + 1
+    bad = _box(miss, Rn) > 0
+    # a horizontal pair (x, x+1) counts when both ends are inside the neighbourhood: left ends x in [u-Rn, u+Rn-1]
+    k = 2 * Rn + 1
+    sj = np.zeros((h + 1, w + 1)); sj[1:, 1:] = np.cumsum(np.cumsum(jr, axis=0), axis=1)
+    sd = np.zeros((h + 1, w + 1)); sd[1:, 1:] = np.cumsum(np.cumsum(jd, axis=0), axis=1)
+    ok = np.zeros((h, w), dtype=bool)
+    vs, us = np.arange(Rn, h - Rn), np.arange(Rn, w - Rn)
+    if len(vs) and len(us):
+        V, U = np.meshgrid(vs, us, indexing="ij")
+        y0, y1, x0, x1 = V - Rn, V + Rn + 1, U - Rn, U + Rn + 1
+        nh = sj[y1, x1 - 1] - sj[y0, x1 - 1] - sj[y1, x0] + sj[y0, x0]        # rows all, left ends x0 .. x1-2
+        nv = sd[y1 - 1, x1] - sd[y0, x1] - sd[y1 - 1, x0] + sd[y0, x0]        # top ends y0 .. y1-2, columns all
+        ok[Rn:h - Rn, Rn:w - Rn] = (nh == 0) & (nv == 0)
+    ok &= ~bad
+    gh = np.zeros_like(P); gv = np.zeros_like(P)
+    gh[:, 1:-1] = P[:, 2:] - P[:, :-2]
+    gv[1:-1, :] = P[2:, :] - P[:-2, :]
+    dh = _box(gh, R); dv = _box(gv, R)
+    n = np.cross(dv, dh)
+    nn = np.linalg.norm(n, axis=-1)
+    ok &= nn > 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = n / nn[..., None]
+    flip = np.sum(n * P, axis=-1) > 0
+    n[flip] = -n[flip]
+    n32 = n.astype(np.float32)
+    P32 = P.astype(np.float32)
+    d = -(n32[..., 0] * P32[..., 0] + n32[..., 1] * P32[..., 1] + n32[..., 2] * P32[..., 2])
+    out = np.concatenate([n32, d[..., None].astype(np.float32)], axis=-1)
+    out[~ok] = 0
+    out[~ok, 0] = np.nan
+    return out
+
+
+def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smoothing=10, factor=0.05, min_inliers=100):
+    depth = np.asarray(depth, dtype=np.uint16)
+    intr = np.asarray(intr, dtype=np.float64)
+    h, w = depth.shape
+    nr = normals(depth, intr, smoothing, factor)
+    valid = ~np.isnan(nr[..., 0])
+    idx = np.arange(h * w).reshape(h, w)
+    cos_ang = np.float32(np.cos(angle_deg * 0.017453)); dist = np.float32(dist)
+
+    def links(a, b, ia, ib):
+        dot = a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1] + a[..., 2] * b[..., 2]
+        with np.errstate(invalid="ignore"):
+            m = (np.abs(a[..., 3] - b[..., 3]) < dist) & (dot > cos_ang)
+        m &= ~np.isnan(a[..., 0]) & ~np.isnan(b[..., 0])
+        return ia[m], ib[m]
+    r0, c0 = links(nr[:, :-1], nr[:, 1:], idx[:, :-1], idx[:, 1:])
+    r1, c1 = links(nr[:-1, :], nr[1:, :], idx[:-1, :], idx[1:, :])
+    rows = np.concatenate([r0, r1]); cols = np.concatenate([c0, c1])
+    g = coo_matrix((np.ones(len(rows), dtype=np.int8), (rows, cols)), shape=(h * w, h * w))
+    _, lab = connected_components(g, directed=False)
+    lab = lab.reshape(h, w)
+    labs, first, counts = np.unique(lab[valid], return_index=True, return_counts=True)
+    root = idx[valid][first]                       # smallest pixel index of each component (np.unique keeps the first)
+    P = points(depth, intr).astype(np.float64)
+    need = max(min_size, min_inliers)
+    planes = []
+    for l, c, r in zip(labs, counts, root):
+        if c < need:
+            continue
+        pts = P[(lab == l) & valid]
+        cen = pts.mean(axis=0)
+        C = (pts - cen).T @ (pts - cen) / len(pts)
+        wv, V = np.linalg.eigh(C)
+        n = V[:, 0]
+        pl = np.array([n[0], n[1], n[2], -n @ cen])
+        if pl[3] < 0:
+            pl = -pl
+        planes.append((int(c), int(r), pl))
+    cand = []
+    for c, r, pl in planes:
+        th = np.arccos(pl[1] / np.linalg.norm(pl[:3]))
+        if np.pi / 4 < th < 3 * np.pi / 4:
+            continue
+        cand.append((c, r, pl))
+    out = dict(ok=False, plane=np.zeros(4), n_planes=len(planes), n_pixels=0, normals=nr)
+    if cand:
+        cand.sort(key=lambda t: (-t[0], t[1]))
+        out.update(ok=True, plane=cand[0][2], n_pixels=cand[0][0])
+    return out

@@ -212,6 +212,27 @@ def fit_frame_ex(depth, bboxes, labels, Twc, intr, ground, params=None):
     return ell, prob, st, dbg, out
 
 
+def extract_ground_plane(depth, intr, params=None, want_normals=False):
+    """Returns dict(ok, plane, n_planes, n_pixels[, normals (h, w, 4) float32])."""
+    from importlib import import_module
+    abi = import_module("object-oriented-slam_amd.abi")
+    p = params if params is not None else abi.default_plane_params()
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    h, w = depth.shape
+    intr = np.ascontiguousarray(intr, dtype=np.float64)
+    plane = np.zeros(4); ok = C.c_int32(0); npl = C.c_int32(0); npx = C.c_int32(0)
+    nrm = np.zeros((h, w, 4), dtype=np.float32) if want_normals else None
+    rc = lib().esl_oracle_extract_ground_plane(depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                                               intr.ctypes.data_as(C.POINTER(C.c_double)), C.byref(p),
+                                               plane.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ok), C.byref(npl), C.byref(npx),
+                                               nrm.ctypes.data_as(C.POINTER(C.c_float)) if want_normals else None)
+    assert rc == 0
+    out = dict(ok=bool(ok.value), plane=plane, n_planes=npl.value, n_pixels=npx.value)
+    if want_normals:
+        out["normals"] = nrm
+    return out
+
+
 def set_bbox_residual(mode):
     lib().esl_oracle_set_bbox_residual(C.c_int(mode))
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Generates tests/golden/cabinet_plane.npz: the ground plane of two depth frames of the reference's demo clip
+(Example/dataset/cabinet, first frame and frame 30) computed by the INDEPENDENT numpy / scipy version oracle/np_plane.py.
+Run in the development container only (reads the reference's DATA files; needs scipy + PIL).  Stored: the two depth
+images (x-differenced so that deflate gets PNG-like ratios), the mocap poses of the frames, the expected plane, segment
+count, pixel count and the count of pixels with a normal.  No reference source text is stored.
+
+  python tests/golden/gen_golden_plane.py
+"""
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/Example/dataset/cabinet/"
+OUT = os.path.join(ROOT, "tests", "golden", "cabinet_plane.npz")
+
+
+def main():
+    from oracle import np_plane
+    intr = np.array([535.4, 539.2, 320.1, 247.6, 5000.0])       # Example/param/TUM3.yaml:62-70
+    lines = [l.split() for l in open(REF + "associateGroundtruth.txt")]
+    assoc = {a.split()[0]: a.split()[3] for a in open(REF + "associate.txt")}
+    store = dict(intr=intr)
+    for k, li in enumerate((0, 30)):
+        l = lines[li]
+        depth = np.array(Image.open(REF + assoc[l[0]])).astype(np.uint16)
+        diff = depth.copy()
+        diff[:, 1:] = depth[:, 1:] - depth[:, :-1]
+        r = np_plane.extract_ground_plane(depth, intr)
+        store[f"depth_{k}"] = diff
+        store[f"pose_{k}"] = np.array(l[3:10], float)
+        store[f"plane_{k}"] = r["plane"]
+        store[f"counts_{k}"] = np.array([r["n_planes"], r["n_pixels"], int(np.isfinite(r["normals"][..., 0]).sum())])
+        print(li, r["plane"], r["n_planes"], r["n_pixels"])
+    np.savez_compressed(OUT, **store)
+    print(OUT, os.path.getsize(OUT))
+
+
+if __name__ == "__main__":
+    main()

@@ -29,7 +29,7 @@ def main():
         for tag, args in (("ref", []), ("tight", ["--delta", "1e-6", "--sym-iters", "0"])):
             od = os.path.join(td, tag)
             os.makedirs(od)
-            print(subprocess.check_output([exe, REF, od] + args).decode().strip())
+            print(subprocess.check_output([exe, REF, od, "--ground", "0", "0", "1", "0"] + args).decode().strip())
             out[tag + "_objects"] = np.array(hu.read_table(os.path.join(od, "objects.txt")))
             out[tag + "_graph_log"] = np.array(hu.read_table(os.path.join(od, "graph_log.txt")))
             out[tag + "_history"] = np.array(open(os.path.join(od, "object_history.txt")).read())

@@ -15,6 +15,12 @@ struct OracleBackend {
     *state = st;
     return 0;
   }
+  int ground_plane(const uint16_t* depth, int w, int h, const double intr[5], const esl_plane_params* p, double plane[4], int* ok) {
+    int32_t k = 0;
+    const int rc = esl_oracle_extract_ground_plane(depth, w, h, intr, p, plane, &k, nullptr, nullptr, nullptr);
+    *ok = k;
+    return rc;
+  }
   int init_quadric(const double* poses, const double* boxes, int n, const double K[4], int rows, int cols, double e10[10], int* ok) {
     double Q[16];
     return esl_oracle_init_quadric(poses, boxes, n, K, rows, cols, 1, e10, Q, ok), 0;
@@ -31,9 +37,10 @@ int main(int argc, char** argv) {
   s.fit.cluster_tolerance = 0.02; s.fit.min_cluster_size = 100; s.fit.center_dis = 0.5; s.fit.symmetry_open = 1; s.fit.symmetry_grid = 0.1;
   s.fit.symmetry_sigma = 0.1; s.fit.symmetry_lm_iters = 5;
   double ground[4] = {0, 0, 1, 0};
+  bool have_ground = false;   // default: estimated from the depth images as the reference does (System.cpp:46)
   for (int i = 3; i < argc; ++i) {
     const std::string a = argv[i];
-    if (a == "--ground" && i + 4 < argc) { for (int k = 0; k < 4; ++k) ground[k] = std::atof(argv[i + 1 + k]); i += 4; }
+    if (a == "--ground" && i + 4 < argc) { for (int k = 0; k < 4; ++k) ground[k] = std::atof(argv[i + 1 + k]); i += 4; have_ground = true; }
     else if (a == "--delta" && i + 1 < argc) be.lm.numeric_delta = std::atof(argv[++i]);
     else if (a == "--no-symmetry") s.symmetry = false;
     else if (a == "--auto-association") s.with_association = false;
@@ -41,5 +48,5 @@ int main(int argc, char** argv) {
     else if (a == "--jacobian" && i + 1 < argc) ++i;   // the checker only has g2o's numeric scheme
     else return 1;
   }
-  return esl_harness::run_clip(be, argv[1], argv[2], ground, s);
+  return esl_harness::run_clip(be, argv[1], argv[2], have_ground ? ground : nullptr, s);
 }

@@ -34,9 +34,12 @@ def clip_dir(tmp_path_factory):
     return str(d)
 
 
-def run(exe, clip, out, *args):
+MOCAP_FLOOR = ["--ground", "0", "0", "1", "0"]   # the clips of these tests carry the bbox crops only: the floor is given (mocap z = 0)
+
+
+def run(exe, clip, out, *args, ground=MOCAP_FLOOR):
     os.makedirs(out, exist_ok=True)
-    txt = subprocess.check_output([exe, clip, out] + list(args), stderr=subprocess.STDOUT).decode()
+    txt = subprocess.check_output([exe, clip, out] + list(ground) + list(args), stderr=subprocess.STDOUT).decode()
     return (txt, np.array(hu.read_table(os.path.join(out, "objects.txt"))), np.array(hu.read_table(os.path.join(out, "graph_log.txt"))),
             open(os.path.join(out, "object_history.txt")).read())
 
