@@ -332,6 +332,15 @@ void esl_plane_params_default(esl_plane_params* p);
 int esl_extract_ground_plane(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
                              const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels);
 
+/* PlaneExtractor::extractPlanes + GetCoefficients + GetPoints (PlaneExtractor.cpp:22-104, 113-123): every plane segment of
+ * >= max(min_size, min_inliers) pixels, in raster order of each segment's first pixel.  planes_out: max_planes x 4 (camera
+ * frame, normalised, d >= 0), sizes_out: pixels per plane; *n_planes = segments found (only the first max_planes are
+ * written); labels_out: width x height plane index per pixel (-1: none; indices >= max_planes are reported as found) or NULL.
+ * Labels with indices are what GetPoints() needs to rebuild the per-plane clouds on the host. */
+int esl_extract_planes(esl_ctx* ctx, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
+                       const esl_plane_params* p, int32_t max_planes, double* planes_out, int32_t* sizes_out,
+                       int32_t* n_planes, int32_t* labels_out);
+
 /* ---- SVD quadric initialisation -----------------------------------------------------------------*/
 int esl_init_quadric(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, const double* bboxes /* n x 4 */,
                      int32_t n, const double K[4], int32_t rows, int32_t cols, int32_t faithful,

@@ -22,6 +22,8 @@
 //               centre is on the positive side (:165-167)
 // Runs once per sequence (until it succeeds): nothing here is tuned for throughput, everything for determinism.
 #include <cmath>
+#include <string>
+#include <vector>
 
 #include "esl_ctx.hpp"
 
@@ -36,9 +38,13 @@ struct PlaneArgs {
   int* cnt;              // pixels per root
   long long* mom;        // per root: 9 fixed-point sums  x y z xx xy xz yy yz zz
   double* out;           // [0..3] plane, [4] ok, [5] planes >= min size, [6] pixels of the chosen plane, [7] components with normals
+  int* plane_of_root;    // esl_extract_planes: index of the plane a root belongs to, -1 = none
+  double* list;          // esl_extract_planes: 5 per plane (a b c d pixels), in raster order of each segment's first pixel
+  int list_cap;
+  int* labels;           // esl_extract_planes: plane index per pixel, -1 = none
 };
-constexpr double kFix1 = 1048576.0;        // 2^20: first moments in 2^-20 m
-constexpr double kFix2 = 1048576.0;        // second moments in 2^-20 m^2
+constexpr double kFix1 = 4294967296.0;     // first moments in 2^-32 m   (65 m x 2^19 pixels x 2^32 < 2^63)
+constexpr double kFix2 = 1073741824.0;     // second moments in 2^-30 m^2 (4300 m^2 x 2^19 pixels x 2^30 < 2^63)
 
 __device__ __forceinline__ bool px_point(const PlaneArgs& a, int u, int v, float p[3]) {
   const uint16_t d = a.depth[(size_t)v * a.w + u];
@@ -161,6 +167,61 @@ __device__ void smallest_eigvec3(const double C[9], double n[3]) {
   for (int k = 0; k < 3; ++k) n[k] = V[k * 3 + m];
 }
 
+__device__ void plane_from_moments(const long long* m, int cnt, double pl[4]) {
+  const double inv = 1.0 / (double)cnt;
+  const double cx = (double)m[0] / kFix1 * inv, cy = (double)m[1] / kFix1 * inv, cz = (double)m[2] / kFix1 * inv;
+  const double C[9] = {(double)m[3] / kFix2 * inv - cx * cx, (double)m[4] / kFix2 * inv - cx * cy, (double)m[5] / kFix2 * inv - cx * cz,
+                       (double)m[4] / kFix2 * inv - cx * cy, (double)m[6] / kFix2 * inv - cy * cy, (double)m[7] / kFix2 * inv - cy * cz,
+                       (double)m[5] / kFix2 * inv - cx * cz, (double)m[7] / kFix2 * inv - cy * cz, (double)m[8] / kFix2 * inv - cz * cz};
+  double n[3];
+  smallest_eigvec3(C, n);
+  const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  pl[0] = n[0] / nn; pl[1] = n[1] / nn; pl[2] = n[2] / nn;
+  pl[3] = -(pl[0] * cx + pl[1] * cy + pl[2] * cz);
+  if (pl[3] < 0) for (int k = 0; k < 4; ++k) pl[k] = -pl[k];   // camera centre on the positive side (PlaneExtractor.cpp:95-96, 165-167)
+}
+
+// one workgroup: the planes of all segments of >= min_size pixels in raster order of their first pixel (= their root: the
+// union-find keeps the smallest index on top), as extractPlanes stores them (PlaneExtractor.cpp:85-103)
+static __global__ __launch_bounds__(256) void k_plane_list(PlaneArgs a) {
+  __shared__ int s_scan[256];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  const int N = a.w * a.h;
+  for (int r0 = 0; r0 < N; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    const int c = r < N ? a.cnt[r] : 0;
+    const int flag = c >= a.min_size && c > 0;
+    s_scan[threadIdx.x] = flag;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int idx = s_base + s_scan[threadIdx.x] - flag;
+    if (r < N) a.plane_of_root[r] = flag ? idx : -1;
+    if (flag && idx < a.list_cap) {
+      double pl[4];
+      plane_from_moments(a.mom + (size_t)r * 9, c, pl);
+      for (int k = 0; k < 4; ++k) a.list[(size_t)idx * 5 + k] = pl[k];
+      a.list[(size_t)idx * 5 + 4] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 255) s_base += s_scan[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.out[5] = s_base;
+}
+static __global__ __launch_bounds__(256) void k_plane_labels(PlaneArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  const float* ni = a.nrm + 4 * (size_t)i;
+  a.labels[i] = ni[0] != ni[0] ? -1 : a.plane_of_root[uf_find(a.parent, i)];
+}
+
 // one workgroup: every component of >= min_size pixels -> its plane; the ground-plane candidate with the most pixels wins
 static __global__ __launch_bounds__(256) void k_plane_select(PlaneArgs a) {
   __shared__ int s_cnt[256], s_root[256], s_np[256], s_nc[256];
@@ -172,14 +233,8 @@ static __global__ __launch_bounds__(256) void k_plane_select(PlaneArgs a) {
     ++n_comp;
     if (c < a.min_size) continue;
     ++n_planes;
-    const long long* m = a.mom + (size_t)r * 9;
-    const double inv = 1.0 / (double)c;
-    const double cx = (double)m[0] / kFix1 * inv, cy = (double)m[1] / kFix1 * inv, cz = (double)m[2] / kFix1 * inv;
-    const double C[9] = {(double)m[3] / kFix2 * inv - cx * cx, (double)m[4] / kFix2 * inv - cx * cy, (double)m[5] / kFix2 * inv - cx * cz,
-                         (double)m[4] / kFix2 * inv - cx * cy, (double)m[6] / kFix2 * inv - cy * cy, (double)m[7] / kFix2 * inv - cy * cz,
-                         (double)m[5] / kFix2 * inv - cx * cz, (double)m[7] / kFix2 * inv - cy * cz, (double)m[8] / kFix2 * inv - cz * cz};
-    double n[3];
-    smallest_eigvec3(C, n);
+    double n[4];
+    plane_from_moments(a.mom + (size_t)r * 9, c, n);
     // wall filter: the angle between the normal and the camera's y axis must not lie in (pi/4, 3 pi/4)
     const double th = acos(n[1] / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]));
     if (th > M_PI / 4 && th < 3 * M_PI / 4) continue;
@@ -195,18 +250,8 @@ static __global__ __launch_bounds__(256) void k_plane_select(PlaneArgs a) {
   for (int k = 0; k < 8; ++k) a.out[k] = 0;
   a.out[5] = n_planes; a.out[7] = n_comp;
   if (best_root < 0) return;
-  const long long* m = a.mom + (size_t)best_root * 9;
-  const double inv = 1.0 / (double)best_cnt;
-  const double cx = (double)m[0] / kFix1 * inv, cy = (double)m[1] / kFix1 * inv, cz = (double)m[2] / kFix1 * inv;
-  const double C[9] = {(double)m[3] / kFix2 * inv - cx * cx, (double)m[4] / kFix2 * inv - cx * cy, (double)m[5] / kFix2 * inv - cx * cz,
-                       (double)m[4] / kFix2 * inv - cx * cy, (double)m[6] / kFix2 * inv - cy * cy, (double)m[7] / kFix2 * inv - cy * cz,
-                       (double)m[5] / kFix2 * inv - cx * cz, (double)m[7] / kFix2 * inv - cy * cz, (double)m[8] / kFix2 * inv - cz * cz};
-  double n[3];
-  smallest_eigvec3(C, n);
-  const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-  double pl[4] = {n[0] / nn, n[1] / nn, n[2] / nn, 0};
-  pl[3] = -(pl[0] * cx + pl[1] * cy + pl[2] * cz);
-  if (pl[3] < 0) for (int k = 0; k < 4; ++k) pl[k] = -pl[k];   // camera centre on the positive side (PlaneExtractor.cpp:95-96, 165-167)
+  double pl[4];
+  plane_from_moments(a.mom + (size_t)best_root * 9, best_cnt, pl);
   for (int k = 0; k < 4; ++k) a.out[k] = pl[k];
   a.out[4] = 1; a.out[6] = best_cnt;
 }
@@ -221,38 +266,89 @@ extern "C" void esl_plane_params_default(esl_plane_params* p) {
   p->min_inliers = 100;                                                           // PlaneExtractor.cpp:74
 }
 
-extern "C" int esl_extract_ground_plane(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
-                                        const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels) {
-  if (!c || !depth || !intr || !p || !plane_out || !ok || width <= 0 || height <= 0) { set_error("esl_extract_ground_plane: bad argument"); return ESL_ERR_INVALID; }
-  if (p->normal_smoothing < 2 || p->distance_threshold <= 0 || p->angle_threshold_deg <= 0) { set_error("esl_extract_ground_plane: bad parameters"); return ESL_ERR_INVALID; }
+namespace {
+struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } };
+struct PlaneWork { Buf depth, nrm, par, cnt, mom, out, map, list, labels; };
+
+// normals -> segments -> moments on the context's stream; fills `a`
+int plane_segment(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5], const esl_plane_params* p,
+                  PlaneWork& w, PlaneArgs& a, const char* who) {
+  if (!c || !depth || !intr || !p || width <= 0 || height <= 0) { set_error(std::string(who) + ": bad argument"); return ESL_ERR_INVALID; }
+  if (p->normal_smoothing < 2 || p->distance_threshold <= 0 || p->angle_threshold_deg <= 0 || p->max_depth_change_factor <= 0) {
+    set_error(std::string(who) + ": bad parameters"); return ESL_ERR_INVALID;
+  }
   ESL_HIP_TRY(hipSetDevice(c->device));
-  *ok = 0;
-  for (int k = 0; k < 4; ++k) plane_out[k] = 0;
   const size_t npx = (size_t)width * height;
-  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } d_depth, d_nrm, d_par, d_cnt, d_mom, d_out;
-  ESL_HIP_TRY(hipMalloc(&d_depth.p, npx * 2)); ESL_HIP_TRY(hipMalloc(&d_nrm.p, npx * 16)); ESL_HIP_TRY(hipMalloc(&d_par.p, npx * 4));
-  ESL_HIP_TRY(hipMalloc(&d_cnt.p, npx * 4)); ESL_HIP_TRY(hipMalloc(&d_mom.p, npx * 72)); ESL_HIP_TRY(hipMalloc(&d_out.p, 8 * sizeof(double)));
-  ESL_HIP_TRY(hipMemcpyAsync(d_depth.p, depth, npx * 2, hipMemcpyHostToDevice, c->stream));
-  PlaneArgs a;
-  a.depth = (const uint16_t*)d_depth.p; a.w = width; a.h = height;
+  ESL_HIP_TRY(hipMalloc(&w.depth.p, npx * 2)); ESL_HIP_TRY(hipMalloc(&w.nrm.p, npx * 16)); ESL_HIP_TRY(hipMalloc(&w.par.p, npx * 4));
+  ESL_HIP_TRY(hipMalloc(&w.cnt.p, npx * 4)); ESL_HIP_TRY(hipMalloc(&w.mom.p, npx * 72)); ESL_HIP_TRY(hipMalloc(&w.out.p, 8 * sizeof(double)));
+  ESL_HIP_TRY(hipMemcpyAsync(w.depth.p, depth, npx * 2, hipMemcpyHostToDevice, c->stream));
+  a = PlaneArgs{};
+  a.depth = (const uint16_t*)w.depth.p; a.w = width; a.h = height;
   a.fx = intr[0]; a.fy = intr[1]; a.cx = intr[2]; a.cy = intr[3]; a.scale = intr[4];
   a.R = p->normal_smoothing / 2; a.depth_factor = p->max_depth_change_factor;
   a.cos_ang = std::cos(p->angle_threshold_deg * 0.017453);   // the reference's degree-to-radian constant (PlaneExtractor.cpp:75)
   a.dist_th = p->distance_threshold; a.min_size = std::max(p->min_size, p->min_inliers);
-  a.nrm = (float*)d_nrm.p; a.parent = (int*)d_par.p; a.cnt = (int*)d_cnt.p; a.mom = (long long*)d_mom.p; a.out = (double*)d_out.p;
+  a.nrm = (float*)w.nrm.p; a.parent = (int*)w.par.p; a.cnt = (int*)w.cnt.p; a.mom = (long long*)w.mom.p; a.out = (double*)w.out.p;
   const unsigned nb = (unsigned)((npx + 255) / 256);
   hipLaunchKernelGGL(k_plane_normals, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_plane_init, dim3(nb), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_plane_union, dim3(nb), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_plane_moments, dim3(nb), dim3(256), 0, c->stream, a);
+  ESL_HIP_TRY(hipGetLastError());
+  return ESL_OK;
+}
+}  // namespace
+
+extern "C" int esl_extract_ground_plane(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
+                                        const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels) {
+  if (!plane_out || !ok) { set_error("esl_extract_ground_plane: bad argument"); return ESL_ERR_INVALID; }
+  *ok = 0;
+  for (int k = 0; k < 4; ++k) plane_out[k] = 0;
+  PlaneWork w;
+  PlaneArgs a;
+  if (const int rc = plane_segment(c, depth, width, height, intr, p, w, a, "esl_extract_ground_plane")) return rc;
   hipLaunchKernelGGL(k_plane_select, dim3(1), dim3(256), 0, c->stream, a);
   ESL_HIP_TRY(hipGetLastError());
   double h[8];
-  ESL_HIP_TRY(hipMemcpyAsync(h, d_out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipMemcpyAsync(h, w.out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   *ok = h[4] > 0.5 ? 1 : 0;
   if (*ok) for (int k = 0; k < 4; ++k) plane_out[k] = h[k];
   if (n_planes) *n_planes = (int32_t)h[5];
   if (n_pixels) *n_pixels = (int32_t)h[6];
+  return ESL_OK;
+}
+
+extern "C" int esl_extract_planes(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
+                                  const esl_plane_params* p, int32_t max_planes, double* planes_out, int32_t* sizes_out,
+                                  int32_t* n_planes, int32_t* labels_out) {
+  if (!n_planes || max_planes < 0 || (max_planes > 0 && (!planes_out || !sizes_out))) { set_error("esl_extract_planes: bad argument"); return ESL_ERR_INVALID; }
+  *n_planes = 0;
+  PlaneWork w;
+  PlaneArgs a;
+  if (const int rc = plane_segment(c, depth, width, height, intr, p, w, a, "esl_extract_planes")) return rc;
+  const size_t npx = (size_t)width * height;
+  ESL_HIP_TRY(hipMalloc(&w.map.p, npx * 4));
+  ESL_HIP_TRY(hipMalloc(&w.list.p, (size_t)std::max(max_planes, 1) * 5 * sizeof(double)));
+  a.plane_of_root = (int*)w.map.p; a.list = (double*)w.list.p; a.list_cap = max_planes;
+  hipLaunchKernelGGL(k_plane_list, dim3(1), dim3(256), 0, c->stream, a);
+  if (labels_out) {
+    ESL_HIP_TRY(hipMalloc(&w.labels.p, npx * 4));
+    a.labels = (int*)w.labels.p;
+    hipLaunchKernelGGL(k_plane_labels, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, a);
+  }
+  ESL_HIP_TRY(hipGetLastError());
+  double h[8];
+  std::vector<double> list((size_t)std::max(max_planes, 1) * 5);
+  ESL_HIP_TRY(hipMemcpyAsync(h, w.out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipMemcpyAsync(list.data(), w.list.p, list.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (labels_out) ESL_HIP_TRY(hipMemcpyAsync(labels_out, w.labels.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  *n_planes = (int32_t)h[5];
+  const int n = std::min(*n_planes, max_planes);
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 4; ++k) planes_out[(size_t)i * 4 + k] = list[(size_t)i * 5 + k];
+    sizes_out[i] = (int32_t)list[(size_t)i * 5 + 4];
+  }
   return ESL_OK;
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
     "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
-    "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane",
+    "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane", "esl_extract_planes",
 ]
 
 
@@ -297,6 +297,21 @@ class Context:
                                                intr.ctypes.data_as(_dp), C.byref(p), plane.ctypes.data_as(_dp), C.byref(ok),
                                                C.byref(npl), C.byref(npx)), "esl_extract_ground_plane")
         return dict(ok=bool(ok.value), plane=plane, n_planes=npl.value, n_pixels=npx.value)
+
+    def extract_planes(self, depth, intr, params=None, max_planes=64):
+        """PlaneExtractor::extractPlanes: dict(n_planes, planes (n, 4), sizes (n,), labels (h, w) plane index or -1)."""
+        p = params if params is not None else abi.default_plane_params()
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        h, w = depth.shape
+        intr = np.ascontiguousarray(intr, dtype=np.float64)
+        planes = np.zeros((max(max_planes, 1), 4)); sizes = np.zeros(max(max_planes, 1), dtype=np.int32); n = C.c_int32(0)
+        labels = np.zeros((h, w), dtype=np.int32)
+        _check(load().esl_extract_planes(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                                         intr.ctypes.data_as(_dp), C.byref(p), C.c_int32(max_planes), planes.ctypes.data_as(_dp),
+                                         sizes.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n),
+                                         labels.ctypes.data_as(C.POINTER(C.c_int32))), "esl_extract_planes")
+        k = min(n.value, max_planes)
+        return dict(n_planes=n.value, planes=planes[:k], sizes=sizes[:k], labels=labels)
 
     def selftest_cholesky(self, n):
         """(ms, relative residual) of the dense FP64-MFMA Cholesky factor + solve on a generated SPD system."""

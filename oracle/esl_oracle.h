@@ -90,6 +90,9 @@ int esl_oracle_fit_frame_ex(const uint16_t* depth, int32_t width, int32_t height
 int esl_oracle_extract_ground_plane(const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
                                     const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes,
                                     int32_t* n_pixels, float* normals_out);
+/* every plane segment (esl_extract_planes of include/esl.h) */
+int esl_oracle_extract_planes(const uint16_t* depth, int32_t width, int32_t height, const double intr[5], const esl_plane_params* p,
+                              int32_t max_planes, double* planes_out, int32_t* sizes_out, int32_t* n_planes, int32_t* labels_out);
 
 /* 0: the reference's reprojection residual (default); 1: plane-tangency rows (esl_lm_params::bbox_residual).  Applies to
  * esl_oracle_res_bbox / jac_bbox / build_system; esl_oracle_optimize sets it from its params. */

@@ -55,8 +55,8 @@ static void unite(int* parent, int a, int b) {
 }
 
 static void plane_of(const long long* m, int cnt, double pl[4]) {
-  const double f = 1048576.0, inv = 1.0 / (double)cnt;
-  const double cx = (double)m[0] / f * inv, cy = (double)m[1] / f * inv, cz = (double)m[2] / f * inv;
+  const double f1 = 4294967296.0, f = 1073741824.0, inv = 1.0 / (double)cnt;   /* fixed point: 2^-32 m, 2^-30 m^2 */
+  const double cx = (double)m[0] / f1 * inv, cy = (double)m[1] / f1 * inv, cz = (double)m[2] / f1 * inv;
   const double C[9] = {(double)m[3] / f * inv - cx * cx, (double)m[4] / f * inv - cx * cy, (double)m[5] / f * inv - cx * cz,
                        (double)m[4] / f * inv - cx * cy, (double)m[6] / f * inv - cy * cy, (double)m[7] / f * inv - cy * cz,
                        (double)m[5] / f * inv - cx * cz, (double)m[7] / f * inv - cy * cz, (double)m[8] / f * inv - cz * cz};
@@ -68,8 +68,9 @@ static void plane_of(const long long* m, int cnt, double pl[4]) {
   if (pl[3] < 0) for (int k = 0; k < 4; ++k) pl[k] = -pl[k];          /* PlaneExtractor.cpp:95-96 */
 }
 
-int esl_oracle_extract_ground_plane(const uint16_t* depth, int32_t w, int32_t h, const double intr[5], const esl_plane_params* p,
-                                    double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels, float* normals_out) {
+static int plane_core(const uint16_t* depth, int32_t w, int32_t h, const double intr[5], const esl_plane_params* p,
+                      double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels, float* normals_out,
+                      int32_t max_planes, double* planes_out, int32_t* sizes_out, int32_t* labels_out) {
   const size_t npx = (size_t)w * h;
   float* nrm = (float*)malloc(npx * 4 * sizeof(float));
   int* parent = (int*)malloc(npx * sizeof(int));
@@ -138,32 +139,51 @@ int esl_oracle_extract_ground_plane(const uint16_t* depth, int32_t w, int32_t h,
       const int r = find_root(parent, i);
       float pt[3];
       px_point(depth, w, u, v, intr, pt);
-      const double x = pt[0], y = pt[1], z = pt[2], f = 1048576.0;
-      const double v9[9] = {x * f, y * f, z * f, x * x * f, x * y * f, x * z * f, y * y * f, y * z * f, z * z * f};
+      const double x = pt[0], y = pt[1], z = pt[2], f1 = 4294967296.0, f = 1073741824.0;
+      const double v9[9] = {x * f1, y * f1, z * f1, x * x * f, x * y * f, x * z * f, y * y * f, y * z * f, z * z * f};
       ++cnt[r];
       for (int k = 0; k < 9; ++k) mom[(size_t)r * 9 + k] += llrint(v9[k]);
     }
-  /* planes of >= min size; wall filter; the largest one is the ground (:87, :139-162) */
+  /* planes of >= min size (:87) in raster order of each segment's first pixel (= its root); wall filter; the largest one is
+   * the ground (:139-162) */
   const int min_size = p->min_size > p->min_inliers ? p->min_size : p->min_inliers;
   int best = -1, best_cnt = 0, planes = 0;
+  int* plane_idx = labels_out ? (int*)malloc(npx * sizeof(int)) : NULL;
   for (size_t r = 0; r < npx; ++r) {
+    if (plane_idx) plane_idx[r] = -1;
     if (cnt[r] < min_size || cnt[r] <= 0) continue;
-    ++planes;
     double pl[4];
     plane_of(mom + r * 9, cnt[r], pl);
+    if (planes < max_planes && planes_out) { memcpy(planes_out + (size_t)planes * 4, pl, sizeof(pl)); sizes_out[planes] = cnt[r]; }
+    if (plane_idx) plane_idx[r] = planes;
+    ++planes;
     const double th = acos(pl[1] / sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]));
     if (th > M_PI / 4 && th < 3 * M_PI / 4) continue;
     if (cnt[r] > best_cnt) { best_cnt = cnt[r]; best = (int)r; }
   }
-  *ok = 0;
-  for (int k = 0; k < 4; ++k) plane_out[k] = 0;
+  if (labels_out)
+    for (size_t i = 0; i < npx; ++i)
+      labels_out[i] = nrm[4 * i] != nrm[4 * i] ? -1 : plane_idx[find_root(parent, (int)i)];
+  free(plane_idx);
+  if (ok) *ok = 0;
+  if (plane_out) for (int k = 0; k < 4; ++k) plane_out[k] = 0;
   if (n_planes) *n_planes = planes;
   if (n_pixels) *n_pixels = 0;
   if (best >= 0) {
-    plane_of(mom + (size_t)best * 9, best_cnt, plane_out);              /* d >= 0: camera centre on the positive side (:165-167) */
-    *ok = 1;
+    if (plane_out) plane_of(mom + (size_t)best * 9, best_cnt, plane_out);   /* d >= 0: camera centre on the positive side (:165-167) */
+    if (ok) *ok = 1;
     if (n_pixels) *n_pixels = best_cnt;
   }
   free(nrm); free(parent); free(cnt); free(mom);
   return 0;
+}
+
+int esl_oracle_extract_ground_plane(const uint16_t* depth, int32_t w, int32_t h, const double intr[5], const esl_plane_params* p,
+                                    double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels, float* normals_out) {
+  return plane_core(depth, w, h, intr, p, plane_out, ok, n_planes, n_pixels, normals_out, 0, NULL, NULL, NULL);
+}
+
+int esl_oracle_extract_planes(const uint16_t* depth, int32_t w, int32_t h, const double intr[5], const esl_plane_params* p,
+                              int32_t max_planes, double* planes_out, int32_t* sizes_out, int32_t* n_planes, int32_t* labels_out) {
+  return plane_core(depth, w, h, intr, p, NULL, NULL, n_planes, NULL, NULL, max_planes, planes_out, sizes_out, labels_out);
 }

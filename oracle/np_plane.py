@@ -122,7 +122,12 @@ def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smo
         if np.pi / 4 < th < 3 * np.pi / 4:
             continue
         cand.append((c, r, pl))
-    out = dict(ok=False, plane=np.zeros(4), n_planes=len(planes), n_pixels=0, normals=nr)
+    planes.sort(key=lambda t: t[1])                 # raster order of each segment's first pixel
+    lab_img = np.full((h, w), -1, dtype=np.int32)
+    for k, (c, r, pl) in enumerate(planes):
+        lab_img[(lab == lab.reshape(-1)[r]) & valid] = k
+    out = dict(ok=False, plane=np.zeros(4), n_planes=len(planes), n_pixels=0, normals=nr,
+               planes=np.array([t[2] for t in planes]).reshape(-1, 4), sizes=np.array([t[0] for t in planes], dtype=np.int32), labels=lab_img)
     if cand:
         cand.sort(key=lambda t: (-t[0], t[1]))
         out.update(ok=True, plane=cand[0][2], n_pixels=cand[0][0])

@@ -233,6 +233,25 @@ def extract_ground_plane(depth, intr, params=None, want_normals=False):
     return out
 
 
+def extract_planes(depth, intr, params=None, max_planes=64):
+    """Returns dict(n_planes, planes (n, 4), sizes (n,), labels (h, w))."""
+    from importlib import import_module
+    abi = import_module("object-oriented-slam_amd.abi")
+    p = params if params is not None else abi.default_plane_params()
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    h, w = depth.shape
+    intr = np.ascontiguousarray(intr, dtype=np.float64)
+    planes = np.zeros((max(max_planes, 1), 4)); sizes = np.zeros(max(max_planes, 1), dtype=np.int32); n = C.c_int32(0)
+    labels = np.zeros((h, w), dtype=np.int32)
+    rc = lib().esl_oracle_extract_planes(depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                                         intr.ctypes.data_as(C.POINTER(C.c_double)), C.byref(p), C.c_int32(max_planes),
+                                         planes.ctypes.data_as(C.POINTER(C.c_double)), sizes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         C.byref(n), labels.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0
+    k = min(n.value, max_planes)
+    return dict(n_planes=n.value, planes=planes[:k], sizes=sizes[:k], labels=labels)
+
+
 def set_bbox_residual(mode):
     lib().esl_oracle_set_bbox_residual(C.c_int(mode))
 

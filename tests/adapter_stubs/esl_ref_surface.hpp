@@ -1,11 +1,11 @@
 // esl_ref_surface.hpp — COMPILE-ONLY stand-ins for the headers the adapters are built against in the reference tree
-// (Eigen, OpenCV's cv::Mat, the reference's Config / Frame / Map / ellipsoid / plane and the three class declarations
+// (Eigen, OpenCV's cv::Mat, the reference's Config / Frame / Map / ellipsoid / plane and the four class declarations
 // whose BODIES adapter/*.cpp replace).  Test infrastructure for tests/test_adapter_link.py: it lets this container
 // (no Eigen, no OpenCV, no PCL) compile and LINK all three adapters with -DESL_BUILD_IN_REFERENCE_TREE together with
 // Tracking's call sites, so that a member Tracking calls but an adapter forgot to define is a link error here and not at
 // the maintainer's desk.  Only what the adapters and those call sites touch is declared; the public member signatures of
-// Optimizer / Initializer / EllipsoidExtractor are those of reference include/core/Optimizer.h:13-30,
-// include/core/Initializer.h:36-79, src/pca/EllipsoidExtractor.h:42-129.  Nothing here is used by the product.
+// Optimizer / Initializer / EllipsoidExtractor / PlaneExtractor are those of reference include/core/Optimizer.h:13-30,
+// include/core/Initializer.h:36-79, src/pca/EllipsoidExtractor.h:42-129, src/plane/PlaneExtractor.h:41-72.  Nothing here is used by the product.
 #pragma once
 #include <cstdint>
 #include <iostream>
@@ -58,13 +58,34 @@ typedef Eigen::Matrix<double, 7, 1> Vector7d;
 typedef Eigen::Matrix<double, 9, 1> Vector9d;
 typedef Eigen::Matrix<double, 10, 1> Vector10d;
 
+typedef unsigned short ushort;
+#define CV_32F 5
 namespace cv {
 struct Mat {
   int rows = 0, cols = 0;
-  std::vector<uint16_t> px;
+  std::vector<uint16_t> px;     // a 16-bit depth image ...
+  std::vector<float> f32;       // ... or a small float matrix (Mat(rows, cols, CV_32F))
+  Mat() {}
+  Mat(int r, int c, int) : rows(r), cols(c), f32((size_t)r * c) {}
   template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(px.data()) + (size_t)r * cols; }
+  template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(px.data()) + (size_t)r * cols; }
+  template <class T> T& at(int i) { return f32[i]; }
 };
 }  // namespace cv
+
+#include <memory>
+namespace pcl {   // the two cloud types of PlaneExtractor's public interface
+struct PointXYZRGB { float x = 0, y = 0, z = 0; unsigned char r = 0, g = 0, b = 0; };
+template <class P>
+struct PointCloud {
+  typedef std::shared_ptr<PointCloud<P>> Ptr;
+  std::vector<P> points;
+  unsigned width = 0, height = 0;
+  size_t size() const { return points.size(); }
+};
+}  // namespace pcl
+typedef pcl::PointCloud<pcl::PointXYZRGB> PointCloudPCL;
+using std::string;
 
 namespace g2o {
 struct SE3Quat {
@@ -101,6 +122,8 @@ class Config {   // src/config/Config.h: Get<T>(key) reads the yaml, ReadValue<T
   static std::map<std::string, double>& values() { static std::map<std::string, double> m; return m; }
   template <class T> static T Get(const std::string& key) { return T(values()[key]); }
   template <class T> static T ReadValue(const std::string& key, T = 0) { return T(values()[key]); }
+  static void Init() {}
+  static void SetParameterFile(const std::string&) {}
 };
 
 class Frame {
@@ -192,5 +215,33 @@ class EllipsoidExtractor {   // src/pca/EllipsoidExtractor.h:42-129 (public part
   Map* mpMap;
   int miExtractCount;
   bool mbOpenSymmetry;
+};
+
+struct PlaneExtractorParam {   // src/plane/PlaneExtractor.h:32-39
+  double fx, fy, cx, cy;
+  double scale;
+  bool RangeOpen = false;
+  int RangeHeight;
+};
+
+class PlaneExtractor {   // src/plane/PlaneExtractor.h:41-72
+ public:
+  PlaneExtractor() {}
+  PlaneExtractor(const string& settings);
+  bool extractGroundPlane(const cv::Mat& depth, g2o::plane& plane);
+  void extractPlanes(const cv::Mat& depth);
+  void SetParam(PlaneExtractorParam& param);
+  std::vector<PointCloudPCL> GetPoints();
+  std::vector<PointCloudPCL> GetPotentialGroundPlanePoints();
+  std::vector<cv::Mat> GetCoefficients();
+  PointCloudPCL::Ptr GetCloudDense();
+
+ private:
+  int mParamRangeHeight;
+  PlaneExtractorParam mParam;
+  std::vector<PointCloudPCL> mvPlanePoints;
+  std::vector<PointCloudPCL> mvPotentialGroundPlanePoints;
+  std::vector<cv::Mat> mvPlaneCoefficients;
+  PointCloudPCL::Ptr mpCloudDense;
 };
 }  // namespace EllipsoidSLAM

@@ -1,7 +1,7 @@
-// tracking_calls.cpp — the call sites of reference src/core/Tracking.cpp that touch the three replaced classes
+// tracking_calls.cpp — the call sites of reference src/core/Tracking.cpp that touch the four replaced classes
 // (:121-122 construction, :226 optimisation, :299 ClearPointCloudList, :329 EstimateLocalEllipsoid, :338 GetResult,
 // :351 GetSymmetryOutputData, :590-593 initializeQuadric + getInitializeResult, :643-650 OpenDepthEllipsoid,
-// :779/:784 ground plane), linked against adapter/*.cpp built with -DESL_BUILD_IN_REFERENCE_TREE and the stand-in
+// :692-699/:720 ground-plane estimation, :779/:784 ground plane), linked against adapter/*.cpp built with -DESL_BUILD_IN_REFERENCE_TREE and the stand-in
 // headers of this directory.  tests/test_adapter_link.py builds it; without arguments it only proves that everything
 // links and that a machine without a HIP device gets the reference's failure pattern (flags false, nothing thrown);
 // with a scene file it replays a small Tracking-shaped sequence on the GPU and prints what the classes returned.
@@ -86,6 +86,18 @@ int main(int argc, char** argv) {
       raw.read(reinterpret_cast<char*>(fit_depth.px.data()), (std::streamsize)fit_depth.px.size() * 2);
     }
   }
+  cv::Mat plane_depth;
+  bool have_plane = false;
+  if (argc > 1 && have_fit) {   // optional last record: a depth image for the ground-plane estimation
+    std::ifstream in(argv[1]);
+    std::string tok, path;
+    while (in >> tok) if (tok == "GROUNDDEPTH") { in >> plane_depth.cols >> plane_depth.rows >> path; have_plane = true; }
+    if (have_plane) {
+      plane_depth.px.resize((size_t)plane_depth.cols * plane_depth.rows);
+      std::ifstream raw(path, std::ios::binary);
+      raw.read(reinterpret_cast<char*>(plane_depth.px.data()), (std::streamsize)plane_depth.px.size() * 2);
+    }
+  }
   mCalib(0, 0) = mCamera.fx; mCalib(1, 1) = mCamera.fy; mCalib(0, 2) = mCamera.cx; mCalib(1, 2) = mCamera.cy; mCalib(2, 2) = 1;
 
   // Tracking.cpp:121-122
@@ -106,6 +118,26 @@ int main(int argc, char** argv) {
     g2o::ellipsoid e = mpEllipsoidExtractor->EstimateLocalEllipsoid(d, b, 28, pose, mCamera);
     std::printf("NOPLANE %d\n", mpEllipsoidExtractor->GetResult() ? 1 : 0);
     (void)e;
+  }
+  // Tracking.cpp:692-699 (OpenGroundPlaneEstimation) and :720 (ProcessGroundPlaneEstimation)
+  Config::values()["Plane.MinSize"] = 200;
+  Config::values()["Plane.AngleThreshold"] = 5;
+  Config::values()["Plane.DistanceThreshold"] = 0.1;
+  PlaneExtractor* pPlaneExtractor = new PlaneExtractor;
+  {
+    PlaneExtractorParam param;
+    param.fx = mCamera.fx; param.fy = mCamera.fy; param.cx = mCamera.cx; param.cy = mCamera.cy; param.scale = mCamera.scale;
+    pPlaneExtractor->SetParam(param);
+    cv::Mat d = plane_depth;
+    if (!have_plane) { d.rows = 32; d.cols = 32; d.px.assign(32 * 32, 5000); }
+    g2o::plane groundPlane;
+    const bool result = pPlaneExtractor->extractGroundPlane(d, groundPlane);
+    std::printf("GROUND %d", result ? 1 : 0);
+    if (result) for (int k = 0; k < 4; ++k) std::printf(" %.9g", groundPlane.param[k]);
+    std::printf("\nPLANES %zu", pPlaneExtractor->GetCoefficients().size());
+    for (auto& c : pPlaneExtractor->GetPoints()) std::printf(" %zu", c.size());
+    std::printf("\nDENSE %zu %zu\n", pPlaneExtractor->GetCloudDense() ? pPlaneExtractor->GetCloudDense()->size() : 0,
+                pPlaneExtractor->GetPotentialGroundPlanePoints().size());
   }
   // Tracking.cpp:779, 784
   mpEllipsoidExtractor->SetSupportingPlane(&mGroundPlane);
