@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6          # SURVEY.md §8 d (vendor sheet): FP64 matrix
-FP64_MFMA_MEASURED_TF = 35.9      # scripts/mfma_peak.hip on the GPU box (profiles/r1_fp64_ceilings.txt)
+FP64_MFMA_MEASURED_TF = 35.9      # scripts/mfma_peak.hip on the GPU box (profiles/r2_fp64_ceilings.txt)
 
 
 def algorithmic_bytes_linearize(g, slam):
@@ -48,9 +48,9 @@ def algorithmic_bytes_linearize(g, slam):
 def valu_issue_floor(g, avg_ms):
     """What actually bounds the linearisation: FP64 VALU issue, not HBM (DESIGN.md 'kernel rooflines').
     floor = sum over waves of their VALU instruction count x 4 cycles (a wave64 op on a 16-lane SIMD) spread over
-    1024 SIMDs at 2.4 GHz; instruction counts are the static ones of profiles/r1_isa_counts.json."""
+    1024 SIMDs at 2.4 GHz; instruction counts are the static ones of profiles/r2_isa_counts.json."""
     try:
-        isa = json.load(open(os.path.join(ROOT, "profiles", "r1_isa_counts.json")))
+        isa = json.load(open(os.path.join(ROOT, "profiles", "r2_isa_counts.json")))
         bb, e3 = isa["k_chunk_linearize<1, 0, false>"], isa["k_chunk_linearize<1, 1, false>"]
     except Exception:  # noqa: BLE001
         return None
@@ -65,7 +65,7 @@ def valu_issue_floor(g, avg_ms):
             "simds": 1024, "clock_ghz": 2.4, "floor_ms": floor_ms, "frac": floor_ms / avg_ms if avg_ms > 0 else None,
             "floor_ms_at_1p89_ghz": floor_ms * 2.4 / 1.89,
             "note": "kernel duration includes ~4 us of dispatch; static instruction counts (both sides of branches); a pure "
-                    "v_fma_f64 stream pulls the shader clock down to 1.89 GHz on this part (profiles/r1_fp64_ceilings.txt)"}
+                    "v_fma_f64 stream pulls the shader clock down to 1.89 GHz on this part (profiles/r2_fp64_ceilings.txt)"}
 
 
 def host_info():
@@ -239,7 +239,7 @@ def slam_bench(pkg, ctx, with_cpu=True):
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": ch["count"],
                          "measured_ceiling": {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_MEASURED_TF,
                                               "note": "register-only v_mfma_f64_16x16x4_f64 stream on this part (scripts/mfma_peak.hip, "
-                                                      "profiles/r1_fp64_ceilings.txt): half the spec-sheet figure"}},
+                                                      "profiles/r2_fp64_ceilings.txt): half the spec-sheet figure"}},
         }
         if with_cpu:
             from oracle import pyoracle as po
@@ -470,8 +470,8 @@ def main():
             traffic = None
             try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) — same workload only
                 if not slam and a.config == "C4" and a.jacobian == "analytic":
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_device_lm.json")))["kernels"]
-                    traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, false>" in k][0]["traffic_bytes_per_launch"]
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_device_lm.json")))["kernels"]
+                    traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, false" in k][0]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
                 traffic = None
             roof = {"kernel": "k_chunk_linearize_both (bbox + 3-D chunks, one launch)" if not slam else "k_slam_linearize", "bound": "hbm",

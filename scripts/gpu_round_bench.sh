@@ -2,17 +2,19 @@
 # travels back -- and scripts/collect_profiles.sh copies the judged summaries into profiles/ afterwards.
 #   default bench (with CPU baseline) + rocprofv3 kernel stats of the same command, PMC traffic of the LM kernels,
 #   optimiser-only kernel stats, fit pipeline kernel times, dense-Cholesky micro-benchmark, FP64 ceilings, other configs
-R=gpurun_out/r1
+TAG=${1:-r2}
+R=gpurun_out/$TAG
 mkdir -p $R
 export TMPDIR=/tmp
-bash scripts/gpu_pmc.sh r1 > $R/pmc.txt 2>&1
+bash scripts/gpu_pmc.sh $TAG > $R/pmc.txt 2>&1
 timeout 600 python bench.py > $R/bench_default.json 2> $R/bench_default.err
 ESL_BENCH_NO_PROFILE=1 timeout 300 python bench.py --no-cpu-baseline > $R/bench_noprofile.json 2> /dev/null
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$R/prof_bench -- python /root/repo/bench.py --no-cpu-baseline > /root/repo/$R/prof_bench.log 2>&1)
 python profiles/summarize_rocpd.py $R/prof_bench/*/*_results.db > $R/bench_default_kernel_stats.md
-bash scripts/gpu_prof_map.sh r1 > $R/prof_map.txt 2>&1
-python profiles/summarize_rocpd.py gpurun_out/prof_map_r1/*/*_results.db > $R/mapping_c4_kernel_stats.md
-bash scripts/gpu_prof_fit.sh r1 > $R/fit_kernel_times.txt 2>&1
+bash scripts/gpu_prof_map.sh $TAG > $R/prof_map.txt 2>&1
+python profiles/summarize_rocpd.py gpurun_out/prof_map_$TAG/*/*_results.db > $R/mapping_c4_kernel_stats.md
+bash scripts/gpu_prof_fit.sh $TAG > $R/fit_kernel_times.txt 2>&1
+bash scripts/gpu_pmc_lm.sh $TAG > $R/pmc_sq_lm_kernels.md 2>&1
 timeout 300 python scripts/chol_bench.py 2994 8192 16384 24576 32768 > $R/cholesky_microbench.txt 2>&1
 (hipcc -O3 --offload-arch=gfx950 scripts/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && timeout 120 /tmp/mfma_peak) > $R/fp64_ceilings.txt 2>&1
 run() { name=$1; shift; timeout 900 python bench.py --no-cpu-baseline "$@" > $R/$name.json 2> $R/$name.err; }
@@ -20,9 +22,9 @@ run c3_slam --mode slam --config C3 --steps 3 --warmup 1
 run c4_mapping_numeric --jacobian numeric --steps 5 --warmup 1
 run c3_mapping --config C3
 run c4_slam --mode slam --config C4 --steps 1 --warmup 0
-python - <<'PY'
-import json
-R = "gpurun_out/r1"
+python - $R <<'PY'
+import json, sys
+R = sys.argv[1]
 for f in ["bench_default", "bench_noprofile", "c3_slam", "c4_mapping_numeric", "c3_mapping", "c4_slam"]:
     try:
         d = json.loads(open(f"{R}/{f}.json").read().strip().splitlines()[-1])

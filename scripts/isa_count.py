@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Static instruction mix of the gfx950 kernels (device-only compile to assembly, then count by class).
 
-    python scripts/isa_count.py            # writes profiles/r1_isa_counts.json + .md
+    python scripts/isa_count.py [tag]      # writes profiles/<tag>_isa_counts.json + .md (tag defaults to r2)
 
 Classes: f64 = v_*_f64 (FP64 VALU, 4 cycles per wave64 on a 16-lane SIMD), slow = v_div_*/v_rcp/v_sqrt/v_rsq f64,
 valu_other = every other v_* (integer, moves, compares, selects), salu = s_*, lds = ds_* (the wave reduce-scatter's
@@ -66,14 +66,16 @@ def count(path):
 
 
 def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
     res = {}
     res.update(count(assemble("esl_capi.hip", ["-DESL_ISA_PROBE"])))
     res.update(count(assemble("esl_slam.hip")))
-    fit = count(assemble("esl_fit.hip", ["-ffp-contract=off"]))
-    res.update(fit)
+    res.update(count(assemble("esl_fit.hip", ["-ffp-contract=off"])))
+    res.update(count(assemble("esl_init.hip")))
+    res.update(count(assemble("esl_plane.hip", ["-ffp-contract=off"])))
     os.makedirs(OUT, exist_ok=True)
-    json.dump(res, open(os.path.join(OUT, "r1_isa_counts.json"), "w"), indent=1, sort_keys=True)
-    with open(os.path.join(OUT, "r1_isa_counts.md"), "w") as f:
+    json.dump(res, open(os.path.join(OUT, tag + "_isa_counts.json"), "w"), indent=1, sort_keys=True)
+    with open(os.path.join(OUT, tag + "_isa_counts.md"), "w") as f:
         f.write("Static gfx950 instruction mix per kernel (scripts/isa_count.py; both sides of every branch counted).\n\n")
         f.write("| kernel | total | f64 VALU | of which div/rcp/sqrt | other VALU | SALU | LDS | mem | VGPR | AGPR | scratch B | waves/SIMD |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
@@ -81,7 +83,7 @@ def main():
             v = res[k]
             f.write(f"| `{k}` | {v['total']} | {v['f64']} | {v['slow']} | {v['valu_other']} | {v['salu']} | {v['lds']} | {v['mem']} | "
                     f"{v['vgpr']} | {v['agpr']} | {v['scratch_bytes']} | {v['occupancy']} |\n")
-    print(open(os.path.join(OUT, "r1_isa_counts.md")).read())
+    print(open(os.path.join(OUT, tag + "_isa_counts.md")).read())
 
 
 if __name__ == "__main__":
