@@ -18,6 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace esl {
 
 constexpr int kNB = 128;       // panel width
@@ -345,9 +347,19 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 // trailing update), which halves the read-modify-write traffic on C per flop.
 // The product is formed TRANSPOSED (B-fragment as the MFMA A operand): in the f64 D layout lane & 15 is then the
 // row index of C, so 16 lanes touch 128 contiguous bytes of the column-major matrix.
-constexpr int kBM = 256, kBN = 128, kKC = 16, kLdA = 272, kLdB = 144;
+// Small trailing matrices (the reduced system of a C3-sized graph, n ~ 3k) use a 128 x 64 tile (32 x 32 per wave): the
+// chain of one wave is then 4 MFMAs per k-step instead of 16 and a trailing matrix of 1,500 rows still spreads over ~140
+// workgroups; with the big tile it occupied 20 CUs for 86 us whatever its size.
+constexpr int kKC = 16;
+template <int BM, int BN>
 static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
                                                                 int kcol0, int K, long base, int ntJ) {
+  static_assert(BM == 2 * BN && BM % 64 == 0, "tile shape");
+  constexpr int kLdA = BM + 16, kLdB = BN + 16;   // +16: the 4 k-groups of a fragment read land in different banks
+  constexpr int SM = BM / 4, SN = BN / 2;         // rows x columns of one wave's sub-tile
+  constexpr int MI = SM / 16, NJ = SN / 16;
+  constexpr int QA = BM * kKC / 2 / 512, QB = BN * kKC / 2 / 512;   // double2 per thread per chunk
+  static_assert(QA >= 1 && QB >= 1, "chunk smaller than the workgroup");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* As = sm;                               // [2][kKC][kLdA]
   double* Bs = sm + 2 * kKC * kLdA;              // [2][kKC][kLdB]
@@ -357,18 +369,18 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
   while ((ti + 1) * (ti + 2) <= b) ++ti;
   const long tj = b - ti * (ti + 1);             // 0 .. 2 ti + 1
   if (tj >= ntJ) return;
-  const long i0 = base + ti * kBM, j0 = base + tj * kBN;
+  const long i0 = base + ti * BM, j0 = base + tj * BN;
   if (i0 >= rows || j0 >= ncols) return;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int wi = wave >> 1, wj = wave & 1;
   const double* P = M + (long)kcol0 * lda;
-  // global -> register staging: A chunk = 256 x 16 doubles = 2048 double2 (4 per thread), B chunk = 1024 double2 (2 per thread)
+  // global -> register staging: A chunk = BM x 16 doubles, B chunk = BN x 16 doubles, as double2
   typedef double double2_t __attribute__((ext_vector_type(2)));
-  double2_t ra[4], rb[2];
+  double2_t ra[QA], rb[QB];
   auto gload = [&](int kc) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = t + 512 * q, pr = e & 127, k = e >> 7;
+    for (int q = 0; q < QA; ++q) {
+      const int e = t + 512 * q, pr = e % (BM / 2), k = e / (BM / 2);
       const long row = i0 + 2 * pr;
       const bool kv = (kc + k) < K;
       double2_t v = {0.0, 0.0};
@@ -377,8 +389,8 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
       ra[q] = v;
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = t + 512 * q, pr = e & 63, k = e >> 6;
+    for (int q = 0; q < QB; ++q) {
+      const int e = t + 512 * q, pr = e % (BN / 2), k = e / (BN / 2);
       const long row = j0 + 2 * pr;
       const bool kv = (kc + k) < K;
       double2_t v = {0.0, 0.0};
@@ -389,55 +401,95 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = t + 512 * q, pr = e & 127, k = e >> 7;
+    for (int q = 0; q < QA; ++q) {
+      const int e = t + 512 * q, pr = e % (BM / 2), k = e / (BM / 2);
       *reinterpret_cast<double2_t*>(As + (buf * kKC + k) * kLdA + 2 * pr) = ra[q];
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = t + 512 * q, pr = e & 63, k = e >> 6;
+    for (int q = 0; q < QB; ++q) {
+      const int e = t + 512 * q, pr = e % (BN / 2), k = e / (BN / 2);
       *reinterpret_cast<double2_t*>(Bs + (buf * kKC + k) * kLdB + 2 * pr) = rb[q];
     }
   };
-  double4_t acc[4][4];   // acc[nj][mi]: rows = j (tile columns), cols = i (tile rows)
+  double4_t acc[NJ][MI];   // acc[nj][mi]: rows = j (tile columns), cols = i (tile rows)
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < NJ; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = double4_t{0, 0, 0, 0};
-  const bool skip = (j0 + wj * 64) > (i0 + wi * 64 + 63) || (i0 + wi * 64) >= rows || (j0 + wj * 64) >= ncols;  // sub-tile above the diagonal / outside
+    for (int y = 0; y < MI; ++y) acc[x][y] = double4_t{0, 0, 0, 0};
+  const bool skip = (j0 + wj * SN) > (i0 + wi * SM + SM - 1) || (i0 + wi * SM) >= rows || (j0 + wj * SN) >= ncols;  // sub-tile above the diagonal / outside
   const int r = lane & 15, kq = lane >> 4;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kc = 0; kc < K; kc += kKC) {
-    const bool more = kc + kKC < K;
-    if (more) gload(kc + kKC);
-    if (!skip) {
-      const double* Ab = As + buf * kKC * kLdA + wi * 64 + r;
-      const double* Bb = Bs + buf * kKC * kLdB + wj * 64 + r;
+  // interior tiles (all rows of the tile inside the matrix, K a multiple of the chunk): the same staging without a single
+  // guard -- the guarded form costs ~250 instructions and 22 branches per 64 MFMAs, in phase on all 8 waves after each barrier
+  const bool interior = (i0 + BM <= rows) && (K % kKC == 0);
+  const double* pA[QA];
+  const double* pB[QB];
 #pragma unroll
-      for (int kk = 0; kk < kKC; kk += 4) {
-        double a[4], bq[4];
+  for (int q = 0; q < QA; ++q) { const int e = t + 512 * q; pA[q] = P + i0 + 2 * (e % (BM / 2)) + (long)(e / (BM / 2)) * lda; }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { a[m] = Ab[(kk + kq) * kLdA + m * 16]; bq[m] = Bb[(kk + kq) * kLdB + m * 16]; }
+  for (int q = 0; q < QB; ++q) { const int e = t + 512 * q; pB[q] = P + j0 + 2 * (e % (BN / 2)) + (long)(e / (BN / 2)) * lda; }
+  auto gload_fast = [&](int kc) {
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj)
+    for (int q = 0; q < QA; ++q) ra[q] = *reinterpret_cast<const double2_t*>(pA[q] + (long)kc * lda);
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi) acc[nj][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[nj], a[mi], acc[nj][mi], 0, 0, 0);
-      }
-    }
-    if (more) sstore(buf ^ 1);
+    for (int q = 0; q < QB; ++q) rb[q] = *reinterpret_cast<const double2_t*>(pB[q] + (long)kc * lda);
+  };
+  auto mainloop = [&](auto fast) {
+    if constexpr (decltype(fast)::value) gload_fast(0); else gload(0);
+    sstore(0);
     __syncthreads();
-    buf ^= 1;
-  }
+    int buf = 0;
+    for (int kc = 0; kc < K; kc += kKC) {
+      const bool more = kc + kKC < K;
+      if (more) { if constexpr (decltype(fast)::value) gload_fast(kc + kKC); else gload(kc + kKC); }
+      if (!skip) {
+        const double* Ab = As + buf * kKC * kLdA + wi * SM + r;
+        const double* Bb = Bs + buf * kKC * kLdB + wj * SN + r;
+#pragma unroll
+        for (int kk = 0; kk < kKC; kk += 4) {
+          double a[MI], bq[NJ];
+#pragma unroll
+          for (int m = 0; m < MI; ++m) a[m] = Ab[(kk + kq) * kLdA + m * 16];
+#pragma unroll
+          for (int m = 0; m < NJ; ++m) bq[m] = Bb[(kk + kq) * kLdB + m * 16];
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[nj][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[nj], a[mi], acc[nj][mi], 0, 0, 0);
+        }
+      }
+      if (more) sstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  };
+  if (interior) mainloop(std::true_type{}); else mainloop(std::false_type{});
   if (skip) return;
-  const long iw = i0 + wi * 64, jw = j0 + wj * 64;
+  const long iw = i0 + wi * SM, jw = j0 + wj * SN;
   const int rq = lane >> 4;
+  // C -= acc.  Sub-tiles that lie entirely inside the matrix and strictly below the diagonal (all but a sliver) take the
+  // unguarded form: 4 MI independent loads in flight per column group, then the subtracts and stores.  The guarded form
+  // compiled to load / wait / subtract / store one element at a time -- 64 exposed memory round trips per lane, which
+  // cost more than the whole K loop of the tile.
+  const bool full = (iw + SM <= rows) && (jw + SN <= ncols) && (jw + SN - 1 <= iw);
+  if (full) {
 #pragma unroll
-  for (int nj = 0; nj < 4; ++nj)
+    for (int nj = 0; nj < NJ; ++nj) {
+      double cv[MI][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cv[mi][g] = M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda] = cv[mi][g] - acc[nj][mi][g];
+    }
+    return;
+  }
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const long col = jw + nj * 16 + rq + 4 * g;   // D row  -> j
@@ -489,10 +541,11 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     attr_set = true;
   }
   int np = (n + kNB - 1) / kNB;
-  const size_t lds_u = (size_t)(2 * kKC * (kLdA + kLdB)) * sizeof(double);
+  constexpr size_t lds_big = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
+  constexpr size_t lds_small = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
   static bool attr2_set = false;
   if (!attr2_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_chol_update_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_u);
+    hipError_t e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     if (e != hipSuccess) return e;
     attr2_set = true;
   }
@@ -500,10 +553,19 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     // trailing region: rows [base, rows), cols [base, col_limit)
     const long nrows = rows - base, nc = col_limit - base;
     if (nrows <= 0 || nc <= 0) return;
-    const long ntI = (nrows + kBM - 1) / kBM, ntJ = (nc + kBN - 1) / kBN;
-    const long nblk = ntI * (ntI + 1);   // sum over ti of (2 ti + 2) tiles; tiles with tj >= ntJ exit immediately
-    hipLaunchKernelGGL(k_chol_update_lds, dim3((unsigned)nblk), dim3(512), lds_u, st, M, lda, rows, col_limit, kcol0, K, base,
-                       (int)ntJ);
+    // the big tile only when it still gives every CU a few workgroups
+    const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (nc == nrows ? 2 : 1);
+    if (big_tiles >= 1024) {
+      const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
+      const long nblk = ntI * (ntI + 1);   // sum over ti of (2 ti + 2) tiles; tiles with tj >= ntJ exit immediately
+      hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), lds_big, st, M, lda, rows, col_limit, kcol0, K,
+                         base, (int)ntJ);
+    } else {
+      const long ntI = (nrows + 127) / 128, ntJ = (nc + 63) / 64;
+      const long nblk = ntI * (ntI + 1);
+      hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), lds_small, st, M, lda, rows, col_limit, kcol0, K,
+                         base, (int)ntJ);
+    }
   };
   for (int p = 0; p < np; p += 2) {
     // outer panel = up to two 128-wide inner panels; the big trailing update uses K = 256
