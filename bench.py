@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6          # SURVEY.md §8 d (vendor sheet): FP64 matrix
-FP64_MFMA_MEASURED_TF = 35.9      # scripts/mfma_peak.hip on the GPU box (profiles/r2_fp64_ceilings.txt)
+FP64_MFMA_MEASURED_TF = 78.2      # scripts/mfma_peak.hip on the GPU box (profiles/r2_fp64_ceilings.txt); round 1's 35.9 was a benchmark artefact
 
 
 def algorithmic_bytes_linearize(g, slam):
@@ -238,8 +238,9 @@ def slam_bench(pkg, ctx, with_cpu=True):
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
                          "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": ch["count"],
                          "measured_ceiling": {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_MEASURED_TF,
-                                              "note": "register-only v_mfma_f64_16x16x4_f64 stream on this part (scripts/mfma_peak.hip, "
-                                                      "profiles/r2_fp64_ceilings.txt): half the spec-sheet figure"}},
+                                              "note": "register-only v_mfma_f64_16x16x4_f64 stream with the accumulators in VGPRs: one MFMA per 64 cycles per SIMD at "
+                                                      "2.4 GHz (scripts/mfma_peak.hip, profiles/r2_fp64_ceilings.txt). Round 1 reported 35.9: that stream "
+                                                      "bounced its accumulators through AGPRs every iteration"}},
         }
         if with_cpu:
             from oracle import pyoracle as po
@@ -490,9 +491,9 @@ def main():
                     "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None,
                     "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": dom["count"],
                     "measured_ceiling": {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_MEASURED_TF,
-                                         "note": "register-only v_mfma_f64_16x16x4_f64 stream on this MI355X at 2.39 GHz "
-                                                 "(scripts/mfma_peak.hip): one MFMA per 128 cycles per SIMD, half the 78.6 TFLOP/s "
-                                                 "of the spec sheet; v_fma_f64 tops out at 55 TFLOP/s (clock drops to 1.9 GHz)"}}
+                                         "note": "register-only v_mfma_f64_16x16x4_f64 stream, accumulators in VGPRs: one MFMA per 64 cycles per SIMD "
+                                                 "(scripts/mfma_peak.hip, profiles/r2_fp64_ceilings.txt); round 1's 35.9 was a benchmark artefact "
+                                                 "(accumulators bounced through AGPRs); v_fma_f64 tops out at 55 TFLOP/s (clock drops to 1.9 GHz)"}}
         out = {
             "metric": "LM iterations/sec (cams+ellipsoids)",
             "value": iters / dt,

@@ -18,7 +18,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace esl {
 
@@ -353,7 +355,7 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 constexpr int kKC = 16;
 template <int BM, int BN>
 static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
-                                                                int kcol0, int K, long base, int ntJ) {
+                                                                int kcol0, int K, long base, int ntJ, int rect) {
   static_assert(BM == 2 * BN && BM % 64 == 0, "tile shape");
   constexpr int kLdA = BM + 16, kLdB = BN + 16;   // +16: the 4 k-groups of a fragment read land in different banks
   constexpr int SM = BM / 4, SN = BN / 2;         // rows x columns of one wave's sub-tile
@@ -364,11 +366,17 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
   double* As = sm;                               // [2][kKC][kLdA]
   double* Bs = sm + 2 * kKC * kLdA;              // [2][kKC][kLdB]
   const long b = blockIdx.x;
-  long ti = (long)((sqrt(1.0 + 4.0 * (double)b) - 1.0) * 0.5);
-  while (ti * (ti + 1) > b) --ti;
-  while ((ti + 1) * (ti + 2) <= b) ++ti;
-  const long tj = b - ti * (ti + 1);             // 0 .. 2 ti + 1
-  if (tj >= ntJ) return;
+  long ti, tj;
+  if (rect) {                                    // a few tile columns of a tall region: ntJ tiles per tile row
+    ti = b / ntJ; tj = b - ti * ntJ;
+    if (tj > 2 * ti + 1) return;                 // above the diagonal
+  } else {                                       // the whole lower triangle: tile row ti holds 2 ti + 2 tiles
+    ti = (long)((sqrt(1.0 + 4.0 * (double)b) - 1.0) * 0.5);
+    while (ti * (ti + 1) > b) --ti;
+    while ((ti + 1) * (ti + 2) <= b) ++ti;
+    tj = b - ti * (ti + 1);                      // 0 .. 2 ti + 1
+    if (tj >= ntJ) return;
+  }
   const long i0 = base + ti * BM, j0 = base + tj * BN;
   if (i0 >= rows || j0 >= ncols) return;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -549,43 +557,77 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     if (e != hipSuccess) return e;
     attr2_set = true;
   }
-  auto launch_update = [&](int kcol0, int K, long base, long col_limit) {
+  auto launch_update = [&](hipStream_t stream, int kcol0, int K, long base, long col_limit) {
     // trailing region: rows [base, rows), cols [base, col_limit)
     const long nrows = rows - base, nc = col_limit - base;
     if (nrows <= 0 || nc <= 0) return;
     // the big tile only when it still gives every CU a few workgroups
-    const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (nc == nrows ? 2 : 1);
+    const bool whole = (nc >= nrows - 1);
+    const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (whole ? 2 : 1);
     if (big_tiles >= 1024) {
       const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
-      const long nblk = ntI * (ntI + 1);   // sum over ti of (2 ti + 2) tiles; tiles with tj >= ntJ exit immediately
-      hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), lds_big, st, M, lda, rows, col_limit, kcol0, K,
-                         base, (int)ntJ);
+      const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
+      hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), lds_big, stream, M, lda, rows, col_limit, kcol0, K,
+                         base, (int)ntJ, whole ? 0 : 1);
     } else {
       const long ntI = (nrows + 127) / 128, ntJ = (nc + 63) / 64;
-      const long nblk = ntI * (ntI + 1);
-      hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), lds_small, st, M, lda, rows, col_limit, kcol0, K,
-                         base, (int)ntJ);
+      const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;
+      hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), lds_small, stream, M, lda, rows, col_limit, kcol0, K,
+                         base, (int)ntJ, whole ? 0 : 1);
     }
   };
-  for (int p = 0; p < np; p += 2) {
-    // outer panel = up to two 128-wide inner panels; the big trailing update uses K = 256
-    const int k0 = p * kNB, nb1 = (n - k0 < kNB) ? (n - k0) : kNB;
-    double* Linv1 = Linv_ws + (size_t)p * kNB * kNB;
-    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb1, Linv1, info);
-    long below = rows - (k0 + nb1);
-    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb1, Linv1);
-    const int k1 = k0 + nb1;
-    if (k1 >= n) break;
-    const int nb2 = (n - k1 < kNB) ? (n - k1) : kNB;
-    // bring the second inner panel's columns up to date (rank-nb1 update restricted to those columns)
-    launch_update(k0, nb1, (long)k1, (long)k1 + nb2);
-    double* Linv2 = Linv_ws + (size_t)(p + 1) * kNB * kNB;
-    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k1, nb2, Linv2, info);
-    below = rows - (k1 + nb2);
-    if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k1, nb2, Linv2);
-    // rank-(nb1+nb2) update of everything to the right of the outer panel
-    launch_update(k0, nb1 + nb2, (long)k1 + nb2, (long)n);
+  // Outer panels of W inner panels (W x 128 columns): the inner panels are factored one after the other on the caller's
+  // stream, each followed by a rank-128 update of the rest of the outer panel; the trailing matrix then gets ONE rank-(W x 128)
+  // update (W = 2 halves, W = 4 quarters the read-modify-write traffic on C and the per-tile prologue / epilogue per flop).
+  // Look-ahead: that update is split -- the columns of the NEXT outer panel are updated on the caller's stream, the rest on a
+  // second stream, so the next outer panel's potrf / panel solves (single-workgroup and short kernels that leave the chip
+  // empty) run underneath the big update instead of in front of it.
+  static hipStream_t side = nullptr;
+  static std::vector<hipEvent_t> ev_panel, ev_trail;
+  if (!side) { hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+  const int W = (n >= 8192) ? 4 : 2;
+  const int n_outer = (np + W - 1) / W;
+  while ((int)ev_panel.size() < n_outer) {
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreateWithFlags(&a, hipEventDisableTiming); if (e != hipSuccess) return e;
+    e = hipEventCreateWithFlags(&b, hipEventDisableTiming); if (e != hipSuccess) return e;
+    ev_panel.push_back(a); ev_trail.push_back(b);
   }
+  // below ~8k unknowns the chain of single-workgroup potrf launches is the critical path whatever runs beside it (measured:
+  // n = 2994 4.55 ms without, 4.75 ms with look-ahead), from 16k on it buys 12-15 %
+  const bool lookahead = n >= 8192 && getenv("ESL_CHOL_NO_LOOKAHEAD") == nullptr;
+  bool trail_pending = false;   // ev_trail[o - 1] has been recorded and not yet waited for
+  for (int o = 0; o < n_outer; ++o) {
+    const int p0 = o * W, p1 = (p0 + W < np) ? p0 + W : np;
+    const int c_begin = p0 * kNB, c_end = (p1 * kNB < n) ? p1 * kNB : n;   // columns of this outer panel
+    for (int p = p0; p < p1; ++p) {
+      const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+      double* Linv = Linv_ws + (size_t)p * kNB * kNB;
+      hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb, Linv, info);
+      const long below = rows - (k0 + nb);
+      if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb, Linv);
+      // bring the rest of the outer panel's columns up to date (rank-nb update restricted to those columns)
+      if (p + 1 < p1) launch_update(st, k0, nb, (long)k0 + nb, (long)c_end);
+    }
+    if (c_end >= n) break;
+    const int K = c_end - c_begin;
+    const int next_end = ((p1 + W) * kNB < n) ? (p1 + W) * kNB : n;        // end of the next outer panel's columns
+    if (!lookahead || next_end >= n) {
+      if (trail_pending) { hipError_t e = hipStreamWaitEvent(st, ev_trail[o - 1], 0); if (e != hipSuccess) return e; trail_pending = false; }
+      launch_update(st, c_begin, K, (long)c_end, (long)n);
+      continue;
+    }
+    hipError_t e = hipEventRecord(ev_panel[o], st); if (e != hipSuccess) return e;
+    // the next outer panel's columns: written by the previous side-stream update as well -> wait for it first
+    if (trail_pending) { e = hipStreamWaitEvent(st, ev_trail[o - 1], 0); if (e != hipSuccess) return e; trail_pending = false; }
+    launch_update(st, c_begin, K, (long)c_end, (long)next_end);
+    // everything to the right of them, underneath the next outer panel's factorisation
+    e = hipStreamWaitEvent(side, ev_panel[o], 0); if (e != hipSuccess) return e;
+    launch_update(side, c_begin, K, (long)next_end, (long)n);
+    e = hipEventRecord(ev_trail[o], side); if (e != hipSuccess) return e;
+    trail_pending = true;
+  }
+  if (trail_pending) { hipError_t e = hipStreamWaitEvent(st, ev_trail[n_outer - 2], 0); if (e != hipSuccess) return e; }
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
     hipLaunchKernelGGL(k_chol_backdot, dim3(nb), dim3(256), 0, st, M, lda, n, k0, nb, x, z_ws);

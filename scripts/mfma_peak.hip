@@ -5,8 +5,29 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// NOTE on launch bounds: with __launch_bounds__(256) (512 registers per lane available) the compiler parks the accumulators
+// in AGPRs and copies all of them to VGPRs and back EVERY loop iteration (256 v_accvgpr moves per 16 MFMAs); that stream
+// measures 36 TFLOP/s and was round 1's "measured ceiling".  It is an artefact of the benchmark: with the accumulators in
+// VGPRs (bounds 512 -> 256 registers) the same instruction stream issues one v_mfma_f64_16x16x4 per 64 cycles = 78 TFLOP/s,
+// the spec-sheet figure.  Both forms are kept so that the difference stays on record.
 template <int NACC>
-__global__ __launch_bounds__(256) void k_mfma(double* out, long long* clk, int iters) {
+__global__ __launch_bounds__(256) void k_mfma_agpr(double* out, long long* clk, int iters) {
+  double4_t acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = double4_t{0, 0, 0, 0};
+  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  double s = 0;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+}
+template <int NACC>
+__global__ __launch_bounds__(512) void k_mfma(double* out, long long* clk, int iters) {
   double4_t acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = double4_t{0, 0, 0, 0};
   double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
@@ -122,10 +143,15 @@ void run(const char* what, F launch, int blocks, double flops) {
   hipFree(out); hipFree(clk);
 }
 int main() {
-  for (int wps : {1, 2, 4}) {
+  for (int wps : {1, 2}) {
     const int blocks = 256 * wps, iters = 20000;
     char name[64]; snprintf(name, sizeof name, "mfma_f64_16x16x4, %d waves/SIMD", wps);
     run(name, [&](double* o, long long* c, bool warm) { hipLaunchKernelGGL(k_mfma<16>, dim3(blocks), dim3(256), 0, 0, o, c, warm ? 10 : iters); },
+        blocks, (double)blocks * 4 * iters * 16 * 2048.0);
+  }
+  {
+    const int blocks = 256, iters = 20000;
+    run("  same, accumulators via AGPRs (r1)", [&](double* o, long long* c, bool warm) { hipLaunchKernelGGL(k_mfma_agpr<16>, dim3(blocks), dim3(256), 0, 0, o, c, warm ? 10 : iters); },
         blocks, (double)blocks * 4 * iters * 16 * 2048.0);
   }
   for (int wps : {1, 2, 4}) {
