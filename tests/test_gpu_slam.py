@@ -145,10 +145,11 @@ def test_c3_slam_full_run_vs_faithful_dense_delta_1e9(pkg, po, ctx, c3_dense):
     assert cam_err(cn, c6) < max(1e-4, 0.1 * floor_cam)
 
 
-@pytest.mark.parametrize("n", [1, 7, 130, 777, 3000])
+@pytest.mark.parametrize("n", [1, 7, 130, 777, 3000, 8192, 9001])
 def test_dense_cholesky_selftest_residual(ctx, n):
     """Known-answer test of the MFMA Cholesky on a generated diagonally dominant system (sizes straddle the 128-wide
-    inner panels and the 256-wide outer ones): |A x - b| / |b| at fp64 round-off."""
+    inner panels and the outer panels of 2 / 4 of them; from 8,192 on the factorisation runs with the look-ahead split on two
+    streams, rectangular head updates and both tile sizes): |A x - b| / |b| at fp64 round-off."""
     ms, res = ctx.selftest_cholesky(n)
     assert res < 1e-12, (n, res)
     assert ms >= 0
