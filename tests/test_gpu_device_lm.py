@@ -34,6 +34,37 @@ def test_gravity_only_graph(pkg, po, ctx):
     np.testing.assert_allclose(og, oo, atol=2e-5)
 
 
+def test_rank_deficient_ellipsoid_blocks_take_the_oracles_decisions(pkg, po, ctx):
+    """Ellipsoid blocks of rank 4 (a single bbox edge), rank 1 (only the gravity prior) and rank 0 (no edge at all) next to
+    well-constrained ones.  g2o solves them with Eigen's PIVOTED LDLT + isPositive (linear_solver_dense.h:65-113), the HIP path
+    with an unpivoted row-parallel LDL^T: with the LM damping both must call the same blocks solvable, take the same
+    accept / reject sequence and end in the same states (the singular directions just do not move)."""
+    g0, c, o, _ = pkg.synth.make_graph(30, 6, 300, seed=12)
+    keep = np.ones(len(g0.bbox_obj), bool)
+    for obj, n_keep in ((1, 1), (2, 0), (3, 0)):
+        idx = np.nonzero(g0.bbox_obj == obj)[0]
+        keep[idx[n_keep:]] = False
+    k3 = ~np.isin(g0.e3d_obj, [1, 2, 3])
+    grav = np.array([0, 2, 4, 5])                     # ellipsoid 2: gravity only; 3: nothing at all; 1: one bbox edge
+    g = pkg.Graph(g0.K, g0.n_cams, g0.n_objs, None, g0.bbox_cam[keep], g0.bbox_obj[keep], g0.bbox_meas.reshape(-1, 4)[keep],
+                  g0.bbox_weight[keep], g0.e3d_cam[k3], g0.e3d_obj[k3], g0.e3d_meas.reshape(-1, 10)[k3], g0.e3d_weight[k3],
+                  grav, g0.grav_normal, g0.grav_weight)
+    for jac, delta in ((0, 1e-6), (1, 1e-9)):
+        p = pkg.default_lm_params(jacobian_mode=jac, numeric_delta=delta)
+        _, oo, ro = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=1e-6), solver=1)
+        _, og, rg = ctx.optimize(g, c, o, p)
+        assert rg["iterations"] == ro["iterations"] and rg["total_trials"] == ro["total_trials"], jac
+        assert_traces_match(rg, ro, rtol=1e-5)
+        np.testing.assert_allclose(og, oo, atol=5e-5)
+        np.testing.assert_array_equal(og[3], o[3])    # the ellipsoid without edges does not move
+    # the step API's flag: every block of the damped system is solvable, as the pivoted LDLT says
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ctx.lm_begin(pkg.default_lm_params(numeric_delta=1e-6))
+    part = ctx.lm_linearize()
+    out = ctx.lm_try_step(1e-5 * max(part.max_diag, 1e-300))
+    assert out.solve_ok == 1
+
+
 def test_all_bbox_edges_nan_is_an_empty_graph(pkg, po, ctx):
     """Every camera sits inside the only ellipsoid: each bbox edge is NaN at the start state and is dropped
     (Optimizer.cpp:234-243); nothing is left to optimise and the states come back untouched."""
