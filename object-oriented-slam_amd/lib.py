@@ -71,6 +71,7 @@ class Context:
     def __init__(self, device=0):
         L = load()
         self._h = C.c_void_p()
+        self.device = int(device)
         _check(L.esl_ctx_create(C.c_int(device), C.byref(self._h)), "esl_ctx_create")
         self._graph = None
 

@@ -119,3 +119,38 @@ def test_append_new_ellipsoids_gravity_and_errors(pkg, ctx):
     with pytest.raises(pkg.EslError, match="mapping-mode"):
         cx.append_graph(new_cams=cs[:1])
     cx.close()
+
+
+def test_fit_and_optimise_overlap_on_two_contexts(pkg, ctx):
+    """Two contexts = two HIP streams: a worker thread fits frames on one while the main thread optimises on the other (the
+    pipelined streaming mode of bench.py).  Same results as when the calls run one after the other, every time."""
+    import threading
+    sc = pkg.synth.make_depth_scene(n_objs=6, seed=4, spread=1.2, size=(0.1, 0.3))
+    P = pkg.lib.default_fit_params()
+    g, c, o, _ = pkg.synth.make_graph(40, 8, 400, seed=8)
+    p = pkg.default_lm_params(jacobian_mode=1)
+    e_ref, pr_ref, st_ref = ctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], P)[:3]
+    _, o_ref, r_ref = ctx.optimize(g, c, o, p)
+    fctx = pkg.Context(0)
+    fits, errs = [], []
+
+    def worker():
+        try:
+            for _ in range(12):
+                fits.append(fctx.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], P)[:3])
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    try:
+        th = threading.Thread(target=worker)
+        th.start()
+        runs = [ctx.optimize(g, c, o, p) for _ in range(12)]
+        th.join(120)
+        assert not th.is_alive() and not errs, errs
+    finally:
+        fctx.close()
+    for _, oo, rr in runs:
+        assert rr["trace_trials"] == r_ref["trace_trials"]
+        np.testing.assert_array_equal(oo, o_ref)
+    for e, pr, st in fits:
+        assert np.array_equal(st, st_ref)
+        np.testing.assert_allclose(e, e_ref, atol=1e-7)      # run-to-run spread of the fit itself (DESIGN.md §7)
