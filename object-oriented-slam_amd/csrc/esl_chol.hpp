@@ -353,14 +353,18 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 // chain of one wave is then 4 MFMAs per k-step instead of 16 and a trailing matrix of 1,500 rows still spreads over ~140
 // workgroups; with the big tile it occupied 20 CUs for 86 us whatever its size.
 constexpr int kKC = 16;
-template <int BM, int BN>
-static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
-                                                                int kcol0, int K, long base, int ntJ, int rect) {
-  static_assert(BM == 2 * BN && BM % 64 == 0, "tile shape");
+// <128, 128, 2, 2>: four waves of 64 x 64, 74 KB of LDS and <= 256 registers per lane, so TWO workgroups share a CU and one
+// tile's prologue (first staging loads) and epilogue (C read-modify-write) run under the other tile's K loop.
+template <int BM, int BN, int WM = 4, int WN = 2>
+static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
+                                                                           int kcol0, int K, long base, int ntJ, int rect) {
+  static_assert((BM == 2 * BN || BM == BN) && BM % 64 == 0, "tile shape");
+  constexpr int NT = 64 * WM * WN;                // threads per workgroup
+  constexpr int RT = BM / BN;                     // tile row ti of the lower triangle holds RT (ti + 1) tiles
   constexpr int kLdA = BM + 16, kLdB = BN + 16;   // +16: the 4 k-groups of a fragment read land in different banks
-  constexpr int SM = BM / 4, SN = BN / 2;         // rows x columns of one wave's sub-tile
+  constexpr int SM = BM / WM, SN = BN / WN;       // rows x columns of one wave's sub-tile
   constexpr int MI = SM / 16, NJ = SN / 16;
-  constexpr int QA = BM * kKC / 2 / 512, QB = BN * kKC / 2 / 512;   // double2 per thread per chunk
+  constexpr int QA = BM * kKC / 2 / NT, QB = BN * kKC / 2 / NT;   // double2 per thread per chunk
   static_assert(QA >= 1 && QB >= 1, "chunk smaller than the workgroup");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* As = sm;                               // [2][kKC][kLdA]
@@ -369,18 +373,18 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
   long ti, tj;
   if (rect) {                                    // a few tile columns of a tall region: ntJ tiles per tile row
     ti = b / ntJ; tj = b - ti * ntJ;
-    if (tj > 2 * ti + 1) return;                 // above the diagonal
-  } else {                                       // the whole lower triangle: tile row ti holds 2 ti + 2 tiles
-    ti = (long)((sqrt(1.0 + 4.0 * (double)b) - 1.0) * 0.5);
-    while (ti * (ti + 1) > b) --ti;
-    while ((ti + 1) * (ti + 2) <= b) ++ti;
-    tj = b - ti * (ti + 1);                      // 0 .. 2 ti + 1
+    if (tj > RT * ti + RT - 1) return;           // above the diagonal
+  } else {                                       // the whole lower triangle: rows 0 .. ti-1 hold RT ti (ti + 1) / 2 tiles
+    ti = (long)((sqrt(1.0 + 8.0 * (double)b / RT) - 1.0) * 0.5);
+    while (RT * ti * (ti + 1) / 2 > b) --ti;
+    while (RT * (ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    tj = b - RT * ti * (ti + 1) / 2;             // 0 .. RT (ti + 1) - 1
     if (tj >= ntJ) return;
   }
   const long i0 = base + ti * BM, j0 = base + tj * BN;
   if (i0 >= rows || j0 >= ncols) return;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int wi = wave >> 1, wj = wave & 1;
+  const int wi = wave / WN, wj = wave % WN;
   const double* P = M + (long)kcol0 * lda;
   // global -> register staging: A chunk = BM x 16 doubles, B chunk = BN x 16 doubles, as double2
   typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -388,7 +392,7 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
   auto gload = [&](int kc) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-      const int e = t + 512 * q, pr = e % (BM / 2), k = e / (BM / 2);
+      const int e = t + NT * q, pr = e % (BM / 2), k = e / (BM / 2);
       const long row = i0 + 2 * pr;
       const bool kv = (kc + k) < K;
       double2_t v = {0.0, 0.0};
@@ -398,7 +402,7 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-      const int e = t + 512 * q, pr = e % (BN / 2), k = e / (BN / 2);
+      const int e = t + NT * q, pr = e % (BN / 2), k = e / (BN / 2);
       const long row = j0 + 2 * pr;
       const bool kv = (kc + k) < K;
       double2_t v = {0.0, 0.0};
@@ -410,12 +414,12 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-      const int e = t + 512 * q, pr = e % (BM / 2), k = e / (BM / 2);
+      const int e = t + NT * q, pr = e % (BM / 2), k = e / (BM / 2);
       *reinterpret_cast<double2_t*>(As + (buf * kKC + k) * kLdA + 2 * pr) = ra[q];
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-      const int e = t + 512 * q, pr = e % (BN / 2), k = e / (BN / 2);
+      const int e = t + NT * q, pr = e % (BN / 2), k = e / (BN / 2);
       *reinterpret_cast<double2_t*>(Bs + (buf * kKC + k) * kLdB + 2 * pr) = rb[q];
     }
   };
@@ -432,9 +436,9 @@ static __global__ __launch_bounds__(512) void k_chol_update_lds(double* __restri
   const double* pA[QA];
   const double* pB[QB];
 #pragma unroll
-  for (int q = 0; q < QA; ++q) { const int e = t + 512 * q; pA[q] = P + i0 + 2 * (e % (BM / 2)) + (long)(e / (BM / 2)) * lda; }
+  for (int q = 0; q < QA; ++q) { const int e = t + NT * q; pA[q] = P + i0 + 2 * (e % (BM / 2)) + (long)(e / (BM / 2)) * lda; }
 #pragma unroll
-  for (int q = 0; q < QB; ++q) { const int e = t + 512 * q; pB[q] = P + j0 + 2 * (e % (BN / 2)) + (long)(e / (BN / 2)) * lda; }
+  for (int q = 0; q < QB; ++q) { const int e = t + NT * q; pB[q] = P + j0 + 2 * (e % (BN / 2)) + (long)(e / (BN / 2)) * lda; }
   auto gload_fast = [&](int kc) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) ra[q] = *reinterpret_cast<const double2_t*>(pA[q] + (long)kc * lda);
@@ -551,12 +555,18 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   int np = (n + kNB - 1) / kNB;
   constexpr size_t lds_big = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
   constexpr size_t lds_small = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
+  constexpr size_t lds_sq = (size_t)(2 * kKC * (128 + 16 + 128 + 16)) * sizeof(double);
   static bool attr2_set = false;
   if (!attr2_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_chol_update_lds<128, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sq);
+    if (e != hipSuccess) return e;
     attr2_set = true;
   }
+  // measured (n = 32,768): 238.7 ms with the square two-per-CU tiles, 231.6 ms with 256 x 128 -- the tile prologue / epilogue is
+  // not what is left; the square form stays selectable for experiments
+  const bool square_tiles = getenv("ESL_CHOL_TILE_SQUARE") != nullptr;
   auto launch_update = [&](hipStream_t stream, int kcol0, int K, long base, long col_limit) {
     // trailing region: rows [base, rows), cols [base, col_limit)
     const long nrows = rows - base, nc = col_limit - base;
@@ -564,7 +574,12 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     // the big tile only when it still gives every CU a few workgroups
     const bool whole = (nc >= nrows - 1);
     const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (whole ? 2 : 1);
-    if (big_tiles >= 1024) {
+    if (big_tiles >= 1024 && square_tiles) {
+      const long ntI = (nrows + 127) / 128, ntJ = (nc + 127) / 128;
+      const long nblk = whole ? ntI * (ntI + 1) / 2 : ntI * ntJ;
+      hipLaunchKernelGGL((k_chol_update_lds<128, 128, 2, 2>), dim3((unsigned)nblk), dim3(256), lds_sq, stream, M, lda, rows, col_limit, kcol0,
+                         K, base, (int)ntJ, whole ? 0 : 1);
+    } else if (big_tiles >= 1024) {
       const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
       const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
       hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), lds_big, stream, M, lda, rows, col_limit, kcol0, K,
