@@ -41,6 +41,9 @@ constexpr int kChunkOut = 56;  // 45 packed H + 9 b + chi2 + pad
 // waves per workgroup of the linearisation kernels.  Measured at C4: 1-wave workgroups make the launch 0.8 us shorter
 // (finer spreading over the 1024 SIMDs) and k_lm_step 0.8 us longer (4x the per-workgroup chi2 partials to add): a wash.
 constexpr int kLinWaves = 4;
+#ifndef ESL_LIN_MIN_WAVES
+#define ESL_LIN_MIN_WAVES 1   // waves per SIMD the linearisation is compiled for (tuning: scripts/build_variants.sh)
+#endif
 // k_lm_step: ellipsoids per workgroup (one lane each in the solve phase) and the row stride of their H, b sums in LDS
 constexpr int kStepObjs = 16, kHbStride = 55;   // 16: the gather is 864 sums per workgroup = 3.4 per thread, all loads in flight
 
@@ -411,7 +414,7 @@ __device__ double block256_max(double v, double* sm) {
 // chip for long (3-D: ~0.7 waves per SIMD on a 4.8k-instruction stream; bbox: 3 waves per SIMD, 1.7k instructions);
 // together they take 27 us.
 template <int JAC, bool VALIDATE = false, bool TANG = false>
-static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize_both(DevGraph g, ChunkTable ct, const int* __restrict__ ids_e3, int n_e3,
+static __global__ __launch_bounds__(64 * kLinWaves, ESL_LIN_MIN_WAVES) void k_chunk_linearize_both(DevGraph g, ChunkTable ct, const int* __restrict__ ids_e3, int n_e3,
                                                                      int nb_e3, const int* __restrict__ ids_bb, int n_bb,
                                                                      const double* __restrict__ cams,
                                                                      const double* __restrict__ objs_a, const double* __restrict__ objs_b,
