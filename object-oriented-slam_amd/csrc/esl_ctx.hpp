@@ -56,6 +56,8 @@ struct DevGraph {
   // per ellipsoid: unified list of edges whose camera is free (u = bbox index, or n_bbox + 3-D index)
   int* ue_start = nullptr; int* ue_id = nullptr; int* ue_slot = nullptr;
   int n_ue = 0;
+  // per free camera (slot): its edges sorted by (ellipsoid, u) -- the deterministic Schur complement walks two of these lists
+  int* cu_start = nullptr; int* cu_obj = nullptr; int* cu_id = nullptr;
   // sharding (SLAM mode): odometry edges, the camera blocks' lambda and the camera part of the LM scale are
   // replicated on every rank and must enter the summed system once -> only shard_rank 0 contributes them
   int shard_rank = 0;
@@ -116,6 +118,7 @@ struct esl_ctx {
   double* Aod = nullptr;      // n_odom x (2*27 + 36): per-edge Hii, bi, Hjj, bj packed, Hij full
   double* Dinv = nullptr;     // n_objs x 81
   double* Yb = nullptr;       // n_bbox x 54 : W D^-1
+  double* Tb = nullptr;       // [6][EU] : Y_e b_o per edge (its share of b_s), summed per camera by the Schur kernel
   double* Ye3 = nullptr;      // n_e3d x 54
   double* S = nullptr;        // n x (n+1) column-major reduced system [S | b_s], n = 6 n_free_cams
   int64_t S_n = 0;

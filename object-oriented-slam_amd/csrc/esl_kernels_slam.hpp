@@ -15,7 +15,8 @@
 //   k_slam_odom        one lane per odometry edge
 //   k_slam_cam_gather  one lane per free camera: Hcc, b_c from its edges (camera-side CSR; deterministic)
 //   k_slam_prepare     one wave per ellipsoid: Dinv = (Hoo+lambda I)^-1, Y_e = W_e Dinv, b_s -= Y_e b_o
-//   k_slam_schur       one workgroup per ellipsoid: S[c1,c2] -= Y_e1 W_e2^T over the ellipsoid's edge pairs
+//   k_slam_schur_pull  one lane per block (c1, c2) of S: intersects the two cameras' edge lists, S[c1,c2] -= sum Y_e1 W_e2^T in
+//                      list order (deterministic); k_slam_schur = round 1's scatter form with fp64 atomics (ESL_SCHUR_ATOMIC=1)
 //   dense Cholesky     esl_chol.hpp (FP64 MFMA)
 //   k_slam_backsub     one wave per ellipsoid: x_o, retraction, trial states
 //   k_slam_cam_update  one lane per camera: retraction exp(x_c) * Tcw
@@ -296,7 +297,7 @@ static __global__ void k_slam_S_init(DevGraph g, const double* __restrict__ Hcc,
 static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
     DevGraph g, double lambda, const double* __restrict__ Hoo, const double* __restrict__ bo,
     const double* __restrict__ W, double* __restrict__ Y, double* __restrict__ Dinv, double* __restrict__ S, long lda,
-    long n, double* __restrict__ part) {
+    long n, double* __restrict__ part, double* __restrict__ Tb /* [6][EU] or null: atomics into the b_s row of S */) {
   __shared__ double sD[kWavesPerBlock][81];
   __shared__ double sb[kWavesPerBlock][9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -337,8 +338,79 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
         t[a] += s * sb[wv][b];
       }
     }
+    if (Tb) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a) atomicAdd(&S[n + (long)(6 * slot + a) * lda], -t[a]);
+      for (int a = 0; a < 6; ++a) Tb[(long)a * EU + u] = t[a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) atomicAdd(&S[n + (long)(6 * slot + a) * lda], -t[a]);
+    }
+  }
+}
+
+// Schur complement, output-owner form (round 2; deterministic): one LANE per lower block (sp, sq) of S.  The lane intersects
+// the two cameras' edge lists (both sorted by ellipsoid), and for every ellipsoid both cameras observe subtracts
+// Y_e1 W_e2^T over the edge pairs (e1 of camera sp, e2 of camera sq) in list order -- the sum the scatter form below builds
+// with fp64 atomics in whatever order the hardware serves them.  The diagonal lane (s, s) also folds its camera's share of
+// b_s (sum over its edges of Y_e b_o, stored per edge by k_slam_prepare).  grid.y = sp, grid.x * 64 + lane = sq.
+static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const double* __restrict__ W, const double* __restrict__ Y,
+                                                        const double* __restrict__ Tb, double* __restrict__ S, long lda, long n) {
+  const int sp = blockIdx.y, sq = blockIdx.x * 64 + threadIdx.x;
+  if (sq > sp) return;
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  int i = g.cu_start[sp], j = g.cu_start[sq];
+  const int ie = g.cu_start[sp + 1], je = g.cu_start[sq + 1];
+  double out[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) out[k] = 0;
+  bool any = false;
+  while (i < ie && j < je) {
+    const int oi = g.cu_obj[i], oj = g.cu_obj[j];
+    if (oi < oj) { ++i; continue; }
+    if (oj < oi) { ++j; continue; }
+    int i1 = i + 1, j1 = j + 1;                       // runs of this ellipsoid in both lists (a bbox and a 3-D edge at most)
+    while (i1 < ie && g.cu_obj[i1] == oi) ++i1;
+    while (j1 < je && g.cu_obj[j1] == oi) ++j1;
+    for (int a1 = i; a1 < i1; ++a1) {
+      const long up = g.cu_id[a1];
+      if (up < g.n_bbox && !g.bb_valid[up]) continue;
+      double yp[54];
+#pragma unroll
+      for (int k = 0; k < 54; ++k) yp[k] = Y[(long)k * EU + up];
+      for (int a2 = j; a2 < j1; ++a2) {
+        const long uq = g.cu_id[a2];
+        if (uq < g.n_bbox && !g.bb_valid[uq]) continue;
+        any = true;
+#pragma unroll
+        for (int b = 0; b < 9; ++b) {
+          double wq[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) wq[c] = W[(long)(c * 9 + b) * EU + uq];
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) out[a * 6 + c] += yp[a * 9 + b] * wq[c];
+        }
+      }
+    }
+    i = i1; j = j1;
+  }
+  if (any) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) S[(long)(6 * sp + a) + (long)(6 * sq + c) * lda] -= out[a * 6 + c];
+  }
+  if (sp == sq) {
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    for (int a1 = g.cu_start[sp]; a1 < ie; ++a1) {
+      const long u = g.cu_id[a1];
+      if (u < g.n_bbox && !g.bb_valid[u]) continue;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) t[a] += Tb[(long)a * EU + u];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) S[n + (long)(6 * sp + a) * lda] -= t[a];
   }
 }
 

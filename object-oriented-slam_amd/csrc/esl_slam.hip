@@ -48,6 +48,23 @@ int slam_alloc(esl_ctx* c) {
     }
   }
   g.n_ue = (int)id.size();
+  // the same edges per free camera, sorted by (ellipsoid, u): two of these lists are intersected per block of S
+  {
+    std::vector<int> cstart((size_t)nf + 1, 0), cobj(id.size()), cid(id.size());
+    for (size_t k = 0; k < id.size(); ++k) ++cstart[(size_t)slot[k] + 1];
+    for (int sidx = 0; sidx < nf; ++sidx) cstart[(size_t)sidx + 1] += cstart[sidx];
+    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
+    // walking the ellipsoids in order and, inside one, its edges in ascending u keeps every camera's list sorted
+    for (int o = 0; o < N; ++o) {
+      std::vector<std::pair<int, int>> es;   // (u, slot)
+      for (int k = start[o]; k < start[(size_t)o + 1]; ++k) es.push_back({id[k], slot[k]});
+      std::sort(es.begin(), es.end());
+      for (auto& e : es) { const int at = fill[e.second]++; cobj[at] = o; cid[at] = e.first; }
+    }
+    if ((rc = up(&g.cu_start, cstart.data(), cstart.size(), c->stream))) return rc;
+    if ((rc = up(&g.cu_obj, cobj.data(), cobj.size(), c->stream))) return rc;
+    if ((rc = up(&g.cu_id, cid.data(), cid.size(), c->stream))) return rc;
+  }
   if ((rc = up(&g.ue_start, start.data(), start.size(), c->stream))) return rc;
   if ((rc = up(&g.ue_id, id.data(), id.size(), c->stream))) return rc;
   if ((rc = up(&g.ue_slot, slot.data(), slot.size(), c->stream))) return rc;
@@ -58,6 +75,7 @@ int slam_alloc(esl_ctx* c) {
   if ((rc = al(&c->Wbb, EU * 54))) return rc;   // unified W  [54][EU]
   if ((rc = al(&c->Abb, EU * 27))) return rc;   // unified A  [27][EU]
   if ((rc = al(&c->Yb, EU * 54))) return rc;    // unified Y  [54][EU]
+  if ((rc = al(&c->Tb, EU * 6))) return rc;     // Y_e b_o    [6][EU]
   if ((rc = al(&c->Aod, (size_t)g.n_odom * 90))) return rc;
   if ((rc = al(&c->Dinv, (size_t)N * 81))) return rc;
   if ((rc = al(&c->cam_part, (size_t)F * 4))) return rc;
@@ -133,9 +151,14 @@ int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out
                        lda, n);
     if (N > 0) {
       const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+      // ESL_SCHUR_ATOMIC=1: round 1's scatter form (fp64 atomics into S, summation order left to the hardware) for A/B runs
+      const bool atomic_form = getenv("ESL_SCHUR_ATOMIC") != nullptr || g.n_free_cams > 65535;   // grid.y limit of the pull form
       hipLaunchKernelGGL(k_slam_prepare, grid, block, 0, c->stream, g, lambda, c->Hoo, c->bo, c->Wbb, c->Yb, c->Dinv, c->S, lda,
-                         n, c->obj_part);
-      hipLaunchKernelGGL(k_slam_schur, dim3(N, 8), dim3(256), 0, c->stream, g, c->Wbb, c->Yb, c->S, lda);
+                         n, c->obj_part, atomic_form ? nullptr : c->Tb);
+      if (atomic_form) hipLaunchKernelGGL(k_slam_schur, dim3(N, 8), dim3(256), 0, c->stream, g, c->Wbb, c->Yb, c->S, lda);
+      else if (g.n_free_cams > 0)
+        hipLaunchKernelGGL(k_slam_schur_pull, dim3((g.n_free_cams + 63) / 64, g.n_free_cams), dim3(64), 0, c->stream, g, c->Wbb, c->Yb,
+                           c->Tb, c->S, lda, n);
     }
   }
   ESL_HIP_TRY(hipGetLastError());

@@ -110,15 +110,15 @@ def test_slam_two_shards_match_single_context(pkg, ctx, jac):
     n = len(ref["trace_chi2"])
     for rep in reps:
         assert rep["chi2_initial"] == pytest.approx(ref["chi2_initial"], rel=1e-12)
-        # same trajectory while chi2 is still moving.  The partial sums are formed in another order (per shard, and the
-        # Schur scatter's fp64 atomics land in a different order from run to run): ~1e-13 relative on the first
-        # iterations, growing along the trajectory (numeric Jacobians amplify it)
+        # same trajectory while chi2 is still moving.  The partial sums are formed in another association (per shard, then
+        # summed over the shards): ~1e-13 relative on the first iterations, growing along the trajectory (numeric
+        # Jacobians amplify it).  Each side is reproducible run to run since the Schur complement lost its atomics.
         k = next((i for i in range(1, n) if abs(ref["trace_chi2"][i] - ref["trace_chi2"][i - 1]) < 1e-7 * ref["trace_chi2"][i]), n)
         k = max(k, 3)
         np.testing.assert_allclose(rep["trace_chi2"][:2], ref["trace_chi2"][:2], rtol=1e-7)   # x cond(S) already after one step
         np.testing.assert_allclose(rep["trace_chi2"][:k], ref["trace_chi2"][:k], rtol=1e-6)
         assert rep["trace_trials"][:k] == ref["trace_trials"][:k]
-        assert rep["chi2_final"] == pytest.approx(ref["chi2_final"], rel=1e-4)   # converged tail: fp64-atomic summation order differs run to run
+        assert rep["chi2_final"] == pytest.approx(ref["chi2_final"], rel=1e-4)   # converged tail: accept / reject there is round-off
     assert reps[0]["trace_chi2"] == reps[1]["trace_chi2"]
     assert reps[0]["trace_lambda"] == reps[1]["trace_lambda"]
     # every rank solved the same summed camera system: identical camera trajectories on both, equal to single-GPU
@@ -170,7 +170,7 @@ def test_slam_first_reduced_system_is_the_sum_of_the_shards(pkg, ctx):
         assert chi2 == pytest.approx(lin.chi2, rel=1e-12)
         assert md == pytest.approx(lin.max_diag, rel=1e-12)
         np.testing.assert_allclose(Hcc, Hcc_ref, rtol=1e-11, atol=1e-9 * np.abs(Hcc_ref).max())
-        np.testing.assert_allclose(S, S_ref, rtol=0, atol=1e-10 * np.abs(S_ref).max())
+        np.testing.assert_allclose(S, S_ref, rtol=0, atol=1e-12 * np.abs(S_ref).max())
     np.testing.assert_array_equal(out[0][2], out[1][2])
 
 

@@ -153,3 +153,15 @@ def test_dense_cholesky_selftest_residual(ctx, n):
     ms, res = ctx.selftest_cholesky(n)
     assert res < 1e-12, (n, res)
     assert ms >= 0
+
+
+def test_slam_runs_are_bitwise_reproducible(pkg, ctx):
+    """SLAM mode has no order-dependent reduction left (round 1's Schur complement scattered into S with fp64 atomics): the
+    same graph twice gives the same bits, trace and states."""
+    g, c, o, _ = pkg.synth.make_graph(60, 12, 700, seed=17, slam=True)
+    p = pkg.default_lm_params(jacobian_mode=1)
+    runs = [ctx.optimize(g, c, o, p) for _ in range(3)]
+    for cc, oo, rep in runs[1:]:
+        assert rep["trace_chi2"] == runs[0][2]["trace_chi2"]
+        np.testing.assert_array_equal(cc, runs[0][0])
+        np.testing.assert_array_equal(oo, runs[0][1])
