@@ -237,6 +237,178 @@ static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ 
 #undef LL
 }
 
+// ---- diagonal block, second form (round 2): the 128 column steps run over the WHOLE block with one barrier each --------------
+// 528 threads each OWN a 4 x 4 block of the lower triangle in 16 registers for the whole factorisation; only the current
+// column travels through LDS (128 doubles, double-buffered).  Step j: every thread reads the pivot d = a(j,j), the four column
+// entries of its rows and of its columns, and subtracts a(i,j) a(c,j) / d from its elements right of column j -- the column is
+// NOT scaled on the way (that would need a second barrier): the unscaled entries stay in their owners' registers and all
+// columns are scaled by 1/sqrt(d_j) at the end.  The owners of column j+1 publish it (and the diagonal block's owner the
+// reciprocal square root of its pivot) after their update; one barrier; next step.  Measured: 590 ns per column -- the step is
+// all latency (LDS write -> barrier of ten waves -> LDS read; dropping the Newton steps or the 16 FMAs changes it by 4 %), so
+// the column loop itself is no faster than the blocked form above (76 vs 66 us); the kernel wins on everything around it:
+// load 10 -> 2 us (each thread fetches its own block), blocked triangular inverse on ten waves instead of four 20 -> 13 us,
+// stores 7 -> 2 us, L written back under the sub-block inverses: 136 -> 118 us per launch, n = 2,994 4.5 -> 4.0 ms.
+constexpr int kP2Threads = 640;
+static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __restrict__ M, long lda, int k0, int nb,
+                                                            double* __restrict__ Linv /* kNB x kNB col-major */,
+                                                            int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* L = sm;                          // kNB x kNB, column stride kLdsPad: the factor, later its inverse
+  double* T = sm + kNB * kLdsPad;          // 96 x 32 temporary of the inverse; the column buffers of the factorisation before that
+  double* dinv = T + 96 * kSB;             // kNB reciprocals of the diagonal
+  constexpr int NT = kP2Threads, NW = kP2Threads / 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#define LL(i, j) L[(i) + (j) * kLdsPad]
+  POTRF_MARK(0);
+  // the thread's 4 x 4 block (bi >= bj) of the 32 x 32 grid of blocks, enumerated column by column: the blocks of the first
+  // block columns are finished first, so whole waves drop out of the update as the factorisation moves right
+  const bool own = t < 528;
+  int bi = 0, bj = 0;
+  if (own) {
+    int off = 0;
+    while (off + (32 - bj) <= t) { off += 32 - bj; ++bj; }
+    bi = bj + (t - off);
+  }
+  double a[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * bi + r, j = 4 * bj + c;
+      a[r][c] = (own && i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);   // identity padding
+    }
+  constexpr int kCB = kNB + 8;             // column buffer: 128 entries + [kNB] = 1 / sqrt(pivot)
+  double* colbuf = T;                      // [2][kCB]
+  // 1/sqrt(d) from the hardware estimate + two Newton steps (no fp64 sqrt, no divide); done by the pivot's owner only
+  auto publish_pivot = [&](double d, double* buf, int j) {
+    if (!(d > 0)) atomicOr(info, 1);
+    double is = __builtin_amdgcn_rsq(d);
+    is = is * (1.5 - 0.5 * d * is * is);
+    is = is * (1.5 - 0.5 * d * is * is);
+    buf[kNB] = is;
+    dinv[j] = is;
+  };
+  if (own && bj == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) colbuf[4 * bi + r] = a[r][0];
+    if (bi == 0) publish_pivot(a[0][0], colbuf, 0);
+  }
+  __syncthreads();
+  POTRF_MARK(1);
+  for (int j = 0; j < kNB; ++j) {
+    const double* cur = colbuf + (j & 1) * kCB;
+    double* nxt = colbuf + ((j + 1) & 1) * kCB;
+    const int jb = j >> 2;
+    if (own && bj >= jb) {
+      const double is = cur[kNB];
+      const double is2 = is * is;
+      double rv[4], cv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rv[r] = cur[4 * bi + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cv[c] = (4 * bj + c > j) ? cur[4 * bj + c] * is2 : 0.0;   // columns <= j are final
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[r][c] -= rv[r] * cv[c];
+      const int jn = j + 1;
+      if (bj == (jn >> 2) && jn < kNB) {   // publish column j + 1 (unscaled) and, from the diagonal block, its pivot
+        const int c = jn & 3;
+        double col[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) col[r] = (c == 0) ? a[r][0] : (c == 1) ? a[r][1] : (c == 2) ? a[r][2] : a[r][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[4 * bi + r] = col[r];
+        if (bi == bj) publish_pivot((c == 0) ? col[0] : (c == 1) ? col[1] : (c == 2) ? col[2] : col[3], nxt, jn);
+      }
+    }
+    __syncthreads();
+  }
+  POTRF_MARK(2); POTRF_MARK(3); POTRF_MARK(4);   // (marks 2..4 of the blocked form collapse: the whole column loop is "factor32[0]")
+  // scale the columns and lay the factor out in LDS for the inverse (dinv[j] = 1 / L(j,j))
+  if (own) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double sc = dinv[4 * bj + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * bi + r >= 4 * bj + c) LL(4 * bi + r, 4 * bj + c) = a[r][c] * sc;
+    }
+  }
+  __syncthreads();
+  POTRF_MARK(5);
+  // inverses of the four diagonal sub-blocks, one wave each, side by side (parked in the upper triangles)
+  if (wave < kNB / kSB) {
+    const int c0 = wave * kSB, r = lane & 31;
+    double row[kSB], invd[kSB], x[kSB];
+#pragma unroll
+    for (int c = 0; c < kSB; ++c) { row[c] = (c <= r) ? LL(c0 + r, c0 + c) : 0.0; invd[c] = dinv[c0 + c]; }
+    trtri32_wave(row, invd, lane, x);
+    if (lane < kSB) {
+#pragma unroll
+      for (int c = 0; c < kSB; ++c)
+        if (c > lane) LL(c0 + lane, c0 + c) = x[c];    // lane = column of X, x[c] = X(c, lane), parked transposed
+    }
+  } else {
+    // the other waves write L11 back meanwhile (the factor itself is part of the result; the parked inverses live above the diagonal)
+    for (int idx = t - 256; idx < nb * nb; idx += NT - 256) {
+      const int i = idx % nb, j = idx / nb;
+      if (i >= j) M[(long)(k0 + i) + (long)(k0 + j) * lda] = LL(i, j);
+    }
+  }
+  __syncthreads();
+  POTRF_MARK(6); POTRF_MARK(7);
+  constexpr int nB = kNB / kSB;
+  for (int J = nB - 1; J >= 0; --J) {
+    const int c0 = J * kSB, r0 = c0 + kSB, mrows = kNB - r0;
+    {
+      const int r = lane & 15, kq = lane >> 4;
+      const int nout = (mrows / 16) * 2;
+      for (int ob = wave; ob < nout; ob += NW) {
+        const int ib = ob >> 1, cb = ob & 1;
+        double4_t acc = {0, 0, 0, 0};
+        for (int kk = 0; kk < (ib + 1) * 16; kk += 4) {
+          const int i = ib * 16 + r, k = kk + kq;
+          const double av = (k <= i) ? LL(r0 + i, r0 + k) : 0.0;
+          const double bv = LL(r0 + k, c0 + cb * 16 + r);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) T[(ib * 16 + kq + 4 * g) + (cb * 16 + r) * 96] = acc[g];
+      }
+    }
+    __syncthreads();
+    for (int idx = t; idx < kSB * kSB; idx += NT) { const int i = idx % kSB, c = idx / kSB; if (i > c) LL(c0 + i, c0 + c) = LL(c0 + c, c0 + i); }
+    {
+      const int r = lane & 15, kq = lane >> 4;
+      const int nout = (mrows / 16) * 2;
+      for (int ob = wave; ob < nout; ob += NW) {
+        const int ib = ob >> 1, cb = ob & 1;
+        double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < kSB; kk += 4) {
+          const int k = kk + kq, c = cb * 16 + r;
+          const double av = T[(ib * 16 + r) + k * 96];
+          const double bv = (k > c) ? LL(c0 + c, c0 + k) : ((k == c) ? dinv[c0 + c] : 0.0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) LL(r0 + ib * 16 + kq + 4 * g, c0 + cb * 16 + r) = -acc[g];
+      }
+    }
+    __syncthreads();
+    if (t < kSB) LL(c0 + t, c0 + t) = dinv[c0 + t];
+    __syncthreads();
+  }
+  POTRF_MARK(8);
+  for (int idx = t; idx < kNB * kNB; idx += NT) {
+    const int i = idx % kNB, j = idx / kNB;
+    Linv[idx] = (i < nb && j < nb && i >= j) ? LL(i, j) : 0.0;
+  }
+  POTRF_MARK(9);
+#undef LL
+}
+
 // ---- MFMA micro-kernel: acc(64x64 per wave) += X[i0.., 0..K) * Y[j0.., 0..K)^T ------------------------------
 // X, Y column-major (element (r,k) at X[r + k*ld]); rows beyond the limits read as zero.
 // acc[mi][nj] is the 16x16 tile (mi,nj) in the f64 MFMA C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
@@ -550,8 +722,11 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_chol_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     attr_set = true;
   }
+  const bool potrf_old = getenv("ESL_CHOL_POTRF_OLD") != nullptr;   // round 1's blocked diagonal factorisation, for A/B runs
   int np = (n + kNB - 1) / kNB;
   constexpr size_t lds_big = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
   constexpr size_t lds_small = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
@@ -618,7 +793,8 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     for (int p = p0; p < p1; ++p) {
       const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
       double* Linv = Linv_ws + (size_t)p * kNB * kNB;
-      hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb, Linv, info);
+      if (potrf_old) hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb, Linv, info);
+      else hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
       const long below = rows - (k0 + nb);
       if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb, Linv);
       // bring the rest of the outer panel's columns up to date (rank-nb update restricted to those columns)
