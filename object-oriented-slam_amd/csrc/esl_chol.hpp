@@ -248,6 +248,8 @@ static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ 
 // the column loop itself is no faster than the blocked form above (76 vs 66 us); the kernel wins on everything around it:
 // load 10 -> 2 us (each thread fetches its own block), blocked triangular inverse on ten waves instead of four 20 -> 13 us,
 // stores 7 -> 2 us, L written back under the sub-block inverses: 136 -> 118 us per launch, n = 2,994 4.5 -> 4.0 ms.
+// (Also measured: the blocked loop of k_chol_potrf moved into this kernel's frame on eight waves with the sub-block inverses
+// overlapped -- slower, 4.9 ms: at two waves per SIMD and 244 registers the wave-synchronous column steps went 12 -> 17 us.)
 constexpr int kP2Threads = 640;
 static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __restrict__ M, long lda, int k0, int nb,
                                                             double* __restrict__ Linv /* kNB x kNB col-major */,
