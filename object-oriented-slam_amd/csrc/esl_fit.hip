@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <climits>
 #include <cmath>
@@ -1410,6 +1411,9 @@ static int fit_frame_impl(esl_ctx* c, const uint16_t* depth, int32_t width, int3
   a.out_ell = (double*)(slab + o_ell); a.out_prob = (double*)(slab + o_prob); a.out_status = (int*)(slab + o_st); a.out_dbg = (double*)(slab + o_dbg);
   a.out_sym = (double*)(slab + o_sym);
   hipStream_t st = c->stream;
+  const bool host_timing = std::getenv("ESL_FIT_HOST_TIMING") != nullptr;   // diagnostic: where the host call's time goes
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double ht0 = host_timing ? now_us() : 0;
   // stage the inputs (the previous call synchronised the stream: the staging block is free)
   {
     FitFrame fr;
@@ -1423,6 +1427,7 @@ static int fit_frame_impl(esl_ctx* c, const uint16_t* depth, int32_t width, int3
     for (int b = 0; b < n_boxes; ++b) lab[b] = labels ? labels[b] : -1;
     std::memcpy(c->fit_in + o_depth, depth, (size_t)width * height * 2);
   }
+  const double ht1 = host_timing ? now_us() : 0;
   int rc = ESL_OK;
   auto fail = [&](hipError_t e, const char* what) { set_error(std::string(what) + ": " + hipGetErrorString(e)); rc = ESL_ERR_HIP; };
   hipError_t e;
@@ -1476,7 +1481,9 @@ static int fit_frame_impl(esl_ctx* c, const uint16_t* depth, int32_t width, int3
   } else {
     enqueue(true);
   }
+  const double ht2 = host_timing ? now_us() : 0;
   if ((e = hipStreamSynchronize(st)) != hipSuccess && !rc) fail(e, "sync");
+  if (host_timing) fprintf(stderr, "[esl_fit host, us] stage %.0f  enqueue %.0f  wait %.0f\n", ht1 - ht0, ht2 - ht1, now_us() - ht2);
   const char* outs_data = c->fit_out;
   // the four output arrays are contiguous in the slab: one D2H copy into the pinned block, scattered on the host
   if (!rc) {

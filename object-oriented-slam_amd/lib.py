@@ -7,6 +7,7 @@ imported from this package).
 import ctypes as C
 import os
 import subprocess
+import time
 
 import numpy as np
 
@@ -244,20 +245,29 @@ class Context:
     def fit_frame(self, depth, bboxes, labels, Twc, intr, ground, params=None):
         """EllipsoidExtractor::EstimateLocalEllipsoid for every box of one frame.
         Returns (ellipsoids (B,10) in the camera frame, prob (B,), status (B,), debug (B,16))."""
+        ta = time.perf_counter()
         p = params if params is not None else default_fit_params()
         depth = np.ascontiguousarray(depth, dtype=np.uint16)
         h, w = depth.shape
+        tb = time.perf_counter()
         boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
         B = len(boxes)
         lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
         Twc = np.ascontiguousarray(Twc, dtype=np.float64); intr = np.ascontiguousarray(intr, dtype=np.float64)
         ground = np.ascontiguousarray(ground, dtype=np.float64)
+        tc = time.perf_counter()
         ell = np.zeros((B, 10)); prob = np.zeros(B); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 16))
-        _check(load().esl_fit_frame_debug(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
-                                          boxes.ctypes.data_as(_dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(B),
-                                          Twc.ctypes.data_as(_dp), intr.ctypes.data_as(_dp), ground.ctypes.data_as(_dp),
-                                          C.byref(p), ell.ctypes.data_as(_dp), prob.ctypes.data_as(_dp),
-                                          st.ctypes.data_as(C.POINTER(C.c_int32)), dbg.ctypes.data_as(_dp)), "esl_fit_frame")
+        self.last_prep_s = (tb - ta, tc - tb, time.perf_counter() - tc)
+        fn = load().esl_fit_frame_debug
+        cargs = (self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
+                 boxes.ctypes.data_as(_dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(B),
+                 Twc.ctypes.data_as(_dp), intr.ctypes.data_as(_dp), ground.ctypes.data_as(_dp),
+                 C.byref(p), ell.ctypes.data_as(_dp), prob.ctypes.data_as(_dp),
+                 st.ctypes.data_as(C.POINTER(C.c_int32)), dbg.ctypes.data_as(_dp))
+        t0 = time.perf_counter()
+        rc = fn(*cargs)
+        self.last_call_s = time.perf_counter() - t0      # the C-ABI call alone (bench.py reports it next to the Python-inclusive time)
+        _check(rc, "esl_fit_frame")
         return ell, prob, st, dbg
 
     def fit_frame_ex(self, depth, bboxes, labels, Twc, intr, ground, params=None):
