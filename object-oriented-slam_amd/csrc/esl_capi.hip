@@ -873,12 +873,12 @@ static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_obj
         hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1, false>), dim3(nb_e3), block, 0, c->stream, g, ct, c->ck_ids_e3,
                            c->n_ids_e3, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, 0, st, cnt);
       if (nb_bb > 0) {
-        if (validate)
-          hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 0, true>), dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb,
-                             c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, nb_e3, st, cnt);
-        else
-          hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 0, false>), dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb,
-                             c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, nb_e3, st, cnt);
+        auto launch_bb = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b,
+                             c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, nb_e3, st, cnt);
+        };
+        if (g.bbox_mode) { if (validate) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, true, true>); else launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, false, true>); }
+        else { if (validate) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, true, false>); else launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, false, false>); }
       }
     }
   }
