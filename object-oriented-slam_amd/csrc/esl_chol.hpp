@@ -714,10 +714,23 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
   if (lane == 0) x[k0 + r] = s;
 }
 
+// Distributed form (one process per GPU; SURVEY.md section 8 e).  Outer panel o (W x 128 columns) belongs to rank o mod R.
+// Every rank holds the full-size matrix, but only the columns of ITS outer panels are kept up to date: the owner factors
+// its panel (diagonal blocks, panel solves, inner updates), broadcasts the factored columns (+ the inverses of the diagonal
+// blocks for the back-substitution), and every rank applies the rank-(W x 128) update to its own later panels only --
+// n^3 / (3 R) flops per rank instead of the replicated n^3 / 3.  After the last panel every rank holds the whole factor,
+// so the O(n^2) back-substitution runs replicated and all ranks end with the same x, bit for bit.
+struct CholDist {
+  int rank = 0, n_ranks = 1;
+  void* user = nullptr;
+  int (*bcast)(void* user, double* dev, size_t count, int root) = nullptr;   // on the factorisation's stream
+};
+inline int chol_outer_panels(int n) { return (n >= 8192) ? 4 : 2; }   // inner 128-panels per outer panel
+
 // Host driver.  M: (n+1) x n col-major (lda), Linv_ws: ceil(n/NB) * NB*NB doubles, z_ws: NB doubles,
 // x: n doubles (output), info: device int (bit 0 set on a non-positive pivot).
 inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws, double* z_ws, double* x, int* info,
-                                    hipStream_t st) {
+                                    hipStream_t st, const CholDist* dist = nullptr) {
   const long rows = (long)n + 1;
   const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
   static bool attr_set = false;
@@ -777,7 +790,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   static hipStream_t side = nullptr;
   static std::vector<hipEvent_t> ev_panel, ev_trail;
   if (!side) { hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking); if (e != hipSuccess) return e; }
-  const int W = (n >= 8192) ? 4 : 2;
+  const int W = chol_outer_panels(n);
   const int n_outer = (np + W - 1) / W;
   while ((int)ev_panel.size() < n_outer) {
     hipEvent_t a, b;
@@ -788,6 +801,35 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   // below ~8k unknowns the chain of single-workgroup potrf launches is the critical path whatever runs beside it (measured:
   // n = 2994 4.55 ms without, 4.75 ms with look-ahead), from 16k on it buys 12-15 %
   const bool lookahead = n >= 8192 && getenv("ESL_CHOL_NO_LOOKAHEAD") == nullptr;
+  if (dist && dist->n_ranks > 1) {
+    for (int o = 0; o < n_outer; ++o) {
+      const int owner = o % dist->n_ranks;
+      const int p0 = o * W, p1 = (p0 + W < np) ? p0 + W : np;
+      const int c_begin = p0 * kNB, c_end = (p1 * kNB < n) ? p1 * kNB : n;
+      if (owner == dist->rank) {
+        for (int p = p0; p < p1; ++p) {
+          const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+          double* Linv = Linv_ws + (size_t)p * kNB * kNB;
+          if (potrf_old) hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb, Linv, info);
+          else hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
+          const long below = rows - (k0 + nb);
+          if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb, Linv);
+          if (p + 1 < p1) launch_update(st, k0, nb, (long)k0 + nb, (long)c_end);
+        }
+        hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
+      }
+      // the factored columns (whole columns: the rows above the diagonal travel along, unused) and the diagonal blocks' inverses
+      if (dist->bcast(dist->user, M + (size_t)c_begin * lda, (size_t)lda * (size_t)(c_end - c_begin), owner)) return hipErrorUnknown;
+      if (dist->bcast(dist->user, Linv_ws + (size_t)p0 * kNB * kNB, (size_t)(p1 - p0) * kNB * kNB, owner)) return hipErrorUnknown;
+      // this rank's later outer panels
+      for (int o2 = o + 1; o2 < n_outer; ++o2) {
+        if (o2 % dist->n_ranks != dist->rank) continue;
+        const int q0 = o2 * W, q1 = (q0 + W < np) ? q0 + W : np;
+        const long b2 = (long)q0 * kNB, e2 = ((long)q1 * kNB < n) ? (long)q1 * kNB : n;
+        launch_update(st, c_begin, c_end - c_begin, b2, e2);
+      }
+    }
+  } else {
   bool trail_pending = false;   // ev_trail[o - 1] has been recorded and not yet waited for
   for (int o = 0; o < n_outer; ++o) {
     const int p0 = o * W, p1 = (p0 + W < np) ? p0 + W : np;
@@ -821,6 +863,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     trail_pending = true;
   }
   if (trail_pending) { hipError_t e = hipStreamWaitEvent(st, ev_trail[n_outer - 2], 0); if (e != hipSuccess) return e; }
+  }
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
     hipLaunchKernelGGL(k_chol_backdot, dim3(nb), dim3(256), 0, st, M, lda, n, k0, nb, x, z_ws);

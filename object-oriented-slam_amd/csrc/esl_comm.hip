@@ -13,11 +13,13 @@ typedef int (*fn_getid)(NcclUniqueId*);
 typedef int (*fn_init)(void**, int, NcclUniqueId, int);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t);      // ..., op, root, comm, stream
+typedef int (*fn_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t);            // ..., root, comm, stream
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 struct Rccl {
   void* h = nullptr;
-  fn_getid getid = nullptr; fn_init init = nullptr; fn_allgather allgather = nullptr; fn_allreduce allreduce = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
+  fn_getid getid = nullptr; fn_init init = nullptr; fn_allgather allgather = nullptr; fn_allreduce allreduce = nullptr; fn_reduce reduce = nullptr; fn_bcast bcast = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
 };
 Rccl g_rccl;
 constexpr int kNcclDouble = 8;  // ncclFloat64 in rccl.h
@@ -34,6 +36,8 @@ int load_rccl() {
   g_rccl.init = (fn_init)dlsym(g_rccl.h, "ncclCommInitRank");
   g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather");
   g_rccl.allreduce = (fn_allreduce)dlsym(g_rccl.h, "ncclAllReduce");
+  g_rccl.reduce = (fn_reduce)dlsym(g_rccl.h, "ncclReduce");          // optional: the distributed factorisation falls back to
+  g_rccl.bcast = (fn_bcast)dlsym(g_rccl.h, "ncclBroadcast");         // all-reduce forms of both when they are missing
   g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
   g_rccl.errstr = (fn_errstr)dlsym(g_rccl.h, "ncclGetErrorString");
   if (!g_rccl.getid || !g_rccl.init || !g_rccl.allgather || !g_rccl.allreduce || !g_rccl.destroy) {
@@ -104,6 +108,32 @@ int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count) {
   }
   const int rc = g_rccl.allreduce(dev_buf, dev_buf, count, kNcclDouble, /*ncclSum*/ 0, c->comm, c->stream);
   if (rc != 0) return nccl_fail(rc, "ncclAllReduce");
+  return ESL_OK;
+}
+// sum over the ranks delivered to `root` (the other ranks' buffers are unspecified afterwards: with the fallbacks they hold the
+// sum as well).  The distributed factorisation uses it to hand every outer panel of the reduced system to its owner.
+int comm_reduce_sum_root(esl_ctx* c, double* dev_buf, size_t count, int root) {
+  if (!c->comm || count == 0) return ESL_OK;
+  if (c->host_allreduce || !g_rccl.reduce) return comm_allreduce_sum(c, dev_buf, count);
+  const int rc = g_rccl.reduce(dev_buf, dev_buf, count, kNcclDouble, /*ncclSum*/ 0, root, c->comm, c->stream);
+  if (rc != 0) return nccl_fail(rc, "ncclReduce");
+  return ESL_OK;
+}
+// root's buffer to every rank.  Host transport / missing symbol: a sum in which only root contributes (x + 0 is exact).
+static __global__ void k_zero_fill(double* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+int comm_bcast(esl_ctx* c, double* dev_buf, size_t count, int root) {
+  if (!c->comm || count == 0) return ESL_OK;
+  if (c->host_allreduce || !g_rccl.bcast) {
+    if (c->comm_rank != root) {
+      hipLaunchKernelGGL(k_zero_fill, dim3(256), dim3(256), 0, c->stream, dev_buf, count);
+      ESL_HIP_TRY(hipGetLastError());
+    }
+    return comm_allreduce_sum(c, dev_buf, count);
+  }
+  const int rc = g_rccl.bcast(dev_buf, dev_buf, count, kNcclDouble, root, c->comm, c->stream);
+  if (rc != 0) return nccl_fail(rc, "ncclBroadcast");
   return ESL_OK;
 }
 int comm_reduce4(esl_ctx* c, const double* dev_src4, double out[4]) {

@@ -89,6 +89,8 @@ void fit_release(esl_ctx* c);
 int comm_gather_scalars_device(esl_ctx* c);
 // SLAM mode: in-place sum over ranks of a device buffer (RCCL all-reduce); no-op without a communicator
 int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count);
+int comm_reduce_sum_root(esl_ctx* c, double* dev_buf, size_t count, int root);   // sum over the ranks, delivered to root
+int comm_bcast(esl_ctx* c, double* dev_buf, size_t count, int root);
 // {sum, max, sum, min} of 4 device scalars over ranks -> host
 int comm_reduce4(esl_ctx* c, const double* dev_src4, double out[4]);
 }  // namespace esl

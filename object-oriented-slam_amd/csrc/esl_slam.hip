@@ -95,6 +95,15 @@ int slam_alloc(esl_ctx* c) {
   return ESL_OK;
 }
 
+// Sharded runs: factor the reduced camera system distributed over the ranks (esl_chol.hpp, CholDist) instead of all-reducing
+// it and factoring it on every rank.  Default from 8,192 unknowns (below that the chain of diagonal blocks is the whole cost and
+// a broadcast per panel only adds to it); ESL_CHOL_DIST=1 / 0 forces it on / off.
+static bool slam_dist_chol(esl_ctx* c) {
+  if (!c->comm || c->comm_ranks < 2) return false;
+  if (const char* e = getenv("ESL_CHOL_DIST")) return e[0] == '1';
+  return c->S_n >= 8192;
+}
+
 static int reduce_all(esl_ctx* c) {
   const DevGraph& g = c->g;
   hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, g.n_objs, c->dev_part, 0);
@@ -162,7 +171,16 @@ int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out
     }
   }
   ESL_HIP_TRY(hipGetLastError());
-  if (c->comm) {   // sum of the shards' partial reduced systems (and b_s row): the RCCL all-reduce over xGMI of SURVEY.md §8 e
+  if (c->comm && !dev_ptr && slam_dist_chol(c)) {
+    // distributed factorisation: every outer panel of the summed system goes to its owner only (ncclReduce per panel)
+    ProfScope ps(c, 6);
+    const int W = chol_outer_panels((int)n), np = (int)((n + kNB - 1) / kNB), n_outer = (np + W - 1) / W;
+    for (int o = 0; o < n_outer; ++o) {
+      const long c_begin = (long)o * W * kNB, c_end = std::min<long>((long)(o + 1) * W * kNB, (long)n);
+      const int rc2 = comm_reduce_sum_root(c, c->S + (size_t)c_begin * lda, (size_t)lda * (size_t)(c_end - c_begin), o % c->comm_ranks);
+      if (rc2) return rc2;
+    }
+  } else if (c->comm) {   // sum of the shards' partial reduced systems (and b_s row): the RCCL all-reduce over xGMI of SURVEY.md §8 e
     ProfScope ps(c, 6);
     int rc2 = comm_allreduce_sum(c, c->S, (size_t)lda * (size_t)n);
     if (rc2) return rc2;
@@ -181,7 +199,14 @@ int slam_try_step(esl_ctx* c, double lambda) {
   {
     ProfScope ps(c, 3);
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
-    ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream));
+    if (c->comm && slam_dist_chol(c)) {
+      CholDist d;
+      d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
+      d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
+      ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, &d));
+    } else {
+      ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream));
+    }
   }
   {
     ProfScope ps(c, 1);

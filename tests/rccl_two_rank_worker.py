@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("object-oriented-slam_amd")
 rank, id_file, out_file, slam = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4] == "1"
-g, c, o, _ = pkg.synth.make_graph(30, 8, 300, seed=21, slam=slam)
+g, c, o, _ = pkg.synth.make_graph(120 if slam else 30, 10 if slam else 8, 1500 if slam else 300, seed=21, slam=slam)
 part = pkg.lib.partition_objects(g, 2)
 idx = np.nonzero(part == rank)[0]
 ctx = pkg.Context(rank)                       # one GPU per rank

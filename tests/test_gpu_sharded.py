@@ -213,14 +213,15 @@ def test_rccl_two_ranks_on_two_gpus(pkg, ctx, slam, tmp_path):
     import sys
     if pkg.lib.device_count() < 2:
         pytest.skip("needs two visible GPUs")
-    g, c, o, _ = pkg.synth.make_graph(30, 8, 300, seed=21, slam=slam)
+    g, c, o, _ = pkg.synth.make_graph(120 if slam else 30, 10 if slam else 8, 1500 if slam else 300, seed=21, slam=slam)
     p = pkg.default_lm_params(jacobian_mode=1)
     ctx.upload_graph(g); ctx.upload_states(c, o)
     ref = ctx.optimize_resident(p)
     rc, ro = ctx.download_states()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_two_rank_worker.py")
     id_file = str(tmp_path / "nccl_id.bin")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), id_file, str(tmp_path / f"rank{r}.npz"), "1" if slam else "0"])
+    env = dict(os.environ, ESL_CHOL_DIST="1")      # SLAM: ncclReduce per outer panel + ncclBroadcast of the factored panels
+    procs = [subprocess.Popen([sys.executable, worker, str(r), id_file, str(tmp_path / f"rank{r}.npz"), "1" if slam else "0"], env=env)
              for r in range(2)]
     for pr in procs:
         assert pr.wait(timeout=180) == 0
@@ -235,3 +236,34 @@ def test_rccl_two_ranks_on_two_gpus(pkg, ctx, slam, tmp_path):
     if slam:
         np.testing.assert_array_equal(outs[0]["cams"], outs[1]["cams"])
         np.testing.assert_allclose(outs[0]["cams"], rc, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_slam_distributed_factorisation_matches_replicated(pkg, ctx, monkeypatch, n_shards):
+    """ESL_CHOL_DIST=1: every outer panel of the reduced camera system is reduced to its owner, factored there, broadcast, and
+    each shard updates only its own later panels (esl_chol.hpp, CholDist) -- against the same sharded run with the replicated
+    factorisation and against the single-context run.  714 unknowns = 6 inner / 3 outer panels, dealt 0, 1, 0 (2 shards) or
+    0, 1, 2 (3 shards)."""
+    g, c, o, _ = pkg.synth.make_graph(120, 10, 1500, seed=33, slam=True)
+    p = pkg.default_lm_params(jacobian_mode=1)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ref = ctx.optimize_resident(p)
+    rc, ro = ctx.download_states()
+    assert ref["chi2_final"] < 0.5 * ref["chi2_initial"]
+    monkeypatch.setenv("ESL_CHOL_DIST", "0")
+    reps_r, cams_r, objs_r, ar_r = run_sharded(pkg, g, c, o, p, n_shards=n_shards)
+    monkeypatch.setenv("ESL_CHOL_DIST", "1")
+    reps_d, cams_d, objs_d, ar = run_sharded(pkg, g, c, o, p, n_shards=n_shards)
+    # the distributed path really ran: 3 reductions + 6 broadcasts per trial instead of one all-reduce of the whole system
+    assert ar.calls[0] > ar_r.calls[0] + 5 * sum(reps_d[0]["trace_trials"])
+    for rep in reps_d:
+        assert rep["iterations"] == ref["iterations"] and rep["trace_trials"] == ref["trace_trials"]
+        np.testing.assert_allclose(rep["trace_chi2"], reps_r[0]["trace_chi2"], rtol=1e-9)     # same sums, another elimination order
+        np.testing.assert_allclose(rep["trace_chi2"][:3], ref["trace_chi2"][:3], rtol=1e-6)
+    for r in range(1, n_shards):
+        assert reps_d[r]["trace_chi2"] == reps_d[0]["trace_chi2"]                               # identical decisions on every rank
+        np.testing.assert_array_equal(cams_d[r], cams_d[0])                                     # ... and identical camera updates
+    np.testing.assert_allclose(cams_d[0], cams_r[0], atol=1e-9)
+    np.testing.assert_allclose(objs_d, objs_r, atol=1e-9)
+    np.testing.assert_allclose(cams_d[0], rc, atol=2e-6)
+    np.testing.assert_allclose(objs_d, ro, atol=2e-5)
