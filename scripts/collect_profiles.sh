@@ -9,5 +9,7 @@ python profiles/summarize_rocpd.py gpurun_out/prof_map_$TAG/*/*_results.db > pro
 [ -f $R/fit_kernel_times.txt ] && cp $R/fit_kernel_times.txt profiles/${TAG}_fit_kernel_times.txt
 [ -f $R/cholesky_microbench.txt ] && cp $R/cholesky_microbench.txt profiles/${TAG}_cholesky_microbench.txt
 [ -f $R/fp64_ceilings.txt ] && cp $R/fp64_ceilings.txt profiles/${TAG}_fp64_ceilings_raw.txt
+[ -f $R/cholesky_n32768_kernel_stats.md ] && cp $R/cholesky_n32768_kernel_stats.md profiles/${TAG}_cholesky_n32768_kernel_stats.md
+[ -f $R/fp64_ceilings.txt ] && cp $R/fp64_ceilings.txt profiles/${TAG}_fp64_ceilings_raw.txt
 [ -f $R/pmc_sq_lm_kernels.md ] && cp $R/pmc_sq_lm_kernels.md profiles/${TAG}_pmc_sq_lm_kernels.md
 ls -la profiles

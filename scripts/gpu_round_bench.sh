@@ -16,11 +16,13 @@ python profiles/summarize_rocpd.py gpurun_out/prof_map_$TAG/*/*_results.db > $R/
 bash scripts/gpu_prof_fit.sh $TAG > $R/fit_kernel_times.txt 2>&1
 bash scripts/gpu_pmc_lm.sh $TAG > $R/pmc_sq_lm_kernels.md 2>&1
 timeout 300 python scripts/chol_bench.py 2994 8192 16384 24576 32768 > $R/cholesky_microbench.txt 2>&1
+bash scripts/gpu_prof_chol.sh $TAG 32768 > $R/prof_chol.txt 2>&1
+python profiles/summarize_rocpd.py gpurun_out/prof_chol_$TAG/*/*_results.db > $R/cholesky_n32768_kernel_stats.md
 (hipcc -O3 --offload-arch=gfx950 scripts/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && timeout 120 /tmp/mfma_peak) > $R/fp64_ceilings.txt 2>&1
 run() { name=$1; shift; timeout 900 python bench.py --no-cpu-baseline "$@" > $R/$name.json 2> $R/$name.err; }
 run c3_slam --mode slam --config C3 --steps 3 --warmup 1
-run c4_mapping_numeric --jacobian numeric --steps 5 --warmup 1
-run c3_mapping --config C3
+run c4_mapping_numeric --no-slam --jacobian numeric --steps 5 --warmup 1
+run c3_mapping --no-slam --config C3
 run c4_slam --mode slam --config C4 --steps 1 --warmup 0
 python - $R <<'PY'
 import json, sys
