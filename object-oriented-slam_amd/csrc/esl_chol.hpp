@@ -237,17 +237,14 @@ static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ 
 #undef LL
 }
 
-// ---- diagonal block, second form (round 2): the 128 column steps run over the WHOLE block with one barrier each --------------
-// 528 threads each OWN a 4 x 4 block of the lower triangle in 16 registers for the whole factorisation; only the current
-// column travels through LDS (128 doubles, double-buffered).  Step j: every thread reads the pivot d = a(j,j), the four column
-// entries of its rows and of its columns, and subtracts a(i,j) a(c,j) / d from its elements right of column j -- the column is
-// NOT scaled on the way (that would need a second barrier): the unscaled entries stay in their owners' registers and all
-// columns are scaled by 1/sqrt(d_j) at the end.  The owners of column j+1 publish it (and the diagonal block's owner the
-// reciprocal square root of its pivot) after their update; one barrier; next step.  Measured: 590 ns per column -- the step is
-// all latency (LDS write -> barrier of ten waves -> LDS read; dropping the Newton steps or the 16 FMAs changes it by 4 %), so
-// the column loop itself is no faster than the blocked form above (76 vs 66 us); the kernel wins on everything around it:
-// load 10 -> 2 us (each thread fetches its own block), blocked triangular inverse on ten waves instead of four 20 -> 13 us,
-// stores 7 -> 2 us, L written back under the sub-block inverses: 136 -> 118 us per launch, n = 2,994 4.5 -> 4.0 ms.
+// ---- diagonal block, second form (round 2): right-looking over the WHOLE block in rank-4 steps ---------------------------------
+// 528 threads each OWN a 4 x 4 block of the lower triangle in 16 registers for the whole factorisation; only the current block
+// column (4 x 128 doubles) and the inverse of its diagonal block (10 doubles) travel through LDS.  32 steps of two barriers each
+// (see the loop).  History of this kernel, n = 2,994 factor + solve: blocked form of round 1 (k_chol_potrf: 32 x 32 sub-blocks
+// factored by one wave with v_readlane broadcasts) 4.5 ms; one column per step with one barrier (590 ns per column, all of it
+// latency of LDS write -> 10-wave barrier -> LDS read) 4.0 ms; rank-4 steps (column loop 76 -> 28 us, kernel 118 -> 72 us) 2.86 ms.  Around the loop: every thread
+// fetches its own block (load 10 -> 2 us), the blocked triangular inverse runs on ten waves instead of four (20 -> 13 us), L is
+// written back under the sub-block inverses.
 // (Also measured: the blocked loop of k_chol_potrf moved into this kernel's frame on eight waves with the sub-block inverses
 // overlapped -- slower, 4.9 ms: at two waves per SIMD and 244 registers the wave-synchronous column steps went 12 -> 17 us.)
 constexpr int kP2Threads = 640;
@@ -279,63 +276,106 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
       const int i = 4 * bi + r, j = 4 * bj + c;
       a[r][c] = (own && i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);   // identity padding
     }
-  constexpr int kCB = kNB + 8;             // column buffer: 128 entries + [kNB] = 1 / sqrt(pivot)
-  double* colbuf = T;                      // [2][kCB]
-  // 1/sqrt(d) from the hardware estimate + two Newton steps (no fp64 sqrt, no divide); done by the pivot's owner only
-  auto publish_pivot = [&](double d, double* buf, int j) {
-    if (!(d > 0)) atomicOr(info, 1);
-    double is = __builtin_amdgcn_rsq(d);
-    is = is * (1.5 - 0.5 * d * is * is);
-    is = is * (1.5 - 0.5 * d * is * is);
-    buf[kNB] = is;
-    dinv[j] = is;
-  };
-  if (own && bj == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) colbuf[4 * bi + r] = a[r][0];
-    if (bi == 0) publish_pivot(a[0][0], colbuf, 0);
-  }
-  __syncthreads();
-  POTRF_MARK(1);
-  for (int j = 0; j < kNB; ++j) {
-    const double* cur = colbuf + (j & 1) * kCB;
-    double* nxt = colbuf + ((j + 1) & 1) * kCB;
-    const int jb = j >> 2;
-    if (own && bj >= jb) {
-      const double is = cur[kNB];
-      const double is2 = is * is;
-      double rv[4], cv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rv[r] = cur[4 * bi + r];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) cv[c] = (4 * bj + c > j) ? cur[4 * bj + c] * is2 : 0.0;   // columns <= j are final
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a[r][c] -= rv[r] * cv[c];
-      const int jn = j + 1;
-      if (bj == (jn >> 2) && jn < kNB) {   // publish column j + 1 (unscaled) and, from the diagonal block, its pivot
-        const int c = jn & 3;
-        double col[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) col[r] = (c == 0) ? a[r][0] : (c == 1) ? a[r][1] : (c == 2) ? a[r][2] : a[r][3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nxt[4 * bi + r] = col[r];
-        if (bi == bj) publish_pivot((c == 0) ? col[0] : (c == 1) ? col[1] : (c == 2) ? col[2] : col[3], nxt, jn);
-      }
-    }
-    __syncthreads();
-  }
-  POTRF_MARK(2); POTRF_MARK(3); POTRF_MARK(4);   // (marks 2..4 of the blocked form collapse: the whole column loop is "factor32[0]")
-  // scale the columns and lay the factor out in LDS for the inverse (dinv[j] = 1 / L(j,j))
-  if (own) {
+  // Rank-4 steps: block column J = the four columns of the 4 x 4 blocks (., J).  Per step, two barriers instead of four:
+  //   (a) the owner of the diagonal block (J, J) factors it in registers (four dependent rsqrt chains) and publishes its
+  //       inverse (10 numbers)                                                                       -> barrier A
+  //   (b) the blocks below it solve X = A L_JJ^-T with that inverse, keep X (their part of L) and publish its four columns
+  //                                                                                                   -> barrier B
+  //   (c) every block to the right subtracts the rank-4 product of its rows' and its columns' entries; the owner of the NEXT
+  //       diagonal block goes straight on to (a), so barrier A of step J + 1 is the barrier that ends step J.
+  double* colbuf = T;                      // [4][kNB]: the four columns of the current block column (rows below the diagonal block)
+  double* dblk = T + 4 * kNB;              // [10]: inverse of the current diagonal block, packed rows (0,0) (1,0) (1,1) (2,0) ...
+  // 4 x 4 Cholesky of the thread's own block (lower triangle), in place; returns the inverse of the factor, publishes 1 / L(c,c)
+  auto factor_diag = [&](int J) {
+    double is[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const double sc = dinv[4 * bj + c];
+      double d = a[c][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) d -= a[c][k] * a[c][k];
+      if (!(d > 0)) atomicOr(info, 1);
+      double r = __builtin_amdgcn_rsq(d);   // 1/sqrt(d): hardware estimate + two Newton steps (no fp64 sqrt, no divide)
+      r = r * (1.5 - 0.5 * d * r * r);
+      r = r * (1.5 - 0.5 * d * r * r);
+      is[c] = r;
+      a[c][c] = d * r;
+#pragma unroll
+      for (int rr = c + 1; rr < 4; ++rr) {
+        double v = a[rr][c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= a[rr][k] * a[c][k];
+        a[rr][c] = v * r;
+      }
+      dinv[4 * J + c] = r;
+    }
+    // X = L^-1 (lower): X(c,c) = 1 / L(c,c), X(r,c) = -(sum_{k=c}^{r-1} L(r,k) X(k,c)) / L(r,r)
+    double x[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      x[c][c] = is[c];
+#pragma unroll
+      for (int rr = c + 1; rr < 4; ++rr) {
+        double v = 0;
+#pragma unroll
+        for (int k = c; k < rr; ++k) v += a[rr][k] * x[k][c];
+        x[rr][c] = -v * is[rr];
+      }
+    }
+    int q = 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int c = 0; c <= rr; ++c) dblk[q++] = x[rr][c];
+  };
+  if (own && bi == 0 && bj == 0) factor_diag(0);
+  __syncthreads();                                      // barrier A of step 0
+  POTRF_MARK(1);
+  for (int J = 0; J < kNB / 4; ++J) {
+    if (own && bj == J && bi > J) {                     // (b) X = A L_JJ^-T: X(r,c) = sum_{k <= c} A(r,k) Linv(c,k)
+      double li[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) li[q] = dblk[q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double a0 = a[r][0], a1 = a[r][1], a2 = a[r][2], a3 = a[r][3];
+        a[r][0] = a0 * li[0];
+        a[r][1] = a0 * li[1] + a1 * li[2];
+        a[r][2] = a0 * li[3] + a1 * li[4] + a2 * li[5];
+        a[r][3] = a0 * li[6] + a1 * li[7] + a2 * li[8] + a3 * li[9];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) colbuf[c * kNB + 4 * bi + r] = a[r][c];
+    }
+    __syncthreads();                                    // barrier B
+    if (own && bj > J) {                                // (c) rank-4 update
+      double rv[4][4], cv[4][4];                        // [k][r]: entries of column k of the block column in this block's rows / columns
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rv[k][r] = colbuf[k * kNB + 4 * bi + r]; cv[k][r] = colbuf[k * kNB + 4 * bj + r]; }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * bi + r >= 4 * bj + c) LL(4 * bi + r, 4 * bj + c) = a[r][c] * sc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = a[r][c];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v -= rv[k][r] * cv[k][c];
+          a[r][c] = v;
+        }
+      if (bi == bj && bj == J + 1) factor_diag(J + 1);  // (a) of the next step
     }
+    __syncthreads();                                    // barrier A of step J + 1
+  }
+  POTRF_MARK(2); POTRF_MARK(3); POTRF_MARK(4);   // (marks 2..4 of the blocked form collapse: the whole column loop is "factor32[0]")
+  // lay the factor out in LDS for the inverse (dinv[j] = 1 / L(j,j))
+  if (own) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * bi + r >= 4 * bj + c) LL(4 * bi + r, 4 * bj + c) = a[r][c];
   }
   __syncthreads();
   POTRF_MARK(5);
