@@ -485,7 +485,7 @@ def main():
     # per-frame fit (second half of the metric) right after the timed region: measured later in the process, the Python loop
     # around the 1280 x 960 case sees ~2 ms more per call than the C-ABI call itself takes (0.7 ms in every order; both are
     # reported, see fit_bench)
-    fit_record = fit_bench(pkg, ctx, with_cpu=not a.no_cpu_baseline) if (rank == 0 and world == 1) else None
+    fit_record = fit_bench(pkg, ctx, with_cpu=not a.no_cpu_baseline) if (rank == 0 and world == 1 and not sharded) else None
     if fit_record is not None:
         ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
     # the same K-step block ten more times, events off: how much one scheduler hiccup moves a 5 ms timed region
@@ -574,7 +574,7 @@ def main():
                                     "min": float(np.min(blocks)), "max": float(np.max(blocks)),
                                     "note": "LM iterations/s of 10 further K-step blocks (HIP events off); `value` is the first, timed block"}
         out["host"] = host_info()
-        if world == 1:
+        if world == 1 and not sharded:   # the single-GPU extras (a context with a communicator is a shard of a collective run)
             out["fit"] = fit_record
             out["streaming_c5"] = streaming_bench(pkg, ctx)
             if not slam and not a.no_slam:
