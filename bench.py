@@ -165,7 +165,6 @@ def fit_bench(pkg, ctx, with_cpu=True):
         for _ in range(n):
             res = ctx.fit_frame(*args)
             t_abi += ctx.last_call_s
-            if os.environ.get("ESL_BENCH_PREP"): print("[prep]", name, [round(1e6 * v) for v in ctx.last_prep_s], round(1e6 * ctx.last_call_s), file=sys.stderr)
         dt_py = (time.perf_counter() - t0) / n
         dt = t_abi / n                     # the C-ABI call (esl_fit_frame) alone; dt_py adds the ctypes / numpy wrapper
         ctx.profile_enable(True)           # kernel time: direct launches bracketed by HIP events

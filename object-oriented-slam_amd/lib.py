@@ -245,19 +245,15 @@ class Context:
     def fit_frame(self, depth, bboxes, labels, Twc, intr, ground, params=None):
         """EllipsoidExtractor::EstimateLocalEllipsoid for every box of one frame.
         Returns (ellipsoids (B,10) in the camera frame, prob (B,), status (B,), debug (B,16))."""
-        ta = time.perf_counter()
         p = params if params is not None else default_fit_params()
         depth = np.ascontiguousarray(depth, dtype=np.uint16)
         h, w = depth.shape
-        tb = time.perf_counter()
         boxes = np.ascontiguousarray(bboxes, dtype=np.float64).reshape(-1, 4)
         B = len(boxes)
         lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
         Twc = np.ascontiguousarray(Twc, dtype=np.float64); intr = np.ascontiguousarray(intr, dtype=np.float64)
         ground = np.ascontiguousarray(ground, dtype=np.float64)
-        tc = time.perf_counter()
         ell = np.zeros((B, 10)); prob = np.zeros(B); st = np.zeros(B, dtype=np.int32); dbg = np.zeros((B, 16))
-        self.last_prep_s = (tb - ta, tc - tb, time.perf_counter() - tc)
         fn = load().esl_fit_frame_debug
         cargs = (self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_int32(w), C.c_int32(h),
                  boxes.ctypes.data_as(_dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(B),
