@@ -243,8 +243,8 @@ static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ 
 // (see the loop).  History of this kernel, n = 2,994 factor + solve: blocked form of round 1 (k_chol_potrf: 32 x 32 sub-blocks
 // factored by one wave with v_readlane broadcasts) 4.5 ms; one column per step with one barrier (590 ns per column, all of it
 // latency of LDS write -> 10-wave barrier -> LDS read) 4.0 ms; rank-4 steps (column loop 76 -> 28 us, kernel 118 -> 72 us) 2.86 ms.  Around the loop: every thread
-// fetches its own block (load 10 -> 2 us), the blocked triangular inverse runs on ten waves instead of four (20 -> 13 us), L is
-// written back under the sub-block inverses.
+// fetches its own block (load 10 -> 2 us) and writes its part of L back from registers; the triangular inverse is computed in
+// place by recursive doubling from the 4 x 4 inverses the factorisation produces anyway (see below).
 // (Also measured: the blocked loop of k_chol_potrf moved into this kernel's frame on eight waves with the sub-block inverses
 // overlapped -- slower, 4.9 ms: at two waves per SIMD and 244 registers the wave-synchronous column steps went 12 -> 17 us.)
 constexpr int kP2Threads = 640;
@@ -285,6 +285,7 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
   //       diagonal block goes straight on to (a), so barrier A of step J + 1 is the barrier that ends step J.
   double* colbuf = T;                      // [4][kNB]: the four columns of the current block column (rows below the diagonal block)
   double* dblk = T + 4 * kNB;              // [10]: inverse of the current diagonal block, packed rows (0,0) (1,0) (1,1) (2,0) ...
+  double xd[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // diagonal-block owners: the inverse of their factored block
   // 4 x 4 Cholesky of the thread's own block (lower triangle), in place; returns the inverse of the factor, publishes 1 / L(c,c)
   auto factor_diag = [&](int J) {
     double is[4];
@@ -325,7 +326,7 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-      for (int c = 0; c <= rr; ++c) dblk[q++] = x[rr][c];
+      for (int c = 0; c <= rr; ++c) { dblk[q++] = x[rr][c]; xd[rr][c] = x[rr][c]; }
   };
   if (own && bi == 0 && bj == 0) factor_diag(0);
   __syncthreads();                                      // barrier A of step 0
@@ -369,77 +370,81 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
     __syncthreads();                                    // barrier A of step J + 1
   }
   POTRF_MARK(2); POTRF_MARK(3); POTRF_MARK(4);   // (marks 2..4 of the blocked form collapse: the whole column loop is "factor32[0]")
-  // lay the factor out in LDS for the inverse (dinv[j] = 1 / L(j,j))
+  // L11 back to memory straight from the owners' registers (the factor itself is part of the result), and into LDS for the
+  // inverse: off-diagonal 4 x 4 blocks as they are, diagonal blocks as their INVERSES (computed during the factorisation)
   if (own) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * bi + r >= 4 * bj + c) LL(4 * bi + r, 4 * bj + c) = a[r][c];
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * bi + r, j = 4 * bj + c;
+        if (i >= j) {
+          if (i < nb && j < nb) M[(long)(k0 + i) + (long)(k0 + j) * lda] = a[r][c];
+          LL(i, j) = (bi == bj) ? xd[r][c] : a[r][c];
+        }
+      }
   }
   __syncthreads();
-  POTRF_MARK(5);
-  // inverses of the four diagonal sub-blocks, one wave each, side by side (parked in the upper triangles)
-  if (wave < kNB / kSB) {
-    const int c0 = wave * kSB, r = lane & 31;
-    double row[kSB], invd[kSB], x[kSB];
-#pragma unroll
-    for (int c = 0; c < kSB; ++c) { row[c] = (c <= r) ? LL(c0 + r, c0 + c) : 0.0; invd[c] = dinv[c0 + c]; }
-    trtri32_wave(row, invd, lane, x);
-    if (lane < kSB) {
-#pragma unroll
-      for (int c = 0; c < kSB; ++c)
-        if (c > lane) LL(c0 + lane, c0 + c) = x[c];    // lane = column of X, x[c] = X(c, lane), parked transposed
+  POTRF_MARK(5); POTRF_MARK(6); POTRF_MARK(7);
+  // ---- Linv = L^-1 IN PLACE by recursive doubling: the inverse of [A 0; C D] is [A^-1 0; -D^-1 C A^-1  D^-1].  Level b merges
+  // pairs of adjacent b x b diagonal inverses; C (original L) is overwritten by its block of the inverse, which no later level
+  // reads as L.  b = 4, 8: one thread per output entry; b = 16, 32, 64: two MFMA products, the intermediate T = C A^-1 parked
+  // in the (unused) block above the diagonal that mirrors C.  8 barriers in all, against the 32-step triangular inverses of
+  // the four 32 x 32 sub-blocks + 3 dependent block columns of the blocked form (25.6 -> 16.4 us; n = 2,994 2.86 -> 2.60 ms).
+#pragma unroll 1
+  for (int b = 4; b <= 8; b *= 2) {
+    const int per = b * b, total = (kNB / (2 * b)) * per;
+    for (int e = t; e < total; e += NT) {
+      const int mg = e / per, ij = e - mg * per, i = ij / b, j = ij - i * b;
+      const int r0 = mg * 2 * b;
+      double acc = 0;
+      for (int m = 0; m <= i; ++m) {                 // D^-1 lower
+        double s2 = 0;
+        for (int k = j; k < b; ++k) s2 += LL(r0 + b + m, r0 + k) * LL(r0 + k, r0 + j);   // C(m,k) A^-1(k,j), A^-1 lower
+        acc += LL(r0 + b + i, r0 + b + m) * s2;
+      }
+      T[e] = -acc;                                   // every output of the level first (C is still being read)
     }
-  } else {
-    // the other waves write L11 back meanwhile (the factor itself is part of the result; the parked inverses live above the diagonal)
-    for (int idx = t - 256; idx < nb * nb; idx += NT - 256) {
-      const int i = idx % nb, j = idx / nb;
-      if (i >= j) M[(long)(k0 + i) + (long)(k0 + j) * lda] = LL(i, j);
+    __syncthreads();
+    for (int e = t; e < total; e += NT) {
+      const int mg = e / per, ij = e - mg * per, i = ij / b, j = ij - i * b;
+      LL(mg * 2 * b + b + i, mg * 2 * b + j) = T[e];
     }
+    __syncthreads();
   }
-  __syncthreads();
-  POTRF_MARK(6); POTRF_MARK(7);
-  constexpr int nB = kNB / kSB;
-  for (int J = nB - 1; J >= 0; --J) {
-    const int c0 = J * kSB, r0 = c0 + kSB, mrows = kNB - r0;
-    {
-      const int r = lane & 15, kq = lane >> 4;
-      const int nout = (mrows / 16) * 2;
-      for (int ob = wave; ob < nout; ob += NW) {
-        const int ib = ob >> 1, cb = ob & 1;
-        double4_t acc = {0, 0, 0, 0};
-        for (int kk = 0; kk < (ib + 1) * 16; kk += 4) {
-          const int i = ib * 16 + r, k = kk + kq;
-          const double av = (k <= i) ? LL(r0 + i, r0 + k) : 0.0;
-          const double bv = LL(r0 + k, c0 + cb * 16 + r);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) T[(ib * 16 + kq + 4 * g) + (cb * 16 + r) * 96] = acc[g];
+#pragma unroll 1
+  for (int b = 16; b <= 64; b *= 2) {
+    const int nt = b / 16, tiles = (kNB / (2 * b)) * nt * nt;
+    const int r = lane & 15, kq = lane >> 4;
+    // T = C A^-1  -> parked at LL(r0 + i, r0 + b + j)
+    for (int tl = wave; tl < tiles; tl += NW) {
+      const int mg = tl / (nt * nt), ij = tl - mg * nt * nt, ib = ij / nt, jb = ij - ib * nt;
+      const int r0 = mg * 2 * b;
+      double4_t acc = {0, 0, 0, 0};
+      for (int kk = jb * 16; kk < b; kk += 4) {      // A^-1(k, j) = 0 for k < j
+        const int k = kk + kq, j = jb * 16 + r;
+        const double av = LL(r0 + b + ib * 16 + r, r0 + k);
+        const double bv = (k >= j) ? LL(r0 + k, r0 + j) : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) LL(r0 + ib * 16 + kq + 4 * g, r0 + b + jb * 16 + r) = acc[g];   // D: row = (lane >> 4) + 4 g, col = lane & 15
     }
     __syncthreads();
-    for (int idx = t; idx < kSB * kSB; idx += NT) { const int i = idx % kSB, c = idx / kSB; if (i > c) LL(c0 + i, c0 + c) = LL(c0 + c, c0 + i); }
-    {
-      const int r = lane & 15, kq = lane >> 4;
-      const int nout = (mrows / 16) * 2;
-      for (int ob = wave; ob < nout; ob += NW) {
-        const int ib = ob >> 1, cb = ob & 1;
-        double4_t acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int kk = 0; kk < kSB; kk += 4) {
-          const int k = kk + kq, c = cb * 16 + r;
-          const double av = T[(ib * 16 + r) + k * 96];
-          const double bv = (k > c) ? LL(c0 + c, c0 + k) : ((k == c) ? dinv[c0 + c] : 0.0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) LL(r0 + ib * 16 + kq + 4 * g, c0 + cb * 16 + r) = -acc[g];
+    // X21 = -D^-1 T  -> in C's place
+    for (int tl = wave; tl < tiles; tl += NW) {
+      const int mg = tl / (nt * nt), ij = tl - mg * nt * nt, ib = ij / nt, jb = ij - ib * nt;
+      const int r0 = mg * 2 * b;
+      double4_t acc = {0, 0, 0, 0};
+      for (int mm = 0; mm < (ib + 1) * 16; mm += 4) {   // D^-1(i, m) = 0 for m > i
+        const int m = mm + kq, i = ib * 16 + r;
+        const double av = (m <= i) ? LL(r0 + b + i, r0 + b + m) : 0.0;
+        const double bv = LL(r0 + m, r0 + b + jb * 16 + r);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) LL(r0 + b + ib * 16 + kq + 4 * g, r0 + jb * 16 + r) = -acc[g];
     }
-    __syncthreads();
-    if (t < kSB) LL(c0 + t, c0 + t) = dinv[c0 + t];
     __syncthreads();
   }
   POTRF_MARK(8);
