@@ -525,6 +525,30 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
     xp[m] = P + (xv[m] ? xr : 0) + (long)kq * lda;
     yp[m] = Linv + (cg + m * 16 + r) + (long)kq * kNB;
   }
+  if (nb == kNB && r0 + 32 <= rows) {   // wave-uniform: the MFMAs below need every lane
+    // full panel, rows inside: 16 k-steps of operands in flight at a time (a slot is reloaded with step s + 16 right after step s
+    // used it).  Two steps deep, the loop waited for a global load per step: 25 us per launch whatever the panel height.
+    double ra[16][2], rb[16][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) { ra[s2][m] = xp[m][(long)(4 * s2) * lda]; rb[s2][m] = yp[m][(long)(4 * s2) * kNB]; }
+    __builtin_amdgcn_sched_barrier(0);   // all 64 loads are issued HERE (left alone, the scheduler sinks them to three steps ahead of their use)
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[s2][nj], ra[s2][mi], acc[mi][nj], 0, 0, 0);
+        if (half == 0) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) { ra[s2][m] = xp[m][(long)(4 * (s2 + 16)) * lda]; rb[s2][m] = yp[m][(long)(4 * (s2 + 16)) * kNB]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  } else {
   // software pipeline, two k-steps deep
   double a[2], b[2], an[2], bn[2];
   {
@@ -543,9 +567,10 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[nj], a[mi], acc[mi][nj], 0, 0, 0);
 #pragma unroll
     for (int m = 0; m < 2; ++m) { a[m] = an[m]; b[m] = bn[m]; }
+  }
   }
   __syncthreads();   // every wave of the workgroup has read its input rows
 #pragma unroll
@@ -554,8 +579,10 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
     for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const long row = r0 + mi * 16 + kq + 4 * g;
-        const int col = cg + nj * 16 + r;
+        // the product is formed TRANSPOSED (Linv fragment as the MFMA A operand): D's lane & 15 is then the panel ROW, so 16 lanes
+        // store 128 contiguous bytes of a column (row-major-in-lanes stores touched 64 different cache lines per instruction)
+        const long row = r0 + mi * 16 + r;
+        const int col = cg + nj * 16 + kq + 4 * g;
         if (row < rows && col < nb) M[row + (long)(k0 + col) * lda] = acc[mi][nj][g];
       }
 }
