@@ -534,8 +534,9 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms,
                     "launches": dom["count"],
-                    "sampling": "HIP events around ONE linearisation launch per optimize() (the second trial's); bracketing "
-                                "every launch costs 13 % of the run because each event record splits two back-to-back dispatches"}
+                    "sampling": "HIP events around ONE linearisation launch (the second trial's) of every FOURTH optimize() of the timed "
+                                "region: an event pair splits two back-to-back dispatches and costs that trial ~20 us, so one sample per "
+                                "run cost 10 % of `value` and bracketing every launch 13 %"}
             if not slam and a.jacobian == "analytic":
                 roof["valu_issue_floor"] = valu_issue_floor(g, avg_ms)
         else:

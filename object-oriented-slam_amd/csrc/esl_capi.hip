@@ -1099,6 +1099,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
     if (hv->done) out->stop_reason = hv->core.stop_reason;
     return ESL_OK;
   }
+  const bool sample_run = c->prof_on && c->prof_level == 1 && (c->prof_runs++ % 4 == 0);
   const int max_total = p->max_iters * std::max(1, p->max_trials);
   const int depth = 2;   // trials kept in flight ahead of the device's progress counter
   // ESL_LM_STEP_OLD=1: round 1's step kernel (16 ellipsoids per workgroup, one lane each) for A/B measurements
@@ -1131,7 +1132,9 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
                            sharded ? c->dev_gather : (const double*)nullptr, sharded ? c->comm_ranks : 0, p->tau);
         ESL_HIP_TRY(hipGetLastError());
       }
-      c->prof_gate = (enq == 1);   // the second trial's linearisation is the sampled one (always a live launch when it exists)
+      // the second trial's linearisation (always a live launch when it exists) of every FOURTH run is the sampled one: an event
+      // pair splits two back-to-back dispatches and costs that trial ~20 us -- one per run was 10 % of a 0.2 ms run
+      c->prof_gate = (enq == 1) && (sample_run);
       rc = map_launch_linearize(c, false, nullptr, nullptr, nxt);
       c->prof_gate = true;
       if (rc) return rc;
@@ -1312,6 +1315,7 @@ int esl_profile_enable(esl_ctx* c, int enable) {
   if (c->prof_on) prof_drain(c);
   c->prof_on = enable != 0;
   c->prof_level = enable;
+  c->prof_runs = 0;
   for (int k = 0; k < ESL_PROF_KINDS; ++k) { c->prof_count[k] = 0; c->prof_ms[k] = 0; }
   return ESL_OK;
 }

@@ -135,6 +135,7 @@ struct esl_ctx {
   // profiling (HIP events on this stream)
   bool prof_on = false;
   int prof_level = 0;   // 1: only kernel class 0 (linearise) is bracketed; 2: every class
+  unsigned prof_runs = 0; // level 1: device-driven runs since esl_profile_enable (every 4th one carries the sampled launch)
   bool prof_gate = true; // level 1 inside a device-driven run: bracket ONE linearisation per run (event records break
                          // the back-to-back dispatch: bracketing all of them cost 13 % of the C4 run)
   std::vector<hipEvent_t> prof_ev;   // pairs
