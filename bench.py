@@ -391,7 +391,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)   # 0.2 ms steps: the clocks are still ramping after 3
     ap.add_argument("--mode", default="mapping", choices=["mapping", "slam"])
     ap.add_argument("--config", default="C4")
     ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
