@@ -525,7 +525,8 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
     xp[m] = P + (xv[m] ? xr : 0) + (long)kq * lda;
     yp[m] = Linv + (cg + m * 16 + r) + (long)kq * kNB;
   }
-  if (nb == kNB && r0 + 32 <= rows) {   // wave-uniform: the MFMAs below need every lane
+  if (nb == kNB) {   // (rows past the end read row 0 -- xp[] is clamped -- and are dropped at the store: one straggling wave on the
+                     //  two-deep path below used to set the duration of the whole launch, 22 us whatever the rest did)
     // full panel, rows inside: 16 k-steps of operands in flight at a time (a slot is reloaded with step s + 16 right after step s
     // used it).  Two steps deep, the loop waited for a global load per step: 25 us per launch whatever the panel height.
     double ra[16][2], rb[16][2];
@@ -641,20 +642,19 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
       const int e = t + NT * q, pr = e % (BM / 2), k = e / (BM / 2);
       const long row = i0 + 2 * pr;
       const bool kv = (kc + k) < K;
-      double2_t v = {0.0, 0.0};
-      if (kv && row + 1 < rows) v = *reinterpret_cast<const double2_t*>(P + row + (long)(kc + k) * lda);
-      else if (kv && row < rows) v[0] = P[row + (long)(kc + k) * lda];
-      ra[q] = v;
+      // edge tiles: clamped addresses + selects, no branches (a branchy load per element made the edge workgroups the stragglers)
+      const long kcl = kv ? (long)(kc + k) : (long)(K - 1);
+      const double v0 = P[(row < rows ? row : rows - 1) + kcl * lda], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * lda];
+      ra[q] = double2_t{(kv && row < rows) ? v0 : 0.0, (kv && row + 1 < rows) ? v1 : 0.0};
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
       const int e = t + NT * q, pr = e % (BN / 2), k = e / (BN / 2);
       const long row = j0 + 2 * pr;
       const bool kv = (kc + k) < K;
-      double2_t v = {0.0, 0.0};
-      if (kv && row + 1 < rows) v = *reinterpret_cast<const double2_t*>(P + row + (long)(kc + k) * lda);
-      else if (kv && row < rows) v[0] = P[row + (long)(kc + k) * lda];
-      rb[q] = v;
+      const long kcl = kv ? (long)(kc + k) : (long)(K - 1);
+      const double v0 = P[(row < rows ? row : rows - 1) + kcl * lda], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * lda];
+      rb[q] = double2_t{(kv && row < rows) ? v0 : 0.0, (kv && row + 1 < rows) ? v1 : 0.0};
     }
   };
   auto sstore = [&](int buf) {
@@ -744,16 +744,28 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
     }
     return;
   }
+  // edge and diagonal sub-tiles: the same batching with clamped addresses and predicated stores (an `if` around the whole
+  // read-modify-write compiles to one exposed memory round trip per element, and the workgroup doing that is the last to finish)
 #pragma unroll
-  for (int nj = 0; nj < NJ; ++nj)
+  for (int nj = 0; nj < NJ; ++nj) {
+    double cv[MI][4];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const long col = jw + nj * 16 + rq + 4 * g;   // D row  -> j
         const long row = iw + mi * 16 + r;            // D col  -> i (contiguous across lanes)
-        if (row < rows && col < ncols && row >= col) M[row + col * lda] -= acc[nj][mi][g];
+        cv[mi][g] = M[(row < rows ? row : rows - 1) + (col < ncols ? col : ncols - 1) * lda];
       }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long col = jw + nj * 16 + rq + 4 * g;
+        const long row = iw + mi * 16 + r;
+        if (row < rows && col < ncols && row >= col) M[row + col * lda] = cv[mi][g] - acc[nj][mi][g];
+      }
+  }
 }
 
 // ---- backward substitution L^T x = y, panel by panel from the last ------------------------------------------
