@@ -51,7 +51,7 @@ def valu_issue_floor(g, avg_ms):
     1024 SIMDs at 2.4 GHz; instruction counts are the static ones of profiles/r2_isa_counts.json."""
     try:
         isa = json.load(open(os.path.join(ROOT, "profiles", "r2_isa_counts.json")))
-        bb, e3 = isa["k_chunk_linearize<1, 0, false>"], isa["k_chunk_linearize<1, 1, false>"]
+        bb, e3 = isa["k_chunk_linearize<1, 0, 0, false>"], isa["k_chunk_linearize<1, 1, 0, false>"]   # <JAC, TYPE, VALIDATE, TANG>
     except Exception:  # noqa: BLE001
         return None
     cb = np.bincount(g.bbox_obj, minlength=g.n_objs) if len(g.bbox_obj) else np.zeros(1, int)
@@ -527,7 +527,7 @@ def main():
             try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) — same workload only
                 if not slam and a.config == "C4" and a.jacobian == "analytic":
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_device_lm.json")))["kernels"]
-                    traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, false" in k][0]["traffic_bytes_per_launch"]
+                    traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, 0" in k or "k_chunk_linearize_both<1, false" in k][0]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
                 traffic = None
             roof = {"kernel": "k_chunk_linearize_both (bbox + 3-D chunks, one launch)" if not slam else "k_slam_linearize", "bound": "hbm",

@@ -851,34 +851,43 @@ static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_obj
     int* cnt = c->chol_info + 2;
     if (an && g.bbox_mode) {   // plane-tangency rows instead of the reprojection residual (never NaN: nothing to validate, but the
                                // flags are (re)set to valid by the VALIDATE instantiation)
-      if (validate)
-        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, true, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+      if (validate && g.check_vis)
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, 2, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+                           c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
+                           chunk_b, c->blk_chi, st, cnt);
+      else if (validate)
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, 1, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
                            c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
                            chunk_b, c->blk_chi, st, cnt);
       else
-        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, false, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, 0, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
                            c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
                            chunk_b, c->blk_chi, st, cnt);
     } else if (an) {   // both edge types in one launch, 3-D workgroups first
-      if (validate)
-        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, true>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+      if (validate && g.check_vis)
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, 2>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+                           c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
+                           chunk_b, c->blk_chi, st, cnt);
+      else if (validate)
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, 1>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
                            c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
                            chunk_b, c->blk_chi, st, cnt);
       else
-        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, false>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
+        hipLaunchKernelGGL((k_chunk_linearize_both<ESL_JAC_ANALYTIC, 0>), dim3(nb_e3 + nb_bb), block, 0, c->stream, g, ct, c->ck_ids_e3,
                            c->n_ids_e3, nb_e3, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk,
                            chunk_b, c->blk_chi, st, cnt);
     } else {    // numeric Jacobians: one kernel per edge type (very different register needs), the long tasks first
       if (nb_e3 > 0)
-        hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1, false>), dim3(nb_e3), block, 0, c->stream, g, ct, c->ck_ids_e3,
+        hipLaunchKernelGGL((k_chunk_linearize<ESL_JAC_NUMERIC, 1, 0>), dim3(nb_e3), block, 0, c->stream, g, ct, c->ck_ids_e3,
                            c->n_ids_e3, c->cams, src_objs, objs_b, c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, 0, st, cnt);
       if (nb_bb > 0) {
         auto launch_bb = [&](auto kern) {
           hipLaunchKernelGGL(kern, dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb, c->cams, src_objs, objs_b,
                              c->lm.p.numeric_delta, dst_chunk, chunk_b, c->blk_chi, nb_e3, st, cnt);
         };
-        if (g.bbox_mode) { if (validate) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, true, true>); else launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, false, true>); }
-        else { if (validate) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, true, false>); else launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, false, false>); }
+        const int vmode = !validate ? 0 : (g.check_vis ? 2 : 1);
+        if (g.bbox_mode) { if (vmode == 2) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, 2, true>); else if (vmode == 1) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, 1, true>); else launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, 0, true>); }
+        else { if (vmode == 2) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, 2, false>); else if (vmode == 1) launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, 1, false>); else launch_bb(k_chunk_linearize<ESL_JAC_NUMERIC, 0, 0, false>); }
       }
     }
   }

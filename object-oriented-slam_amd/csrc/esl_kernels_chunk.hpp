@@ -171,7 +171,7 @@ __device__ __forceinline__ void reduce_group_e3d_lds(const double* Jp, const dou
 // VALIDATE (bbox only): this is the first linearisation of a run and doubles as the reference's NaN pre-check of the
 // bbox edges (Optimizer.cpp:234-243): an edge whose residual is NaN at the start state is marked invalid for the
 // whole run and counted in *n_dropped (same residual code as k_bbox_validate, which the synchronous API still uses).
-template <int JAC, int TYPE, bool VALIDATE = false, bool TANG = false>
+template <int JAC, int TYPE, int VALIDATE = 0, bool TANG = false>
 __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const ChunkTable& ct, const int* __restrict__ ids, int n_ids,
                                                      const double* __restrict__ cams, const double* __restrict__ objs, double delta,
                                                      double* __restrict__ chunk_out, double* __restrict__ wg_chi /* LDS, 8 slots */,
@@ -236,7 +236,9 @@ __device__ __forceinline__ void chunk_linearize_body(const DevGraph& g, const Ch
       }
       chi = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
       if (VALIDATE) {
-        const bool bad = (chi != chi) || (g.check_vis && !bbox_edge_visible(T, e, g.K, g.img_rows, g.img_cols));
+        // VALIDATE == 2 adds checkVisibility (esl_graph::check_visibility); as a run-time flag inside the NaN-only form it cost the
+        // first linearisation of EVERY run a third of its occupancy (203 instead of 144 registers)
+        const bool bad = (chi != chi) || (VALIDATE == 2 && !bbox_edge_visible(T, e, g.K, g.img_rows, g.img_cols));
         g.bb_valid[i] = bad ? 0 : 1;
         if (bad) {   // dropped: contributes nothing (its J / r may hold NaN)
           atomicAdd(n_dropped, 1);
@@ -416,7 +418,7 @@ __device__ double block256_max(double v, double* sm) {
 // the rest the bbox chunks.  Launched back to back the two kernels ran 18 + 17.5 us at C4 although neither fills the
 // chip for long (3-D: ~0.7 waves per SIMD on a 4.8k-instruction stream; bbox: 3 waves per SIMD, 1.7k instructions);
 // together they take 27 us.
-template <int JAC, bool VALIDATE = false, bool TANG = false>
+template <int JAC, int VALIDATE = 0, bool TANG = false>
 static __global__ __launch_bounds__(64 * kLinWaves, ESL_LIN_MIN_WAVES) void k_chunk_linearize_both(DevGraph g, ChunkTable ct, const int* __restrict__ ids_e3, int n_e3,
                                                                      int nb_e3, const int* __restrict__ ids_bb, int n_bb,
                                                                      const double* __restrict__ cams,
@@ -437,7 +439,7 @@ static __global__ __launch_bounds__(64 * kLinWaves, ESL_LIN_MIN_WAVES) void k_ch
   else chunk_linearize_body<JAC, 0, VALIDATE, TANG>(g, ct, ids_bb, n_bb, cams, objs, delta, chunk_out, wg_chi, tr_all, blockIdx.x - nb_e3, n_dropped);
   wg_chi_end(wg_chi, blk_chi, blockIdx.x);
 }
-template <int JAC, int TYPE, bool VALIDATE = false, bool TANG = false>
+template <int JAC, int TYPE, int VALIDATE = 0, bool TANG = false>
 static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize(DevGraph g, ChunkTable ct, const int* __restrict__ ids, int n_ids,
                                                                 const double* __restrict__ cams,
                                                                 const double* __restrict__ objs_a, const double* __restrict__ objs_b,
