@@ -416,7 +416,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     wk.add(&c->chunk_out, (size_t)c->n_chunks * kChunkOut);
     wk.add(&c->chunk_out2, (size_t)c->n_chunks * kChunkOut);
     wk.add(&c->chunk_chi, (size_t)c->n_chunks);
-    wk.add(&c->blk_part, (size_t)((N + 255) / 256 + 1) * 2);
+    wk.add(&c->blk_part, (size_t)((N + kStepWaves - 1) / kStepWaves + 2) * 2);   // k_chunk_finalize[_rows]: one pair per workgroup
     wk.add(&c->solve_part, (size_t)((N + kStepWaves - 1) / kStepWaves + (N + 63) / 64 + 2) * 4 * 2);   // k_obj_solve / k_lm_step* (x2: ping-pong)
     wk.add(&c->blk_chi, (size_t)(c->n_chunks + 2));                 // <= one workgroup per chunk
   }
@@ -627,7 +627,7 @@ static int image_upload(esl_ctx* c, const HostImage& im, const double* cams, con
   up.add(&d.cod_start, one.data(), 2); up.add(&d.cod_edge, one.data(), 1);
   wk.add(&c->chunk_out, cap_chunks * kChunkOut); wk.add(&c->chunk_out2, cap_chunks * kChunkOut);
   wk.add(&c->chunk_chi, cap_chunks);
-  wk.add(&c->blk_part, (size_t)((cN + 255) / 256 + 1) * 2);
+  wk.add(&c->blk_part, (size_t)((cN + kStepWaves - 1) / kStepWaves + 2) * 2);
   wk.add(&c->solve_part, (size_t)((cN + kStepWaves - 1) / kStepWaves + (cN + 63) / 64 + 2) * 4 * 2);
   wk.add(&c->blk_chi, cap_chunks + 2);
   wk.add(&c->cams, cF * 7); wk.add(&c->cams_trial, cF * 7);
@@ -1092,7 +1092,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   if (rc) return rc;
   {
     ProfScope ps(c, 4);
-    hipLaunchKernelGGL(k_chunk_finalize, dim3(std::max(1, (g.n_objs + 255) / 256)), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out,
+    hipLaunchKernelGGL(k_chunk_finalize_rows, dim3(std::max(1, (g.n_objs + kStepWaves - 1) / kStepWaves)), dim3(64 * kStepWaves), 0, c->stream, g, chunk_table(c), c->chunk_out,
                        c->objs, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part, c->tickets, c->dev_scal,
                        (LmScalars*)c->host_scal_dev, p->tau, sharded ? (LmCore*)nullptr : core, c->chol_info + 2, c->n_grav_edges,
                        (LmHostView*)c->lm_host_dev);

@@ -863,6 +863,94 @@ __device__ __forceinline__ bool lm_solve9_rows(const double* __restrict__ hb, do
 // (one coalesced 432-byte row per chunk, the rows of BOTH state pairs already in flight while the decision is taken), the
 // gravity prior is linearised uniformly by the wave, and the system is solved row-parallel on lanes 0..8 (lm_solve9_rows).
 constexpr int kStepWaves = 4;
+// k_chunk_finalize with one WAVE per ellipsoid (the device-driven run's form): the chunk rows are read as coalesced rows (lane =
+// entry, up to four rows in flight) instead of ten scattered entries per chunk by one thread -- 12.7 -> see profiles/ us, once
+// per run.  Same outputs, same last-workgroup reduction.
+static __global__ __launch_bounds__(64 * kStepWaves) void k_chunk_finalize_rows(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
+                                                                                 const double* __restrict__ objs, int jac, double delta,
+                                                                                 double* __restrict__ blk_part /* gridDim x 2 */,
+                                                                                 unsigned int* __restrict__ ticket, double* __restrict__ dev_scal,
+                                                                                 LmScalars* __restrict__ host, double tau, LmCore* __restrict__ st,
+                                                                                 int* __restrict__ n_dropped, int n_grav,
+                                                                                 LmHostView* __restrict__ hv) {
+  __shared__ double sm[256];
+  __shared__ double wpart[2 * kStepWaves];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int o = blockIdx.x * kStepWaves + wave;
+  double chi = 0, md = 0;
+  if (o < g.n_objs) {
+    const int c0 = ct.ostart[o], c1 = ct.ostart[o + 1];
+    double v = 0;                                   // lane < 54: entry `lane` of the summed system, lane 54: chi2
+    if (lane < 55) {
+      double r4[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c0 + q < c1) r4[q] = chunk_out[(size_t)(c0 + q) * kChunkOut + lane];
+      v = ((r4[0] + r4[1]) + r4[2]) + r4[3];
+      for (int ch = c0 + 4; ch < c1; ++ch) v += chunk_out[(size_t)ch * kChunkOut + lane];
+    }
+    // position of diagonal entry a in the packed upper triangle: 0 9 17 24 30 35 39 42 44
+    int a_of = -1;
+#pragma unroll
+    for (int a = 0, q = 0; a < 9; ++a) { if (lane == q) a_of = a; q += 9 - a; }
+    double gchi = 0;
+    const int ng = g.gr_cnt[o];
+    if (ng > 0) {   // gravity prior lives on the ellipsoid itself (see k_obj_solve); evaluated uniformly by the wave
+      const Ell e = ell_load(objs + 10 * o);
+      const double wg = g.grav_w * ng;
+      double Jg[9], rg;
+      if (jac == ESL_JAC_ANALYTIC) rg = jac_grav(e, g.grav_n, Jg);
+      else {
+        rg = res_grav(e, g.grav_n);
+        numeric_jac_obj(e, delta, 1, Jg, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
+      }
+      gchi = wg * rg * rg;
+#pragma unroll
+      for (int a = 0; a < 9; ++a) if (a_of == a) v += wg * Jg[a] * Jg[a];
+    }
+    md = wave_max((a_of >= 0) ? fabs(v) : 0.0);
+    chi = lm_readlane(v, 54) + gchi;
+  }
+  if (lane == 0) { wpart[wave] = chi; wpart[kStepWaves + wave] = md; }
+  __syncthreads();
+  if (tid == 0) {
+    double c = 0, m = 0;
+#pragma unroll
+    for (int k = 0; k < kStepWaves; ++k) { c += wpart[k]; m = fmax(m, wpart[kStepWaves + k]); }
+    __hip_atomic_store(&blk_part[2 * blockIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&blk_part[2 * blockIdx.x + 1], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (last_block_arrives_wt(ticket)) {
+    double c = 0, m = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { c += blk_part[2 * b]; m = fmax(m, blk_part[2 * b + 1]); }
+    c = block256_sum(c, sm);
+    m = block256_max(m, sm);
+    if (threadIdx.x == 0) {
+      dev_scal[0] = c; dev_scal[1] = m;
+      host->chi2_lin = c; host->max_diag = m;
+      if (hv) {
+        const int nd = *n_dropped;
+        hv->n_dropped = nd;
+        *n_dropped = 0;
+        const bool any_edge = (g.n_bbox_edges - nd > 0) || g.n_e3d > 0 || n_grav > 0;
+        dev_scal[5] = any_edge ? 1.0 : 0.0;
+        if (st) {
+          LmCore s;
+          lm_core_init(s, c, m, tau);
+          if (!any_edge) {
+            s.done = 1; s.stop_reason = 3;
+            hv->core = s;
+            hv->trace_len = 0;
+            __hip_atomic_store(&hv->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          *st = s;
+        }
+      }
+      *ticket = 0;
+    }
+  }
+}
+
 static __global__ __launch_bounds__(64 * kStepWaves) void k_lm_step_rows(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_a,
                                                                           const double* __restrict__ chunk_b, double* __restrict__ objs_a,
                                                                           double* __restrict__ objs_b, const LmCore* __restrict__ in,
