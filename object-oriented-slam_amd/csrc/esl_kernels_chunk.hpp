@@ -864,8 +864,8 @@ __device__ __forceinline__ bool lm_solve9_rows(const double* __restrict__ hb, do
 // gravity prior is linearised uniformly by the wave, and the system is solved row-parallel on lanes 0..8 (lm_solve9_rows).
 constexpr int kStepWaves = 4;
 // k_chunk_finalize with one WAVE per ellipsoid (the device-driven run's form): the chunk rows are read as coalesced rows (lane =
-// entry, up to four rows in flight) instead of ten scattered entries per chunk by one thread -- 12.7 -> see profiles/ us, once
-// per run.  Same outputs, same last-workgroup reduction.
+// entry, up to four rows in flight) instead of ten scattered entries per chunk by one thread.  Same outputs, same last-workgroup
+// reduction -- and the same 12.5 us (once per run): the ticket and the serial tail are what the time is, not the per-ellipsoid part.
 static __global__ __launch_bounds__(64 * kStepWaves) void k_chunk_finalize_rows(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
                                                                                  const double* __restrict__ objs, int jac, double delta,
                                                                                  double* __restrict__ blk_part /* gridDim x 2 */,
