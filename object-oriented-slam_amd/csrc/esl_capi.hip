@@ -8,6 +8,7 @@
 // on states, residuals, Jacobians and normal equations runs in the HIP kernels of esl_kernels_*.hpp.  There is no CPU
 // fallback: without a HIP device every compute entry point fails with ESL_ERR_NO_DEVICE.
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -118,15 +119,42 @@ struct UploadStage {   // arrays are packed straight into the context's pinned s
     used = off + bytes;
     fixes.push_back({(void**)dst, off});
   }
+  // the caller fills the returned block itself (no intermediate copy); after begin() the block never moves
+  template <class T>
+  T* alloc(T** dst, size_t n) {
+    const size_t off = align_up(used, 256), bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (err || !reserve(off + bytes)) return nullptr;
+    used = off + bytes;
+    fixes.push_back({(void**)dst, off});
+    return (T*)(c->stage_host + off);
+  }
+  // sizes both ends for `bound` bytes up front, so that flush() can ship finished sections while the host packs the next
+  int begin(size_t bound) {
+    if (!reserve(bound)) return err;
+    if (int rc = arena_reserve(&c->arena_graph, &c->arena_graph_cap, std::max<size_t>(bound, 256))) return err = rc;
+    early = true;
+    return ESL_OK;
+  }
+  int flush() {
+    if (err) return err;
+    if (!early || used > c->arena_graph_cap) return ESL_OK;   // commit() ships everything
+    if (used > sent) ESL_HIP_TRY(hipMemcpyAsync(c->arena_graph + sent, c->stage_host + sent, used - sent, hipMemcpyHostToDevice, c->stream));
+    sent = used;
+    return ESL_OK;
+  }
   int commit() {
     if (err) return err;
     const size_t need = std::max<size_t>(used, 256);
+    if (need > c->arena_graph_cap) sent = 0;   // the arena moves: ship the whole blob again
     int rc = arena_reserve(&c->arena_graph, &c->arena_graph_cap, need);
     if (rc) return rc;
-    if (used) ESL_HIP_TRY(hipMemcpyAsync(c->arena_graph, c->stage_host, used, hipMemcpyHostToDevice, c->stream));
+    if (used > sent) ESL_HIP_TRY(hipMemcpyAsync(c->arena_graph + sent, c->stage_host + sent, used - sent, hipMemcpyHostToDevice, c->stream));
+    sent = used;
     for (const Fix& f : fixes) *f.dst = c->arena_graph + f.off;
     return ESL_OK;
   }
+  size_t sent = 0;
+  bool early = false;
 };
 struct WorkStage {
   struct Fix { void** dst; size_t off; };
@@ -302,17 +330,27 @@ static int validate_graph(const esl_graph* g) {
   return ESL_OK;
 }
 
-static void csr_by_key(const int32_t* key, int n, int n_keys, std::vector<int>& start, std::vector<int>& perm) {
-  start.assign((size_t)n_keys + 1, 0);
+static void csr_by_key(const int32_t* key, int n, int n_keys, int* start, int* perm, std::vector<int>& pos) {
+  std::fill(start, start + n_keys + 1, 0);
   for (int i = 0; i < n; ++i) start[(size_t)key[i] + 1]++;
   for (int k = 0; k < n_keys; ++k) start[(size_t)k + 1] += start[k];
-  perm.resize((size_t)n);
-  std::vector<int> pos(start.begin(), start.end() - 1);
+  pos.assign(start, start + n_keys);
   for (int i = 0; i < n; ++i) perm[(size_t)pos[key[i]]++] = i;
+}
+static void csr_by_key(const int32_t* key, int n, int n_keys, std::vector<int>& start, std::vector<int>& perm) {
+  std::vector<int> pos;
+  start.resize((size_t)n_keys + 1);
+  perm.resize((size_t)n);
+  csr_by_key(key, n, n_keys, start.data(), perm.data(), pos);
 }
 
 int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   if (!c) return ESL_ERR_INVALID;
+  const bool host_timing = std::getenv("ESL_UPLOAD_HOST_TIMING") != nullptr;   // diagnostic: where the host call's time goes
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double ht[16]; int nht = 0;
+  auto mark = [&] { if (host_timing && nht < 16) ht[nht++] = now_us(); };
+  mark();
   int rc = validate_graph(g);
   if (rc) return rc;
   ESL_HIP_TRY(hipSetDevice(c->device));
@@ -336,54 +374,64 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     yaw_table_fill(d.yt, hs, hc);
   }
   const int N = g->n_objs, F = g->n_cams;
-  std::vector<int> start, perm, h_bb_start, h_e3_start;
-  // bbox
-  csr_by_key(g->bbox_obj, g->n_bbox, N, start, perm);
-  {
-    std::vector<int> cam(g->n_bbox), obj(g->n_bbox);
-    std::vector<double> meas((size_t)g->n_bbox * 4), w(g->n_bbox);
-    std::vector<unsigned char> valid((size_t)g->n_bbox, 1);
-    for (int k = 0; k < g->n_bbox; ++k) {
-      const int i = perm[k];
-      cam[k] = g->bbox_cam[i]; obj[k] = g->bbox_obj[i]; w[k] = g->bbox_weight[i];
-      for (int j = 0; j < 4; ++j) meas[(size_t)k * 4 + j] = g->bbox_meas[(size_t)i * 4 + j];
-    }
-    c->h_bb_cam = cam; c->h_bb_obj = obj;
-    h_bb_start = start;
-    up.add(&d.bb_start, start.data(), start.size());
-    up.add(&d.bb_cam, cam.data(), cam.size());
-    up.add(&d.bb_obj, obj.data(), obj.size());
-    up.add(&d.bb_meas, meas.data(), meas.size());
-    up.add(&d.bb_w, w.data(), w.size());
-    up.add(&d.bb_valid, valid.data(), valid.size());
-    // camera-side CSR over the SORTED bbox edges
-    std::vector<int> cs, cp;
-    csr_by_key(cam.data(), g->n_bbox, F, cs, cp);
-    up.add(&d.cbb_start, cs.data(), cs.size());
-    up.add(&d.cbb_edge, cp.data(), cp.size());
+  {  // upper bound of the staging blob: lets finished sections go over PCIe while the host packs the next one
+    auto blk = [](size_t n, size_t sz) { return align_up(std::max<size_t>(n, 1) * sz, 256) + 256; };
+    const size_t nb = (size_t)g->n_bbox, ne = (size_t)g->n_e3d, no = (size_t)g->n_odom;
+    const size_t max_chunks = nb / 64 + ne / 32 + 2 * (size_t)N + 2;
+    const size_t bound = 3 * blk((size_t)N + 1, 4) + 3 * blk(nb, 4) + blk(nb * 4, 8) + blk(nb, 8) + blk(nb, 1) + 3 * blk((size_t)F + 1, 4) +
+                         3 * blk(ne, 4) + blk(ne * 10, 8) + blk(ne, 8) + blk((size_t)N, 4) + 7 * blk(max_chunks, 4) + blk((size_t)F, 1) +
+                         blk((size_t)F, 4) + 2 * blk(no, 4) + blk(no * 7, 8) + blk(no * 6, 8) + blk(no * 2, 4);
+    if ((rc = up.begin(bound))) return rc;
   }
-  // 3-D edges
-  csr_by_key(g->e3d_obj, g->n_e3d, N, start, perm);
+  std::vector<int> perm, perm3, pos, h_bb_start, h_e3_start;
+  mark();   // 1: validated, staging sized
   {
-    std::vector<int> cam(g->n_e3d), obj(g->n_e3d);
-    std::vector<double> meas((size_t)g->n_e3d * 10), w(g->n_e3d);
-    for (int k = 0; k < g->n_e3d; ++k) {
-      const int i = perm[k];
-      cam[k] = g->e3d_cam[i]; obj[k] = g->e3d_obj[i]; w[k] = g->e3d_weight[i];
-      for (int j = 0; j < 10; ++j) meas[(size_t)k * 10 + j] = g->e3d_meas[(size_t)i * 10 + j];
+    // edges are gathered in ellipsoid order straight into the pinned blob (C4: ~15 MB); the blob's edge arrays then go over
+    // PCIe while the host builds the camera-side lists, the chunk table and the camera slots.  (Splitting the gather over
+    // helper threads was measured and is not faster: profiles/r2_fused_experiments.txt)
+    const size_t nb = (size_t)g->n_bbox, ne = (size_t)g->n_e3d;
+    csr_by_key(g->bbox_obj, g->n_bbox, N, h_bb_start, perm);
+    csr_by_key(g->e3d_obj, g->n_e3d, N, h_e3_start, perm3);
+    int* b_start = up.alloc(&d.bb_start, (size_t)N + 1);
+    int* b_cam = up.alloc(&d.bb_cam, nb);
+    int* b_obj = up.alloc(&d.bb_obj, nb);
+    double* b_meas = up.alloc(&d.bb_meas, nb * 4);
+    double* b_w = up.alloc(&d.bb_w, nb);
+    unsigned char* b_valid = up.alloc(&d.bb_valid, nb);
+    int* e_start = up.alloc(&d.e3_start, (size_t)N + 1);
+    int* e_cam = up.alloc(&d.e3_cam, ne);
+    int* e_obj = up.alloc(&d.e3_obj, ne);
+    double* e_meas = up.alloc(&d.e3_meas, ne * 10);
+    double* e_w = up.alloc(&d.e3_w, ne);
+    if (up.err) return up.err;
+    std::copy(h_bb_start.begin(), h_bb_start.end(), b_start);
+    std::copy(h_e3_start.begin(), h_e3_start.end(), e_start);
+    mark();   // 2: both edge sets sorted by ellipsoid
+    for (size_t k = 0; k < nb; ++k) {
+      const size_t i = (size_t)perm[k];
+      b_cam[k] = g->bbox_cam[i]; b_obj[k] = g->bbox_obj[i]; b_w[k] = g->bbox_weight[i];
+      std::memcpy(b_meas + k * 4, g->bbox_meas + i * 4, 4 * sizeof(double));
     }
-    c->h_e3_cam = cam; c->h_e3_obj = obj;
-    h_e3_start = start;
-    up.add(&d.e3_start, start.data(), start.size());
-    up.add(&d.e3_cam, cam.data(), cam.size());
-    up.add(&d.e3_obj, obj.data(), obj.size());
-    up.add(&d.e3_meas, meas.data(), meas.size());
-    up.add(&d.e3_w, w.data(), w.size());
-    std::vector<int> cs, cp;
-    csr_by_key(cam.data(), g->n_e3d, F, cs, cp);
-    up.add(&d.ce3_start, cs.data(), cs.size());
-    up.add(&d.ce3_edge, cp.data(), cp.size());
+    if (nb) std::memset(b_valid, 1, nb);
+    for (size_t k = 0; k < ne; ++k) {
+      const size_t i = (size_t)perm3[k];
+      e_cam[k] = g->e3d_cam[i]; e_obj[k] = g->e3d_obj[i]; e_w[k] = g->e3d_weight[i];
+      std::memcpy(e_meas + k * 10, g->e3d_meas + i * 10, 10 * sizeof(double));
+    }
+    mark();   // 3: gathered
+    if ((rc = up.flush())) return rc;
+    c->h_bb_cam.assign(b_cam, b_cam + nb); c->h_bb_obj.assign(b_obj, b_obj + nb);
+    c->h_e3_cam.assign(e_cam, e_cam + ne); c->h_e3_obj.assign(e_obj, e_obj + ne);
+    // camera-side CSRs over the SORTED edges
+    int* cs = up.alloc(&d.cbb_start, (size_t)F + 1);
+    int* cp = up.alloc(&d.cbb_edge, nb);
+    int* cs3 = up.alloc(&d.ce3_start, (size_t)F + 1);
+    int* cp3 = up.alloc(&d.ce3_edge, ne);
+    if (up.err) return up.err;
+    csr_by_key(b_cam, g->n_bbox, F, cs, cp, pos);
+    csr_by_key(e_cam, g->n_e3d, F, cs3, cp3, pos);
   }
+  mark();   // 4: camera-side lists
   // gravity
   {
     std::vector<int> cnt((size_t)N, 0);
@@ -420,6 +468,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
     wk.add(&c->solve_part, (size_t)((N + kStepWaves - 1) / kStepWaves + (N + 63) / 64 + 2) * 4 * 2);   // k_obj_solve / k_lm_step* (x2: ping-pong)
     wk.add(&c->blk_chi, (size_t)(c->n_chunks + 2));                 // <= one workgroup per chunk
   }
+  mark();   // 5: chunk table
   // cameras + odometry
   {
     std::vector<unsigned char> fixed((size_t)F, 1);
@@ -461,13 +510,21 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   wk.add(&c->bo, (size_t)N * 9);
   wk.add(&c->xo, (size_t)N * 9);
   wk.add(&c->obj_part, (size_t)N * 4);
+  mark();   // 6: cameras + odometry
   if ((rc = up.commit())) return rc;
   if ((rc = wk.commit(c))) return rc;
   ESL_HIP_TRY(hipMemsetAsync(c->obj_part, 0, std::max<size_t>(N, 1) * 4 * sizeof(double), st));
   if (d.n_free_cams > 0) {
     if ((rc = slam_alloc(c))) return rc;
   }
+  mark();   // 7: commit + work arena + slam_alloc
   ESL_HIP_TRY(hipStreamSynchronize(st));
+  mark();   // 8: copies landed
+  if (host_timing) {
+    std::fprintf(stderr, "esl_graph_upload us:");
+    for (int i = 1; i < nht; ++i) std::fprintf(stderr, " %.0f", ht[i] - ht[i - 1]);
+    std::fprintf(stderr, "  (validate, sort, gather, camera lists, chunks, cameras, commit, wait)\n");
+  }
   c->graph_loaded = true;
   return ESL_OK;
 }
