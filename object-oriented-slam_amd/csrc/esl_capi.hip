@@ -257,7 +257,7 @@ static void free_graph(esl_ctx* c) {
   dev_free(&g.cu_start); dev_free(&g.cu_obj); dev_free(&g.cu_id);
   dev_free(&c->Linv_ws); dev_free(&c->z_ws);
   dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
-  dev_free(&c->Abb); dev_free(&c->Ae3); dev_free(&c->Aod); dev_free(&c->Dinv); dev_free(&c->Yb); dev_free(&c->Tb); dev_free(&c->Ye3);
+  dev_free(&c->Abb); dev_free(&c->Ae3); dev_free(&c->Aod); dev_free(&c->Dinv); dev_free(&c->Yb); dev_free(&c->Wt); dev_free(&c->Tb); dev_free(&c->Ye3);
   dev_free(&c->S); dev_free(&c->cam_part); dev_free(&c->od_part);
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->S_n = 0;

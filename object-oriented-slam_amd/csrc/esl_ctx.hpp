@@ -58,6 +58,7 @@ struct DevGraph {
   int n_ue = 0;
   // per free camera (slot): its edges sorted by (ellipsoid, u) -- the deterministic Schur complement walks two of these lists
   int* cu_start = nullptr; int* cu_obj = nullptr; int* cu_id = nullptr;
+  int cu_max = 0;   // longest per-camera list (k_slam_schur_pull stages the row camera's Y blocks in LDS when they fit)
   // sharding (SLAM mode): odometry edges, the camera blocks' lambda and the camera part of the LM scale are
   // replicated on every rank and must enter the summed system once -> only shard_rank 0 contributes them
   int shard_rank = 0;
@@ -119,7 +120,8 @@ struct esl_ctx {
   double* Ae3 = nullptr;      // n_e3d x 27
   double* Aod = nullptr;      // n_odom x (2*27 + 36): per-edge Hii, bi, Hjj, bj packed, Hij full
   double* Dinv = nullptr;     // n_objs x 81
-  double* Yb = nullptr;       // n_bbox x 54 : W D^-1
+  double* Yb = nullptr;       // [EU][54] : W D^-1, one record per edge
+  double* Wt = nullptr;       // [EU][9][6] : W as per-edge records (k_slam_schur_pull)
   double* Tb = nullptr;       // [6][EU] : Y_e b_o per edge (its share of b_s), summed per camera by the Schur kernel
   double* Ye3 = nullptr;      // n_e3d x 54
   double* S = nullptr;        // n x (n+1) column-major reduced system [S | b_s], n = 6 n_free_cams

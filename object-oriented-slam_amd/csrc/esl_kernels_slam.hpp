@@ -42,7 +42,7 @@ __device__ __forceinline__ void numeric_jac_cam(const SE3& T, double delta, int 
   }
 }
 
-// per-edge camera-side products, written SoA (index k * EU + u)
+// per-edge camera-side products, written SoA (index k * EU + u); Y and the pull kernel's copy of W are per-edge records ([u][54])
 template <int D>
 __device__ __forceinline__ void store_cam_terms(const double* Jc, const double* Jo, const double* r, double w,
                                                 double* __restrict__ W, double* __restrict__ A, long EU, long u) {
@@ -297,7 +297,8 @@ static __global__ void k_slam_S_init(DevGraph g, const double* __restrict__ Hcc,
 static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
     DevGraph g, double lambda, const double* __restrict__ Hoo, const double* __restrict__ bo,
     const double* __restrict__ W, double* __restrict__ Y, double* __restrict__ Dinv, double* __restrict__ S, long lda,
-    long n, double* __restrict__ part, double* __restrict__ Tb /* [6][EU] or null: atomics into the b_s row of S */) {
+    long n, double* __restrict__ part, double* __restrict__ Tb /* [6][EU] or null: atomics into the b_s row of S */,
+    double* __restrict__ Wt /* [EU][9][6] copy of W for k_slam_schur_pull, or null */) {
   __shared__ double sD[kWavesPerBlock][81];
   __shared__ double sb[kWavesPerBlock][9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -329,12 +330,16 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
       double wrow[9];
 #pragma unroll
       for (int b = 0; b < 9; ++b) wrow[b] = W[(long)(a * 9 + b) * EU + u];
+      if (Wt) {
+#pragma unroll
+        for (int b = 0; b < 9; ++b) Wt[u * 54 + b * 6 + a] = wrow[b];
+      }
 #pragma unroll
       for (int b = 0; b < 9; ++b) {
         double s = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) s += wrow[k] * sD[wv][k * 9 + b];
-        Y[(long)(a * 9 + b) * EU + u] = s;
+        Y[u * 54 + a * 9 + b] = s;
         t[a] += s * sb[wv][b];
       }
     }
@@ -353,13 +358,28 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
 // Y_e1 W_e2^T over the edge pairs (e1 of camera sp, e2 of camera sq) in list order -- the sum the scatter form below builds
 // with fp64 atomics in whatever order the hardware serves them.  The diagonal lane (s, s) also folds its camera's share of
 // b_s (sum over its edges of Y_e b_o, stored per edge by k_slam_prepare).  grid.y = sp, grid.x * 64 + lane = sq.
-static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const double* __restrict__ W, const double* __restrict__ Y,
+constexpr int kSchurYStride = 55;   // 54 doubles of one edge's Y block + 1 of padding (lanes read different edges: no bank conflicts)
+template <bool YLDS>
+static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const double* __restrict__ Wt, const double* __restrict__ Y,
                                                         const double* __restrict__ Tb, double* __restrict__ S, long lda, long n) {
+  extern __shared__ double ysh[];   // YLDS: [edge of the row camera][kSchurYStride]
   const int sp = blockIdx.y, sq = blockIdx.x * 64 + threadIdx.x;
-  if (sq > sp) return;
+  if ((int)(blockIdx.x * 64) > sp) return;   // the whole workgroup lies right of the diagonal
   const long EU = (long)g.n_bbox + g.n_e3d;
-  int i = g.cu_start[sp], j = g.cu_start[sq];
-  const int ie = g.cu_start[sp + 1], je = g.cu_start[sq + 1];
+  const int i0 = g.cu_start[sp];
+  int i = i0, j = (sq <= sp) ? g.cu_start[sq] : 0;
+  const int ie = g.cu_start[sp + 1], je = (sq <= sp) ? g.cu_start[sq + 1] : 0;
+  if (YLDS) {
+    // every lane of the row needs the Y block of whichever of the row camera's edges it matches: fetched once per workgroup
+    // (54 scattered 8-byte loads per edge) instead of once per match and lane
+    const int ne = ie - i0;
+    for (int idx = threadIdx.x; idx < ne * 54; idx += 64) {
+      const int e = idx / 54, k = idx - e * 54;
+      ysh[e * kSchurYStride + k] = Y[(long)g.cu_id[i0 + e] * 54 + k];
+    }
+    __syncthreads();
+  }
+  if (sq > sp) return;
   double out[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) out[k] = 0;
@@ -376,7 +396,7 @@ static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const
       if (up < g.n_bbox && !g.bb_valid[up]) continue;
       double yp[54];
 #pragma unroll
-      for (int k = 0; k < 54; ++k) yp[k] = Y[(long)k * EU + up];
+      for (int k = 0; k < 54; ++k) yp[k] = YLDS ? ysh[(a1 - i0) * kSchurYStride + k] : Y[up * 54 + k];
       for (int a2 = j; a2 < j1; ++a2) {
         const long uq = g.cu_id[a2];
         if (uq < g.n_bbox && !g.bb_valid[uq]) continue;
@@ -385,7 +405,7 @@ static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const
         for (int b = 0; b < 9; ++b) {
           double wq[6];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) wq[c] = W[(long)(c * 9 + b) * EU + uq];
+          for (int c = 0; c < 6; ++c) wq[c] = Wt[uq * 54 + b * 6 + c];
 #pragma unroll
           for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -431,7 +451,7 @@ static __global__ __launch_bounds__(256) void k_slam_schur(DevGraph g, const dou
     if ((up < g.n_bbox && !g.bb_valid[up]) || (uq < g.n_bbox && !g.bb_valid[uq])) continue;
     double yp[54];
 #pragma unroll
-    for (int k = 0; k < 54; ++k) yp[k] = Y[(long)k * EU + up];
+    for (int k = 0; k < 54; ++k) yp[k] = Y[up * 54 + k];
     double out[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) out[k] = 0;

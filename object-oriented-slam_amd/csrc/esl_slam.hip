@@ -61,6 +61,8 @@ int slam_alloc(esl_ctx* c) {
       std::sort(es.begin(), es.end());
       for (auto& e : es) { const int at = fill[e.second]++; cobj[at] = o; cid[at] = e.first; }
     }
+    g.cu_max = 0;
+    for (int sidx = 0; sidx < nf; ++sidx) g.cu_max = std::max(g.cu_max, cstart[(size_t)sidx + 1] - cstart[sidx]);
     if ((rc = up(&g.cu_start, cstart.data(), cstart.size(), c->stream))) return rc;
     if ((rc = up(&g.cu_obj, cobj.data(), cobj.size(), c->stream))) return rc;
     if ((rc = up(&g.cu_id, cid.data(), cid.size(), c->stream))) return rc;
@@ -74,7 +76,8 @@ int slam_alloc(esl_ctx* c) {
   if ((rc = al(&c->bc, (size_t)nf * 6))) return rc;
   if ((rc = al(&c->Wbb, EU * 54))) return rc;   // unified W  [54][EU]
   if ((rc = al(&c->Abb, EU * 27))) return rc;   // unified A  [27][EU]
-  if ((rc = al(&c->Yb, EU * 54))) return rc;    // unified Y  [54][EU]
+  if ((rc = al(&c->Yb, EU * 54))) return rc;    // unified Y  [EU][54]
+  if ((rc = al(&c->Wt, EU * 54))) return rc;    // W once more as per-edge records [EU][9][6]: what k_slam_schur_pull gathers
   if ((rc = al(&c->Tb, EU * 6))) return rc;     // Y_e b_o    [6][EU]
   if ((rc = al(&c->Aod, (size_t)g.n_odom * 90))) return rc;
   if ((rc = al(&c->Dinv, (size_t)N * 81))) return rc;
@@ -163,11 +166,20 @@ int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out
       // ESL_SCHUR_ATOMIC=1: round 1's scatter form (fp64 atomics into S, summation order left to the hardware) for A/B runs
       const bool atomic_form = getenv("ESL_SCHUR_ATOMIC") != nullptr || g.n_free_cams > 65535;   // grid.y limit of the pull form
       hipLaunchKernelGGL(k_slam_prepare, grid, block, 0, c->stream, g, lambda, c->Hoo, c->bo, c->Wbb, c->Yb, c->Dinv, c->S, lda,
-                         n, c->obj_part, atomic_form ? nullptr : c->Tb);
+                         n, c->obj_part, atomic_form ? nullptr : c->Tb, atomic_form ? nullptr : c->Wt);
       if (atomic_form) hipLaunchKernelGGL(k_slam_schur, dim3(N, 8), dim3(256), 0, c->stream, g, c->Wbb, c->Yb, c->S, lda);
-      else if (g.n_free_cams > 0)
-        hipLaunchKernelGGL(k_slam_schur_pull, dim3((g.n_free_cams + 63) / 64, g.n_free_cams), dim3(64), 0, c->stream, g, c->Wbb, c->Yb,
-                           c->Tb, c->S, lda, n);
+      else if (g.n_free_cams > 0) {
+        // the row camera's Y blocks (54 doubles per edge, padded to 55) go through LDS when its list fits 64 KB
+        const size_t ylds = (size_t)g.cu_max * kSchurYStride * sizeof(double);
+        const dim3 sgrid((g.n_free_cams + 63) / 64, g.n_free_cams);
+        if (ylds <= 65536 && !getenv("ESL_SCHUR_NO_LDS")) {
+          static bool attr = false;
+          if (!attr) { ESL_HIP_TRY(hipFuncSetAttribute((const void*)k_slam_schur_pull<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+          hipLaunchKernelGGL(k_slam_schur_pull<true>, sgrid, dim3(64), ylds, c->stream, g, c->Wt, c->Yb, c->Tb, c->S, lda, n);
+        } else {
+          hipLaunchKernelGGL(k_slam_schur_pull<false>, sgrid, dim3(64), 0, c->stream, g, c->Wt, c->Yb, c->Tb, c->S, lda, n);
+        }
+      }
     }
   }
   ESL_HIP_TRY(hipGetLastError());
