@@ -359,61 +359,102 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
 // with fp64 atomics in whatever order the hardware serves them.  The diagonal lane (s, s) also folds its camera's share of
 // b_s (sum over its edges of Y_e b_o, stored per edge by k_slam_prepare).  grid.y = sp, grid.x * 64 + lane = sq.
 constexpr int kSchurYStride = 55;   // 54 doubles of one edge's Y block + 1 of padding (lanes read different edges: no bank conflicts)
+// dynamic LDS of the staged form: the row camera's Y blocks, its list (ellipsoid, edge id) and a bitmap of its ellipsoids
+inline size_t schur_pull_lds_bytes(int cu_max, int n_objs) {
+  return (size_t)cu_max * kSchurYStride * sizeof(double) + (size_t)cu_max * 2 * sizeof(int) + (size_t)((n_objs + 31) / 32) * sizeof(unsigned);
+}
+// one (row edge e1, column edge e2) contribution: out += Y_e1 W_e2^T
+#define ESL_SCHUR_ACCUM(yp, uq)                                                     \
+  _Pragma("unroll") for (int b = 0; b < 9; ++b) {                                   \
+    double wq[6];                                                                   \
+    _Pragma("unroll") for (int c = 0; c < 6; ++c) wq[c] = Wt[(uq) * 54 + b * 6 + c]; \
+    _Pragma("unroll") for (int a = 0; a < 6; ++a)                                   \
+      _Pragma("unroll") for (int c = 0; c < 6; ++c) out[a * 6 + c] += yp[a * 9 + b] * wq[c]; \
+  }
 template <bool YLDS>
 static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const double* __restrict__ Wt, const double* __restrict__ Y,
                                                         const double* __restrict__ Tb, double* __restrict__ S, long lda, long n) {
-  extern __shared__ double ysh[];   // YLDS: [edge of the row camera][kSchurYStride]
+  extern __shared__ double ysh[];   // YLDS: [edge of the row camera][kSchurYStride], then robj / rid / rbits
   const int sp = blockIdx.y, sq = blockIdx.x * 64 + threadIdx.x;
   if ((int)(blockIdx.x * 64) > sp) return;   // the whole workgroup lies right of the diagonal
   const long EU = (long)g.n_bbox + g.n_e3d;
   const int i0 = g.cu_start[sp];
   int i = i0, j = (sq <= sp) ? g.cu_start[sq] : 0;
   const int ie = g.cu_start[sp + 1], je = (sq <= sp) ? g.cu_start[sq + 1] : 0;
-  if (YLDS) {
-    // every lane of the row needs the Y block of whichever of the row camera's edges it matches: fetched once per workgroup
-    // (54 scattered 8-byte loads per edge) instead of once per match and lane
-    const int ne = ie - i0;
-    for (int idx = threadIdx.x; idx < ne * 54; idx += 64) {
-      const int e = idx / 54, k = idx - e * 54;
-      ysh[e * kSchurYStride + k] = Y[(long)g.cu_id[i0 + e] * 54 + k];
-    }
-    __syncthreads();
-  }
-  if (sq > sp) return;
   double out[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) out[k] = 0;
   bool any = false;
-  while (i < ie && j < je) {
-    const int oi = g.cu_obj[i], oj = g.cu_obj[j];
-    if (oi < oj) { ++i; continue; }
-    if (oj < oi) { ++j; continue; }
-    int i1 = i + 1, j1 = j + 1;                       // runs of this ellipsoid in both lists (a bbox and a 3-D edge at most)
-    while (i1 < ie && g.cu_obj[i1] == oi) ++i1;
-    while (j1 < je && g.cu_obj[j1] == oi) ++j1;
-    for (int a1 = i; a1 < i1; ++a1) {
-      const long up = g.cu_id[a1];
-      if (up < g.n_bbox && !g.bb_valid[up]) continue;
-      double yp[54];
+  if (YLDS) {
+    // Staged form.  Every lane of the workgroup intersects ITS camera's list with the same row camera's list: the row
+    // camera's Y blocks (54 scattered 8-byte loads per edge), its list and a bitmap of its ellipsoids are put in LDS once.
+    // A lane then walks only its own list (one load per entry instead of two dependent loads per merge step), tests the
+    // bitmap, and on a hit finds the row camera's run of that ellipsoid by binary search in LDS.  Same ellipsoid order, same
+    // (row edge, column edge) order inside a run as the merge below: bit-identical S.
+    const int ne = ie - i0, nw = (g.n_objs + 31) / 32;
+    int* robj = (int*)(ysh + (size_t)g.cu_max * kSchurYStride);
+    int* rid = robj + g.cu_max;
+    unsigned* rbits = (unsigned*)(rid + g.cu_max);
+    for (int w = threadIdx.x; w < nw; w += 64) rbits[w] = 0u;
+    for (int e = threadIdx.x; e < ne; e += 64) { robj[e] = g.cu_obj[i0 + e]; rid[e] = g.cu_id[i0 + e]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ne; e += 64) atomicOr(&rbits[robj[e] >> 5], 1u << (robj[e] & 31));
+    for (int idx = threadIdx.x; idx < ne * 54; idx += 64) {
+      const int e = idx / 54, k = idx - e * 54;
+      ysh[e * kSchurYStride + k] = Y[(long)rid[e] * 54 + k];
+    }
+    __syncthreads();
+    if (sq > sp) return;
+    int oj = (j < je) ? g.cu_obj[j] : -1;
+    while (j < je) {
+      int j1 = j + 1;
+      int on = (j1 < je) ? g.cu_obj[j1] : -1;
+      while (on == oj) { ++j1; on = (j1 < je) ? g.cu_obj[j1] : -1; }   // run of this ellipsoid (a bbox and a 3-D edge at most)
+      if ((rbits[oj >> 5] >> (oj & 31)) & 1u) {
+        int lo = 0, hi = ne;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (robj[mid] < oj) lo = mid + 1; else hi = mid; }
+        int e1 = lo + 1;
+        while (e1 < ne && robj[e1] == oj) ++e1;
+        for (int e = lo; e < e1; ++e) {
+          const long up = rid[e];
+          if (up < g.n_bbox && !g.bb_valid[up]) continue;
+          double yp[54];
 #pragma unroll
-      for (int k = 0; k < 54; ++k) yp[k] = YLDS ? ysh[(a1 - i0) * kSchurYStride + k] : Y[up * 54 + k];
-      for (int a2 = j; a2 < j1; ++a2) {
-        const long uq = g.cu_id[a2];
-        if (uq < g.n_bbox && !g.bb_valid[uq]) continue;
-        any = true;
-#pragma unroll
-        for (int b = 0; b < 9; ++b) {
-          double wq[6];
-#pragma unroll
-          for (int c = 0; c < 6; ++c) wq[c] = Wt[uq * 54 + b * 6 + c];
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) out[a * 6 + c] += yp[a * 9 + b] * wq[c];
+          for (int k = 0; k < 54; ++k) yp[k] = ysh[e * kSchurYStride + k];
+          for (int a2 = j; a2 < j1; ++a2) {
+            const long uq = g.cu_id[a2];
+            if (uq < g.n_bbox && !g.bb_valid[uq]) continue;
+            any = true;
+            ESL_SCHUR_ACCUM(yp, uq)
+          }
         }
       }
+      j = j1; oj = on;
     }
-    i = i1; j = j1;
+  } else {
+    if (sq > sp) return;
+    while (i < ie && j < je) {
+      const int oi = g.cu_obj[i], oj = g.cu_obj[j];
+      if (oi < oj) { ++i; continue; }
+      if (oj < oi) { ++j; continue; }
+      int i1 = i + 1, j1 = j + 1;                       // runs of this ellipsoid in both lists (a bbox and a 3-D edge at most)
+      while (i1 < ie && g.cu_obj[i1] == oi) ++i1;
+      while (j1 < je && g.cu_obj[j1] == oi) ++j1;
+      for (int a1 = i; a1 < i1; ++a1) {
+        const long up = g.cu_id[a1];
+        if (up < g.n_bbox && !g.bb_valid[up]) continue;
+        double yp[54];
+#pragma unroll
+        for (int k = 0; k < 54; ++k) yp[k] = Y[up * 54 + k];
+        for (int a2 = j; a2 < j1; ++a2) {
+          const long uq = g.cu_id[a2];
+          if (uq < g.n_bbox && !g.bb_valid[uq]) continue;
+          any = true;
+          ESL_SCHUR_ACCUM(yp, uq)
+        }
+      }
+      i = i1; j = j1;
+    }
   }
   if (any) {
 #pragma unroll

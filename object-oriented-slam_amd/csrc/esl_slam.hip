@@ -169,8 +169,8 @@ int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out
                          n, c->obj_part, atomic_form ? nullptr : c->Tb, atomic_form ? nullptr : c->Wt);
       if (atomic_form) hipLaunchKernelGGL(k_slam_schur, dim3(N, 8), dim3(256), 0, c->stream, g, c->Wbb, c->Yb, c->S, lda);
       else if (g.n_free_cams > 0) {
-        // the row camera's Y blocks (54 doubles per edge, padded to 55) go through LDS when its list fits 64 KB
-        const size_t ylds = (size_t)g.cu_max * kSchurYStride * sizeof(double);
+        // the row camera's Y blocks (54 doubles per edge, padded to 55), its list and its ellipsoid bitmap go through LDS when they fit 64 KB
+        const size_t ylds = schur_pull_lds_bytes(g.cu_max, g.n_objs);
         const dim3 sgrid((g.n_free_cams + 63) / 64, g.n_free_cams);
         if (ylds <= 65536 && !getenv("ESL_SCHUR_NO_LDS")) {
           static bool attr = false;
