@@ -16,7 +16,8 @@
 //   k_slam_cam_gather  one lane per free camera: Hcc, b_c from its edges (camera-side CSR; deterministic)
 //   k_slam_prepare     one wave per ellipsoid: Dinv = (Hoo+lambda I)^-1, Y_e = W_e Dinv, b_s -= Y_e b_o
 //   k_slam_schur_pull  one lane per block (c1, c2) of S: intersects the two cameras' edge lists, S[c1,c2] -= sum Y_e1 W_e2^T in
-//                      list order (deterministic); k_slam_schur = round 1's scatter form with fp64 atomics (ESL_SCHUR_ATOMIC=1)
+//                      list order (deterministic); the row camera's Y blocks, list and ellipsoid bitmap are staged in LDS per
+//                      workgroup; k_slam_schur = round 1's scatter form with fp64 atomics (ESL_SCHUR_ATOMIC=1)
 //   dense Cholesky     esl_chol.hpp (FP64 MFMA)
 //   k_slam_backsub     one wave per ellipsoid: x_o, retraction, trial states
 //   k_slam_cam_update  one lane per camera: retraction exp(x_c) * Tcw
