@@ -9,11 +9,17 @@
 //
 // What it mirrors (reference src/core/Optimizer.cpp):
 //   :88-90   config keys Optimizer.Edges.3DEllipsoid.Scale / GravityPrior.Open / GravityPrior.Scale
-//   :127-139 one camera vertex per frame (Tcw), all fixed in mapping mode
+//   :126     bSLAM_mode -- a constant `false` in the reference; here the config key Optimizer.SLAMMode (absent from the
+//            shipped yaml => 0 => the shipped mapping mode), esl_adapter::Options::slam_mode in the template below
+//   :127-139 one camera vertex per frame (Tcw), all fixed in mapping mode; SLAM mode: only frame 0 fixed (:137)
+//   :142-158 SLAM mode: one EdgeSE3Expmap per consecutive frame pair, vertices (prev, curr), measurement
+//            curr_Tcw * prev_Tcw^-1 of the INPUT poses (both from cam_pose_Twc.inverse()), information I6
 //   :166-180 one ellipsoid vertex per instance that exists in the map (ascending instance id)
 //   :183-196 gravity prior per ellipsoid when a ground plane is set, information = Scale^2
 //   :201-245 bbox edges only if the instance has > 2 observations; information = rate * I4;
-//            NaN pre-check (done on the GPU: esl_lm_params::drop_nan_bbox = 1)
+//            NaN pre-check (done on the GPU: esl_lm_params::drop_nan_bbox = 1); the optional visibility test
+//            (checkVisibility, :35-81, argument check_visibility with rows / cols) also runs on the GPU:
+//            esl_graph::check_visibility / image_rows / image_cols
 //   :249-279 one 3-D edge per non-null local ellipsoid of every frame, information = Scale * prob * I9
 //   :290-291 optimize(10)
 //   :294-306 write the estimates back into the map's ellipsoids IN PLACE (pose, scale, vec_minimal)
@@ -32,16 +38,41 @@ struct FlatGraph {
   std::vector<int> instance_of_obj;             // N
   std::vector<int32_t> bbox_cam, bbox_obj, e3d_cam, e3d_obj, grav_obj;
   std::vector<double> bbox_meas, bbox_weight, e3d_meas, e3d_weight;
+  // SLAM mode only (Optimizer.cpp:126-158); empty in mapping mode
+  std::vector<uint8_t> cam_fixed;               // F: 1 for frame 0
+  std::vector<int32_t> odom_i, odom_j;          // vertex 0 = frame i - 1, vertex 1 = frame i
+  std::vector<double> odom_meas;                // (F - 1) x 7
+};
+
+// What the reference hard-codes or passes as arguments and a caller may now choose
+struct Options {
+  bool slam_mode = false;          // bSLAM_mode (Optimizer.cpp:126): cameras free except frame 0 + odometry edges
+  bool check_visibility = false;   // argument check_visibility (Optimizer.h:20-22; false at Tracking.cpp:226)
+  int rows = 0, cols = 0;          // image size the visibility test uses
 };
 
 template <class FramePtrVec, class EllipsoidMap, class ObservationMap>
 FlatGraph Flatten(const FramePtrVec& frames, const EllipsoidMap& map_ellipsoids, const ObservationMap& object_observations,
-                  double scale_3d, bool gravity_on) {
+                  double scale_3d, bool gravity_on, bool slam_mode = false) {
   FlatGraph f;
   std::map<int, int> obj_index;  // instance id -> ellipsoid vertex index
+  int fi = 0;
   for (const auto& fr : frames) {
     const auto v = fr->cam_pose_Tcw.toVector();
     for (int k = 0; k < 7; ++k) f.cams.push_back(v[k]);
+    if (slam_mode) {
+      f.cam_fixed.push_back(fi == 0 ? 1 : 0);                   // vSE3->setFixed(frame_index == 0), Optimizer.cpp:137
+      if (fi > 0) {                                             // Optimizer.cpp:142-158
+        const auto prev_Tcw = frames[fi - 1]->cam_pose_Twc.inverse();
+        const auto curr_Tcw = fr->cam_pose_Twc.inverse();
+        const auto odom_val = curr_Tcw * prev_Tcw.inverse();
+        const auto z = odom_val.toVector();
+        for (int k = 0; k < 7; ++k) f.odom_meas.push_back(z[k]);
+        f.odom_i.push_back(fi - 1);                             // setVertex(0, vSE3Vertex[frame_index - 1])
+        f.odom_j.push_back(fi);                                 // setVertex(1, vSE3Vertex[frame_index])
+      }
+    }
+    ++fi;
   }
   for (const auto& inst_obs : object_observations) {           // std::map => ascending instance id (Optimizer.cpp:166)
     const int instance = inst_obs.first;
@@ -80,12 +111,20 @@ FlatGraph Flatten(const FramePtrVec& frames, const EllipsoidMap& map_ellipsoids,
   return f;
 }
 
-inline esl_graph MakeGraph(const FlatGraph& f, const double K[4], const double ground[4], double grav_scale) {
+inline esl_graph MakeGraph(const FlatGraph& f, const double K[4], const double ground[4], double grav_scale,
+                           const Options& opt = Options()) {
   esl_graph g{};
   g.fx = K[0]; g.fy = K[1]; g.cx = K[2]; g.cy = K[3];
   g.n_cams = (int32_t)(f.cams.size() / 7);
   g.n_objs = (int32_t)(f.objs.size() / 10);
-  g.cam_fixed = nullptr;  // mapping mode: bSLAM_mode = false (Optimizer.cpp:126)
+  // mapping mode (bSLAM_mode = false, Optimizer.cpp:126): all cameras fixed = NULL; SLAM mode: the flags Flatten built
+  g.cam_fixed = f.cam_fixed.empty() ? nullptr : f.cam_fixed.data();
+  g.n_odom = (int32_t)f.odom_i.size();
+  g.odom_i = f.odom_i.data(); g.odom_j = f.odom_j.data();
+  g.odom_meas = f.odom_meas.data();
+  g.odom_info = nullptr;  // identity: inv_sigma = 1 (Optimizer.cpp:152-155)
+  g.check_visibility = opt.check_visibility ? 1 : 0;
+  g.image_rows = opt.rows; g.image_cols = opt.cols;
   g.n_bbox = (int32_t)f.bbox_cam.size();
   g.bbox_cam = f.bbox_cam.data(); g.bbox_obj = f.bbox_obj.data();
   g.bbox_meas = f.bbox_meas.data(); g.bbox_weight = f.bbox_weight.data();
@@ -114,20 +153,27 @@ namespace EllipsoidSLAM {
 Optimizer::Optimizer() { mbGroundPlaneSet = false; }
 void Optimizer::SetGroundPlane(Vector4d& normal) { mbGroundPlaneSet = true; mGroundPlaneNormal = normal; }
 
-// rows, cols, save_graph, withAssociation are unused by the reference unless check_visibility is set, and Tracking never
-// sets it (Tracking.cpp:226; the visibility check of Optimizer.cpp:35-81 is dead code there)
-void Optimizer::GlobalObjectGraphOptimization(std::vector<Frame*>& pFrames, Map* pMap, int, int, Matrix3d& mCalib,
-                                              std::map<int, Observations>& objectObservations, bool, bool, bool) {
+// save_graph and withAssociation are unused by the reference; rows / cols only feed checkVisibility (Optimizer.cpp:35-81),
+// which Tracking never switches on (Tracking.cpp:226) -- it is passed through all the same.
+// Optimizer.SLAMMode = 1 selects the reference's bSLAM_mode branch (Optimizer.cpp:126-158; a compile-time `false` there): the
+// key is absent from the shipped yaml files, cv::FileStorage returns 0 for a missing key, so the default is the shipped mapping
+// mode.  As in the reference, only the ellipsoids are written back (Optimizer.cpp:294-306) -- the optimised camera poses stay in
+// the solver's vertices and are dropped.
+void Optimizer::GlobalObjectGraphOptimization(std::vector<Frame*>& pFrames, Map* pMap, int rows, int cols, Matrix3d& mCalib,
+                                              std::map<int, Observations>& objectObservations, bool, bool, bool check_visibility) {
   const double scale3d = Config::Get<double>("Optimizer.Edges.3DEllipsoid.Scale");
   const bool grav = mbGroundPlaneSet && Config::Get<int>("Optimizer.Edges.GravityPrior.Open") == 1;
   const double grav_scale = Config::Get<double>("Optimizer.Edges.GravityPrior.Scale");
+  esl_adapter::Options opt;
+  opt.slam_mode = Config::Get<int>("Optimizer.SLAMMode") == 1;
+  opt.check_visibility = check_visibility; opt.rows = rows; opt.cols = cols;
   std::map<int, g2o::ellipsoid*> ells = pMap->GetAllEllipsoidsMap();
-  esl_adapter::FlatGraph f = esl_adapter::Flatten(pFrames, ells, objectObservations, scale3d, grav);
+  esl_adapter::FlatGraph f = esl_adapter::Flatten(pFrames, ells, objectObservations, scale3d, grav, opt.slam_mode);
   const double K[4] = {mCalib(0, 0), mCalib(1, 1), mCalib(0, 2), mCalib(1, 2)};
   double ground[4] = {0, 0, 0, 0};
   if (mbGroundPlaneSet)
     for (int k = 0; k < 4; ++k) ground[k] = mGroundPlaneNormal[k];
-  esl_graph g = esl_adapter::MakeGraph(f, K, mbGroundPlaneSet ? ground : nullptr, grav_scale);
+  esl_graph g = esl_adapter::MakeGraph(f, K, mbGroundPlaneSet ? ground : nullptr, grav_scale, opt);
   esl_lm_params p; esl_lm_params_default(&p);
   esl_lm_report rep;
   {

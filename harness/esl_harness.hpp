@@ -256,6 +256,8 @@ struct Settings {   // Example/param/TUM3.yaml + src/config/Config.cpp:29-30
   esl_fit_params fit;                                // filled by the backend's defaults, then overridden from here
   esl_plane_params plane = {200, 5.0, 0.1, 10, 0.05, 100};   // Plane.MinSize / AngleThreshold / DistanceThreshold + PlaneExtractor.cpp:57-58, 74
   bool with_association = true;                      // rgbd.cpp:73
+  bool slam_mode = false;                            // Optimizer.cpp:126 bSLAM_mode (a constant false in the reference)
+  bool check_visibility = false;                     // GlobalObjectGraphOptimization's last argument (false at Tracking.cpp:226)
 };
 
 // calibrateMeasurement: true = the box touches the border band (or is too small); the box is overwritten as the reference does
@@ -273,7 +275,12 @@ inline bool border_filter(double m[4], int rows, int cols, int border, int min_s
 }
 
 // the types esl_adapter::Flatten walks (member names as in the reference's Frame / Observation / g2o::ellipsoid)
-struct Pose7 { Vec7 v; Vec7 toVector() const { return v; } };
+struct Pose7 {
+  Vec7 v;
+  Vec7 toVector() const { return v; }
+  Pose7 inverse() const { return Pose7{se3_inverse(v)}; }                        // g2o::SE3Quat::inverse
+  Pose7 operator*(const Pose7& b) const { return Pose7{se3_mul(v, b.v)}; }       // g2o::SE3Quat::operator*
+};
 struct Ell {
   Vec10 v{};
   double prob = 0;
@@ -397,6 +404,7 @@ class Tracker {
   const std::vector<GraphInfo>& graph_log() const { return log_; }
   const std::map<int, Ell*>& map_ellipsoids() const { return map_; }
   const std::vector<Frame*>& frames() const { return frames_; }
+  const std::vector<double>& last_optimized_cams() const { return last_cams_; }   // SLAM mode: Tcw of every frame after the last run
   int fits_attempted = 0, fits_ok = 0;
 
  private:
@@ -529,15 +537,20 @@ class Tracker {
 
   bool Optimize() {   // Optimizer::GlobalObjectGraphOptimization through the adapter's flattening
     const bool grav = ground_set_ && s_.gravity_open;
-    esl_adapter::FlatGraph fg = esl_adapter::Flatten(frames_, map_, obs_, s_.scale_3d, grav);
+    esl_adapter::Options opt;
+    opt.slam_mode = s_.slam_mode; opt.check_visibility = s_.check_visibility; opt.rows = s_.rows; opt.cols = s_.cols;
+    esl_adapter::FlatGraph fg = esl_adapter::Flatten(frames_, map_, obs_, s_.scale_3d, grav, opt.slam_mode);
     const double K[4] = {s_.fx, s_.fy, s_.cx, s_.cy};
-    esl_graph g = esl_adapter::MakeGraph(fg, K, ground_set_ ? ground_ : nullptr, s_.gravity_scale);
+    esl_graph g = esl_adapter::MakeGraph(fg, K, ground_set_ ? ground_ : nullptr, s_.gravity_scale, opt);
     esl_lm_report rep;
     if (be_.optimize(&g, fg.cams.data(), fg.objs.data(), &rep) != 0) return false;
     for (size_t o = 0; o < fg.instance_of_obj.size(); ++o) {
       Ell* e = map_[fg.instance_of_obj[o]];
       for (int k = 0; k < 10; ++k) e->v[k] = fg.objs[o * 10 + k];
     }
+    // as in the reference the optimised camera poses are NOT written back to the frames (Optimizer.cpp:294-306 copies the
+    // ellipsoids only); the last run's poses are kept for the output file cameras_slam.txt
+    if (s_.slam_mode) last_cams_ = fg.cams;
     log_.push_back(GraphInfo{(int)frames_.size() - 1, g.n_objs, g.n_cams + g.n_objs, g.n_bbox, rep.n_bbox_valid, rep.n_bbox_dropped, g.n_e3d, g.n_grav,
                              rep.iterations, rep.chi2_initial, rep.chi2_final});
     return true;
@@ -568,6 +581,7 @@ class Tracker {
   std::vector<int> map_order_;
   std::map<int, std::vector<std::vector<double>>> history_;
   std::vector<GraphInfo> log_;
+  std::vector<double> last_cams_;
 };
 
 // Example/interface/rgbd.cpp: every frame of the clip through the tracker, then objects.txt / object_history.txt and the
@@ -596,6 +610,12 @@ int run_clip(Backend& be, const std::string& dataset_dir, const std::string& out
     rows.push_back({(double)gi.frame, (double)gi.objects, (double)gi.vertices, (double)gi.edges_2d, (double)gi.valid_2d, (double)gi.invalid_2d,
                     (double)gi.edges_3d, (double)gi.gravity, (double)gi.lm_iterations, gi.chi2_initial, gi.chi2_final});
   save_number_table(rows, od + "graph_log.txt");
+  if (s.slam_mode) {   // Tcw of every frame as the last optimisation left them (the reference drops them)
+    std::vector<std::vector<double>> crow;
+    const std::vector<double>& lc = tr.last_optimized_cams();
+    for (size_t i = 0; i + 7 <= lc.size(); i += 7) crow.push_back(std::vector<double>(lc.begin() + i, lc.begin() + i + 7));
+    save_number_table(crow, od + "cameras_slam.txt");
+  }
   if (tr.GetGroundPlaneEstimationState() == 2) {
     const double* gp = tr.ground_plane();
     save_number_table({{(double)tr.ground_frame(), gp[0], gp[1], gp[2], gp[3]}}, od + "ground_plane.txt");

@@ -2,7 +2,7 @@
 // ground-truth poses, one bbox file per frame) through the Tracking-side logic of esl_harness.hpp with every fit, every
 // quadric initialisation and every graph optimisation done by libesl_hip.so through the C-ABI of include/esl.h.
 //
-//   esl_rgbd <dataset_dir> <out_dir> [--ground a b c d] [--jacobian numeric|analytic] [--delta 1e-9] [--no-symmetry] [--sym-iters n] [--auto-association]
+//   esl_rgbd <dataset_dir> <out_dir> [--ground a b c d] [--jacobian numeric|analytic] [--delta 1e-9] [--no-symmetry] [--sym-iters n] [--auto-association] [--slam-mode] [--check-visibility]
 //
 // Writes objects.txt (System::SaveObjectsToFile), object_history.txt (Tracking::SaveObjectHistory) and graph_log.txt (one
 // row per GlobalObjectGraphOptimization call: frame, objects, vertices, 2-D edges, valid, invalid, 3-D edges, gravity edges,
@@ -59,6 +59,8 @@ int main(int argc, char** argv) {
     else if (a == "--no-symmetry") s.symmetry = false;
     else if (a == "--auto-association") s.with_association = false;   // ignore the instance column: DataAssociationSolver
     else if (a == "--sym-iters" && i + 1 < argc) s.fit.symmetry_lm_iters = std::atoi(argv[++i]);
+    else if (a == "--slam-mode") s.slam_mode = true;             // Optimizer.cpp:126 bSLAM_mode: frame 0 fixed + odometry edges
+    else if (a == "--check-visibility") s.check_visibility = true;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
   }
   if (esl_ctx_create(0, &be.ctx) != ESL_OK) { std::fprintf(stderr, "esl: %s\n", esl_last_error()); return 4; }

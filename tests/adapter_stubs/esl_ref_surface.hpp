@@ -88,10 +88,41 @@ typedef pcl::PointCloud<pcl::PointXYZRGB> PointCloudPCL;
 using std::string;
 
 namespace g2o {
-struct SE3Quat {
+struct SE3Quat {   // types/se3quat.h:110-134, 345-350: the two operations the SLAM branch of the Optimizer adapter needs
   Vector7d v;
   SE3Quat() { v[6] = 1; }
   Vector7d toVector() const { return v; }
+  static void rot(const double q[4], const double p[3], double out[3]) {   // Eigen: v + 2 w (u x v) + 2 u x (u x v)
+    const double ux = q[1] * p[2] - q[2] * p[1], uy = q[2] * p[0] - q[0] * p[2], uz = q[0] * p[1] - q[1] * p[0];
+    out[0] = p[0] + 2 * (q[3] * ux + q[1] * uz - q[2] * uy);
+    out[1] = p[1] + 2 * (q[3] * uy + q[2] * ux - q[0] * uz);
+    out[2] = p[2] + 2 * (q[3] * uz + q[0] * uy - q[1] * ux);
+  }
+  SE3Quat inverse() const {   // conjugate, t' = q^-1 (-t); not normalised
+    SE3Quat r;
+    const double qc[4] = {-v[3], -v[4], -v[5], v[6]}, nt[3] = {-v[0], -v[1], -v[2]};
+    double t[3];
+    rot(qc, nt, t);
+    for (int k = 0; k < 3; ++k) { r.v[k] = t[k]; r.v[3 + k] = qc[k]; }
+    r.v[6] = qc[3];
+    return r;
+  }
+  SE3Quat operator*(const SE3Quat& b) const {   // t = ta + Ra tb, q = qa qb, then w >= 0 and unit norm (normalizeRotation)
+    SE3Quat r;
+    const double qa[4] = {v[3], v[4], v[5], v[6]}, tb[3] = {b.v[0], b.v[1], b.v[2]};
+    double t[3];
+    rot(qa, tb, t);
+    const double ax = v[3], ay = v[4], az = v[5], aw = v[6], bx = b.v[3], by = b.v[4], bz = b.v[5], bw = b.v[6];
+    double q[4] = {aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw,
+                   aw * bw - ax * bx - ay * by - az * bz};
+    if (q[3] < 0) for (double& c : q) c = -c;
+    double n = 0;
+    for (double c : q) n += c * c;
+    n = __builtin_sqrt(n);
+    for (int k = 0; k < 3; ++k) r.v[k] = v[k] + t[k];
+    for (int k = 0; k < 4; ++k) r.v[3 + k] = q[k] / n;
+    return r;
+  }
 };
 class ellipsoid {
  public:

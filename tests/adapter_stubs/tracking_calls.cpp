@@ -209,8 +209,17 @@ int main(int argc, char** argv) {
   }
   // Tracking.cpp:226
   bool withAssociation = false;
+  std::map<int, Vector10d> before;   // the estimates the optimisation starts from (it overwrites the map's ellipsoids in place)
+  for (auto& kv : mpMap->GetAllEllipsoidsMap()) before[kv.first] = kv.second->toVector();
   mpOptimizer->GlobalObjectGraphOptimization(mvpFrames, mpMap, mRows, mCols, mCalib, mmObjectObservations, true, withAssociation);
   for (auto& kv : mpMap->GetAllEllipsoidsMap()) print10("OPT", kv.first, kv.second->toVector());
+  // the same call with the reference's bSLAM_mode branch (Optimizer.cpp:126-158; config key Optimizer.SLAMMode here) and the
+  // last argument of the signature, check_visibility (Optimizer.h:20-22), from the same start
+  for (auto& kv : mpMap->GetAllEllipsoidsMap()) kv.second->fromVector(before[kv.first]);
+  Config::values()["Optimizer.SLAMMode"] = 1;
+  mpOptimizer->GlobalObjectGraphOptimization(mvpFrames, mpMap, mRows, mCols, mCalib, mmObjectObservations, true, withAssociation, true);
+  for (auto& kv : mpMap->GetAllEllipsoidsMap()) print10("OPTSLAM", kv.first, kv.second->toVector());
+  Config::values()["Optimizer.SLAMMode"] = 0;
   std::printf("LINK-OK\n");
   return 0;
 }

@@ -45,6 +45,8 @@ int main(int argc, char** argv) {
     else if (a == "--no-symmetry") s.symmetry = false;
     else if (a == "--auto-association") s.with_association = false;
     else if (a == "--sym-iters" && i + 1 < argc) s.fit.symmetry_lm_iters = std::atoi(argv[++i]);
+    else if (a == "--slam-mode") { s.slam_mode = true; be.solver = 0; }   // bSLAM_mode + the faithful dense pivoted LDLT of the whole free system
+    else if (a == "--check-visibility") s.check_visibility = true;
     else if (a == "--jacobian" && i + 1 < argc) ++i;   // the checker only has g2o's numeric scheme
     else return 1;
   }

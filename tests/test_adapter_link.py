@@ -161,10 +161,27 @@ def test_adapters_replay_tracking_sequence_on_gpu(pkg, ctx, tmp_path):
     for k, inst in enumerate(inst_of):
         np.testing.assert_allclose(opt[inst], oo[k], rtol=0, atol=1e-9)
     assert rep["iterations"] >= 1
+    # the same call in SLAM mode (config key Optimizer.SLAMMode = 1: frame 0 fixed, odometry edges between consecutive frames,
+    # Optimizer.cpp:126-158) with check_visibility = true, rows, cols passed through (Optimizer.h:20-22)
+    from oracle import pyoracle as po
+    fixed = np.zeros(len(c), np.uint8); fixed[0] = 1
+    Tcw_in = np.array([po.se3_inv(t) for t in Twc])                       # the adapter takes cam_pose_Twc.inverse() for the odometry
+    Z = np.array([po.se3_mul(Tcw_in[i], po.se3_inv(Tcw_in[i - 1])) for i in range(1, len(c))])
+    gs = pkg.Graph(K, len(c), len(objs), fixed, g.bbox_cam[mb], remap[g.bbox_obj[mb]], meas[mb], g.bbox_weight[mb],
+                   g.e3d_cam[me][order_e], remap[g.e3d_obj[me]][order_e], e3[me][order_e], g.e3d_weight[me][order_e],
+                   np.arange(len(objs)), ground, 100.0 ** 2, odom_i=np.arange(len(c) - 1), odom_j=np.arange(1, len(c)), odom_meas=Z,
+                   check_visibility=1, image_rows=rows, image_cols=cols)
+    _, os_, reps = ctx.optimize(gs, c, np.array(objs), pkg.default_lm_params())
+    opts = {int(r[0]): np.array([float(v) for v in r[1:]]) for r in rec["OPTSLAM"]}
+    assert reps["iterations"] >= 1 and len(opts) == len(inst_of)
+    for k, inst in enumerate(inst_of):
+        np.testing.assert_allclose(opts[inst], os_[k], rtol=0, atol=1e-7)
+        assert np.abs(opts[inst] - opt[inst]).max() > 1e-9          # and it is a different optimisation than the mapping one
+    assert out.count("GRAPH INFORMATION") == 2
     # side effects the reference has and the adapter keeps: graph summary on stdout, ./object_list.txt
     assert "GRAPH INFORMATION" in out and "2d Edges [Valid/Invalid] : %d" % int(mb.sum()) in out
     listed = [l.split("\t") for l in (tmp_path / "object_list.txt").read_text().splitlines()]
-    assert [int(l[0]) for l in listed] == inst_of and all(len(l) == 3 for l in listed)
+    assert [int(l[0]) for l in listed] == inst_of and all(len(l) == 3 for l in listed)   # (rewritten by the second call: same instances)
     # getEllipsoidFromQStar of a known quadric
     Q = np.zeros((4, 4)); t = np.array([1, -2, 0.5]); Q[:3, :3] = np.diag([0.09, 0.04, 0.25]) - np.outer(t, t); Q[:3, 3] = -t; Q[3, :3] = -t; Q[3, 3] = -1
     eq, okq = ctx.init_from_qstar(Q, faithful=1)

@@ -100,8 +100,13 @@ def test_gating_rules_on_a_hand_made_clip(tmp_path, oracle_exe):
 
 def test_cabinet_clip_on_the_checker_matches_golden(oracle_exe, clip_dir, tmp_path):
     R = np.load(GOLD_RUN)
-    for tag, args in (("ref", []), ("tight", ["--delta", "1e-6", "--sym-iters", "0"])):
+    for tag, args in (("ref", []), ("tight", ["--delta", "1e-6", "--sym-iters", "0"]), ("slamref", ["--slam-mode"]),
+                      ("slamtight", ["--slam-mode", "--delta", "1e-6", "--sym-iters", "0"])):
         txt, objs, log, hist = run(oracle_exe, clip_dir, str(tmp_path / tag), *args)
+        if "slam" in tag:   # the reference's bSLAM_mode branch (Optimizer.cpp:126-158) through the adapter's flattening
+            cams = np.array(hu.read_table(os.path.join(str(tmp_path / tag), "cameras_slam.txt")))
+            np.testing.assert_allclose(cams, R[tag + "_cameras"], rtol=0, atol=1e-9)
+            assert cams.shape == (58, 7) and np.abs(objs - R[tag.replace("slam", "") + "_objects"]).max() > 1e-3   # a different optimum than mapping
         assert "frames 58 (valid 58), fits 49 / 49 ok, objects 1, optimisations 58" in txt
         np.testing.assert_allclose(objs, R[tag + "_objects"], rtol=0, atol=1e-9)
         np.testing.assert_array_equal(log[:, :8], R[tag + "_graph_log"][:, :8])                  # the graph after every frame
@@ -118,6 +123,45 @@ def test_cabinet_clip_on_the_checker_matches_golden(oracle_exe, clip_dir, tmp_pa
 
 
 # ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_cabinet_clip_in_slam_mode_on_gpu(oracle_exe, clip_dir, tmp_path):
+    """The reference's SLAM branch (frame 0 fixed, odometry edges, Optimizer.cpp:126-158) reached through the class surface:
+    harness -> esl_adapter::Flatten(slam_mode) -> esl_optimize -> Schur complement + dense Cholesky on the GPU, against the
+    checker harness, which solves the same graphs with the faithful dense pivoted LDLT of the whole free system."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "harness")])
+    exe = os.path.join(ROOT, "harness", "esl_rgbd")
+    R = np.load(GOLD_RUN)
+    targs = ["--slam-mode", "--delta", "1e-6", "--sym-iters", "0"]
+    txt, o_gpu, g_gpu, _ = run(exe, clip_dir, str(tmp_path / "g_slam"), *targs)
+    assert "frames 58 (valid 58), fits 49 / 49 ok, objects 1, optimisations 58" in txt
+    np.testing.assert_array_equal(g_gpu[:, :9], R["slamtight_graph_log"][:, :9])      # graph after every frame AND the LM iteration counts
+    c_gpu = np.array(hu.read_table(os.path.join(str(tmp_path / "g_slam"), "cameras_slam.txt")))
+    d_obj = np.abs(o_gpu - R["slamtight_objects"]).max()
+    d_cam = np.abs(c_gpu - R["slamtight_cameras"]).max()
+    d_chi = np.abs(g_gpu[:, 9:] / R["slamtight_graph_log"][:, 9:] - 1).max()
+    print("cabinet clip, SLAM mode, GPU vs checker (delta 1e-6): object %.2e, cameras %.2e, chi2 rel %.2e" % (d_obj, d_cam, d_chi))
+    assert d_obj < 1e-6 and d_cam < 1e-6 and d_chi < 1e-6
+    # the product default (analytic Jacobians) against the checker at the reference's delta = 1e-9: north-star tolerance
+    _, o_an, g_an, _ = run(exe, clip_dir, str(tmp_path / "g_slam_an"), "--slam-mode", "--jacobian", "analytic")
+    np.testing.assert_array_equal(g_an[:, :8], R["slamref_graph_log"][:, :8])
+    rel = np.linalg.norm(o_an[0, 1:] - R["slamref_objects"][0, 1:]) / np.linalg.norm(R["slamref_objects"][0, 1:])
+    print("cabinet clip, SLAM mode, GPU analytic vs checker (reference settings): relative difference of the final ellipsoid %.2e" % rel)
+    assert rel < 1e-4
+
+
+@pytest.mark.gpu
+def test_cabinet_clip_with_automatic_association_on_gpu(clip_dir, tmp_path):
+    """f-4 on the product: DataAssociationSolver (src/core/DataAssociation.cpp:16-135) driven by the ellipsoids the GPU fits, the
+    instance column of the clip ignored -- one object throughout, the run of the golden fixture"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "harness")])
+    exe = os.path.join(ROOT, "harness", "esl_rgbd")
+    R = np.load(GOLD_RUN)
+    txt, objs, log, _ = run(exe, clip_dir, str(tmp_path / "auto_gpu"), "--auto-association", "--delta", "1e-6", "--sym-iters", "0")
+    assert "objects 1" in txt and len(log) == 58
+    np.testing.assert_array_equal(log[:, :8], R["tight_graph_log"][:, :8])
+    np.testing.assert_allclose(objs, R["tight_objects"], rtol=0, atol=1e-5)
+
+
 @pytest.mark.gpu
 def test_cabinet_clip_end_to_end_on_gpu(oracle_exe, clip_dir, tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "harness")])
