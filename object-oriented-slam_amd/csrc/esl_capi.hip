@@ -275,6 +275,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->append_dev) (void)hipFree(c->append_dev);
   fit_release(c);
+  plane_release(c);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->host_part) (void)hipHostFree(c->host_part);
   dev_free(&c->dev_part);
@@ -285,6 +286,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (c->lm_dev) (void)hipFree(c->lm_dev);
   if (c->ev_try) (void)hipEventDestroy(c->ev_try);
   esl_comm_destroy(c);
+  slam_release_runtime(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ESL_OK;
@@ -649,14 +651,20 @@ static int image_upload(esl_ctx* c, const HostImage& im, const double* cams, con
   d.grav_w = grav_w; d.yt = yt; d.check_vis = check_vis; d.img_rows = rows; d.img_cols = cols;
   const size_t cN = (size_t)im.cap_objs, cF = (size_t)im.cap_cams;
   std::vector<int> start((size_t)im.cap_objs + 1, 0), gr((size_t)im.cap_objs, 0);
+  // start[o] = begin of ellipsoid o's slice, start[n_objs] = end of the laid-out extent (a real end sentinel: a kernel that walks
+  // start[o] .. start[o + 1] sees the slice WITH its slack, whose slots carry obj = -1, weight 0 and -- bbox -- valid = 0)
   for (int o = 0; o < im.n_objs; ++o) { start[o] = im.bb_begin[o]; gr[o] = im.gr_cnt[o]; }
+  start[im.n_objs] = (int)im.used_bb;
   up.add(&d.bb_start, start.data(), start.size());
   for (int o = 0; o < im.n_objs; ++o) start[o] = im.e3_begin[o];
+  start[im.n_objs] = (int)im.used_e3;
   up.add(&d.e3_start, start.data(), start.size());
   up.add(&d.gr_cnt, gr.data(), gr.size());
   up.add(&d.bb_cam, im.bb_cam.data(), im.cap_bb); up.add(&d.bb_obj, im.bb_obj.data(), im.cap_bb);
   up.add(&d.bb_meas, im.bb_meas.data(), im.cap_bb * 4); up.add(&d.bb_w, im.bb_w.data(), im.cap_bb);
-  std::vector<unsigned char> valid(im.cap_bb, 1);
+  std::vector<unsigned char> valid(im.cap_bb, 0);   // slack slots stay invalid; an append marks the slots it fills
+  for (int o = 0; o < im.n_objs; ++o)
+    for (int k = 0; k < im.bb_cnt[o]; ++k) valid[(size_t)im.bb_begin[o] + k] = 1;
   up.add(&d.bb_valid, valid.data(), valid.size());
   up.add(&d.e3_cam, im.e3_cam.data(), im.cap_e3); up.add(&d.e3_obj, im.e3_obj.data(), im.cap_e3);
   up.add(&d.e3_meas, im.e3_meas.data(), im.cap_e3 * 10); up.add(&d.e3_w, im.e3_w.data(), im.cap_e3);
@@ -815,6 +823,7 @@ int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
   std::vector<int> co, cty, cb, ce, cos, ib, ie, bbs((size_t)N + 1, 0), e3s((size_t)N + 1, 0);
   image_chunks(im, co, cty, cb, ce, cos, ib, ie);
   for (int o = 0; o < N; ++o) { bbs[o] = im.bb_begin[o]; e3s[o] = im.e3_begin[o]; }
+  bbs[N] = (int)im.used_bb; e3s[N] = (int)im.used_e3;   // end sentinel, as in image_upload
   // one staged blob: tables | bbox records | 3-D records
   UploadStage st(c);   // (re)uses the context's pinned staging block; `fixes` is not used here
   struct Part { size_t off, bytes; };
@@ -952,7 +961,7 @@ static int map_launch_linearize(esl_ctx* c, bool finalize, const double* src_obj
   c->sys_combined = false;
   if (finalize) {
     ProfScope ps(c, 4);
-    hipLaunchKernelGGL(k_chunk_finalize, dim3((g.n_objs + 255) / 256), dim3(256), 0, c->stream, g, ct, dst_chunk, src_objs,
+    hipLaunchKernelGGL(k_chunk_finalize_rows, dim3(std::max(1, (g.n_objs + kStepWaves - 1) / kStepWaves)), dim3(64 * kStepWaves), 0, c->stream, g, ct, dst_chunk, src_objs,
                        c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->blk_part,
                        c->tickets, c->dev_scal, (LmScalars*)c->host_scal_dev, c->lm.p.tau, (LmCore*)nullptr, (int*)nullptr, 0,
                        (LmHostView*)nullptr);
@@ -1116,7 +1125,7 @@ int esl_lm_reduced_system(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n,
   ESL_HIP_TRY(hipSetDevice(c->device));
   if (!c->lm.slam) { *dev_ptr = nullptr; *n = 0; *lda = 0; return ESL_OK; }
   *lda = c->S_lda;
-  int rc = slam_build_reduced(c, lambda, dev_ptr, n);
+  int rc = slam_build_reduced(c, lambda, true, dev_ptr, n);
   if (rc) return rc;
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   return ESL_OK;
@@ -1168,9 +1177,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   const bool sample_run = c->prof_on && c->prof_level == 1 && (c->prof_runs++ % 4 == 0);
   const int max_total = p->max_iters * std::max(1, p->max_trials);
   const int depth = 2;   // trials kept in flight ahead of the device's progress counter
-  // ESL_LM_STEP_OLD=1: round 1's step kernel (16 ellipsoids per workgroup, one lane each) for A/B measurements
-  const bool step_rows = std::getenv("ESL_LM_STEP_OLD") == nullptr;
-  const int n_step_blocks = std::max(1, step_rows ? (g.n_objs + kStepWaves - 1) / kStepWaves : (g.n_objs + kStepObjs - 1) / kStepObjs);
+  const int n_step_blocks = std::max(1, (g.n_objs + kStepWaves - 1) / kStepWaves);
   const int batch = 4;   // sharded: trials enqueued per round (a fixed number, so that all ranks issue the same collectives)
   const int n_lin_blocks = (c->n_ids_e3 + 2 * kLinWaves - 1) / (2 * kLinWaves) + (c->n_ids_bb + kLinWaves - 1) / kLinWaves;
   // launch k carries trial k's solve and trial k-1's decision: one launch more than there are trials
@@ -1184,17 +1191,10 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
       LmCore* nxt = core + ((enq + 1) & 1);
       {
         ProfScope ps(c, 1);
-        if (step_rows)
-          hipLaunchKernelGGL(k_lm_step_rows, dim3(n_step_blocks), dim3(64 * kStepWaves), 0, c->stream, g, chunk_table(c), c->chunk_out,
-                             c->chunk_out2, c->objs, c->objs_trial, in, nxt, c->blk_chi, n_lin_blocks, c->solve_part + 4 * n_step_blocks * (enq & 1),
-                             c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? (sharded ? 2 : 1) : 0, p->max_iters, p->max_trials,
-                             (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo,
-                             sharded ? c->dev_gather : (const double*)nullptr, sharded ? c->comm_ranks : 0, p->tau);
-        else
-          hipLaunchKernelGGL(k_lm_step, dim3(n_step_blocks), dim3(256), 0, c->stream, g, chunk_table(c), c->chunk_out, c->chunk_out2,
-                           c->objs, c->objs_trial, in, nxt, c->blk_chi, n_lin_blocks, c->solve_part + 4 * n_step_blocks * (enq & 1),
-                           c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? (sharded ? 2 : 1) : 0, p->max_iters,
-                           p->max_trials, (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo, c->obj_part,
+        hipLaunchKernelGGL(k_lm_step_rows, dim3(n_step_blocks), dim3(64 * kStepWaves), 0, c->stream, g, chunk_table(c), c->chunk_out,
+                           c->chunk_out2, c->objs, c->objs_trial, in, nxt, c->blk_chi, n_lin_blocks, c->solve_part + 4 * n_step_blocks * (enq & 1),
+                           c->solve_part + 4 * n_step_blocks * ((enq + 1) & 1), enq == 0 ? (sharded ? 2 : 1) : 0, p->max_iters, p->max_trials,
+                           (LmHostView*)c->lm_host_dev, c->lm.p.jacobian_mode, c->lm.p.numeric_delta, c->xo,
                            sharded ? c->dev_gather : (const double*)nullptr, sharded ? c->comm_ranks : 0, p->tau);
         ESL_HIP_TRY(hipGetLastError());
       }

@@ -12,7 +12,7 @@
 // L^T x = y is separate.
 //
 // Blocked right-looking, NB = 128:
-//   k_potrf   one workgroup: diagonal block -> L11 in LDS, then Linv = L11^-1 (in-place trtri)
+//   k_potrf2  one workgroup: diagonal block -> L11 in registers / LDS, then Linv = L11^-1 (in-place, recursive doubling)
 //   k_panel   P <- P * Linv^T           (rows below the diagonal block; MFMA, X*Y^T form)
 //   k_update  C <- C - P_i * P_j^T      (lower-triangle tiles of the trailing matrix; MFMA)
 #pragma once
@@ -29,215 +29,20 @@ constexpr int kLdsPad = 129;   // column stride of the LDS copy of the diagonal 
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// ---- diagonal block: blocked Cholesky in LDS (32-wide sub-blocks), then blocked triangular inverse --------------
+// ---- diagonal block -----------------------------------------------------------------------------------------
 // info[0] |= 1 when a pivot is not positive (g2o: LDLT not positive => solve fails => step rejected).
-// The serial chain is 4 x 32 small column steps; the rank-32 updates and the 32x32 block products of the
-// inverse use all 256 threads.  (The first version ran 128 full-size column steps + a serial trtri: 793 us.)
-constexpr int kSB = 32;
+constexpr int kSB = 32;   // (LDS sizing only: the 96 x 32 temporary of the triangular inverse)
 // value of `v` in lane `src` (a compile-time constant after unrolling) -> every lane: two v_readlane_b32 (a few cycles
 // each); __shfl() would go through ds_bpermute, ~100 cycles of LDS-crossbar latency on a dependent chain
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
-// 32x32 diagonal sub-block, wave-synchronous in registers (no workgroup barriers inside the 32 column steps):
-// lane r holds row r of the sub-block.  Returns the factor in `row` and 1/L(j,j) in invd[j] (uniform).
-__device__ __forceinline__ void potrf32_wave(double (&row)[kSB], double (&invd)[kSB], int lane, int* info) {
-#pragma unroll
-  for (int j = 0; j < kSB; ++j) {
-    const double d = readlane_f64(row[j], j);
-    if (!(d > 0) && lane == 0) atomicOr(info, 1);
-    // 1/sqrt(d) from the hardware estimate + two Newton steps, L(j,j) = d * that: the sqrt + divide pair of the first version was
-    // ~500 of the ~1,000 cycles of a column step (each is a 20-30 instruction sequence in fp64)
-    double is = __builtin_amdgcn_rsq(d);
-    is = is * (1.5 - 0.5 * d * is * is);
-    is = is * (1.5 - 0.5 * d * is * is);
-    const double s = d * is;
-    invd[j] = is;
-    const double lij = (lane == j) ? s : row[j] * is;   // lanes above the diagonal carry unused values
-    row[j] = lij;
-#pragma unroll
-    for (int c = j + 1; c < kSB; ++c) row[c] -= lij * readlane_f64(lij, c);
-  }
-}
-// X = D^-1 for the lower-triangular 32x32 factor held row-per-lane in `row`: lane c computes column c of X by forward
-// substitution (L X = I); L(i,k) comes from lane i by shuffle.
-__device__ __forceinline__ void trtri32_wave(const double (&row)[kSB], const double (&invd)[kSB], int lane, double (&x)[kSB]) {
-#pragma unroll
-  for (int i = 0; i < kSB; ++i) {
-    double acc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < i; ++k) acc -= readlane_f64(row[k], i) * x[k];
-    x[i] = acc * invd[i];
-  }
-}
-
-// diagnostic: wall_clock64() marks (100 MHz) of the last k_chol_potrf launch, read by esl_selftest_cholesky when
+// diagnostic: wall_clock64() marks (100 MHz) of the last k_chol_potrf2 launch, read by esl_selftest_cholesky when
 // ESL_CHOL_TIMING is set
 __device__ long long g_potrf_clk[16];
 #define POTRF_MARK(k) do { if (t == 0) g_potrf_clk[k] = (long long)wall_clock64(); } while (0)
-static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ M, long lda, int k0, int nb,
-                                                    double* __restrict__ Linv /* kNB x kNB col-major */,
-                                                    int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* L = sm;                          // kNB x kNB, column stride kLdsPad: the factor, later its inverse
-  double* T = sm + kNB * kLdsPad;          // 96 x 32 temporary
-  double* dinv = T + 96 * kSB;             // kNB reciprocals of the diagonal
-  // The inverse X_J of diagonal sub-block J is parked in the block's own (otherwise unused) strictly upper triangle,
-  // transposed: X_J(i,c), i > c, lives at L(c0 + c, c0 + i); its diagonal is dinv.  (157.9 of the 160 KB of LDS are taken.)
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-#define LL(i, j) L[(i) + (j) * kLdsPad]
-#define DV(J, i, j) (((i) == (j)) ? dinv[(J) * kSB + (i)] : LL((J) * kSB + (j), (J) * kSB + (i)))
-  POTRF_MARK(0);
-  for (int idx = t; idx < kNB * kNB; idx += 256) {
-    const int i = idx % kNB, j = idx / kNB;
-    LL(i, j) = (i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  POTRF_MARK(1);
-  for (int c0 = 0; c0 < kNB; c0 += kSB) {   // rows/columns >= nb are identity padding: factoring them is a no-op
-    // 1. the 32 x 32 diagonal sub-block: wave 0, in registers (the only serial part: 32 dependent column steps)
-    if (wave == 0) {
-      double row[kSB], invd[kSB];
-      const int r = lane & 31;
-#pragma unroll
-      for (int c = 0; c < kSB; ++c) row[c] = (c <= r) ? LL(c0 + r, c0 + c) : 0.0;
-      potrf32_wave(row, invd, lane, info);
-      if (lane < kSB) {
-#pragma unroll
-        for (int c = 0; c < kSB; ++c) {
-          if (c <= r) LL(c0 + r, c0 + c) = row[c];
-          if (c == lane) dinv[c0 + c] = invd[c];
-        }
-      }
-    }
-    __syncthreads();
-    if (c0 == 0) POTRF_MARK(2);
-    const int r0 = c0 + kSB, m2 = kNB - r0;   // rows below the sub-block
-    if (m2 > 0) {
-      // 2. sub-panel solve X D^T = A by forward substitution, one lane per row (D's entries are broadcast LDS reads)
-      if (t < m2) {
-        const int i = r0 + t;
-        double v[kSB];
-#pragma unroll
-        for (int c = 0; c < kSB; ++c) {
-          double acc = LL(i, c0 + c);
-#pragma unroll
-          for (int k = 0; k < c; ++k) acc -= v[k] * LL(c0 + c, c0 + k);
-          v[c] = acc * dinv[c0 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < kSB; ++c) LL(i, c0 + c) = v[c];
-      }
-      __syncthreads();
-      if (c0 == 0) POTRF_MARK(3);
-      // 3. rank-32 update of the trailing lower triangle on the matrix cores: 16 x 16 blocks (ib >= jb) dealt to the 4 waves
-      {
-        const int nbk = m2 / 16, npair = nbk * (nbk + 1) / 2;
-        const int r = lane & 15, kq = lane >> 4;
-        for (int pidx = wave; pidx < npair; pidx += 4) {
-          int ib = (int)((sqrtf(8.0f * (float)pidx + 1.0f) - 1.0f) * 0.5f);
-          while (ib * (ib + 1) / 2 > pidx) --ib;
-          while ((ib + 1) * (ib + 2) / 2 <= pidx) ++ib;
-          const int jb = pidx - ib * (ib + 1) / 2;
-          const int i0 = r0 + ib * 16, j0 = r0 + jb * 16;
-          double4_t acc = {0, 0, 0, 0};
-#pragma unroll
-          for (int kk = 0; kk < kSB; kk += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(LL(i0 + r, c0 + kk + kq), LL(j0 + r, c0 + kk + kq), acc, 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int i = i0 + kq + 4 * g, c = j0 + r;   // D: row = (lane >> 4) + 4 g, col = lane & 15
-            if (i >= c) LL(i, c) -= acc[g];
-          }
-        }
-      }
-      __syncthreads();
-      if (c0 == 0) POTRF_MARK(4);
-    }
-  }
-  POTRF_MARK(5);
-  // inverses of the four diagonal sub-blocks, one wave each, side by side (parked in the upper triangles)
-  {
-    const int c0 = wave * kSB, r = lane & 31;
-    double row[kSB], invd[kSB], x[kSB];
-#pragma unroll
-    for (int c = 0; c < kSB; ++c) { row[c] = (c <= r) ? LL(c0 + r, c0 + c) : 0.0; invd[c] = dinv[c0 + c]; }
-    trtri32_wave(row, invd, lane, x);
-    if (lane < kSB) {
-#pragma unroll
-      for (int c = 0; c < kSB; ++c)
-        if (c > lane) LL(c0 + lane, c0 + c) = x[c];    // lane = column of X, x[c] = X(c, lane), parked transposed
-    }
-  }
-  __syncthreads();
-  POTRF_MARK(6);
-  // write L11 back (the factor itself is part of the result)
-  for (int idx = t; idx < nb * nb; idx += 256) {
-    const int i = idx % nb, j = idx / nb;
-    if (i >= j) M[(long)(k0 + i) + (long)(k0 + j) * lda] = LL(i, j);
-  }
-  // ---- Linv = L^-1 IN PLACE in LDS (blocked dtrtri, lower): block columns right to left; the diagonal blocks' inverses
-  // are parked in the upper triangles
-  __syncthreads();
-  POTRF_MARK(7);
-  constexpr int nB = kNB / kSB;
-  for (int J = nB - 1; J >= 0; --J) {
-    const int c0 = J * kSB, r0 = c0 + kSB, mrows = kNB - r0;
-    // (a) T = Linv[r0.., r0..] * L[r0.., c0..c0+32)    (lower-triangular times panel) -- MFMA; entries above the diagonal of
-    //     the left factor are masked (the diagonal sub-blocks' upper triangles hold parked inverses)
-    {
-      const int r = lane & 15, kq = lane >> 4;
-      const int nout = (mrows / 16) * 2;
-      for (int ob = wave; ob < nout; ob += 4) {
-        const int ib = ob >> 1, cb = ob & 1;
-        double4_t acc = {0, 0, 0, 0};
-        for (int kk = 0; kk < (ib + 1) * 16; kk += 4) {
-          const int i = ib * 16 + r, k = kk + kq;
-          const double av = (k <= i) ? LL(r0 + i, r0 + k) : 0.0;
-          const double bv = LL(r0 + k, c0 + cb * 16 + r);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) T[(ib * 16 + kq + 4 * g) + (cb * 16 + r) * 96] = acc[g];
-      }
-    }
-    __syncthreads();
-    // (b) diagonal block <- its inverse
-    for (int idx = t; idx < kSB * kSB; idx += 256) { const int i = idx % kSB, c = idx / kSB; if (i > c) LL(c0 + i, c0 + c) = LL(c0 + c, c0 + i); }
-    // (c) panel = -T * Dinv  (Dinv lower: read from its parked, transposed copy)
-    {
-      const int r = lane & 15, kq = lane >> 4;
-      const int nout = (mrows / 16) * 2;
-      for (int ob = wave; ob < nout; ob += 4) {
-        const int ib = ob >> 1, cb = ob & 1;
-        double4_t acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int kk = 0; kk < kSB; kk += 4) {
-          const int k = kk + kq, c = cb * 16 + r;
-          const double av = T[(ib * 16 + r) + k * 96];
-          const double bv = (k > c) ? LL(c0 + c, c0 + k) : ((k == c) ? dinv[c0 + c] : 0.0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) LL(r0 + ib * 16 + kq + 4 * g, c0 + cb * 16 + r) = -acc[g];
-      }
-    }
-    __syncthreads();
-    if (t < kSB) LL(c0 + t, c0 + t) = dinv[c0 + t];   // diagonal of the inverse (after (c) has read dinv / before the next (a))
-    __syncthreads();
-  }
-  POTRF_MARK(8);
-  for (int idx = t; idx < kNB * kNB; idx += 256) {
-    const int i = idx % kNB, j = idx / kNB;
-    Linv[idx] = (i < nb && j < nb && i >= j) ? LL(i, j) : 0.0;
-  }
-  POTRF_MARK(9);
-#undef DV
-#undef LL
-}
-
-// ---- diagonal block, second form (round 2): right-looking over the WHOLE block in rank-4 steps ---------------------------------
+// ---- k_chol_potrf2: right-looking over the WHOLE 128 x 128 block in rank-4 steps ------------------------------------------------
 // 528 threads each OWN a 4 x 4 block of the lower triangle in 16 registers for the whole factorisation; only the current block
 // column (4 x 128 doubles) and the inverse of its diagonal block (10 doubles) travel through LDS.  32 steps of two barriers each
 // (see the loop).  History of this kernel, n = 2,994 factor + solve: blocked form of round 1 (k_chol_potrf: 32 x 32 sub-blocks
@@ -245,8 +50,9 @@ static __global__ __launch_bounds__(256) void k_chol_potrf(double* __restrict__ 
 // latency of LDS write -> 10-wave barrier -> LDS read) 4.0 ms; rank-4 steps (column loop 76 -> 28 us, kernel 118 -> 72 us) 2.86 ms.  Around the loop: every thread
 // fetches its own block (load 10 -> 2 us) and writes its part of L back from registers; the triangular inverse is computed in
 // place by recursive doubling from the 4 x 4 inverses the factorisation produces anyway (see below).
-// (Also measured: the blocked loop of k_chol_potrf moved into this kernel's frame on eight waves with the sub-block inverses
-// overlapped -- slower, 4.9 ms: at two waves per SIMD and 244 registers the wave-synchronous column steps went 12 -> 17 us.)
+// (Also measured: round 1's blocked loop moved into this kernel's frame on eight waves with the sub-block inverses
+// overlapped -- slower, 4.9 ms: at two waves per SIMD and 244 registers the wave-synchronous column steps went 12 -> 17 us.
+// Round 1's kernel itself was deleted in round 3 after its equivalence runs.)
 constexpr int kP2Threads = 640;
 static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __restrict__ M, long lda, int k0, int nb,
                                                             double* __restrict__ Linv /* kNB x kNB col-major */,
@@ -600,8 +406,6 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 // chain of one wave is then 4 MFMAs per k-step instead of 16 and a trailing matrix of 1,500 rows still spreads over ~140
 // workgroups; with the big tile it occupied 20 CUs for 86 us whatever its size.
 constexpr int kKC = 16;
-// <128, 128, 2, 2>: four waves of 64 x 64, 74 KB of LDS and <= 256 registers per lane, so TWO workgroups share a CU and one
-// tile's prologue (first staging loads) and epilogue (C read-modify-write) run under the other tile's K loop.
 template <int BM, int BN, int WM = 4, int WN = 2>
 static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
                                                                            int kcol0, int K, long base, int ntJ, int rect) {
@@ -811,36 +615,38 @@ struct CholDist {
 };
 inline int chol_outer_panels(int n) { return (n >= 8192) ? 4 : 2; }   // inner 128-panels per outer panel
 
+// Per-context state of the host driver: the look-ahead stream and its events live on the CONTEXT's device and are used by one
+// context only (two contexts sharing them could wait on each other's records), and hipFuncSetAttribute is per device.
+struct CholRuntime {
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev_panel, ev_trail;
+  bool attr_set = false;
+  void release() {
+    for (hipEvent_t e : ev_panel) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_trail) (void)hipEventDestroy(e);
+    ev_panel.clear(); ev_trail.clear();
+    if (side) { (void)hipStreamDestroy(side); side = nullptr; }
+    attr_set = false;
+  }
+};
+
 // Host driver.  M: (n+1) x n col-major (lda), Linv_ws: ceil(n/NB) * NB*NB doubles, z_ws: NB doubles,
-// x: n doubles (output), info: device int (bit 0 set on a non-positive pivot).
+// x: n doubles (output), info: device int (bit 0 set on a non-positive pivot).  The current device must be the one `rt` and
+// `st` belong to.
 inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws, double* z_ws, double* x, int* info,
-                                    hipStream_t st, const CholDist* dist = nullptr) {
+                                    hipStream_t st, CholRuntime& rt, const CholDist* dist = nullptr) {
   const long rows = (long)n + 1;
   const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_chol_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const bool potrf_old = getenv("ESL_CHOL_POTRF_OLD") != nullptr;   // round 1's blocked diagonal factorisation, for A/B runs
   int np = (n + kNB - 1) / kNB;
   constexpr size_t lds_big = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
   constexpr size_t lds_small = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
-  constexpr size_t lds_sq = (size_t)(2 * kKC * (128 + 16 + 128 + 16)) * sizeof(double);
-  static bool attr2_set = false;
-  if (!attr2_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+  if (!rt.attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_chol_update_lds<128, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sq);
+    e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
     if (e != hipSuccess) return e;
-    attr2_set = true;
+    rt.attr_set = true;
   }
-  // measured (n = 32,768): 238.7 ms with the square two-per-CU tiles, 231.6 ms with 256 x 128 -- the tile prologue / epilogue is
-  // not what is left; the square form stays selectable for experiments
-  const bool square_tiles = getenv("ESL_CHOL_TILE_SQUARE") != nullptr;
   auto launch_update = [&](hipStream_t stream, int kcol0, int K, long base, long col_limit) {
     // trailing region: rows [base, rows), cols [base, col_limit)
     const long nrows = rows - base, nc = col_limit - base;
@@ -848,12 +654,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     // the big tile only when it still gives every CU a few workgroups
     const bool whole = (nc >= nrows - 1);
     const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (whole ? 2 : 1);
-    if (big_tiles >= 1024 && square_tiles) {
-      const long ntI = (nrows + 127) / 128, ntJ = (nc + 127) / 128;
-      const long nblk = whole ? ntI * (ntI + 1) / 2 : ntI * ntJ;
-      hipLaunchKernelGGL((k_chol_update_lds<128, 128, 2, 2>), dim3((unsigned)nblk), dim3(256), lds_sq, stream, M, lda, rows, col_limit, kcol0,
-                         K, base, (int)ntJ, whole ? 0 : 1);
-    } else if (big_tiles >= 1024) {
+    if (big_tiles >= 1024) {   // (square 128 x 128 tiles, two workgroups per CU, measured at n = 32,768: 238.7 vs 231.6 ms -- dropped)
       const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
       const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
       hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), lds_big, stream, M, lda, rows, col_limit, kcol0, K,
@@ -871,8 +672,9 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   // Look-ahead: that update is split -- the columns of the NEXT outer panel are updated on the caller's stream, the rest on a
   // second stream, so the next outer panel's potrf / panel solves (single-workgroup and short kernels that leave the chip
   // empty) run underneath the big update instead of in front of it.
-  static hipStream_t side = nullptr;
-  static std::vector<hipEvent_t> ev_panel, ev_trail;
+  hipStream_t& side = rt.side;
+  std::vector<hipEvent_t>& ev_panel = rt.ev_panel;
+  std::vector<hipEvent_t>& ev_trail = rt.ev_trail;
   if (!side) { hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking); if (e != hipSuccess) return e; }
   const int W = chol_outer_panels(n);
   const int n_outer = (np + W - 1) / W;
@@ -884,7 +686,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   }
   // below ~8k unknowns the chain of single-workgroup potrf launches is the critical path whatever runs beside it (measured:
   // n = 2994 4.55 ms without, 4.75 ms with look-ahead), from 16k on it buys 12-15 %
-  const bool lookahead = n >= 8192 && getenv("ESL_CHOL_NO_LOOKAHEAD") == nullptr;
+  const bool lookahead = n >= 8192;
   if (dist && dist->n_ranks > 1) {
     for (int o = 0; o < n_outer; ++o) {
       const int owner = o % dist->n_ranks;
@@ -894,8 +696,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
         for (int p = p0; p < p1; ++p) {
           const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
           double* Linv = Linv_ws + (size_t)p * kNB * kNB;
-          if (potrf_old) hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb, Linv, info);
-          else hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
+          hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
           const long below = rows - (k0 + nb);
           if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb, Linv);
           if (p + 1 < p1) launch_update(st, k0, nb, (long)k0 + nb, (long)c_end);
@@ -921,8 +722,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     for (int p = p0; p < p1; ++p) {
       const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
       double* Linv = Linv_ws + (size_t)p * kNB * kNB;
-      if (potrf_old) hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), lds, st, M, lda, k0, nb, Linv, info);
-      else hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
+      hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
       const long below = rows - (k0 + nb);
       if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb, Linv);
       // bring the rest of the outer panel's columns up to date (rank-nb update restricted to those columns)

@@ -2,6 +2,7 @@
 // librccl is dlopen()ed on first use so that libesl_hip.so itself has no link-time dependency on it.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -53,6 +54,11 @@ int nccl_fail(int rc, const char* what) {
 }  // namespace
 
 namespace esl {
+// switches that change the collective sequence are read once per communicator (see esl_ctx::sw_chol_dist)
+static void resolve_switches(esl_ctx* c) {
+  const char* e = std::getenv("ESL_CHOL_DIST");
+  c->sw_chol_dist = e ? (e[0] == '1' ? 1 : 0) : -1;
+}
 // host-staged transport (esl_comm_init_host): the caller's callback sums a host buffer over the ranks
 static int host_fail(int rc) {
   set_error("host all-reduce callback failed with code " + std::to_string(rc));
@@ -179,6 +185,7 @@ int esl_comm_init(esl_ctx* c, int32_t n_ranks, int32_t rank, const char id[128])
   if (rc != 0) return nccl_fail(rc, "ncclCommInitRank");
   c->comm = comm; c->comm_ranks = n_ranks; c->comm_rank = rank;
   c->g.shard_rank = rank;
+  esl::resolve_switches(c);
   ESL_HIP_TRY(hipMalloc((void**)&c->dev_gather, (size_t)n_ranks * 8 * sizeof(double)));
   ESL_HIP_TRY(hipHostMalloc((void**)&c->host_gather, (size_t)n_ranks * 8 * sizeof(double), hipHostMallocDefault));
   ESL_HIP_TRY(hipMemsetAsync(c->dev_scal, 0, 8 * sizeof(double), c->stream));
@@ -194,6 +201,7 @@ int esl_comm_init_host(esl_ctx* c, int32_t n_ranks, int32_t rank, esl_host_allre
   c->comm = (void*)c;   // non-null marks "exchange active"; never handed to RCCL on this transport
   c->comm_ranks = n_ranks; c->comm_rank = rank;
   c->g.shard_rank = rank;
+  esl::resolve_switches(c);
   ESL_HIP_TRY(hipMalloc((void**)&c->dev_gather, (size_t)n_ranks * 8 * sizeof(double)));
   ESL_HIP_TRY(hipHostMalloc((void**)&c->host_gather, (size_t)n_ranks * 8 * sizeof(double), hipHostMallocDefault));
   ESL_HIP_TRY(hipMemsetAsync(c->dev_scal, 0, 8 * sizeof(double), c->stream));

@@ -86,6 +86,7 @@ struct ProfScope {
 int prof_drain(esl_ctx* c);
 void fit_graphs_clear(esl_ctx* c);
 void fit_release(esl_ctx* c);
+void plane_release(esl_ctx* c);
 // all-gather the 8-double dev_scal block of every rank into c->dev_gather (device), ordered on the context's stream
 int comm_gather_scalars_device(esl_ctx* c);
 // SLAM mode: in-place sum over ranks of a device buffer (RCCL all-reduce); no-op without a communicator
@@ -170,6 +171,7 @@ struct esl_ctx {
   char* fit_slab = nullptr; size_t fit_slab_cap = 0;        // esl_fit_frame's device slab (esl_fit.hip)
   char* fit_in = nullptr;  size_t fit_in_cap = 0;           // pinned staging of its inputs / outputs
   char* fit_out = nullptr; size_t fit_out_cap = 0;
+  char* plane_slab = nullptr; size_t plane_slab_cap = 0;    // esl_extract_ground_plane / esl_extract_planes (esl_plane.hip)
   void* fit_graph_cache = nullptr;                          // captured launch sequences (std::vector<FitGraphEntry>)
   bool cams_match_snap = false;  // cameras untouched since the snapshot: esl_states_restore skips their copy
   int n_grav_edges = 0;
@@ -190,4 +192,12 @@ struct esl_ctx {
   double* Linv_ws = nullptr;  // ceil(n/NB) x NB x NB
   double* z_ws = nullptr;
   int64_t S_lda = 0;
+  // per-context runtime of the dense solver (esl_chol.hpp CholRuntime: look-ahead stream + events on THIS device, one-time
+  // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context
+  void* chol_rt = nullptr;
+  bool schur_attr_set = false;
+  // switches resolved ONCE when the communicator is created (every rank must take the same collective sequence for the whole
+  // run; an environment read per trial could change mid-run): ESL_CHOL_DIST = 1 / 0 forces the distributed factorisation
+  // on / off, unset = by size
+  int sw_chol_dist = -1;
 };

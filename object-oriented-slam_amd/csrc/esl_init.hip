@@ -304,7 +304,8 @@ struct DevBuf {   // released on every exit path
   ~DevBuf() { if (p) (void)hipFree(p); }
   int alloc(size_t bytes) { ESL_HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return ESL_OK; }
 };
-constexpr int kInitLdsObs = 480;   // plane matrix of up to 480 observations fits the 160 KB of LDS; beyond that it goes to HBM
+// the plane matrix (40 doubles per observation) stays in LDS while it fits what the context's device offers per workgroup
+// (gfx950: 160 KB => up to 480 observations); beyond that it goes to HBM
 
 int init_launch(esl_ctx* c, const double* poses_Twc, const double* bboxes, int32_t n, const double K[4], int32_t rows, int32_t cols,
                 int32_t faithful, int mode, const double* extra, int n_extra, double h[28]) {
@@ -322,7 +323,9 @@ int init_launch(esl_ctx* c, const double* poses_Twc, const double* bboxes, int32
   a.n = n; a.rows = rows; a.cols = cols; a.faithful = faithful; a.mode = mode;
   for (int i = 0; i < n_extra; ++i) a.extra[i] = extra[i];
   size_t lds = 100 * sizeof(double);
-  if (n > kInitLdsObs) {
+  int lds_max = 0;
+  ESL_HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device));
+  if (lds + (size_t)n * 40 * sizeof(double) > (size_t)lds_max) {
     if ((rc = dA.alloc((size_t)n * 40 * sizeof(double)))) return rc;
     a.a_glob = (double*)dA.p;
   } else {

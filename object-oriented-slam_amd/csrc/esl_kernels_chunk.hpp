@@ -8,9 +8,9 @@
 //                           residual + Jacobian in registers, the 45+9 entries of J^T W J / -J^T W r summed over the wave
 //                           through a wave-private LDS transpose, written as a chunk partial; per-workgroup chi2 partial.
 //                           The first linearisation of a run also performs the NaN pre-check of the bbox edges.
-//   k_chunk_finalize        once per run: per-ellipsoid diagonal of H -> max diag (lambda_0), chi2, LM state initialisation
-//   k_lm_step               one LM trial's head: every workgroup decides the previous trial (accept / reject, lambda, stop
-//                           rule -- lm_decide), then solves its 16 ellipsoids for the new lambda -> trial state.
+//   k_chunk_finalize_rows   once per run: per-ellipsoid diagonal of H -> max diag (lambda_0), chi2, LM state initialisation
+//   k_lm_step_rows          one LM trial's head: every workgroup decides the previous trial (accept / reject, lambda, stop
+//                           rule -- lm_decide), then solves its 4 ellipsoids (a wave each, row-parallel 9x9) for the new lambda -> trial state.
 //                           A trial is linearised AT its trial state, so its chi2 is the sum of the chunk chi2 and its
 //                           H, b are the next iteration's system if it is accepted: no residual-only pass.
 //   k_lm_partials           sharded runs: this rank's share of a trial's scalars -> send buffer of the all-gather
@@ -44,8 +44,6 @@ constexpr int kLinWaves = 4;
 #ifndef ESL_LIN_MIN_WAVES
 #define ESL_LIN_MIN_WAVES 1   // waves per SIMD the linearisation is compiled for (tuning: scripts/build_variants.sh)
 #endif
-// k_lm_step: ellipsoids per workgroup (one lane each in the solve phase) and the row stride of their H, b sums in LDS
-constexpr int kStepObjs = 16, kHbStride = 55;   // 16: the gather is 864 sums per workgroup = 3.4 per thread, all loads in flight
 
 // packed upper-triangle index -> (a, c)
 __device__ __forceinline__ constexpr int tri_a(int p) {
@@ -459,80 +457,6 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_chunk_linearize(DevGr
   wg_chi_end(wg_chi, blk_chi, blk_offset + blockIdx.x);
 }
 
-// first iteration: chi2 of the linearisation point and max |H_kk| (computeLambdaInit); one thread per ellipsoid,
-// the last workgroup reduces the per-workgroup partials in fixed order
-static __global__ __launch_bounds__(256) void k_chunk_finalize(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
-                                                               const double* __restrict__ objs, int jac, double delta,
-                                                               double* __restrict__ blk_part /* gridDim x 2 */,
-                                                               unsigned int* __restrict__ ticket, double* __restrict__ dev_scal,
-                                                               LmScalars* __restrict__ host, double tau, LmCore* __restrict__ st,
-                                                               int* __restrict__ n_dropped, int n_grav,
-                                                               LmHostView* __restrict__ hv) {
-  __shared__ double sm[256];
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  double chi = 0, md = 0;
-  if (o < g.n_objs) {
-    double diag[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int ch = ct.ostart[o]; ch < ct.ostart[o + 1]; ++ch) {
-      const double* p = chunk_out + (size_t)ch * kChunkOut;
-      chi += p[54];
-      int q = 0;
-#pragma unroll
-      for (int a = 0; a < 9; ++a) { diag[a] += p[q]; q += 9 - a; }
-    }
-    if (g.gr_cnt[o] > 0) {  // gravity prior lives on the ellipsoid itself (see k_obj_solve)
-      const Ell e = ell_load(objs + 10 * o);
-      const double wg = g.grav_w * g.gr_cnt[o];
-      double Jg[9], rg;
-      if (jac == ESL_JAC_ANALYTIC) rg = jac_grav(e, g.grav_n, Jg);
-      else {
-        rg = res_grav(e, g.grav_n);
-        numeric_jac_obj(e, delta, 1, Jg, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
-      }
-      chi += wg * rg * rg;
-#pragma unroll
-      for (int a = 0; a < 9; ++a) diag[a] += wg * Jg[a] * Jg[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 9; ++a) md = fmax(md, fabs(diag[a]));
-  }
-  chi = block256_sum(chi, sm);
-  md = block256_max(md, sm);
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&blk_part[2 * blockIdx.x], chi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&blk_part[2 * blockIdx.x + 1], md, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (last_block_arrives_wt(ticket)) {
-    double c = 0, m = 0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { c += blk_part[2 * b]; m = fmax(m, blk_part[2 * b + 1]); }
-    c = block256_sum(c, sm);
-    m = block256_max(m, sm);
-    if (threadIdx.x == 0) {
-      dev_scal[0] = c; dev_scal[1] = m;
-      host->chi2_lin = c; host->max_diag = m;
-      if (hv) {   // start of a device-driven LM run
-        const int nd = *n_dropped;
-        hv->n_dropped = nd;
-        *n_dropped = 0;   // ready for the next run (the first linearisation of a run counts into it)
-        const bool any_edge = (g.n_bbox_edges - nd > 0) || g.n_e3d > 0 || n_grav > 0;
-        dev_scal[5] = any_edge ? 1.0 : 0.0;   // sharded run: the ranks' flags are gathered, k_lm_step initialises
-        if (st) {   // single GPU: computeLambdaInit and the bookkeeping of iteration 0 right here
-          LmCore s;
-          lm_core_init(s, c, m, tau);
-          if (!any_edge) {   // no active edge: nothing to optimise (stop_reason 3)
-            s.done = 1; s.stop_reason = 3;
-            hv->core = s;
-            hv->trace_len = 0;
-            __hip_atomic_store(&hv->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-          *st = s;
-        }
-      }
-      *ticket = 0;
-    }
-  }
-}
-
 __device__ __forceinline__ void obj_solve_one(const DevGraph& g, const ChunkTable& ct, const double* __restrict__ chunk_out,
                                               const double* __restrict__ objs, int jac, double delta, double lambda,
                                               double* __restrict__ xo, double* __restrict__ objs_trial, double* __restrict__ part, int o,
@@ -670,135 +594,14 @@ __device__ __forceinline__ void lm_decide(LmCore& s, double chi, double sc, doub
   }
 }
 
-// One LM trial, device-driven: (1) decide the PREVIOUS trial from the chi2 its linearisation left in blk_chi and the
-// partials the previous k_lm_step left in sp_in -- every workgroup does this redundantly, so there is no grid-wide
-// handshake; (2) solve (H + lambda I) x = b per ellipsoid for the new lambda from the now-current chunk partials and
+// One LM trial, device-driven (k_lm_step_rows below): (1) decide the PREVIOUS trial from the chi2 its linearisation left in
+// blk_chi and the partials the previous step launch left in sp_in -- every workgroup does this redundantly, so there is no
+// grid-wide handshake; (2) solve (H + lambda I) x = b per ellipsoid for the new lambda from the now-current chunk partials and
 // write the next trial state.  LM state ping-pongs between `in` and `out` (other workgroups may still be reading `in`).
-// first != 0: nothing to decide yet (state initialised by k_chunk_finalize).
-static __global__ __launch_bounds__(256) void k_lm_step(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_a,
-                                                        const double* __restrict__ chunk_b, double* __restrict__ objs_a,
-                                                        double* __restrict__ objs_b, const LmCore* __restrict__ in,
-                                                        LmCore* __restrict__ out, const double* __restrict__ blk_chi, int n_lin_blocks,
-                                                        const double* __restrict__ sp_in, double* __restrict__ sp_out, int first,
-                                                        int max_iters, int max_trials, LmHostView* __restrict__ host, int jac,
-                                                        double delta, double* __restrict__ xo, double* __restrict__ part,
-                                                        const double* __restrict__ gathered, int n_ranks, double tau) {
-  // Sharded run (n_ranks > 0): `gathered` holds every rank's 8-double block {chi2_lin, max_diag, chi2_trial, scale, ok,
-  // has_edges, -, -} (all-gathered on this stream); the decision adds them in rank order, so every rank decides alike.
-  // first: 1 = state in `in` is initialised (single GPU), 2 = initialise it here from the gathered linearisation scalars.
-  __shared__ double sm12[12];
-  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
-  long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-  if (writer) tk0 = (long long)wall_clock64();
-  // all loads of the decision go out together (each is an HBM / fabric round trip: the producers ran on other XCDs)
-  double c = 0, sc = 0, okv = 1;
-  if (!first && n_ranks == 0) {
-#pragma unroll 8
-    for (int k = threadIdx.x; k < n_lin_blocks; k += 256) c += blk_chi[k];
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { c += sp_in[b * 4 + 0]; sc += sp_in[b * 4 + 2]; okv = fmin(okv, sp_in[b * 4 + 3]); }
-  }
-  LmCore s;
-  if (first == 2) {
-    double chi = 0, md = 0, any = 0;
-    for (int r = 0; r < n_ranks; ++r) { chi += gathered[r * 8 + 0]; md = fmax(md, gathered[r * 8 + 1]); any = fmax(any, gathered[r * 8 + 5]); }
-    lm_core_init(s, chi, md, tau);
-    if (any < 0.5) {   // no rank has an active edge
-      s.done = 1; s.stop_reason = 3;
-      if (writer) {
-        host->core = s;
-        host->trace_len = 0;
-        __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  } else {
-    s = *in;
-  }
-  if (s.done) {   // queued behind a finished run: pass the state on and leave
-    if (writer) *out = s;
-    return;
-  }
-  if (!first) {
-    if (n_ranks > 0) {
-      for (int r = 0; r < n_ranks; ++r) { c += gathered[r * 8 + 2]; sc += gathered[r * 8 + 3]; okv = fmin(okv, gathered[r * 8 + 4]); }
-    } else {
-      // three block reductions behind one barrier pair
-      c = wave_sum(c); sc = wave_sum(sc); okv = -wave_max(-okv);
-      if ((threadIdx.x & 63) == 0) { sm12[threadIdx.x >> 6] = c; sm12[4 + (threadIdx.x >> 6)] = sc; sm12[8 + (threadIdx.x >> 6)] = okv; }
-      __syncthreads();
-      c = ((sm12[0] + sm12[1]) + sm12[2]) + sm12[3];
-      sc = ((sm12[4] + sm12[5]) + sm12[6]) + sm12[7];
-      okv = fmin(fmin(sm12[8], sm12[9]), fmin(sm12[10], sm12[11]));
-    }
-    lm_decide(s, c, sc, okv, max_iters, max_trials, writer, host);
-    if (writer) {
-      if (s.done) {   // results first, then the flags with release semantics: the host reads them as soon as it sees `done`
-        host->core = s;
-        __hip_atomic_store(&host->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else {        // progress counter only (it throttles the host's enqueueing): no system-scope release fence per trial
-        __hip_atomic_store(&host->seq, s.trial_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
-  if (writer) *out = s;
-  if (s.done) return;
-  if (writer) tk1 = (long long)wall_clock64();
-  const double* chunk_out = s.cur ? chunk_b : chunk_a;
-  const double* objs = s.cur ? objs_b : objs_a;
-  double* objs_trial = s.cur ? objs_a : objs_b;
-  // (2) this workgroup's kStepObjs ellipsoids.  All 256 threads first add up the chunk partials, one (ellipsoid, entry) pair
-  // at a time with the loads of up to four chunks in flight together -- a lane walking its own ellipsoid's chunks one after
-  // the other sat through one L2 round trip per chunk -- then one lane per ellipsoid solves from LDS.
-  __shared__ double hbs[kStepObjs * kHbStride];
-  __shared__ int ost[kStepObjs + 1];
-  const int o0 = blockIdx.x * kStepObjs;
-  for (int j = threadIdx.x; j <= kStepObjs; j += 256) ost[j] = ct.ostart[min(o0 + j, g.n_objs)];
-  __syncthreads();
-  {
-    constexpr int kIt = (kStepObjs * 54 + 255) / 256;
-    double v[kIt][4];
-    int jj[kIt], kk[kIt];
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {   // issue every load of the first four chunks of every pair before using any
-      const int idx = threadIdx.x + 256 * it;
-      const bool on = idx < kStepObjs * 54;
-      const int j = on ? idx / 54 : 0, k = on ? idx - j * 54 : 0;
-      jj[it] = on ? j : -1; kk[it] = k;
-      const int c0 = ost[j], nleft = on ? ost[j + 1] - c0 : 0;
-      const double* p = chunk_out + (size_t)c0 * kChunkOut + k;
-      v[it][0] = nleft > 0 ? p[0] : 0.0;
-      v[it][1] = nleft > 1 ? p[kChunkOut] : 0.0;
-      v[it][2] = nleft > 2 ? p[2 * kChunkOut] : 0.0;
-      v[it][3] = nleft > 3 ? p[3 * kChunkOut] : 0.0;
-    }
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      if (jj[it] < 0) continue;
-      double acc = (((0.0 + v[it][0]) + v[it][1]) + v[it][2]) + v[it][3];   // chunk order, as the serial sum
-      for (int ch = ost[jj[it]] + 4; ch < ost[jj[it] + 1]; ++ch) acc += chunk_out[(size_t)ch * kChunkOut + kk[it]];   // > 4 chunks: rare
-      hbs[jj[it] * kHbStride + kk[it]] = acc;
-    }
-  }
-  __syncthreads();
-  if (writer) tk2 = (long long)wall_clock64();
-  if (threadIdx.x < 64) {   // wave 0, all 64 lanes stay in for the shuffles; the first kStepObjs lanes own an ellipsoid
-    const int o = o0 + threadIdx.x;
-    double cg = 0, scale = 0, okd = 1;
-    if (threadIdx.x < kStepObjs && o < g.n_objs)
-      obj_solve_one(g, ct, chunk_out, objs, jac, delta, s.lambda, xo, objs_trial, part, o, cg, scale, okd, hbs + threadIdx.x * kHbStride);
-    cg = wave_sum(cg); scale = wave_sum(scale);
-    okd = -wave_max(-okd);
-    if (threadIdx.x == 0) {
-      sp_out[blockIdx.x * 4 + 0] = cg; sp_out[blockIdx.x * 4 + 1] = 0;
-      sp_out[blockIdx.x * 4 + 2] = scale; sp_out[blockIdx.x * 4 + 3] = okd;
-    }
-    if (writer) {
-      tk3 = (long long)wall_clock64();
-      host->dbg_clk[0] = tk0; host->dbg_clk[1] = tk1; host->dbg_clk[2] = tk2; host->dbg_clk[3] = tk3;
-    }
-  }
-}
-
+// first != 0: nothing to decide yet (state initialised by k_chunk_finalize_rows).
+// Sharded run (n_ranks > 0): `gathered` holds every rank's 8-double block {chi2_lin, max_diag, chi2_trial, scale, ok,
+// has_edges, -, -} (all-gathered on this stream); the decision adds them in rank order, so every rank decides alike.
+// first: 1 = state in `in` is initialised (single GPU), 2 = initialise it here from the gathered linearisation scalars.
 __device__ __forceinline__ double lm_readlane(double v, int src) {   // src: compile-time constant after unrolling
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
@@ -857,15 +660,15 @@ __device__ __forceinline__ bool lm_solve9_rows(const double* __restrict__ hb, do
   return ok;
 }
 
-// k_lm_step with the per-ellipsoid part on a WAVE per ellipsoid (round 2).  k_lm_step gathered the chunk partials of 16
-// ellipsoids with all 256 threads ((ellipsoid, entry) pairs, 3.4 us of scattered loads) and then solved on 16 lanes with the
-// whole 9x9 system in registers (254 VGPRs, 3.9 us).  Here lane k < 54 of the wave adds entry k over the ellipsoid's chunks
+// The per-ellipsoid part runs on a WAVE per ellipsoid.  (Round 1's form gathered the chunk partials of 16 ellipsoids with all
+// 256 threads -- (ellipsoid, entry) pairs, 3.4 us of scattered loads -- and then solved on 16 lanes with the whole 9x9 system
+// in registers: 254 VGPRs, 3.9 us.)  Here lane k < 54 of the wave adds entry k over the ellipsoid's chunks
 // (one coalesced 432-byte row per chunk, the rows of BOTH state pairs already in flight while the decision is taken), the
 // gravity prior is linearised uniformly by the wave, and the system is solved row-parallel on lanes 0..8 (lm_solve9_rows).
 constexpr int kStepWaves = 4;
-// k_chunk_finalize with one WAVE per ellipsoid (the device-driven run's form): the chunk rows are read as coalesced rows (lane =
-// entry, up to four rows in flight) instead of ten scattered entries per chunk by one thread.  Same outputs, same last-workgroup
-// reduction -- and the same 12.5 us (once per run): the ticket and the serial tail are what the time is, not the per-ellipsoid part.
+// First iteration: chi2 of the linearisation point and max |H_kk| (computeLambdaInit).  One WAVE per ellipsoid: the chunk rows
+// are read as coalesced rows (lane = entry, up to four rows in flight); the last workgroup reduces the per-workgroup partials in
+// fixed order.  12.5 us (once per run): the ticket and the serial tail are what the time is, not the per-ellipsoid part.
 static __global__ __launch_bounds__(64 * kStepWaves) void k_chunk_finalize_rows(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
                                                                                  const double* __restrict__ objs, int jac, double delta,
                                                                                  double* __restrict__ blk_part /* gridDim x 2 */,

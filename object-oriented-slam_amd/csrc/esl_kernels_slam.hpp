@@ -17,7 +17,7 @@
 //   k_slam_prepare     one wave per ellipsoid: Dinv = (Hoo+lambda I)^-1, Y_e = W_e Dinv, b_s -= Y_e b_o
 //   k_slam_schur_pull  one lane per block (c1, c2) of S: intersects the two cameras' edge lists, S[c1,c2] -= sum Y_e1 W_e2^T in
 //                      list order (deterministic); the row camera's Y blocks, list and ellipsoid bitmap are staged in LDS per
-//                      workgroup; k_slam_schur = round 1's scatter form with fp64 atomics (ESL_SCHUR_ATOMIC=1)
+//                      workgroup (round 1's scatter form with fp64 atomics was deleted in round 3)
 //   dense Cholesky     esl_chol.hpp (FP64 MFMA)
 //   k_slam_backsub     one wave per ellipsoid: x_o, retraction, trial states
 //   k_slam_cam_update  one lane per camera: retraction exp(x_c) * Tcw
@@ -297,9 +297,9 @@ static __global__ void k_slam_S_init(DevGraph g, const double* __restrict__ Hcc,
 // then Y_e = W_e Dinv for its free-camera edges and b_s[cam] -= Y_e b_o.  part[o*4+3] = pivots ok.
 static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
     DevGraph g, double lambda, const double* __restrict__ Hoo, const double* __restrict__ bo,
-    const double* __restrict__ W, double* __restrict__ Y, double* __restrict__ Dinv, double* __restrict__ S, long lda,
-    long n, double* __restrict__ part, double* __restrict__ Tb /* [6][EU] or null: atomics into the b_s row of S */,
-    double* __restrict__ Wt /* [EU][9][6] copy of W for k_slam_schur_pull, or null */) {
+    const double* __restrict__ W, double* __restrict__ Y, double* __restrict__ Dinv, double* __restrict__ part,
+    double* __restrict__ Tb /* [6][EU]: Y_e b_o, the edge's share of b_s */,
+    double* __restrict__ Wt /* [EU][9][6]: copy of W as per-edge records for k_slam_schur_pull */) {
   __shared__ double sD[kWavesPerBlock][81];
   __shared__ double sb[kWavesPerBlock][9];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -323,7 +323,6 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   for (int q = g.ue_start[o] + lane; q < g.ue_start[o + 1]; q += 64) {
     const long u = g.ue_id[q];
-    const int slot = g.ue_slot[q];
     if (u < g.n_bbox && !g.bb_valid[u]) continue;
     double t[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -331,10 +330,8 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
       double wrow[9];
 #pragma unroll
       for (int b = 0; b < 9; ++b) wrow[b] = W[(long)(a * 9 + b) * EU + u];
-      if (Wt) {
 #pragma unroll
-        for (int b = 0; b < 9; ++b) Wt[u * 54 + b * 6 + a] = wrow[b];
-      }
+      for (int b = 0; b < 9; ++b) Wt[u * 54 + b * 6 + a] = wrow[b];
 #pragma unroll
       for (int b = 0; b < 9; ++b) {
         double s = 0;
@@ -344,13 +341,8 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
         t[a] += s * sb[wv][b];
       }
     }
-    if (Tb) {
 #pragma unroll
-      for (int a = 0; a < 6; ++a) Tb[(long)a * EU + u] = t[a];
-    } else {
-#pragma unroll
-      for (int a = 0; a < 6; ++a) atomicAdd(&S[n + (long)(6 * slot + a) * lda], -t[a]);
-    }
+    for (int a = 0; a < 6; ++a) Tb[(long)a * EU + u] = t[a];
   }
 }
 
@@ -358,7 +350,8 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_prepare(
 // the two cameras' edge lists (both sorted by ellipsoid), and for every ellipsoid both cameras observe subtracts
 // Y_e1 W_e2^T over the edge pairs (e1 of camera sp, e2 of camera sq) in list order -- the sum the scatter form below builds
 // with fp64 atomics in whatever order the hardware serves them.  The diagonal lane (s, s) also folds its camera's share of
-// b_s (sum over its edges of Y_e b_o, stored per edge by k_slam_prepare).  grid.y = sp, grid.x * 64 + lane = sq.
+// b_s (sum over its edges of Y_e b_o, stored per edge by k_slam_prepare).  1-D grid: workgroup b = (row camera sp = b / groups,
+// column group gx = b % groups), sq = gx * 64 + lane.
 constexpr int kSchurYStride = 55;   // 54 doubles of one edge's Y block + 1 of padding (lanes read different edges: no bank conflicts)
 // dynamic LDS of the staged form: the row camera's Y blocks, its list (ellipsoid, edge id) and a bitmap of its ellipsoids
 inline size_t schur_pull_lds_bytes(int cu_max, int n_objs) {
@@ -374,10 +367,11 @@ inline size_t schur_pull_lds_bytes(int cu_max, int n_objs) {
   }
 template <bool YLDS>
 static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const double* __restrict__ Wt, const double* __restrict__ Y,
-                                                        const double* __restrict__ Tb, double* __restrict__ S, long lda, long n) {
+                                                        const double* __restrict__ Tb, double* __restrict__ S, long lda, long n, unsigned groups) {
   extern __shared__ double ysh[];   // YLDS: [edge of the row camera][kSchurYStride], then robj / rid / rbits
-  const int sp = blockIdx.y, sq = blockIdx.x * 64 + threadIdx.x;
-  if ((int)(blockIdx.x * 64) > sp) return;   // the whole workgroup lies right of the diagonal
+  const int sp = (int)(blockIdx.x / groups), gx = (int)(blockIdx.x - (unsigned)sp * groups);
+  const int sq = gx * 64 + (int)threadIdx.x;
+  if (gx * 64 > sp) return;   // the whole workgroup lies right of the diagonal
   const long EU = (long)g.n_bbox + g.n_e3d;
   const int i0 = g.cu_start[sp];
   int i = i0, j = (sq <= sp) ? g.cu_start[sq] : 0;
@@ -473,44 +467,6 @@ static __global__ __launch_bounds__(64) void k_slam_schur_pull(DevGraph g, const
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a) S[n + (long)(6 * sp + a) * lda] -= t[a];
-  }
-}
-
-// one workgroup per ellipsoid: all ordered pairs (p, q) of its free-camera edges with slot_p >= slot_q:
-// S[block(slot_p, slot_q)] -= Y_p W_q^T   (lower triangle; same-camera pairs hit the diagonal block twice,
-// once as (p,q) and once as (q,p), which is exactly the symmetric sum).
-static __global__ __launch_bounds__(256) void k_slam_schur(DevGraph g, const double* __restrict__ W,
-                                                    const double* __restrict__ Y, double* __restrict__ S, long lda) {
-  const int o = blockIdx.x;
-  const long EU = (long)g.n_bbox + g.n_e3d;
-  const int q0 = g.ue_start[o], m = g.ue_start[o + 1] - q0;
-  const long npairs = (long)m * m;
-  for (long idx = (long)blockIdx.y * blockDim.x + threadIdx.x; idx < npairs; idx += (long)gridDim.y * blockDim.x) {
-    const int p = (int)(idx / m), q = (int)(idx % m);
-    const int sp = g.ue_slot[q0 + p], sq = g.ue_slot[q0 + q];
-    if (sp < sq) continue;
-    const long up = g.ue_id[q0 + p], uq = g.ue_id[q0 + q];
-    if ((up < g.n_bbox && !g.bb_valid[up]) || (uq < g.n_bbox && !g.bb_valid[uq])) continue;
-    double yp[54];
-#pragma unroll
-    for (int k = 0; k < 54; ++k) yp[k] = Y[up * 54 + k];
-    double out[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) out[k] = 0;
-#pragma unroll
-    for (int b = 0; b < 9; ++b) {
-      double wq[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) wq[c] = W[(long)(c * 9 + b) * EU + uq];
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) out[a * 6 + c] += yp[a * 9 + b] * wq[c];
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) atomicAdd(&S[(long)(6 * sp + a) + (long)(6 * sq + c) * lda], -out[a * 6 + c]);
   }
 }
 

@@ -266,21 +266,48 @@ extern "C" void esl_plane_params_default(esl_plane_params* p) {
   p->min_inliers = 100;                                                           // PlaneExtractor.cpp:74
 }
 
+namespace esl {
+void plane_release(esl_ctx* c) {
+  if (c->plane_slab) (void)hipFree(c->plane_slab);
+  c->plane_slab = nullptr; c->plane_slab_cap = 0;
+}
+}  // namespace esl
+
 namespace {
-struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } };
+// every buffer of the plane step is a slice of ONE grow-only slab kept by the context (round 2 paid 33 MB of hipMalloc / hipFree
+// per call): depth u16, normal + offset 4 x f32, union-find parent i32, per-root count i32 and nine i64 moments, results, and
+// (esl_extract_planes) the root -> plane map, the plane list and the label image
+struct Buf { void* p = nullptr; };
 struct PlaneWork { Buf depth, nrm, par, cnt, mom, out, map, list, labels; };
+int plane_reserve(esl_ctx* c, size_t npx, int max_planes, PlaneWork& w) {
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t sz[9] = {al(npx * 2), al(npx * 16), al(npx * 4), al(npx * 4), al(npx * 72), al(8 * sizeof(double)), al(npx * 4),
+                        al((size_t)std::max(max_planes, 1) * 5 * sizeof(double)), al(npx * 4)};
+  size_t need = 0;
+  for (size_t v : sz) need += v;
+  if (need > c->plane_slab_cap) {
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->plane_slab) (void)hipFree(c->plane_slab);
+    c->plane_slab = nullptr; c->plane_slab_cap = 0;
+    ESL_HIP_TRY(hipMalloc((void**)&c->plane_slab, need));
+    c->plane_slab_cap = need;
+  }
+  Buf* b[9] = {&w.depth, &w.nrm, &w.par, &w.cnt, &w.mom, &w.out, &w.map, &w.list, &w.labels};
+  size_t off = 0;
+  for (int k = 0; k < 9; ++k) { b[k]->p = c->plane_slab + off; off += sz[k]; }
+  return ESL_OK;
+}
 
 // normals -> segments -> moments on the context's stream; fills `a`
 int plane_segment(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5], const esl_plane_params* p,
-                  PlaneWork& w, PlaneArgs& a, const char* who) {
+                  PlaneWork& w, PlaneArgs& a, const char* who, int max_planes = 1) {
   if (!c || !depth || !intr || !p || width <= 0 || height <= 0) { set_error(std::string(who) + ": bad argument"); return ESL_ERR_INVALID; }
   if (p->normal_smoothing < 2 || p->distance_threshold <= 0 || p->angle_threshold_deg <= 0 || p->max_depth_change_factor <= 0) {
     set_error(std::string(who) + ": bad parameters"); return ESL_ERR_INVALID;
   }
   ESL_HIP_TRY(hipSetDevice(c->device));
   const size_t npx = (size_t)width * height;
-  ESL_HIP_TRY(hipMalloc(&w.depth.p, npx * 2)); ESL_HIP_TRY(hipMalloc(&w.nrm.p, npx * 16)); ESL_HIP_TRY(hipMalloc(&w.par.p, npx * 4));
-  ESL_HIP_TRY(hipMalloc(&w.cnt.p, npx * 4)); ESL_HIP_TRY(hipMalloc(&w.mom.p, npx * 72)); ESL_HIP_TRY(hipMalloc(&w.out.p, 8 * sizeof(double)));
+  if (const int rc = plane_reserve(c, npx, max_planes, w)) return rc;
   ESL_HIP_TRY(hipMemcpyAsync(w.depth.p, depth, npx * 2, hipMemcpyHostToDevice, c->stream));
   a = PlaneArgs{};
   a.depth = (const uint16_t*)w.depth.p; a.w = width; a.h = height;
@@ -326,14 +353,11 @@ extern "C" int esl_extract_planes(esl_ctx* c, const uint16_t* depth, int32_t wid
   *n_planes = 0;
   PlaneWork w;
   PlaneArgs a;
-  if (const int rc = plane_segment(c, depth, width, height, intr, p, w, a, "esl_extract_planes")) return rc;
+  if (const int rc = plane_segment(c, depth, width, height, intr, p, w, a, "esl_extract_planes", max_planes)) return rc;
   const size_t npx = (size_t)width * height;
-  ESL_HIP_TRY(hipMalloc(&w.map.p, npx * 4));
-  ESL_HIP_TRY(hipMalloc(&w.list.p, (size_t)std::max(max_planes, 1) * 5 * sizeof(double)));
   a.plane_of_root = (int*)w.map.p; a.list = (double*)w.list.p; a.list_cap = max_planes;
   hipLaunchKernelGGL(k_plane_list, dim3(1), dim3(256), 0, c->stream, a);
   if (labels_out) {
-    ESL_HIP_TRY(hipMalloc(&w.labels.p, npx * 4));
     a.labels = (int*)w.labels.p;
     hipLaunchKernelGGL(k_plane_labels, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, a);
   }

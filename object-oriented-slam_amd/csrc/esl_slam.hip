@@ -103,8 +103,19 @@ int slam_alloc(esl_ctx* c) {
 // a broadcast per panel only adds to it); ESL_CHOL_DIST=1 / 0 forces it on / off.
 static bool slam_dist_chol(esl_ctx* c) {
   if (!c->comm || c->comm_ranks < 2) return false;
-  if (const char* e = getenv("ESL_CHOL_DIST")) return e[0] == '1';
+  if (c->sw_chol_dist >= 0) return c->sw_chol_dist == 1;   // ESL_CHOL_DIST as read when the communicator was created
   return c->S_n >= 8192;
+}
+static CholRuntime& chol_rt(esl_ctx* c) {
+  if (!c->chol_rt) c->chol_rt = new CholRuntime();
+  return *(CholRuntime*)c->chol_rt;
+}
+void slam_release_runtime(esl_ctx* c) {
+  if (!c->chol_rt) return;
+  ((CholRuntime*)c->chol_rt)->release();
+  delete (CholRuntime*)c->chol_rt;
+  c->chol_rt = nullptr;
+  c->schur_attr_set = false;
 }
 
 static int reduce_all(esl_ctx* c) {
@@ -151,7 +162,7 @@ int slam_linearize(esl_ctx* c) {
   return reduce_all(c);
 }
 
-int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out) {
+int slam_build_reduced(esl_ctx* c, double lambda, bool full_sum, void** dev_ptr, int64_t* n_out) {
   const DevGraph& g = c->g;
   const int N = g.n_objs;
   const long n = (long)c->S_n, lda = (long)c->S_lda;
@@ -163,27 +174,25 @@ int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out
                        lda, n);
     if (N > 0) {
       const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-      // ESL_SCHUR_ATOMIC=1: round 1's scatter form (fp64 atomics into S, summation order left to the hardware) for A/B runs
-      const bool atomic_form = getenv("ESL_SCHUR_ATOMIC") != nullptr || g.n_free_cams > 65535;   // grid.y limit of the pull form
-      hipLaunchKernelGGL(k_slam_prepare, grid, block, 0, c->stream, g, lambda, c->Hoo, c->bo, c->Wbb, c->Yb, c->Dinv, c->S, lda,
-                         n, c->obj_part, atomic_form ? nullptr : c->Tb, atomic_form ? nullptr : c->Wt);
-      if (atomic_form) hipLaunchKernelGGL(k_slam_schur, dim3(N, 8), dim3(256), 0, c->stream, g, c->Wbb, c->Yb, c->S, lda);
-      else if (g.n_free_cams > 0) {
-        // the row camera's Y blocks (54 doubles per edge, padded to 55), its list and its ellipsoid bitmap go through LDS when they fit 64 KB
+      hipLaunchKernelGGL(k_slam_prepare, grid, block, 0, c->stream, g, lambda, c->Hoo, c->bo, c->Wbb, c->Yb, c->Dinv, c->obj_part, c->Tb,
+                         c->Wt);
+      if (g.n_free_cams > 0) {
+        // the row camera's Y blocks (54 doubles per edge, padded to 55), its list and its ellipsoid bitmap go through LDS when they
+        // fit 64 KB; one workgroup per (row camera, group of 64 column cameras) on a 1-D grid (grid.y would cap the cameras at 65,535)
         const size_t ylds = schur_pull_lds_bytes(g.cu_max, g.n_objs);
-        const dim3 sgrid((g.n_free_cams + 63) / 64, g.n_free_cams);
-        if (ylds <= 65536 && !getenv("ESL_SCHUR_NO_LDS")) {
-          static bool attr = false;
-          if (!attr) { ESL_HIP_TRY(hipFuncSetAttribute((const void*)k_slam_schur_pull<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
-          hipLaunchKernelGGL(k_slam_schur_pull<true>, sgrid, dim3(64), ylds, c->stream, g, c->Wt, c->Yb, c->Tb, c->S, lda, n);
+        const unsigned groups = (unsigned)((g.n_free_cams + 63) / 64);
+        const dim3 sgrid(groups * (unsigned)g.n_free_cams);
+        if (ylds <= 65536) {
+          if (!c->schur_attr_set) { ESL_HIP_TRY(hipFuncSetAttribute((const void*)k_slam_schur_pull<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); c->schur_attr_set = true; }
+          hipLaunchKernelGGL(k_slam_schur_pull<true>, sgrid, dim3(64), ylds, c->stream, g, c->Wt, c->Yb, c->Tb, c->S, lda, n, groups);
         } else {
-          hipLaunchKernelGGL(k_slam_schur_pull<false>, sgrid, dim3(64), 0, c->stream, g, c->Wt, c->Yb, c->Tb, c->S, lda, n);
+          hipLaunchKernelGGL(k_slam_schur_pull<false>, sgrid, dim3(64), 0, c->stream, g, c->Wt, c->Yb, c->Tb, c->S, lda, n, groups);
         }
       }
     }
   }
   ESL_HIP_TRY(hipGetLastError());
-  if (c->comm && !dev_ptr && slam_dist_chol(c)) {
+  if (c->comm && !full_sum && slam_dist_chol(c)) {
     // distributed factorisation: every outer panel of the summed system goes to its owner only (ncclReduce per panel)
     ProfScope ps(c, 6);
     const int W = chol_outer_panels((int)n), np = (int)((n + kNB - 1) / kNB), n_outer = (np + W - 1) / W;
@@ -206,7 +215,7 @@ int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n_out
 int slam_try_step(esl_ctx* c, double lambda) {
   const DevGraph& g = c->g;
   const int N = g.n_objs, F = g.n_cams;
-  int rc = slam_build_reduced(c, lambda, nullptr, nullptr);
+  int rc = slam_build_reduced(c, lambda, false, nullptr, nullptr);
   if (rc) return rc;
   {
     ProfScope ps(c, 3);
@@ -215,9 +224,9 @@ int slam_try_step(esl_ctx* c, double lambda) {
       CholDist d;
       d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
       d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
-      ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, &d));
+      ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, chol_rt(c), &d));
     } else {
-      ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream));
+      ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, chol_rt(c)));
     }
   }
   {
@@ -293,7 +302,9 @@ extern "C" int esl_lm_reduced_residual(esl_ctx* c, double* rel_residual_out) {
   if (!c->lm.begun || !c->lm.slam || !c->xc || c->S_n <= 0) { set_error("esl_lm_reduced_residual: needs a SLAM-mode trial step"); return ESL_ERR_STATE; }
   ESL_HIP_TRY(hipSetDevice(c->device));
   const long n = (long)c->S_n, lda = (long)c->S_lda;
-  int rc = slam_build_reduced(c, c->lm.lambda_used, nullptr, nullptr);   // the factorisation overwrote S and b_s
+  // the factorisation overwrote S and b_s; full_sum: in a sharded run EVERY rank needs the summed system here (the per-panel
+  // reduce of the distributed factorisation would leave unsummed partials outside a rank's own panels)
+  int rc = slam_build_reduced(c, c->lm.lambda_used, true, nullptr, nullptr);
   if (rc) return rc;
   double* y = nullptr;
   ESL_HIP_TRY(hipMalloc((void**)&y, ((size_t)n + 2) * sizeof(double)));
@@ -377,7 +388,7 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
   ST_TRY(hipMemsetAsync(info, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(k_selftest_fill, dim3((unsigned)((n + 1 + 255) / 256), (unsigned)n), dim3(256), 0, c->stream, M, lda, (long)n);
   ST_TRY(hipEventRecord(e0, c->stream));
-  ST_TRY(chol_factor_solve(M, lda, n, Linv, z, x, info, c->stream));
+  ST_TRY(chol_factor_solve(M, lda, n, Linv, z, x, info, c->stream, chol_rt(c)));
   ST_TRY(hipEventRecord(e1, c->stream));
   hipLaunchKernelGGL(k_selftest_resid, dim3((unsigned)n), dim3(256), 0, c->stream, x, (long)n, out2);
   double h2[2] = {0, 0};
@@ -391,8 +402,8 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
   if (std::getenv("ESL_CHOL_TIMING")) {
     long long clk[16];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_potrf_clk), sizeof(clk)) == hipSuccess) {
-      static const char* names[9] = {"load", "factor32[0]", "subpanel[0]", "rank32[0]", "steps 1-3", "trtri x4", "store L", "inverse", "store Linv"};
-      fprintf(stderr, "[k_chol_potrf, last launch, us]");
+      static const char* names[9] = {"load", "rank-4 steps", "-", "-", "-", "store L", "-", "inverse", "store Linv"};
+      fprintf(stderr, "[k_chol_potrf2, last launch, us]");
       for (int k = 0; k < 9; ++k) fprintf(stderr, " %s=%.1f", names[k], (double)(clk[k + 1] - clk[k]) * 0.01);
       fprintf(stderr, "\n");
     }

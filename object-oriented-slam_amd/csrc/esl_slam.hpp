@@ -5,6 +5,10 @@
 namespace esl {
 int slam_alloc(esl_ctx* c);
 int slam_linearize(esl_ctx* c);
-int slam_build_reduced(esl_ctx* c, double lambda, void** dev_ptr, int64_t* n);
+// full_sum (sharded runs): true = every rank ends up with the SUM of the shards' partial systems (all-reduce: callers that read
+// S itself -- esl_lm_reduced_system, the residual diagnostic); false = the form the factorisation that follows wants (per-panel
+// reduce to the panel's owner when the distributed factorisation is on, else the all-reduce)
+int slam_build_reduced(esl_ctx* c, double lambda, bool full_sum, void** dev_ptr, int64_t* n);
 int slam_try_step(esl_ctx* c, double lambda);
+void slam_release_runtime(esl_ctx* c);   // the context's CholRuntime (esl_ctx_destroy)
 }  // namespace esl

@@ -142,6 +142,15 @@ def test_gpu_fit_c2_shape_50k_points(po, ctx, pkg):
     o = po.fit_frame(sc["depth"], [b], [28], sc["Twc"], sc["intr"], sc["ground"], Po)
     assert 45000 < o[3][0][0] < 56000
     _cmp(po, *g, *o, 1e-7)
+    # and with the reference's 5-iteration symmetry LM on (delta = 1e-9 differences: the LM's own noise floor) --
+    # the configuration bench.py times
+    Pg5 = pkg.lib.default_fit_params(stride=1); Po5 = po.default_fit_params(stride=1)
+    assert Pg5.symmetry_lm_iters == 5
+    g5 = ctx.fit_frame(sc["depth"], [b], [28], sc["Twc"], sc["intr"], sc["ground"], Pg5)
+    o5 = po.fit_frame(sc["depth"], [b], [28], sc["Twc"], sc["intr"], sc["ground"], Po5)
+    print("C2 fit with the symmetry LM on: rel_q %.2e, scales %.2e, prob %.2e" % (rel_q(po, g5[0][0], o5[0][0]), np.abs(g5[0][0][7:] - o5[0][0][7:]).max(),
+                                                                                 abs(g5[1][0] - o5[1][0])))
+    _cmp(po, *g5, *o5, 2e-5)
 
 
 @pytest.mark.gpu

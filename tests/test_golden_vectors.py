@@ -47,16 +47,24 @@ def test_oracle_reproduces_golden_lm_runs(po, pkg, seed, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1, 2])
-@pytest.mark.parametrize("mode,jac", [("map", 0), ("map", 1), ("slam", 1)])
+@pytest.mark.parametrize("mode,jac", [("map", 0), ("map", 1), ("slam", 0), ("slam", 1)])
 def test_gpu_lands_on_golden_lm_results(ctx, pkg, seed, mode, jac):
+    """The committed LM runs (faithful dense checker, numeric Jacobians at delta = 1e-6).  jac = 0 is like for like (the same
+    differences on the GPU): objective 1e-6, states 1e-5.  jac = 1 (analytic) differs from the fixture by the truncation error
+    of its central differences (~1e-7 relative in J), amplified by these tiny, poorly conditioned graphs (3..14 observations
+    per ellipsoid): the north-star 1e-4 on the objective, states 1e-3."""
     G = np.load(GOLD)
     g, c, o, _ = pkg.synth.make_graph(20, 5, 80, seed=seed, slam=(mode == "slam"))
     cg, og, rep = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6))
     tag = f"lm_{seed}_{mode}"
     chi = G[tag + "_chi2"]
     n = min(len(chi), len(rep["trace_chi2"]))
-    # tiny graphs (3..14 observations per ellipsoid) are poorly conditioned: compare the objective, and the states loosely
-    np.testing.assert_allclose(rep["trace_chi2"][:2], chi[:2], rtol=1e-3)
-    assert rep["chi2_final"] == pytest.approx(chi[-1], rel=2e-3)
-    if mode == "map":
-        np.testing.assert_allclose(og[:, :3], G[tag + "_objs"][:, :3], atol=5e-3)
+    d_chi = float(np.abs(np.array(rep["trace_chi2"][:n]) / chi[:n] - 1).max())
+    d_obj = float(np.abs(og - G[tag + "_objs"]).max())
+    d_cam = float(np.abs(cg - G[tag + "_cams"]).max())
+    print("golden %s jac %d: chi2 trace rel %.2e (n %d of %d), objs %.2e, cams %.2e" % (tag, jac, d_chi, n, len(chi), d_obj, d_cam))
+    t_chi, t_state = (1e-6, 1e-5) if jac == 0 else (1e-4, 1e-3)
+    assert rep["trace_trials"][:n] == list(G[tag + "_trials"])[:n]
+    assert d_chi < t_chi
+    assert rep["chi2_final"] == pytest.approx(chi[-1], rel=t_chi)
+    assert d_obj < t_state and d_cam < t_state

@@ -208,25 +208,24 @@ def _fused_cases(pkg):
 
 @pytest.mark.parametrize("case", ["plain", "one_iteration", "one_trial_per_iteration", "no_nan_precheck", "gravity_only", "inactive_vertex",
                                   "some_nan_edges", "one_ellipsoid_many_items", "C3"])
-def test_row_parallel_step_equals_round1_step(pkg, ctx, monkeypatch, case):
-    """k_lm_step_rows (a wave per ellipsoid: coalesced gather of the chunk rows, row-parallel 9x9 LDL^T on lanes 0..8) against
-    the step kernel it replaced (k_lm_step: one lane per ellipsoid, left-looking LDL^T in registers; forced with
-    ESL_LM_STEP_OLD=1).  Same sums in the same order, same LM control; the two factorisations round differently ->
-    identical accept / reject sequence, chi2 trace to 1e-9, states to 1e-8."""
+def test_device_driven_step_edge_cases_match_the_checker(pkg, po, ctx, case):
+    """k_lm_step_rows (a wave per ellipsoid: coalesced gather of the chunk rows, row-parallel 9x9 LDL^T on lanes 0..8) on the edge
+    cases of the LM control and of the graph shape, like for like against the checker (numeric Jacobians at delta = 1e-6 on both
+    sides): identical accept / reject sequence and counts, chi2 trace to 1e-6, states to 1e-6.  (Round 2 held this kernel to the
+    round-1 step kernel, which was deleted in round 3.)"""
     g, c, o, kw = _fused_cases(pkg)[case]
-    p = pkg.default_lm_params(jacobian_mode=1, **kw)
-    monkeypatch.setenv("ESL_LM_STEP_OLD", "1")
-    _, o_ref, r_ref = ctx.optimize(g, c, o, p)
-    monkeypatch.delenv("ESL_LM_STEP_OLD")
+    p = pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, **kw)
+    _, o_ref, r_ref = po.optimize(g, c, o, p, solver=po.ORACLE_BLOCK)
     _, o_fz, r_fz = ctx.optimize(g, c, o, p)
     for k in ("iterations", "total_trials", "stop_reason", "n_bbox_valid", "n_bbox_dropped", "trace_trials"):
         assert r_fz[k] == r_ref[k], (k, r_fz[k], r_ref[k])
     if case == "some_nan_edges":
         assert r_fz["n_bbox_dropped"] >= 1
     assert r_fz["chi2_initial"] == pytest.approx(r_ref["chi2_initial"], rel=1e-12)
-    np.testing.assert_allclose(r_fz["trace_chi2"], r_ref["trace_chi2"], rtol=1e-9)
-    np.testing.assert_allclose(r_fz["trace_lambda"], r_ref["trace_lambda"], rtol=1e-7)
-    np.testing.assert_allclose(o_fz, o_ref, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(r_fz["trace_chi2"], r_ref["trace_chi2"], rtol=1e-6)
+    np.testing.assert_allclose(r_fz["trace_lambda"], r_ref["trace_lambda"], rtol=1e-4)
+    print("case %s: max |GPU - checker| = %.2e" % (case, float(np.abs(o_fz - o_ref).max())))
+    np.testing.assert_allclose(o_fz, o_ref, rtol=0, atol=1e-6)
     if case == "inactive_vertex":
         np.testing.assert_array_equal(o_fz[3], o[3])
     # a second run on the same context reproduces the first bit for bit (fixed-order reductions)
@@ -234,6 +233,6 @@ def test_row_parallel_step_equals_round1_step(pkg, ctx, monkeypatch, case):
     assert np.array_equal(o_fz2, o_fz) and r_fz2["trace_chi2"] == r_fz["trace_chi2"]
     if kw.get("max_iters", 10) == 10 and case != "gravity_only":
         # max_iters = 0: the start state is reported, nothing moves
-        _, o0, r0 = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1, max_iters=0, **{k: v for k, v in kw.items() if k != "max_iters"}))
+        _, o0, r0 = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, max_iters=0, **{k: v for k, v in kw.items() if k != "max_iters"}))
         assert r0["iterations"] == 0 and r0["chi2_initial"] == pytest.approx(r_ref["chi2_initial"], rel=1e-12)
         np.testing.assert_array_equal(o0, o)

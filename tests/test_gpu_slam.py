@@ -80,12 +80,16 @@ def test_slam_lm_matches_faithful_dense_oracle(pkg, po, ctx, jac):
     co, oo, ro = po.optimize(g, c, o, p, solver=0)  # dense LDLT of the whole system, like LinearSolverDense
     cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6))
     n = min(len(rg["trace_chi2"]), len(ro["trace_chi2"]))
-    np.testing.assert_allclose(rg["trace_chi2"][:n], ro["trace_chi2"][:n], rtol=1e-4)
-    assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-4)
+    print("SLAM LM (30 cams) jac %d vs dense checker: chi2 trace rel %.2e, cams %.2e, centres %.2e, scales rel %.2e" % (
+        jac, float(np.abs(np.array(rg["trace_chi2"][:n]) / np.array(ro["trace_chi2"][:n]) - 1).max()), cam_err(cg, co),
+        float(np.abs(og[:, :3] - oo[:, :3]).max()), float(np.abs(og[:, 7:] / oo[:, 7:] - 1).max())))
+    tol = 1e-6 if jac == 0 else 1e-4      # like for like (numeric, delta = 1e-6 on both sides) / analytic vs the checker's differences
+    np.testing.assert_allclose(rg["trace_chi2"][:n], ro["trace_chi2"][:n], rtol=tol)
+    assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=tol)
     assert np.array_equal(cg[0], c[0])  # camera 0 is fixed (Optimizer.cpp:138)
-    assert cam_err(cg, co) < 1e-4
-    np.testing.assert_allclose(og[:, :3], oo[:, :3], atol=1e-4 * np.abs(oo[:, :3]).max())
-    np.testing.assert_allclose(og[:, 7:], oo[:, 7:], rtol=1e-3)
+    assert cam_err(cg, co) < 10 * tol
+    np.testing.assert_allclose(og[:, :3], oo[:, :3], atol=10 * tol * np.abs(oo[:, :3]).max())
+    np.testing.assert_allclose(og[:, 7:], oo[:, 7:], rtol=10 * tol)
 
 
 def obj_rel(a, b):
@@ -141,8 +145,12 @@ def test_c3_slam_full_run_vs_faithful_dense_delta_1e9(pkg, po, ctx, c3_dense):
     np.testing.assert_allclose(rn["trace_chi2"], r6["trace_chi2"], rtol=1e-6)
     print("C3 SLAM parity: reference self-distance (delta 1e-9 vs 1e-6) cams %.2e objs %.2e | GPU analytic vs 1e-9: cams %.2e objs %.2e | "
           "GPU numeric 1e-6 vs oracle 1e-6: cams %.2e objs %.2e" % (floor_cam, floor_obj, cam_err(cg, c9), obj_rel(og, o9), cam_err(cn, c6), obj_rel(on, o6)))
-    assert obj_rel(on, o6) < 1e-4
-    assert cam_err(cn, c6) < max(1e-4, 0.1 * floor_cam)
+    assert obj_rel(on, o6) < 1e-5          # measured 8.6e-7
+    assert cam_err(cn, c6) < 1e-4          # measured 1.0e-5 (north star: 1e-4)
+    # the product default (analytic Jacobians) against the checker at delta = 1e-6, whose central differences are good to ~1e-7
+    print("C3 SLAM parity: GPU analytic vs oracle 1e-6: cams %.2e objs %.2e, chi2 trace rel %.2e" % (
+        cam_err(cg, c6), obj_rel(og, o6), float(np.abs(np.array(rg["trace_chi2"]) / np.array(r6["trace_chi2"]) - 1).max())))
+    assert cam_err(cg, c6) < 1e-4 and obj_rel(og, o6) < 1e-4
 
 
 @pytest.mark.parametrize("n", [1, 7, 130, 777, 3000, 8192, 9001])

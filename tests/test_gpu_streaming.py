@@ -84,6 +84,7 @@ def test_streaming_sequence_append_equals_rebuild_and_checker(pkg, po, ctx):
             assert r_gpu["chi2_final"] == pytest.approx(r_orc["chi2_final"], rel=1e-4), f
             assert r_gpu["n_bbox_valid"] == r_orc["n_bbox_valid"]
             err = group_rel_err(o_gpu, o_orc)
+            print("streaming frame %d: GPU vs checker chi2 rel %.2e, states %.2e" % (f, abs(r_gpu["chi2_final"] / r_orc["chi2_final"] - 1), err))
             if err >= 1e-4:
                 # the two runs left a kink on different sides.  What must still hold: the checker computes the SAME chi2 at the
                 # state the GPU ended in (residual arithmetic agrees to 1e-9), and three more iterations of the checker from there gain
