@@ -408,7 +408,8 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 constexpr int kKC = 16;
 template <int BM, int BN, int WM = 4, int WN = 2>
 static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
-                                                                           int kcol0, int K, long base, int ntJ, int rect) {
+                                                                           int kcol0, int K, long base, int ntJ, int rect,
+                                                                           const double* __restrict__ Pext, long ldp) {
   static_assert((BM == 2 * BN || BM == BN) && BM % 64 == 0, "tile shape");
   constexpr int NT = 64 * WM * WN;                // threads per workgroup
   constexpr int RT = BM / BN;                     // tile row ti of the lower triangle holds RT (ti + 1) tiles
@@ -436,7 +437,10 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
   if (i0 >= rows || j0 >= ncols) return;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int wi = wave / WN, wj = wave % WN;
-  const double* P = M + (long)kcol0 * lda;
+  // the rank-K factor: columns [kcol0, kcol0 + K) of M itself (Cholesky trailing update), or an external (rows x K) column-major
+  // matrix Pext with leading dimension ldp (C -= Pext Pext^T: the reduced ellipsoid system of the camera-first elimination, esl_cf.hpp)
+  const double* P = Pext ? Pext : M + (long)kcol0 * lda;
+  if (!Pext) ldp = lda;
   // global -> register staging: A chunk = BM x 16 doubles, B chunk = BN x 16 doubles, as double2
   typedef double double2_t __attribute__((ext_vector_type(2)));
   double2_t ra[QA], rb[QB];
@@ -448,7 +452,7 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
       const bool kv = (kc + k) < K;
       // edge tiles: clamped addresses + selects, no branches (a branchy load per element made the edge workgroups the stragglers)
       const long kcl = kv ? (long)(kc + k) : (long)(K - 1);
-      const double v0 = P[(row < rows ? row : rows - 1) + kcl * lda], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * lda];
+      const double v0 = P[(row < rows ? row : rows - 1) + kcl * ldp], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * ldp];
       ra[q] = double2_t{(kv && row < rows) ? v0 : 0.0, (kv && row + 1 < rows) ? v1 : 0.0};
     }
 #pragma unroll
@@ -457,7 +461,7 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
       const long row = j0 + 2 * pr;
       const bool kv = (kc + k) < K;
       const long kcl = kv ? (long)(kc + k) : (long)(K - 1);
-      const double v0 = P[(row < rows ? row : rows - 1) + kcl * lda], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * lda];
+      const double v0 = P[(row < rows ? row : rows - 1) + kcl * ldp], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * ldp];
       rb[q] = double2_t{(kv && row < rows) ? v0 : 0.0, (kv && row + 1 < rows) ? v1 : 0.0};
     }
   };
@@ -486,14 +490,14 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
   const double* pA[QA];
   const double* pB[QB];
 #pragma unroll
-  for (int q = 0; q < QA; ++q) { const int e = t + NT * q; pA[q] = P + i0 + 2 * (e % (BM / 2)) + (long)(e / (BM / 2)) * lda; }
+  for (int q = 0; q < QA; ++q) { const int e = t + NT * q; pA[q] = P + i0 + 2 * (e % (BM / 2)) + (long)(e / (BM / 2)) * ldp; }
 #pragma unroll
-  for (int q = 0; q < QB; ++q) { const int e = t + NT * q; pB[q] = P + j0 + 2 * (e % (BN / 2)) + (long)(e / (BN / 2)) * lda; }
+  for (int q = 0; q < QB; ++q) { const int e = t + NT * q; pB[q] = P + j0 + 2 * (e % (BN / 2)) + (long)(e / (BN / 2)) * ldp; }
   auto gload_fast = [&](int kc) {
 #pragma unroll
-    for (int q = 0; q < QA; ++q) ra[q] = *reinterpret_cast<const double2_t*>(pA[q] + (long)kc * lda);
+    for (int q = 0; q < QA; ++q) ra[q] = *reinterpret_cast<const double2_t*>(pA[q] + (long)kc * ldp);
 #pragma unroll
-    for (int q = 0; q < QB; ++q) rb[q] = *reinterpret_cast<const double2_t*>(pB[q] + (long)kc * lda);
+    for (int q = 0; q < QB; ++q) rb[q] = *reinterpret_cast<const double2_t*>(pB[q] + (long)kc * ldp);
   };
   auto mainloop = [&](auto fast) {
     if constexpr (decltype(fast)::value) gload_fast(0); else gload(0);
@@ -615,6 +619,31 @@ struct CholDist {
 };
 inline int chol_outer_panels(int n) { return (n >= 8192) ? 4 : 2; }   // inner 128-panels per outer panel
 
+// C[base.., base..col_limit) -= P P^T on the lower triangle of the (rows x *) matrix M; P = columns [kcol0, kcol0 + K) of M, or
+// Pext (rows x K, leading dimension ldp) when given.  Needs chol_set_attributes() on the current device first.
+constexpr size_t kCholLdsBig = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
+constexpr size_t kCholLdsSmall = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
+inline void chol_launch_update(double* M, long lda, long rows, hipStream_t stream, int kcol0, int K, long base, long col_limit,
+                               const double* Pext = nullptr, long ldp = 0) {
+  // trailing region: rows [base, rows), cols [base, col_limit)
+  const long nrows = rows - base, nc = col_limit - base;
+  if (nrows <= 0 || nc <= 0) return;
+  // the big tile only when it still gives every CU a few workgroups
+  const bool whole = (nc >= nrows - 1);
+  const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (whole ? 2 : 1);
+  if (big_tiles >= 1024) {   // (square 128 x 128 tiles, two workgroups per CU, measured at n = 32,768: 238.7 vs 231.6 ms -- dropped)
+    const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
+    const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
+    hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), kCholLdsBig, stream, M, lda, rows, col_limit, kcol0, K,
+                       base, (int)ntJ, whole ? 0 : 1, Pext, ldp);
+  } else {
+    const long ntI = (nrows + 127) / 128, ntJ = (nc + 63) / 64;
+    const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;
+    hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), kCholLdsSmall, stream, M, lda, rows, col_limit, kcol0, K,
+                       base, (int)ntJ, whole ? 0 : 1, Pext, ldp);
+  }
+}
+
 // Per-context state of the host driver: the look-ahead stream and its events live on the CONTEXT's device and are used by one
 // context only (two contexts sharing them could wait on each other's records), and hipFuncSetAttribute is per device.
 struct CholRuntime {
@@ -630,6 +659,17 @@ struct CholRuntime {
   }
 };
 
+inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits of the two big kernels, once per context (= per device)
+  if (rt.attr_set) return hipSuccess;
+  const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBig);
+  if (e != hipSuccess) return e;
+  rt.attr_set = true;
+  return hipSuccess;
+}
+
 // Host driver.  M: (n+1) x n col-major (lda), Linv_ws: ceil(n/NB) * NB*NB doubles, z_ws: NB doubles,
 // x: n doubles (output), info: device int (bit 0 set on a non-positive pivot).  The current device must be the one `rt` and
 // `st` belong to.
@@ -638,33 +678,9 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   const long rows = (long)n + 1;
   const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
   int np = (n + kNB - 1) / kNB;
-  constexpr size_t lds_big = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
-  constexpr size_t lds_small = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
-  if (!rt.attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
-    if (e != hipSuccess) return e;
-    rt.attr_set = true;
-  }
+  { hipError_t e = chol_set_attributes(rt); if (e != hipSuccess) return e; }
   auto launch_update = [&](hipStream_t stream, int kcol0, int K, long base, long col_limit) {
-    // trailing region: rows [base, rows), cols [base, col_limit)
-    const long nrows = rows - base, nc = col_limit - base;
-    if (nrows <= 0 || nc <= 0) return;
-    // the big tile only when it still gives every CU a few workgroups
-    const bool whole = (nc >= nrows - 1);
-    const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (whole ? 2 : 1);
-    if (big_tiles >= 1024) {   // (square 128 x 128 tiles, two workgroups per CU, measured at n = 32,768: 238.7 vs 231.6 ms -- dropped)
-      const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
-      const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
-      hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), lds_big, stream, M, lda, rows, col_limit, kcol0, K,
-                         base, (int)ntJ, whole ? 0 : 1);
-    } else {
-      const long ntI = (nrows + 127) / 128, ntJ = (nc + 63) / 64;
-      const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;
-      hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), lds_small, stream, M, lda, rows, col_limit, kcol0, K,
-                         base, (int)ntJ, whole ? 0 : 1);
-    }
+    chol_launch_update(M, lda, rows, stream, kcol0, K, base, col_limit);
   };
   // Outer panels of W inner panels (W x 128 columns): the inner panels are factored one after the other on the caller's
   // stream, each followed by a rank-128 update of the rest of the outer panel; the trailing matrix then gets ONE rank-(W x 128)

