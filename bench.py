@@ -5,8 +5,11 @@ One "step" = one Optimizer::GlobalObjectGraphOptimization-equivalent call (up to
 reference Optimizer.cpp:291) over one device-resident synthetic graph of the BASELINE.json
 configs[3] shape (10k cams / 2k ellipsoids / ~200k bbox edges, SURVEY.md §8 d), restarted from the
 same initial estimate every step (device-side state restore, no PCIe in the timed region).
+Default = configs[3] AS NAMED: SLAM mode (free cameras, camera 0 fixed, odometry edges: the reference's bSLAM_mode
+branch) with the Schur solve; `--mode mapping` times the reference's shipped setting (all cameras fixed), which the
+default line carries as the `mapping` record.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode mapping|slam] [--config C4|C3]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode slam|mapping] [--config C4|C3] [--solver auto|camera|ellipsoid]
 
 N > 1 is launched by the driver through torch.distributed.run, one rank per GPU (RCCL).  The path
 shards by ellipsoid (SURVEY.md §8 e): the ellipsoids of the ONE named graph are partitioned over the ranks
@@ -14,9 +17,10 @@ shards by ellipsoid (SURVEY.md §8 e): the ellipsoids of the ONE named graph are
 trial, in SLAM mode additionally the all-reduce of the camera blocks and of the reduced camera system.
 value = LM iterations of that one global optimisation / max-over-ranks wall time.
 
-The default single-GPU line also carries: `repeat_blocks` (the K-step block repeated 10 times: median / min / max),
-`slam` (the Schur half of the metric: C3 and C4 with free cameras, FP64-MFMA roofline, CPU baseline), `fit`
-(per-frame ellipsoid fit with its own roofline record), `streaming_c5`, `cpu_baseline` and `host`.
+The default single-GPU line also carries: `slam_reduced_camera` (the same C4 steps with the reduced CAMERA system of the
+north star, FP64-MFMA roofline of its Cholesky) when the timed steps ran the camera-first elimination, `mapping` (C4 with
+all cameras fixed: HBM roofline of the linearisation, repeat blocks, its own CPU baseline), `slam_c3`, `fit` (per-frame
+ellipsoid fit), `ground_plane`, `streaming_c5`, `cpu_baseline` and `host`.
 """
 import argparse
 import importlib
@@ -196,83 +200,219 @@ def fit_bench(pkg, ctx, with_cpu=True):
     return out
 
 
-def slam_bench(pkg, ctx, with_cpu=True):
-    """The Schur half of BASELINE.json's metric: free cameras (cam 0 fixed), odometry edges, ellipsoids eliminated by the
-    Schur complement, dense FP64-MFMA Cholesky of the reduced camera system every LM trial.  C3 (n = 2,994) = several full
-    optimize(10) steps; C4 (n = 59,994, S = 28.8 GB) = ONE optimize(10).  Roofline: the factor + solve launches against
-    the FP64 matrix peak.  CPU: the restatement with its block-Schur solver ("improved over reference": g2o as shipped
-    would factor the whole system densely) measured on C3 on one pinned core, extrapolated to C4 from the LDLT flop rate
-    it reached there."""
-    out = {}
-    params = pkg.default_lm_params(jacobian_mode=1)
-    cpu = {}
-    for name, steps in (("C3", 5), ("C4", 1)):
-        g, c, o, _ = pkg.synth.make_config(name, seed=0, slam=True)
+SOLVER_NAMES = {1: "reduced camera system (ellipsoids eliminated, dense Cholesky of order 6(F-1))",
+                2: "reduced ellipsoid system (cameras eliminated first: block-bidiagonal factor, rank-6(F-1) MFMA update, dense Cholesky of order 9N)"}
+
+
+def slam_flops(n_c, n_o, solver):
+    """algorithmic flops of one damped solve (SURVEY.md section 8 d): the dense figure n_c^3/3 + 2 n_c^2 of the reduced camera
+    system, and what the camera-first elimination actually executes"""
+    dense = n_c ** 3 / 3.0 + 2.0 * n_c * n_c
+    if solver == 2:
+        rank_k = float(n_o) * (n_o + 1) * n_c                    # lower triangle of X^T X: n_o (n_o + 1) / 2 entries x 2 n_c
+        chol = n_o ** 3 / 3.0 + 2.0 * n_o * n_o
+        return {"dense_figure": dense, "rank_k_update": rank_k, "cholesky": chol, "actual": rank_k + chol + 2.0 * n_o * n_c}
+    return {"dense_figure": dense, "cholesky": dense, "actual": dense}
+
+
+def slam_roofline(prof, n_c, n_o, solver, trials):
+    """MFMA roofline of the dominant kernel of a SLAM-mode run from the HIP-event classes of esl_profile_get."""
+    fl = slam_flops(n_c, n_o, solver)
+    ch = prof.get("cholesky_solve", dict(count=0, total_ms=0.0))
+    bd = prof.get("schur_build", dict(count=0, total_ms=0.0))
+    ceiling = {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s",
+               "note": "register-only v_mfma_f64_16x16x4_f64 stream, accumulators in VGPRs: one MFMA per 64 cycles per SIMD at 2.4 GHz "
+                       "(scripts/mfma_peak.hip, profiles/r2_fp64_ceilings.txt)"}
+    solve_ms = (ch["total_ms"] + bd["total_ms"]) / max(ch["count"], 1)       # everything between the linearisation and x, per trial
+    dense_equiv = fl["dense_figure"] / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
+    if solver == 2:
+        rk = prof.get("rank_k_update", dict(count=0, total_ms=0.0))
+        avg = rk["total_ms"] / max(rk["count"], 1)
+        ach = fl["rank_k_update"] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        ch_avg = ch["total_ms"] / max(ch["count"], 1)
+        return {"kernel": "k_chol_update_lds<256,128> as the rank-%d update T -= X^T X of the reduced ellipsoid system (order %d)" % (n_c, n_o),
+                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
+                "algorithmic_flops_per_launch": fl["rank_k_update"], "avg_launch_ms": avg, "launches": rk["count"], "measured_ceiling": ceiling,
+                "linear_solve_ms_per_trial": solve_ms, "cholesky_order_9N_ms_per_trial": ch_avg,
+                "cholesky_order_9N_tflops": (fl["cholesky"] / (ch_avg * 1e-3) / 1e12) if ch_avg > 0 else 0.0,
+                "actual_flops_per_trial": fl["actual"],
+                "dense_figure": {"flops_per_trial": fl["dense_figure"], "equivalent_tflops": dense_equiv, "frac_of_peak": dense_equiv / FP64_MFMA_PEAK_TF,
+                                 "note": "SURVEY.md section 8 d: a cheaper exact solve is reported against the dense reduced-camera figure AND its own "
+                                         "operation count; equivalent = n_c^3/3 flops / the time of the whole linear solve of a trial (it can exceed "
+                                         "the peak: the flops were not executed)"}}
+    avg = ch["total_ms"] / max(ch["count"], 1)
+    ach = fl["cholesky"] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+    return {"kernel": "dense_cholesky_f64 of the reduced camera system (k_chol_potrf2 + k_chol_panel + k_chol_update_lds + triangular solves)",
+            "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
+            "algorithmic_flops_per_launch": fl["cholesky"], "avg_launch_ms": avg, "launches": ch["count"], "measured_ceiling": ceiling,
+            "linear_solve_ms_per_trial": solve_ms}
+
+
+def slam_run(pkg, ctx, g, c, o, solver, steps, warmup, jacobian=1, barrier=None):
+    """K timed optimize(10) steps in SLAM mode on the resident graph (states restored device-side every step); HIP-event classes on
+    (an event pair per kernel class and trial: nothing against the milliseconds of a trial)."""
+    params = pkg.default_lm_params(jacobian_mode=jacobian, linear_solver=solver)
+    for _ in range(warmup):
+        ctx.restore_states(); ctx.optimize_resident(params)
+    ctx.profile_enable(2)
+    (barrier or ctx.synchronize)()
+    t0 = time.perf_counter()
+    its = trials = 0
+    rep = None
+    for _ in range(steps):
+        ctx.restore_states()
+        rep = ctx.optimize_resident(params)
+        its += rep["iterations"]; trials += rep["total_trials"]
+    (barrier or ctx.synchronize)()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    used = ctx.lm_solver_used()
+    n_c, n_o = 6 * int((~g.cam_fixed.astype(bool)).sum()), 9 * g.n_objs
+    return {"value": its / dt, "unit": "LM iterations/s", "ms_per_optimize": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "lm_iterations_per_step": its / steps, "lm_trials_per_step": trials / steps, "linear_solver": used,
+            "linear_solver_name": SOLVER_NAMES.get(used, "?"), "unknowns": {"cameras": n_c, "ellipsoids": n_o},
+            "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]}, "kernel_ms": prof,
+            "roofline": slam_roofline(prof, n_c, n_o, used, trials), "_dt": dt, "_its": its, "_trials": trials}
+
+
+def slam_workload(name, g):
+    n = int((~g.cam_fixed.astype(bool)).sum())
+    return (f"{name} SLAM mode (the reference's bSLAM_mode branch, Optimizer.cpp:126-158): {g.n_cams} cams ({n} free), {g.n_objs} ellipsoids, "
+            f"{len(g.bbox_cam)} bbox + {len(g.e3d_cam)} 3-D + {len(g.grav_obj)} gravity + {len(g.odom_i)} odometry edges; analytic Jacobians; optimize(10) per step")
+
+
+def slam_c3_bench(pkg, ctx, with_cpu=True):
+    """BASELINE.json configs[2] with free cameras: both eliminations, several full optimize(10) steps each; the CPU restatement
+    (block-Schur solver, one pinned core) runs the whole graph and provides the rates the C4 CPU figure is extrapolated from."""
+    g, c, o, _ = pkg.synth.make_config("C3", seed=0, slam=True)
+    ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
+    out = {"workload": slam_workload("C3", g)}
+    for solver, key in ((2, "reduced_ellipsoid"), (1, "reduced_camera")):
+        r = slam_run(pkg, ctx, g, c, o, solver, steps=5, warmup=1)
+        out[key] = {k: v for k, v in r.items() if not k.startswith("_")}
+    out["value"] = max(out["reduced_ellipsoid"]["value"], out["reduced_camera"]["value"])
+    cpu = None
+    if with_cpu:
+        from oracle import pyoracle as po
         n = 6 * int((~g.cam_fixed.astype(bool)).sum())
-        ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
-        if name == "C3":
-            ctx.restore_states(); ctx.optimize_resident(params)          # warm-up
-        ctx.profile_enable(2)
+        with pinned_to_one_core() as pin:
+            t0 = time.perf_counter()
+            _, _, ro = po.optimize(g, c, o, pkg.default_lm_params(), solver=po.ORACLE_BLOCK)
+            dtc = time.perf_counter() - t0
+        tm = po.last_timing()
+        nt = max(ro["total_trials"], 1)
+        cpu = {"n": n, "edges": len(g.bbox_cam) + len(g.e3d_cam), "lin_s_per_it": tm["linearize_s"] / max(ro["iterations"], 1),
+               "err_s_per_trial": tm["errors_s"] / nt, "ldlt_flops_per_s": (n ** 3 / 3.0) * nt / max(tm["solve_s"], 1e-9)}
+        out["cpu_baseline"] = {
+            "value": ro["iterations"] / dtc, "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_to_core": pin.core,
+            "sample": f"oracle/esl_oracle.c, whole C3 SLAM graph, numeric Jacobians (delta 1e-9), block-Schur solver with a dense pivoted LDLT of "
+                      f"the {n} x {n} reduced camera system ('improved over reference'): {ro['iterations']} LM iterations / {ro['total_trials']} trials "
+                      f"in {dtc:.1f} s", "split_s": tm}
+        out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+    return out, cpu
+
+
+def cpu_baseline_c4_slam(g, cpu, its, trials):
+    """C4 SLAM on one CPU core is not runnable (7.2e13 flop per trial): extrapolated from the rates the restatement reached on C3."""
+    n = 6 * int((~g.cam_fixed.astype(bool)).sum())
+    e4 = len(g.bbox_cam) + len(g.e3d_cam)
+    per_trial = (n ** 3 / 3.0) / cpu["ldlt_flops_per_s"] + cpu["err_s_per_trial"] * e4 / cpu["edges"]
+    per_it = cpu["lin_s_per_it"] * e4 / cpu["edges"] + per_trial * (trials / max(its, 1))
+    return {"value": 1.0 / per_it, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": f"EXTRAPOLATED, not run ({n}^3/3 = {n ** 3 / 3.0:.2e} flop per trial): the restatement (block-Schur solver, numeric Jacobians, one "
+                      f"pinned core) was timed on the whole C3 SLAM graph in this run; its linearisation and error evaluation are scaled by the edge "
+                      f"count, the reduced solve by the LDLT flop rate it reached there ({cpu['ldlt_flops_per_s'] / 1e9:.2f} GFLOP/s) -> {per_it:.0f} s "
+                      f"per LM iteration"}
+
+
+def mapping_bench(pkg, ctx, config="C4", jacobian="analytic", steps=20, warmup=10, blocks=10, extra=True):
+    """The shipped setting of the reference (bSLAM_mode = false: all cameras fixed, per-ellipsoid 9x9 systems): device-driven LM,
+    HBM roofline of the linearisation kernel from a sampled HIP-event pair (one launch of every fourth run)."""
+    g, c, o, _ = pkg.synth.make_config(config, seed=0, slam=False)
+    params = pkg.default_lm_params(jacobian_mode=1 if jacobian == "analytic" else 0)
+    ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
+
+    def one_step():
+        ctx.restore_states()
+        return ctx.optimize_resident(params)
+    for _ in range(warmup):
+        one_step()
+    ctx.profile_enable(0 if os.environ.get("ESL_BENCH_NO_PROFILE") == "1" else 1)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    iters = trials = 0
+    rep = None
+    for _ in range(steps):
+        rep = one_step()
+        iters += rep["iterations"]; trials += rep["total_trials"]
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    blk = []
+    for _ in range(blocks):
         ctx.synchronize()
-        t0 = time.perf_counter()
-        its = trials = 0
+        tb = time.perf_counter()
+        ib = 0
         for _ in range(steps):
-            ctx.restore_states()
-            rep = ctx.optimize_resident(params)
-            its += rep["iterations"]; trials += rep["total_trials"]
+            ib += one_step()["iterations"]
         ctx.synchronize()
-        dt = time.perf_counter() - t0
-        prof = ctx.profile_get()
+        blk.append(ib / (time.perf_counter() - tb))
+    if extra:
+        ctx.profile_enable(2)
+        for _ in range(3):
+            one_step()
+        for k, v in ctx.profile_get().items():
+            if k != "linearize":
+                prof[k + " (extra untimed pass)"] = v
         ctx.profile_enable(False)
-        ch = prof.get("cholesky_solve", dict(count=1, total_ms=0.0))
-        avg_ms = ch["total_ms"] / max(ch["count"], 1)
-        flops = n ** 3 / 3.0 + 2.0 * n * n
-        ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        lda = (n + 1 + 15) // 16 * 16
-        entry = {
-            "value": its / dt, "unit": "LM iterations/s", "ms_per_optimize": 1e3 * dt / steps, "steps": steps,
-            "lm_iterations_per_step": its / steps, "lm_trials_per_step": trials / steps,
-            "workload": f"{name} SLAM mode: {g.n_cams} cams ({n // 6} free), {g.n_objs} ellipsoids, {len(g.bbox_cam)} bbox + {len(g.e3d_cam)} 3-D + "
-                        f"{len(g.grav_obj)} gravity + {len(g.odom_i)} odometry edges; analytic Jacobians; optimize(10)",
-            "reduced_system": {"n": n, "bytes": lda * n * 8},
-            "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]},
-            "kernel_ms": prof,
-            "roofline": {"kernel": "dense_cholesky_f64 (k_chol_potrf + k_chol_panel + k_chol_update_lds + triangular solves)", "bound": "mfma",
-                         "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
-                         "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": ch["count"],
-                         "measured_ceiling": {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_MEASURED_TF,
-                                              "note": "register-only v_mfma_f64_16x16x4_f64 stream with the accumulators in VGPRs: one MFMA per 64 cycles per SIMD at "
-                                                      "2.4 GHz (scripts/mfma_peak.hip, profiles/r2_fp64_ceilings.txt). Round 1 reported 35.9: that stream "
-                                                      "bounced its accumulators through AGPRs every iteration"}},
-        }
-        if with_cpu:
-            from oracle import pyoracle as po
-            if name == "C3":
-                with pinned_to_one_core() as pin:
-                    t0 = time.perf_counter()
-                    _, _, ro = po.optimize(g, c, o, pkg.default_lm_params(), solver=po.ORACLE_BLOCK)
-                    dtc = time.perf_counter() - t0
-                tm = po.last_timing()
-                nt = max(ro["total_trials"], 1)
-                cpu = {"n": n, "edges": len(g.bbox_cam) + len(g.e3d_cam), "lin_s_per_it": tm["linearize_s"] / max(ro["iterations"], 1),
-                       "err_s_per_trial": tm["errors_s"] / nt, "ldlt_flops_per_s": (n ** 3 / 3.0) * nt / max(tm["solve_s"], 1e-9)}
-                entry["cpu_baseline"] = {
-                    "value": ro["iterations"] / dtc, "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_to_core": pin.core,
-                    "sample": f"oracle/esl_oracle.c, whole {name} SLAM graph, numeric Jacobians (delta 1e-9), block-Schur solver with a dense "
-                              f"pivoted LDLT of the {n} x {n} reduced system ('improved over reference'): {ro['iterations']} LM iterations / "
-                              f"{ro['total_trials']} trials in {dtc:.1f} s", "split_s": tm}
-            elif cpu:
-                e4 = len(g.bbox_cam) + len(g.e3d_cam)
-                per_trial = (n ** 3 / 3.0) / cpu["ldlt_flops_per_s"] + cpu["err_s_per_trial"] * e4 / cpu["edges"]
-                per_it = cpu["lin_s_per_it"] * e4 / cpu["edges"] + per_trial * (trials / max(its, 1))
-                entry["cpu_baseline"] = {
-                    "value": 1.0 / per_it, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-                    "sample": f"EXTRAPOLATED, not run ({n}^3/3 = {n ** 3 / 3.0:.2e} flop per trial): linearisation and error evaluation of the "
-                              f"C3 run scaled by the edge count, the reduced solve from the LDLT flop rate measured there "
-                              f"({cpu['ldlt_flops_per_s'] / 1e9:.2f} GFLOP/s on one core) -> {per_it:.0f} s per LM iteration"}
-        if "cpu_baseline" in entry:
-            entry["speedup_vs_cpu_port"] = entry["value"] / entry["cpu_baseline"]["value"]
-        out[name] = entry
+    lin = prof.get("linearize", dict(count=0, total_ms=0.0))
+    avg_ms = lin["total_ms"] / max(lin["count"], 1)
+    abytes = algorithmic_bytes_linearize(g, False)
+    achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) -- same workload only
+        if config == "C4" and jacobian == "analytic":
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_device_lm.json")))["kernels"]
+            traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, 0" in k or "k_chunk_linearize_both<1, false" in k][0]["traffic_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        traffic = None
+    roof = {"kernel": "k_chunk_linearize_both (bbox + 3-D chunks, one launch)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r2_pmc_traffic_device_lm.json (committed PMC passes, not this run)",
+            "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms, "launches": lin["count"],
+            "sampling": "HIP events around ONE linearisation launch (the second trial's) of every FOURTH optimize() of the timed region: an event pair "
+                        "splits two back-to-back dispatches and costs that trial ~20 us"}
+    if jacobian == "analytic":
+        roof["valu_issue_floor"] = valu_issue_floor(g, avg_ms)
+    out = {"value": iters / dt, "unit": "LM iterations/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+           "workload": f"{config} synthetic graph: {g.n_cams} cams, {g.n_objs} ellipsoids, {len(g.bbox_cam)} bbox + {len(g.e3d_cam)} 3-D + {len(g.grav_obj)} gravity "
+                       f"edges; mapping mode (all cameras fixed: the reference as shipped, Optimizer.cpp:126); {jacobian} Jacobians; optimize(10) per step",
+           "lm_iterations_per_step": iters / steps, "lm_trials_per_step": trials / steps, "kernel_ms": prof,
+           "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]}, "roofline": roof}
+    if blk:
+        out["repeat_blocks"] = {"blocks": len(blk), "steps_per_block": steps, "median": float(np.median(blk)), "min": float(np.min(blk)), "max": float(np.max(blk)),
+                                "note": "LM iterations/s of further K-step blocks (HIP events off); `value` is the first, timed block"}
+    return out, (g, c, o)
+
+
+def ground_plane_bench(pkg, ctx, with_cpu=True):
+    """The step in front of the fit (SURVEY.md section 8 f-3): PlaneExtractor::extractGroundPlane on one 640 x 480 depth frame."""
+    sc = pkg.synth.make_depth_scene(n_objs=3, seed=5)
+    for _ in range(2):
+        r = ctx.extract_ground_plane(sc["depth"], sc["intr"])
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = ctx.extract_ground_plane(sc["depth"], sc["intr"])
+    out = {"ms_per_frame_host_call": 1e3 * (time.perf_counter() - t0) / n, "ok": bool(r["ok"]), "planes": int(r["n_planes"]), "pixels_of_the_plane": int(r["n_pixels"]),
+           "frame": "640x480 synthetic (ground + 3 ellipsoids)", "note": "host call incl. H2D of the depth image; buffers from a grow-only context slab (round 2: 33 MB of hipMalloc per call)"}
+    if with_cpu:
+        from oracle import pyoracle as po
+        with pinned_to_one_core():
+            t0 = time.perf_counter()
+            po.extract_ground_plane(sc["depth"], sc["intr"])
+            out["cpu_port_ms_per_frame"] = 1e3 * (time.perf_counter() - t0)
     return out
 
 
@@ -390,14 +530,21 @@ def streaming_bench(pkg, ctx, n_frames=120):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)   # 0.2 ms steps: the clocks are still ramping after 3
-    ap.add_argument("--mode", default="mapping", choices=["mapping", "slam"])
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 3 in SLAM mode, 20 in mapping mode)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 1 in SLAM mode, 10 in mapping mode)")
+    ap.add_argument("--mode", default="slam", choices=["mapping", "slam"],
+                    help="slam = BASELINE.json configs[3] as named (free cameras, Schur solve); mapping = the reference as shipped (cameras fixed)")
     ap.add_argument("--config", default="C4")
     ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
+    ap.add_argument("--solver", default="auto", choices=["auto", "camera", "ellipsoid"], help="esl_linear_solver of the SLAM-mode steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-slam", action="store_true", help="skip the C3 / C4 SLAM-mode record of the default run (C4 allocates 28.8 GB)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (no mapping / fit / streaming / C3 / reduced-camera records)")
     a = ap.parse_args()
+    slam = a.mode == "slam"
+    if a.steps is None:
+        a.steps = 3 if slam else 20
+    if a.warmup is None:
+        a.warmup = 1 if slam else 10
 
     # stdout carries exactly ONE line (the JSON).  Libraries (RCCL prints a banner at exit) write to fd 1 too,
     # so keep a private copy of the real stdout and point fd 1 at stderr for everything else.
@@ -420,26 +567,80 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     pkg = importlib.import_module("object-oriented-slam_amd")
-    slam = a.mode == "slam"
+    solver = {"auto": 0, "camera": 1, "ellipsoid": 2}[a.solver]
     # ONE graph of the named shape; N > 1: its ellipsoids (with all their edges) partitioned over the ranks, cameras (and
     # odometry) replicated -> strong scaling of one global LM in both modes
     sharded = world > 1 or force_dist
-    g_full, c, o_full, _ = pkg.synth.make_config(a.config, seed=0, slam=slam)
-    g, o = g_full, o_full
-    if sharded:
+    ctx = pkg.Context(local_rank)
+    with_cpu = not a.no_cpu_baseline
+    out = None
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+
+    if not sharded and slam:
+        # ---- the headline: BASELINE.json configs[3] as named -- 10k cams / 2k ellipsoids / ~200k edges, free cameras, Schur solve
+        g, c, o, _ = pkg.synth.make_config(a.config, seed=0, slam=True)
+        ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
+        r = slam_run(pkg, ctx, g, c, o, solver, a.steps, a.warmup, jacobian=1 if a.jacobian == "analytic" else 0, barrier=barrier)
+        out = {
+            "metric": "LM iterations/sec (cams+ellipsoids)", "value": r["value"], "unit": "LM iterations/s",
+            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * r["_dt"] / a.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": slam_workload(a.config, g).replace("analytic", a.jacobian), "lm_iterations_per_step": r["lm_iterations_per_step"],
+                       "lm_trials_per_step": r["lm_trials_per_step"], "linear_solver": r["linear_solver_name"],
+                       "unknowns": r["unknowns"], "parallelism": "single GPU"},
+            "kernel_ms": r["kernel_ms"], "chi2": r["chi2"], "roofline": r["roofline"], "host": host_info(),
+        }
+        if not a.no_extras:
+            if r["linear_solver"] == 2:   # the elimination the north star names, beside the one that was timed: 2 steps after 1 warm-up
+                rc_ = slam_run(pkg, ctx, g, c, o, 1, steps=2, warmup=1, jacobian=1 if a.jacobian == "analytic" else 0)
+                out["slam_reduced_camera"] = {k: v for k, v in rc_.items() if not k.startswith("_")}
+                out["slam_reduced_camera"]["workload"] = slam_workload(a.config, g)
+            m, _ = mapping_bench(pkg, ctx, a.config, a.jacobian)
+            out["mapping"] = m
+            out["fit"] = fit_bench(pkg, ctx, with_cpu=with_cpu)
+            out["ground_plane"] = ground_plane_bench(pkg, ctx, with_cpu=with_cpu)
+            out["streaming_c5"] = streaming_bench(pkg, ctx)
+            c3, cpu_rates = slam_c3_bench(pkg, ctx, with_cpu=with_cpu)
+            out["slam_c3"] = c3
+            if with_cpu and cpu_rates:
+                out["cpu_baseline"] = cpu_baseline_c4_slam(g, cpu_rates, r["_its"], r["_trials"])
+                out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+                out["mapping"]["cpu_baseline"] = cpu_baseline(pkg, *mapping_graph(pkg, a.config), pkg.default_lm_params())
+                out["mapping"]["speedup_vs_cpu_port"] = out["mapping"]["value"] / out["mapping"]["cpu_baseline"]["value"]
+                out["speedup_note"] = ("GPU: analytic Jacobians; CPU port: g2o's numeric Jacobians with the restatement's block solvers; "
+                                       "a reported baseline, not a kernel-quality figure (that is roofline.frac)")
+    elif not sharded:
+        # ---- mapping mode as the timed region (--mode mapping): the reference as shipped
+        m, (g, c, o) = mapping_bench(pkg, ctx, a.config, a.jacobian, steps=a.steps, warmup=a.warmup)
+        out = {"metric": "LM iterations/sec (cams+ellipsoids)", "value": m["value"], "unit": "LM iterations/s", "n_gpus": 1, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "config": {"workload": m["workload"], "lm_iterations_per_step": m["lm_iterations_per_step"],
+                                               "lm_trials_per_step": m["lm_trials_per_step"], "parallelism": "single GPU"},
+               "kernel_ms": m["kernel_ms"], "chi2": m["chi2"], "roofline": m["roofline"], "host": host_info()}
+        if "repeat_blocks" in m:
+            out["repeat_blocks"] = m["repeat_blocks"]
+        if not a.no_extras:
+            out["fit"] = fit_bench(pkg, ctx, with_cpu=with_cpu)
+            out["ground_plane"] = ground_plane_bench(pkg, ctx, with_cpu=with_cpu)
+            out["streaming_c5"] = streaming_bench(pkg, ctx)
+        if with_cpu:
+            out["cpu_baseline"] = cpu_baseline(pkg, g, c, o, pkg.default_lm_params())
+            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+    else:
+        # ---- N ranks (one per GPU, RCCL): the ellipsoids of the ONE named graph partitioned over the ranks, cameras replicated
+        g_full, c, o_full, _ = pkg.synth.make_config(a.config, seed=0, slam=slam)
         mine = np.nonzero(pkg.lib.partition_objects(g_full, world) == rank)[0]
         g, o = g_full.subset_objects(mine), o_full[mine]
-    params = pkg.default_lm_params(jacobian_mode=1 if a.jacobian == "analytic" else 0)
-    ctx = pkg.Context(local_rank)
-    ctx.upload_graph(g)
-    ctx.upload_states(c, o)
-    ctx.snapshot_states()
-
-    exchange = "none"
-    runner = None
-    if sharded:
-        # preferred: the library's own RCCL exchange (one ncclAllGather per linearisation / trial on its stream);
-        # fallback: the Python step-API driver with torch.distributed collectives
+        params = pkg.default_lm_params(jacobian_mode=1 if a.jacobian == "analytic" else 0, linear_solver=0)   # sharded SLAM: reduced camera system
+        ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
+        runner = None
+        # preferred: the library's own RCCL exchange (collectives on its stream); fallback: the Python step-API driver with
+        # torch.distributed collectives
         try:
             if os.environ.get("ESL_BENCH_PY_EXCHANGE") == "1":
                 raise RuntimeError("python exchange requested")
@@ -453,147 +654,59 @@ def main():
             runner = par.ShardedLM(ctx, dist, device=torch.device("cuda", local_rank), force_collectives=force_dist)
             exchange = "torch.distributed all_gather"
 
-    def one_step():
-        ctx.restore_states()
-        if runner is not None:
-            return runner.optimize(params)
-        return ctx.optimize_resident(params)
-
-    def barrier():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if sharded:
-            dist.barrier()
-
-    for _ in range(a.warmup):
-        one_step()
-    # level 1: only the dominant (linearise) kernels are bracketed by HIP events inside the timed region
-    ctx.profile_enable(0 if os.environ.get("ESL_BENCH_NO_PROFILE") == "1" else (2 if slam else 1))
-    barrier()
-    t0 = time.perf_counter()
-    iters = trials = 0
-    rep = None
-    for _ in range(a.steps):
-        rep = one_step()
-        iters += rep["iterations"]
-        trials += rep["total_trials"]
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile_get()
-    ctx.profile_enable(False)
-    # per-frame fit (second half of the metric) right after the timed region: measured later in the process, the Python loop
-    # around the 1280 x 960 case sees ~2 ms more per call than the C-ABI call itself takes (0.7 ms in every order; both are
-    # reported, see fit_bench)
-    fit_record = fit_bench(pkg, ctx, with_cpu=not a.no_cpu_baseline) if (rank == 0 and world == 1 and not sharded) else None
-    if fit_record is not None:
-        ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()
-    # the same K-step block ten more times, events off: how much one scheduler hiccup moves a 5 ms timed region
-    blocks = []
-    skip = os.environ.get("ESL_BENCH_SKIP", "").split(",")   # bisecting aid: blocks, extra
-    if not slam and "blocks" not in skip:
-        for _ in range(10):
-            barrier()
-            tb = time.perf_counter()
-            ib = 0
-            for _ in range(a.steps):
-                ib += one_step()["iterations"]
-            barrier()
-            blocks.append(ib / (time.perf_counter() - tb))
-    if not slam and "extra" not in skip:   # per-class breakdown from a short extra pass outside the timed region
-        ctx.profile_enable(2)
-        for _ in range(3):
+        def one_step():
+            ctx.restore_states()
+            return runner.optimize(params) if runner is not None else ctx.optimize_resident(params)
+        for _ in range(a.warmup):
             one_step()
-        prof_all = ctx.profile_get()
+        ctx.profile_enable(0 if os.environ.get("ESL_BENCH_NO_PROFILE") == "1" else (2 if slam else 1))
+        barrier()
+        t0 = time.perf_counter()
+        iters = trials = 0
+        rep = None
+        for _ in range(a.steps):
+            rep = one_step()
+            iters += rep["iterations"]; trials += rep["total_trials"]
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = ctx.profile_get()
         ctx.profile_enable(False)
-        for k, v in prof_all.items():
-            if k != "linearize":
-                prof[k + " (extra untimed pass)"] = v
-    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    if rank == 0:
-        lin = prof.get("linearize", dict(count=0, total_ms=0.0))
-        dom_name = "linearize"
-        dom = lin
-        if slam and "cholesky_solve" in prof and prof["cholesky_solve"]["total_ms"] > lin["total_ms"]:
-            dom_name, dom = "cholesky_solve", prof["cholesky_solve"]
-        avg_ms = dom["total_ms"] / max(dom["count"], 1)
-        if dom_name == "linearize":
-            abytes = algorithmic_bytes_linearize(g, slam)
-            achieved = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic = None
-            try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) — same workload only
-                if not slam and a.config == "C4" and a.jacobian == "analytic":
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_device_lm.json")))["kernels"]
-                    traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, 0" in k or "k_chunk_linearize_both<1, false" in k][0]["traffic_bytes_per_launch"]
-            except Exception:  # noqa: BLE001
-                traffic = None
-            roof = {"kernel": "k_chunk_linearize_both (bbox + 3-D chunks, one launch)" if not slam else "k_slam_linearize", "bound": "hbm",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms,
-                    "launches": dom["count"],
-                    "sampling": "HIP events around ONE linearisation launch (the second trial's) of every FOURTH optimize() of the timed "
-                                "region: an event pair splits two back-to-back dispatches and costs that trial ~20 us, so one sample per "
-                                "run cost 10 % of `value` and bracketing every launch 13 %"}
-            if not slam and a.jacobian == "analytic":
-                roof["valu_issue_floor"] = valu_issue_floor(g, avg_ms)
-        else:
-            n = 6 * int((~g.cam_fixed.astype(bool)).sum())
-            flops = n ** 3 / 3.0 + 2.0 * n * n
-            achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            roof = {"kernel": "dense_cholesky_f64", "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None,
-                    "algorithmic_flops_per_launch": flops, "avg_launch_ms": avg_ms, "launches": dom["count"],
-                    "measured_ceiling": {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_MEASURED_TF,
-                                         "note": "register-only v_mfma_f64_16x16x4_f64 stream, accumulators in VGPRs: one MFMA per 64 cycles per SIMD "
-                                                 "(scripts/mfma_peak.hip, profiles/r2_fp64_ceilings.txt); round 1's 35.9 was a benchmark artefact "
-                                                 "(accumulators bounced through AGPRs); v_fma_f64 tops out at 55 TFLOP/s (clock drops to 1.9 GHz)"}}
-        out = {
-            "metric": "LM iterations/sec (cams+ellipsoids)",
-            "value": iters / dt,
-            "unit": "LM iterations/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.config} synthetic graph: {g_full.n_cams} cams, {g_full.n_objs} ellipsoids, "
-                                   f"{len(g_full.bbox_cam)} bbox + {len(g_full.e3d_cam)} 3-D + {len(g_full.grav_obj)} gravity"
-                                   f"{' + %d odometry' % len(g_full.odom_i) if slam else ''} edges; "
-                                   f"{'SLAM mode (free cameras, Schur)' if slam else 'mapping mode (cameras fixed, as shipped)'}; "
-                                   f"{a.jacobian} Jacobians; optimize(10) per step",
-                       "lm_iterations_per_step": iters / a.steps, "lm_trials_per_step": trials / a.steps,
-                       "parallelism": f"ellipsoid-sharded x{world}", "lm_scalar_exchange": exchange},
-            "kernel_ms": prof,
-            "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]},
-            "roofline": roof,
-        }
-        if blocks:
-            out["repeat_blocks"] = {"blocks": len(blocks), "steps_per_block": a.steps, "median": float(np.median(blocks)),
-                                    "min": float(np.min(blocks)), "max": float(np.max(blocks)),
-                                    "note": "LM iterations/s of 10 further K-step blocks (HIP events off); `value` is the first, timed block"}
-        out["host"] = host_info()
-        if world == 1 and not sharded:   # the single-GPU extras (a context with a communicator is a shard of a collective run)
-            out["fit"] = fit_record
-            out["streaming_c5"] = streaming_bench(pkg, ctx)
-            if not slam and not a.no_slam:
-                out["slam"] = slam_bench(pkg, ctx, with_cpu=not a.no_cpu_baseline)
-            ctx.upload_graph(g); ctx.upload_states(c, o)   # leave the context as the timed section found it
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, g, c, o, pkg.default_lm_params())
-            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
-            out["speedup_note"] = ("GPU: analytic Jacobians; CPU port: g2o's numeric Jacobians with the restatement's per-ellipsoid solver; "
-                                   "a reported baseline, not a kernel-quality figure (that is roofline.frac)")
-        final_line = json.dumps(out)
-    else:
-        final_line = None
+        if rank == 0:
+            if slam:
+                n_c, n_o = 6 * int((~g_full.cam_fixed.astype(bool)).sum()), 9 * g_full.n_objs
+                roof = slam_roofline(prof, n_c, n_o, 1, trials)
+                roof["note"] = "rank 0's launches; with the distributed factorisation each rank executes 1 / n_gpus of the update flops"
+                wl = slam_workload(a.config, g_full)
+            else:
+                lin = prof.get("linearize", dict(count=0, total_ms=0.0))
+                avg_ms = lin["total_ms"] / max(lin["count"], 1)
+                abytes = algorithmic_bytes_linearize(g, False)
+                ach = abytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                roof = {"kernel": "k_chunk_linearize_both (rank 0's shard)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms, "launches": lin["count"]}
+                wl = (f"{a.config} synthetic graph: {g_full.n_cams} cams, {g_full.n_objs} ellipsoids, {len(g_full.bbox_cam)} bbox + {len(g_full.e3d_cam)} 3-D + "
+                      f"{len(g_full.grav_obj)} gravity edges; mapping mode; {a.jacobian} Jacobians; optimize(10) per step")
+            out = {"metric": "LM iterations/sec (cams+ellipsoids)", "value": iters / dt, "unit": "LM iterations/s", "n_gpus": world, "steps": a.steps,
+                   "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": wl, "lm_iterations_per_step": iters / a.steps, "lm_trials_per_step": trials / a.steps,
+                              "parallelism": f"ellipsoid-sharded x{world}", "lm_scalar_exchange": exchange},
+                   "kernel_ms": prof, "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]}, "roofline": roof, "host": host_info()}
+    final_line = json.dumps(out) if (rank == 0 and out is not None) else None
     if sharded:
         dist.destroy_process_group()
     ctx.close()
     if final_line is not None:
         os.write(json_fd, (final_line + "\n").encode())
     os.close(json_fd)
+
+
+def mapping_graph(pkg, config):
+    g, c, o, _ = pkg.synth.make_config(config, seed=0, slam=False)
+    return g, c, o
 
 
 if __name__ == "__main__":

@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define ESL_ABI_VERSION 2   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append */
+#define ESL_ABI_VERSION 3   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append
+                             * 3: esl_linear_solver gains ESL_SOLVER_REDUCED_CAMERA / ESL_SOLVER_REDUCED_ELLIPSOID, esl_lm_solver_used */
 #define ESL_MAX_TRACE 32
 
 typedef enum {
@@ -104,11 +105,21 @@ typedef enum {
 } esl_jacobian_mode;
 
 typedef enum {
-  ESL_SOLVER_AUTO = 0         /* all cameras fixed: 9x9 blocks per ellipsoid; else Schur complement on the ellipsoids + dense
-                               * FP64-MFMA Cholesky of the reduced camera system.  Mathematically the solve of g2o's
-                               * LinearSolverDense (one pivoted LDLT of the whole free system, solvers/linear_solver_dense.h:65-113);
-                               * that literal form exists only in the CPU checker (oracle/, ORACLE_DENSE), which the tests compare
-                               * against.  Any other value is rejected with ESL_ERR_INVALID. */
+  /* All cameras fixed (mapping mode, the shipped setting): 9x9 blocks per ellipsoid.  Free cameras (SLAM mode): one of the two
+   * block eliminations below -- both solve EXACTLY the system g2o's LinearSolverDense solves with one pivoted LDLT of the whole
+   * free system (solvers/linear_solver_dense.h:65-113; that literal form exists only in the CPU checker, oracle/ ORACLE_DENSE,
+   * which the tests compare against); which block is eliminated first is what BlockSolver's setMarginalized decides
+   * (core/block_solver.hpp:367-486).  AUTO takes the one with fewer flops that applies. */
+  ESL_SOLVER_AUTO = 0,
+  /* Schur complement onto the CAMERAS: S = Hcc - sum_o W_o (Hoo + lambda I)^-1 W_o^T, dense FP64-MFMA Cholesky of order
+   * 6 (F - 1) -- the reduced camera system of BASELINE.json's north star.  Always applicable; the form sharded runs use. */
+  ESL_SOLVER_REDUCED_CAMERA = 1,
+  /* Cameras first (round 3): in the reference's SLAM branch the camera block is block TRIDIAGONAL (odometry edges join
+   * consecutive frames only, Optimizer.cpp:142-158), so it has a block-bidiagonal Cholesky factor L; the reduced system
+   * T = (Hoo + lambda I) - (L^-1 W)^T (L^-1 W) over the ELLIPSOIDS (order 9 N) is formed with an FP64-MFMA rank-6(F-1) update and
+   * factored densely.  (9N)^2 6F + (9N)^3/3 flops instead of (6F)^3/3 (C4: 2.1e13 vs 7.2e13).  Needs every odometry edge to join
+   * two free cameras that are neighbours in free-camera order, and a single-GPU run; ESL_ERR_INVALID otherwise. */
+  ESL_SOLVER_REDUCED_ELLIPSOID = 2
 } esl_linear_solver;
 
 typedef enum {
@@ -124,7 +135,7 @@ typedef struct {
   double tau;               /* 1e-5 (optimization_algorithm_levenberg.cpp:45) */
   int32_t jacobian_mode;    /* esl_jacobian_mode */
   double numeric_delta;     /* 1e-9 */
-  int32_t linear_solver;    /* esl_linear_solver: must be ESL_SOLVER_AUTO */
+  int32_t linear_solver;    /* esl_linear_solver (SLAM mode only; ignored when all cameras are fixed) */
   int32_t drop_nan_bbox;    /* 1: pre-evaluate bbox edges and drop those with NaN chi2 (Optimizer.cpp:234-243) */
   int32_t bbox_residual;    /* esl_bbox_residual; 0 = the reference */
 } esl_lm_params;
@@ -198,8 +209,10 @@ int esl_graph_append(esl_ctx* ctx, const esl_graph_delta* d);
 int esl_graph_sizes(esl_ctx* ctx, int32_t* n_cams, int32_t* n_objs, int32_t* n_bbox, int32_t* n_e3d, int32_t* relayouts);
 
 /* per-kernel timing with HIP events recorded on the context's own stream.
- * kernel ids: 0 linearise, 1 LM trial (solve + retract + chi2), 2 reduced-system build (Schur),
- *             3 dense Cholesky + solves, 4 reductions / misc, 6 RCCL all-reduce of the reduced system (sharded SLAM).
+ * kernel ids: 0 linearise, 1 LM trial (solve + retract + chi2), 2 reduced-system build (Schur complement / camera-first: factor of
+ *             the camera block + X + the rank-K update), 3 dense Cholesky + solves, 4 reductions / misc, 5 single-frame fit,
+ *             6 RCCL all-reduce of the reduced system (sharded SLAM), 7 the MFMA rank-K update T -= X^T X of the camera-first
+ *             form alone (nested inside class 2).
  * esl_profile_enable(ctx, 0) off; 1 = bracket only kernel class 0, and inside esl_optimize_resident's device-driven
  * mapping run only ONE linearisation launch per run (cheap enough to stay on inside a timed region: an event record
  * is a barrier packet between two otherwise back-to-back dispatches); 2 = bracket every launch of every class.
@@ -223,6 +236,9 @@ int esl_lm_reduced_residual(esl_ctx* ctx, double* rel_residual_out);
 int esl_lm_try_step(esl_ctx* ctx, double lambda, esl_lm_partials* out);
 /* accept != 0: discard backup; accept == 0: restore states from backup */
 int esl_lm_commit(esl_ctx* ctx, int accept);
+/* which esl_linear_solver the last SLAM-mode trial step of this context ran with (ESL_SOLVER_REDUCED_CAMERA or
+ * ESL_SOLVER_REDUCED_ELLIPSOID: what ESL_SOLVER_AUTO resolved to); 0 before any SLAM-mode step */
+int esl_lm_solver_used(esl_ctx* ctx, int32_t* solver_out);
 
 /* inspection (tests, debugging): copy one device array of the current linearisation to the host.
  * which: 0 Hoo (n_objs x 45 packed upper 9x9), 1 bo (n_objs x 9), 2 xo (n_objs x 9, last trial),

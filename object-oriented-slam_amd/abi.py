@@ -108,6 +108,9 @@ def default_plane_params(**kw):
     return p
 
 
+SOLVER_AUTO, SOLVER_REDUCED_CAMERA, SOLVER_REDUCED_ELLIPSOID = 0, 1, 2   # esl_linear_solver (include/esl.h)
+
+
 def default_lm_params(**kw):
     """Reference settings: optimize(10) (Optimizer.cpp:291), tau 1e-5, 10 trials
     (optimization_algorithm_levenberg.cpp:45-49), delta 1e-9 (base_binary_edge.hpp:147)."""

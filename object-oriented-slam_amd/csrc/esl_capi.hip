@@ -259,6 +259,10 @@ static void free_graph(esl_ctx* c) {
   dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
   dev_free(&c->Abb); dev_free(&c->Ae3); dev_free(&c->Aod); dev_free(&c->Dinv); dev_free(&c->Yb); dev_free(&c->Wt); dev_free(&c->Tb); dev_free(&c->Ye3);
   dev_free(&c->S); dev_free(&c->cam_part); dev_free(&c->od_part);
+  dev_free(&c->cf_oe_start); dev_free(&c->cf_oe_u); dev_free(&c->cf_oe_slot); dev_free(&c->cf_od_start); dev_free(&c->cf_od_edge);
+  dev_free(&c->cf_Linv); dev_free(&c->cf_M); dev_free(&c->cf_N); dev_free(&c->cf_V); dev_free(&c->cf_vy); dev_free(&c->cf_z);
+  dev_free(&c->cf_Xt); dev_free(&c->cf_T); dev_free(&c->cf_Linv_ws);
+  c->cf_chain_ok = false;
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->S_n = 0;
   c->graph_loaded = false;
@@ -488,6 +492,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
       if (!fixed[i] && touched[i]) slot[i] = nf++;
     d.n_free_cams = nf;
     c->h_cam_slot = slot;
+    c->h_od_i.assign(g->odom_i, g->odom_i + g->n_odom); c->h_od_j.assign(g->odom_j, g->odom_j + g->n_odom);
     up.add(&d.cam_fixed, fixed.data(), fixed.size());
     up.add(&d.cam_slot, slot.data(), slot.size());
     std::vector<double> info((size_t)g->n_odom * 6, 1.0);
@@ -1263,7 +1268,9 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
 
 int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out) {
   if (!c || !p || !out) return ESL_ERR_INVALID;
-  if (p->linear_solver != ESL_SOLVER_AUTO) { set_error("esl_lm_params::linear_solver: only ESL_SOLVER_AUTO exists"); return ESL_ERR_INVALID; }
+  if (p->linear_solver != ESL_SOLVER_AUTO && p->linear_solver != ESL_SOLVER_REDUCED_CAMERA && p->linear_solver != ESL_SOLVER_REDUCED_ELLIPSOID) {
+    set_error("esl_lm_params::linear_solver: unknown solver"); return ESL_ERR_INVALID;
+  }
   if (p->bbox_residual != ESL_BBOX_REPROJECTION && p->bbox_residual != ESL_BBOX_TANGENCY) { set_error("esl_lm_params::bbox_residual: unknown mode"); return ESL_ERR_INVALID; }
   std::memset(out, 0, sizeof(*out));
   if (c->graph_loaded && c->g.n_free_cams == 0) {   // mapping mode: the LM runs on the device, nothing waits on the host

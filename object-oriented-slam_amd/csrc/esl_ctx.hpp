@@ -148,7 +148,7 @@ struct esl_ctx {
   double prof_ms[ESL_PROF_KINDS] = {0};
   size_t cap_cams = 0, cap_objs = 0;
   // host copies kept from upload (edge -> camera after sorting by ellipsoid)
-  std::vector<int> h_bb_cam, h_bb_obj, h_e3_cam, h_e3_obj, h_cam_slot;
+  std::vector<int> h_bb_cam, h_bb_obj, h_e3_cam, h_e3_obj, h_cam_slot, h_od_i, h_od_j;
   // chunked mapping-mode pipeline (esl_kernels_chunk.hpp)
   int n_chunks = 0;
   int *ck_obj = nullptr, *ck_type = nullptr, *ck_begin = nullptr, *ck_end = nullptr, *ck_ostart = nullptr;
@@ -192,6 +192,15 @@ struct esl_ctx {
   double* Linv_ws = nullptr;  // ceil(n/NB) x NB x NB
   double* z_ws = nullptr;
   int64_t S_lda = 0;
+  // camera-first elimination (esl_cf.hpp; SLAM mode, cameras chained by the odometry edges): per-ellipsoid edge lists sorted by
+  // camera slot, the odometry edges of every consecutive slot pair, the block-bidiagonal factor (Linv, M, N), per-edge V = Linv W,
+  // X^T = (L^-1 [W | b_c])^T, the reduced ellipsoid system T (+ b row) and its solver workspaces.  Big buffers on first use.
+  bool cf_chain_ok = false;
+  int *cf_oe_start = nullptr, *cf_oe_u = nullptr, *cf_oe_slot = nullptr, *cf_od_start = nullptr, *cf_od_edge = nullptr;
+  double *cf_Linv = nullptr, *cf_M = nullptr, *cf_N = nullptr, *cf_V = nullptr, *cf_vy = nullptr, *cf_z = nullptr;
+  double *cf_Xt = nullptr, *cf_T = nullptr, *cf_Linv_ws = nullptr;
+  int64_t cf_ldx = 0, cf_kpad = 0, cf_ldt = 0;
+  int lm_solver_used = 0;   // esl_linear_solver the last trial step ran with (1 reduced camera system, 2 reduced ellipsoid system)
   // per-context runtime of the dense solver (esl_chol.hpp CholRuntime: look-ahead stream + events on THIS device, one-time
   // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context
   void* chol_rt = nullptr;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "esl_cf.hpp"
 #include "esl_chol.hpp"
 #include "esl_kernels_slam.hpp"
 
@@ -67,6 +68,35 @@ int slam_alloc(esl_ctx* c) {
     if ((rc = up(&g.cu_obj, cobj.data(), cobj.size(), c->stream))) return rc;
     if ((rc = up(&g.cu_id, cid.data(), cid.size(), c->stream))) return rc;
   }
+  // camera-first elimination (esl_cf.hpp): every ellipsoid's free-camera edges sorted by (slot, u), and for every pair of
+  // neighbouring slots the odometry edges that join them; it applies when ALL odometry edges between free cameras do
+  {
+    std::vector<int> ou(id.size()), os(id.size());
+    for (int o = 0; o < N; ++o) {
+      std::vector<std::pair<int, int>> es;   // (slot, u)
+      for (int k = start[o]; k < start[(size_t)o + 1]; ++k) es.push_back({slot[k], id[k]});
+      std::sort(es.begin(), es.end());
+      for (size_t k = 0; k < es.size(); ++k) { os[(size_t)start[o] + k] = es[k].first; ou[(size_t)start[o] + k] = es[k].second; }
+    }
+    std::vector<int> ods((size_t)std::max(nf, 1) + 1, 0), ode;
+    bool chain = true;
+    std::vector<std::vector<int>> per_pair((size_t)std::max(nf, 1));
+    for (int e = 0; e < g.n_odom; ++e) {
+      const int si = c->h_cam_slot[c->h_od_i[e]], sj = c->h_cam_slot[c->h_od_j[e]];
+      if (si < 0 || sj < 0) continue;                       // a fixed end: the edge only adds to the free end's diagonal block
+      if (si == sj + 1) per_pair[sj].push_back(e * 2);      // rows = first vertex = the higher slot: B as stored
+      else if (sj == si + 1) per_pair[si].push_back(e * 2 + 1);
+      else chain = false;                                   // (si == sj: a self edge; |si - sj| > 1: fill-in outside the band)
+    }
+    for (int k = 0; k < nf; ++k) { ods[(size_t)k + 1] = ods[k] + (int)per_pair[k].size(); ode.insert(ode.end(), per_pair[k].begin(), per_pair[k].end()); }
+    c->cf_chain_ok = chain && nf > 0 && N > 0;
+    if ((rc = up(&c->cf_oe_start, start.data(), start.size(), c->stream))) return rc;
+    if ((rc = up(&c->cf_oe_u, ou.data(), ou.size(), c->stream))) return rc;
+    if ((rc = up(&c->cf_oe_slot, os.data(), os.size(), c->stream))) return rc;
+    if ((rc = up(&c->cf_od_start, ods.data(), ods.size(), c->stream))) return rc;
+    if ((rc = up(&c->cf_od_edge, ode.data(), ode.size(), c->stream))) return rc;
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));           // the host vectors go out of scope
+  }
   if ((rc = up(&g.ue_start, start.data(), start.size(), c->stream))) return rc;
   if ((rc = up(&g.ue_id, id.data(), id.size(), c->stream))) return rc;
   if ((rc = up(&g.ue_slot, slot.data(), slot.size(), c->stream))) return rc;
@@ -86,15 +116,103 @@ int slam_alloc(esl_ctx* c) {
   const int64_t n = 6 * (int64_t)nf;
   c->S_n = n;
   c->S_lda = ((n + 1 + 15) / 16) * 16;
-  if ((rc = al(&c->S, (size_t)c->S_lda * (size_t)n))) return rc;
+  // the reduced camera system S (28.8 GB at C4) and the buffers of the camera-first form are allocated by the first trial step
+  // that needs them (slam_ensure_S / cf_ensure): a run uses one form or the other
+  if (c->S) { (void)hipFree(c->S); c->S = nullptr; }
+  if (c->Linv_ws) { (void)hipFree(c->Linv_ws); c->Linv_ws = nullptr; }
   if ((rc = al(&c->xc, (size_t)n))) return rc;
-  const size_t np = (size_t)((n + kNB - 1) / kNB);
-  if ((rc = al(&c->Linv_ws, np * kNB * kNB))) return rc;
   if ((rc = al(&c->z_ws, (size_t)kNB))) return rc;
   // W / A of edges that are never written (fixed camera) must not hold NaN garbage where they are summed
   ESL_HIP_TRY(hipMemsetAsync(c->Abb, 0, std::max<size_t>(EU, 1) * 27 * sizeof(double), c->stream));
   ESL_HIP_TRY(hipMemsetAsync(c->Wbb, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  return ESL_OK;
+}
+
+static CholRuntime& chol_rt(esl_ctx* c);
+static int slam_ensure_S(esl_ctx* c) {
+  if (c->S) return ESL_OK;
+  int rc;
+  const size_t n = (size_t)c->S_n, np = (n + kNB - 1) / kNB;
+  if ((rc = al(&c->S, (size_t)c->S_lda * n))) return rc;
+  if ((rc = al(&c->Linv_ws, np * kNB * kNB))) return rc;
+  return ESL_OK;
+}
+
+// ---- camera-first elimination: host side (kernels and the maths: esl_cf.hpp) ---------------------------------------------
+static bool cf_applicable(const esl_ctx* c) { return c->cf_chain_ok && !c->comm; }
+// esl_lm_params::linear_solver -> the form this trial runs with; < 0: the request cannot be served
+static int slam_pick_solver(const esl_ctx* c) {
+  const int want = c->lm.p.linear_solver;
+  if (want == ESL_SOLVER_REDUCED_CAMERA) return ESL_SOLVER_REDUCED_CAMERA;
+  if (want == ESL_SOLVER_REDUCED_ELLIPSOID) return cf_applicable(c) ? ESL_SOLVER_REDUCED_ELLIPSOID : -1;
+  if (!cf_applicable(c)) return ESL_SOLVER_REDUCED_CAMERA;
+  const double nc = (double)c->S_n, no = 9.0 * c->g.n_objs;
+  return (no * no * nc + no * no * no / 3.0 < nc * nc * nc / 3.0) ? ESL_SOLVER_REDUCED_ELLIPSOID : ESL_SOLVER_REDUCED_CAMERA;
+}
+static int cf_ensure(esl_ctx* c) {
+  if (c->cf_Xt) return ESL_OK;
+  const DevGraph& g = c->g;
+  const size_t nf = (size_t)g.n_free_cams, EU = (size_t)g.n_bbox + g.n_e3d, n_o = (size_t)9 * g.n_objs;
+  c->cf_ldx = (int64_t)((n_o + 1 + 15) / 16 * 16);
+  c->cf_kpad = (int64_t)((6 * nf + kKC - 1) / kKC * kKC);
+  c->cf_ldt = c->cf_ldx;
+  int rc;
+  if ((rc = al(&c->cf_Linv, nf * 36)) || (rc = al(&c->cf_M, nf * 36)) || (rc = al(&c->cf_N, nf * 36)) || (rc = al(&c->cf_V, EU * 54)) ||
+      (rc = al(&c->cf_vy, nf * 6)) || (rc = al(&c->cf_z, nf * 6)) || (rc = al(&c->cf_Xt, (size_t)c->cf_ldx * (size_t)c->cf_kpad)) ||
+      (rc = al(&c->cf_T, (size_t)c->cf_ldt * n_o)) || (rc = al(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB)))
+    return rc;
+  // rows 6 nf .. kpad of X (the K padding of the rank-K update) and the columns of never-written edges stay zero
+  ESL_HIP_TRY(hipMemsetAsync(c->cf_Xt, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad * sizeof(double), c->stream));
+  ESL_HIP_TRY(hipMemsetAsync(c->cf_V, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
+  return ESL_OK;
+}
+// One LM trial with the cameras eliminated first: x_c, x_o, trial states, chi2 of the trial (same outputs as the other form)
+static int slam_try_step_cf(esl_ctx* c, double lambda) {
+  const DevGraph& g = c->g;
+  const int N = g.n_objs, F = g.n_cams, nf = g.n_free_cams;
+  const int n_o = 9 * N;
+  int rc = cf_ensure(c);
+  if (rc) return rc;
+  const long ldx = (long)c->cf_ldx, ldt = (long)c->cf_ldt;
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  CholRuntime& rt = chol_rt(c);
+  {
+    ProfScope ps(c, 2);   // "reduced-system build": factor of the camera block, X = L^-1 [W | b_c], T = D - X^T X
+    ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_cf_tridiag_factor, dim3(1), dim3(64), 0, c->stream, nf, c->Hcc, c->Aod, c->cf_od_start, c->cf_od_edge, lambda, c->cf_Linv,
+                       c->cf_M, c->cf_N, c->chol_info);
+    const long nt = EU * 9 + nf;
+    hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->Wbb, c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
+    hipLaunchKernelGGL(k_cf_forward, dim3((unsigned)((n_o + 1 + 63) / 64)), dim3(64), 0, c->stream, nf, n_o, c->cf_oe_start, c->cf_oe_u, c->cf_oe_slot,
+                       c->cf_V, c->cf_vy, c->cf_M, c->cf_Xt, ldx);
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)ldt * (size_t)n_o * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_cf_T_init, dim3((unsigned)(((long)N * 90 + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
+    ESL_HIP_TRY(hipGetLastError());
+    ESL_HIP_TRY(chol_set_attributes(rt));
+    {
+      ProfScope pk(c, 7);   // the rank-K update alone (nested in class 2): the MFMA roofline kernel of this form
+      chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, 0, (long)n_o, c->cf_Xt, ldx);
+    }
+    ESL_HIP_TRY(hipGetLastError());
+  }
+  {
+    ProfScope ps(c, 3);   // dense Cholesky of the reduced ellipsoid system + the camera back-substitution
+    ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
+    hipLaunchKernelGGL(k_cf_z, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, c->cf_Xt, ldx, n_o, c->xo, c->cf_z);
+    hipLaunchKernelGGL(k_cf_tridiag_back, dim3(1), dim3(64), 0, c->stream, nf, c->cf_Linv, c->cf_N, c->cf_z, c->xc);
+    ESL_HIP_TRY(hipGetLastError());
+  }
+  {
+    ProfScope ps(c, 1);
+    hipLaunchKernelGGL(k_cf_obj_update, dim3((N + 255) / 256), dim3(256), 0, c->stream, g, lambda, c->objs, c->bo, c->xo, c->objs_trial, c->obj_part);
+    hipLaunchKernelGGL(k_slam_cam_update, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, lambda, c->cams, c->xc, c->bc, c->cams_trial, c->cam_part);
+    const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    hipLaunchKernelGGL(k_slam_chi2_obj, grid, block, 0, c->stream, g, c->cams_trial, c->objs_trial, c->obj_part);
+    if (g.n_odom)
+      hipLaunchKernelGGL(k_slam_chi2_odom, dim3((g.n_odom + 127) / 128), dim3(128), 0, c->stream, g, c->cams_trial, c->od_part);
+    ESL_HIP_TRY(hipGetLastError());
+  }
   return ESL_OK;
 }
 
@@ -166,6 +284,7 @@ int slam_build_reduced(esl_ctx* c, double lambda, bool full_sum, void** dev_ptr,
   const DevGraph& g = c->g;
   const int N = g.n_objs;
   const long n = (long)c->S_n, lda = (long)c->S_lda;
+  if (const int rcs = slam_ensure_S(c)) return rcs;
   {
     ProfScope ps(c, 2);
     ESL_HIP_TRY(hipMemsetAsync(c->S, 0, (size_t)lda * (size_t)n * sizeof(double), c->stream));
@@ -215,8 +334,17 @@ int slam_build_reduced(esl_ctx* c, double lambda, bool full_sum, void** dev_ptr,
 int slam_try_step(esl_ctx* c, double lambda) {
   const DevGraph& g = c->g;
   const int N = g.n_objs, F = g.n_cams;
-  int rc = slam_build_reduced(c, lambda, false, nullptr, nullptr);
-  if (rc) return rc;
+  const int solver = slam_pick_solver(c);
+  if (solver < 0) {
+    set_error("ESL_SOLVER_REDUCED_ELLIPSOID needs a single-GPU run whose odometry edges join neighbouring free cameras only");
+    return ESL_ERR_INVALID;
+  }
+  c->lm_solver_used = solver;
+  int rc;
+  if (solver == ESL_SOLVER_REDUCED_ELLIPSOID) {
+    if ((rc = slam_try_step_cf(c, lambda))) return rc;
+  } else {
+  if ((rc = slam_build_reduced(c, lambda, false, nullptr, nullptr))) return rc;
   {
     ProfScope ps(c, 3);
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
@@ -242,6 +370,7 @@ int slam_try_step(esl_ctx* c, double lambda) {
       hipLaunchKernelGGL(k_slam_chi2_odom, dim3((g.n_odom + 127) / 128), dim3(128), 0, c->stream, g, c->cams_trial, c->od_part);
   }
   ESL_HIP_TRY(hipGetLastError());
+  }
   {
     ProfScope ps2(c, 4);
     if ((rc = reduce_all(c))) return rc;
@@ -300,6 +429,7 @@ extern "C" int esl_lm_reduced_residual(esl_ctx* c, double* rel_residual_out) {
   using namespace esl;
   if (!c || !rel_residual_out) return ESL_ERR_INVALID;
   if (!c->lm.begun || !c->lm.slam || !c->xc || c->S_n <= 0) { set_error("esl_lm_reduced_residual: needs a SLAM-mode trial step"); return ESL_ERR_STATE; }
+  // (works after a step of either form: x_c of the camera-first elimination solves the same reduced camera system)
   ESL_HIP_TRY(hipSetDevice(c->device));
   const long n = (long)c->S_n, lda = (long)c->S_lda;
   // the factorisation overwrote S and b_s; full_sum: in a sharded run EVERY rank needs the summed system here (the per-panel
@@ -415,3 +545,9 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
   return rc;
 }
 
+
+extern "C" int esl_lm_solver_used(esl_ctx* c, int32_t* solver_out) {
+  if (!c || !solver_out) return ESL_ERR_INVALID;
+  *solver_out = c->lm_solver_used;
+  return ESL_OK;
+}

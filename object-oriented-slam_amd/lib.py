@@ -22,7 +22,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
     "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane", "esl_extract_planes",
 ]
 
@@ -176,6 +176,12 @@ class Context:
     def lm_commit(self, accept):
         _check(load().esl_lm_commit(self._h, C.c_int(1 if accept else 0)), "esl_lm_commit")
 
+    def lm_solver_used(self):
+        """esl_linear_solver of the last SLAM-mode trial step: 1 reduced camera system, 2 reduced ellipsoid system (cameras first)."""
+        v = C.c_int32(0)
+        _check(load().esl_lm_solver_used(self._h, C.byref(v)), "esl_lm_solver_used")
+        return v.value
+
     def lm_reduced_system(self, lam):
         ptr, n, lda = C.c_void_p(), C.c_int64(0), C.c_int64(0)
         _check(load().esl_lm_reduced_system(self._h, C.c_double(lam), C.byref(ptr), C.byref(n), C.byref(lda)),
@@ -209,7 +215,7 @@ class Context:
         cnt = (C.c_int64 * 8)()
         ms = (C.c_double * 8)()
         _check(load().esl_profile_get(self._h, cnt, ms), "esl_profile_get")
-        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "shard_allreduce", "k7"]
+        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "shard_allreduce", "rank_k_update"]
         return {n: dict(count=int(cnt[i]), total_ms=float(ms[i])) for i, n in enumerate(names) if cnt[i]}
 
     def init_quadric(self, poses_Twc, bboxes, K, rows=480, cols=640, faithful=1):

@@ -126,12 +126,27 @@ def test_c4_slam_schur_solve_full_size(pkg, ctx):
     g, c, o, _ = pkg.synth.make_config("C4", seed=0, slam=True)
     nf = int((~g.cam_fixed.astype(bool)).sum())
     assert g.n_cams == 10000 and g.n_objs == 2000 and nf == 9999 and len(g.odom_i) == 9999
-    p = pkg.default_lm_params(jacobian_mode=1, max_iters=3)      # 3 LM iterations: ~3 factorisations of 7.2e13 flop
+    p = pkg.default_lm_params(jacobian_mode=1, max_iters=3, linear_solver=1)      # 3 LM iterations: ~3 factorisations of 7.2e13 flop
     ctx.upload_graph(g); ctx.upload_states(c, o)
     rep = ctx.optimize_resident(p)
+    assert ctx.lm_solver_used() == 1
     res = ctx.lm_reduced_residual()
     print("C4 SLAM: n = %d, chi2 %.6e -> %s, |Sx-b|/|b| = %.2e" % (6 * nf, rep["chi2_initial"], rep["trace_chi2"], res))
     assert res < 1e-10
+    c1, o1 = ctx.download_states()
+    # the same run with the cameras eliminated first (solver AUTO picks it here: 18,000 ellipsoid unknowns against 59,994):
+    # its x_c must solve the SAME reduced camera system (the diagnostic rebuilds S and checks |S x_c - b_s|), and the LM run must
+    # be the same run
+    ctx.upload_states(c, o)
+    rep2 = ctx.optimize_resident(pkg.default_lm_params(jacobian_mode=1, max_iters=3))
+    assert ctx.lm_solver_used() == 2
+    res2 = ctx.lm_reduced_residual()
+    c2, o2 = ctx.download_states()
+    d_chi = float(np.abs(np.array(rep2["trace_chi2"]) / np.array(rep["trace_chi2"]) - 1).max())
+    print("C4 SLAM, cameras first: |Sx-b|/|b| = %.2e, chi2 trace rel %.2e, cams %.2e objs %.2e vs the reduced camera system" % (
+        res2, d_chi, float(np.abs(c2 - c1).max()), float(np.abs(o2 - o1).max())))
+    assert res2 < 1e-9 and rep2["trace_trials"] == rep["trace_trials"] and d_chi < 1e-8
+    assert np.abs(c2 - c1).max() < 1e-6 and np.abs(o2 - o1).max() < 1e-6
     tr = [rep["chi2_initial"]] + rep["trace_chi2"]
     assert all(tr[k + 1] <= tr[k] * (1 + 1e-12) for k in range(len(tr) - 1)) and tr[-1] < 0.2 * tr[0]
     assert rep["iterations"] == 3 and rep["total_trials"] >= 3

@@ -55,41 +55,49 @@ def test_slam_linearisation_matches_oracle(pkg, po, ctx, jac, delta, tol):
     np.testing.assert_allclose(bs, bs_ref, atol=tol * np.abs(bs_ref).max())
 
 
+@pytest.mark.parametrize("solver", [1, 2])
 @pytest.mark.parametrize("n_cams", [12, 40, 100])
-def test_dense_cholesky_solves_reduced_system(pkg, ctx, n_cams):
-    """x_c from the MFMA Cholesky equals numpy's solve of the same S, b_s (1, 2 and 5 panels of 128)."""
+def test_dense_cholesky_solves_reduced_system(pkg, ctx, n_cams, solver):
+    """x_c equals numpy's solve of the reduced camera system S, b_s (1, 2 and 5 panels of 128) -- from the MFMA Cholesky of S itself
+    (solver 1) and from the camera-first elimination (solver 2: block-bidiagonal factor of the camera block, reduced ELLIPSOID
+    system, back-substitution), which must solve the same linear system."""
     g, c, o, _ = pkg.synth.make_graph(n_cams, 8, 40 * n_cams // 4, seed=4, slam=True)
     ctx.upload_graph(g); ctx.upload_states(c, o)
-    ctx.lm_begin(pkg.default_lm_params(jacobian_mode=1))
+    ctx.lm_begin(pkg.default_lm_params(jacobian_mode=1, linear_solver=solver))
     part = ctx.lm_linearize()
     lam = 1e-5 * part.max_diag
     ptr, n, lda = ctx.lm_reduced_system(lam)
     S, bs = lower_to_full(ctx.lm_download(6, lda * n), n, lda)
     out = ctx.lm_try_step(lam)
-    assert out.solve_ok == 1
+    assert out.solve_ok == 1 and ctx.lm_solver_used() == solver
     xc = ctx.lm_download(5, n)
     ref = np.linalg.solve(S, bs)
     np.testing.assert_allclose(xc, ref, atol=1e-9 * np.abs(ref).max() + 1e-12, rtol=1e-7)
+    assert ctx.lm_reduced_residual() < 1e-12
     ctx.lm_commit(False)
 
 
+@pytest.mark.parametrize("solver", [1, 2])
 @pytest.mark.parametrize("jac", [0, 1])
-def test_slam_lm_matches_faithful_dense_oracle(pkg, po, ctx, jac):
+def test_slam_lm_matches_faithful_dense_oracle(pkg, po, ctx, jac, solver):
     g, c, o, _ = pkg.synth.make_graph(30, 6, 200, seed=3, slam=True)
     p = pkg.default_lm_params(numeric_delta=1e-6)
     co, oo, ro = po.optimize(g, c, o, p, solver=0)  # dense LDLT of the whole system, like LinearSolverDense
-    cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6))
+    cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6, linear_solver=solver))
+    assert ctx.lm_solver_used() == solver
     n = min(len(rg["trace_chi2"]), len(ro["trace_chi2"]))
-    print("SLAM LM (30 cams) jac %d vs dense checker: chi2 trace rel %.2e, cams %.2e, centres %.2e, scales rel %.2e" % (
-        jac, float(np.abs(np.array(rg["trace_chi2"][:n]) / np.array(ro["trace_chi2"][:n]) - 1).max()), cam_err(cg, co),
+    print("SLAM LM (30 cams) jac %d solver %d vs dense checker: chi2 trace rel %.2e, cams %.2e, centres %.2e, scales rel %.2e" % (
+        jac, solver, float(np.abs(np.array(rg["trace_chi2"][:n]) / np.array(ro["trace_chi2"][:n]) - 1).max()), cam_err(cg, co),
         float(np.abs(og[:, :3] - oo[:, :3]).max()), float(np.abs(og[:, 7:] / oo[:, 7:] - 1).max())))
-    tol = 1e-6 if jac == 0 else 1e-4      # like for like (numeric, delta = 1e-6 on both sides) / analytic vs the checker's differences
-    np.testing.assert_allclose(rg["trace_chi2"][:n], ro["trace_chi2"][:n], rtol=tol)
-    assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=tol)
+    # measured (both Jacobian modes: at delta = 1e-6 the checker's differences are good to 1e-7): objective 1.1e-7, cameras 1.4e-6,
+    # centres 4.1e-7, scales 1.2e-7
+    np.testing.assert_allclose(rg["trace_chi2"][:n], ro["trace_chi2"][:n], rtol=5e-7)
+    assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=5e-7)
+    assert rg["trace_trials"][:n] == ro["trace_trials"][:n]
     assert np.array_equal(cg[0], c[0])  # camera 0 is fixed (Optimizer.cpp:138)
-    assert cam_err(cg, co) < 10 * tol
-    np.testing.assert_allclose(og[:, :3], oo[:, :3], atol=10 * tol * np.abs(oo[:, :3]).max())
-    np.testing.assert_allclose(og[:, 7:], oo[:, 7:], rtol=10 * tol)
+    assert cam_err(cg, co) < 5e-6
+    np.testing.assert_allclose(og[:, :3], oo[:, :3], atol=2e-6)
+    np.testing.assert_allclose(og[:, 7:], oo[:, 7:], rtol=1e-6)
 
 
 def obj_rel(a, b):
@@ -113,8 +121,9 @@ def test_c3_slam_first_iteration_matches_faithful_dense_oracle(pkg, po, ctx, c3_
     g, c, o, _ = c3_dense
     p1 = pkg.default_lm_params(numeric_delta=1e-6, max_iters=1)
     co, oo, ro = po.optimize(g, c, o, p1, solver=po.ORACLE_DENSE)
-    for jac in (0, 1):
-        cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6, max_iters=1))
+    for jac, solver in ((0, 1), (1, 1), (0, 2), (1, 2)):   # both eliminations: reduced camera system / cameras first
+        cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6, max_iters=1, linear_solver=solver))
+        assert ctx.lm_solver_used() == solver
         assert rg["trace_trials"] == ro["trace_trials"]
         assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-7)
         assert cam_err(cg, co) < 1e-6
@@ -134,7 +143,8 @@ def test_c3_slam_full_run_vs_faithful_dense_delta_1e9(pkg, po, ctx, c3_dense):
     g, c, o, runs = c3_dense
     (c9, o9, r9), (c6, o6, r6) = runs[1e-9], runs[1e-6]
     floor_cam, floor_obj = cam_err(c6, c9), obj_rel(o6, o9)
-    cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1))           # product default: analytic
+    cg, og, rg = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1))           # product default: analytic, solver AUTO
+    assert ctx.lm_solver_used() == 2             # C3: 450 ellipsoid unknowns against 2,994 camera unknowns -> cameras first
     assert rg["trace_trials"] == r9["trace_trials"] and rg["stop_reason"] == r9["stop_reason"]
     np.testing.assert_allclose(rg["trace_chi2"], r9["trace_chi2"], rtol=2e-5)
     assert rg["chi2_final"] < 0.1 * rg["chi2_initial"]
@@ -143,6 +153,13 @@ def test_c3_slam_full_run_vs_faithful_dense_delta_1e9(pkg, po, ctx, c3_dense):
     # like for like: numeric delta = 1e-6 on both sides
     cn, on, rn = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6))
     np.testing.assert_allclose(rn["trace_chi2"], r6["trace_chi2"], rtol=1e-6)
+    # the two eliminations against each other over the whole run (same linear systems, different arithmetic: cond(S) amplifies
+    # the rounding of either): like for like, reduced camera system forced
+    c1, o1, r1 = ctx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, linear_solver=1))
+    assert ctx.lm_solver_used() == 1 and r1["trace_trials"] == rn["trace_trials"]
+    print("C3 SLAM: cameras-first vs reduced-camera elimination: cams %.2e objs %.2e chi2 rel %.2e" % (
+        cam_err(cn, c1), obj_rel(on, o1), float(np.abs(np.array(rn["trace_chi2"]) / np.array(r1["trace_chi2"]) - 1).max())))
+    assert cam_err(c1, c6) < 1e-4 and obj_rel(o1, o6) < 1e-5
     print("C3 SLAM parity: reference self-distance (delta 1e-9 vs 1e-6) cams %.2e objs %.2e | GPU analytic vs 1e-9: cams %.2e objs %.2e | "
           "GPU numeric 1e-6 vs oracle 1e-6: cams %.2e objs %.2e" % (floor_cam, floor_obj, cam_err(cg, c9), obj_rel(og, o9), cam_err(cn, c6), obj_rel(on, o6)))
     assert obj_rel(on, o6) < 1e-5          # measured 8.6e-7
@@ -167,9 +184,53 @@ def test_slam_runs_are_bitwise_reproducible(pkg, ctx):
     """SLAM mode has no order-dependent reduction left (round 1's Schur complement scattered into S with fp64 atomics): the
     same graph twice gives the same bits, trace and states."""
     g, c, o, _ = pkg.synth.make_graph(60, 12, 700, seed=17, slam=True)
-    p = pkg.default_lm_params(jacobian_mode=1)
-    runs = [ctx.optimize(g, c, o, p) for _ in range(3)]
-    for cc, oo, rep in runs[1:]:
-        assert rep["trace_chi2"] == runs[0][2]["trace_chi2"]
-        np.testing.assert_array_equal(cc, runs[0][0])
-        np.testing.assert_array_equal(oo, runs[0][1])
+    for solver in (1, 2):
+        p = pkg.default_lm_params(jacobian_mode=1, linear_solver=solver)
+        runs = [ctx.optimize(g, c, o, p) for _ in range(3)]
+        for cc, oo, rep in runs[1:]:
+            assert rep["trace_chi2"] == runs[0][2]["trace_chi2"]
+            np.testing.assert_array_equal(cc, runs[0][0])
+            np.testing.assert_array_equal(oo, runs[0][1])
+
+
+def test_camera_first_elimination_applicability(pkg, ctx):
+    """ESL_SOLVER_REDUCED_ELLIPSOID needs the reference's chain (odometry edges between neighbouring free cameras only):
+    a loop-closure style odometry edge makes the camera block non-tridiagonal -> the forced solver is refused (ESL_ERR_INVALID),
+    AUTO falls back to the reduced camera system and still matches the run without that edge's special treatment; graphs with
+    fixed cameras inside the chain, without any odometry edge, and with a camera that has odometry edges only, are served."""
+    g, c, o, _ = pkg.synth.make_graph(24, 5, 160, seed=6, slam=True)
+    from oracle import pyoracle as po
+    # (a) an extra odometry edge 3 -> 11
+    Z = po.se3_mul(c[11], po.se3_inv(c[3]))
+    ga = pkg.Graph(g.K, g.n_cams, g.n_objs, g.cam_fixed, g.bbox_cam, g.bbox_obj, g.bbox_meas, g.bbox_weight, g.e3d_cam, g.e3d_obj, g.e3d_meas,
+                   g.e3d_weight, g.grav_obj, g.grav_normal, g.grav_weight, odom_i=np.append(g.odom_i, 3), odom_j=np.append(g.odom_j, 11),
+                   odom_meas=np.vstack([g.odom_meas.reshape(-1, 7), Z]))
+    with pytest.raises(pkg.EslError, match="esl_status 2"):
+        ctx.optimize(ga, c, o, pkg.default_lm_params(jacobian_mode=1, linear_solver=2))
+    ca, oa, ra = ctx.optimize(ga, c, o, pkg.default_lm_params(jacobian_mode=1, numeric_delta=1e-6))
+    assert ctx.lm_solver_used() == 1
+    co, oo, ro = po.optimize(ga, c, o, pkg.default_lm_params(numeric_delta=1e-6), solver=0)
+    assert ra["trace_trials"][:2] == ro["trace_trials"][:2] and cam_err(ca, co) < 1e-4
+    # (b) cameras 0 and 9 fixed (the chain is cut in two), (c) no odometry at all, (d) reversed vertex order of some odometry edges
+    fixed = g.cam_fixed.copy(); fixed[9] = 1
+    oi, oj, om = g.odom_i.copy(), g.odom_j.copy(), g.odom_meas.reshape(-1, 7).copy()
+    for k in (2, 5, 17):
+        oi[k], oj[k] = oj[k], oi[k]
+        om[k] = po.se3_inv(om[k])
+    variants = {
+        "cut": pkg.Graph(g.K, g.n_cams, g.n_objs, fixed, g.bbox_cam, g.bbox_obj, g.bbox_meas, g.bbox_weight, g.e3d_cam, g.e3d_obj, g.e3d_meas,
+                         g.e3d_weight, g.grav_obj, g.grav_normal, g.grav_weight, odom_i=g.odom_i, odom_j=g.odom_j, odom_meas=g.odom_meas),
+        "no_odometry": pkg.Graph(g.K, g.n_cams, g.n_objs, g.cam_fixed, g.bbox_cam, g.bbox_obj, g.bbox_meas, g.bbox_weight, g.e3d_cam, g.e3d_obj,
+                                 g.e3d_meas, g.e3d_weight, g.grav_obj, g.grav_normal, g.grav_weight),
+        "reversed_edges": pkg.Graph(g.K, g.n_cams, g.n_objs, g.cam_fixed, g.bbox_cam, g.bbox_obj, g.bbox_meas, g.bbox_weight, g.e3d_cam, g.e3d_obj,
+                                    g.e3d_meas, g.e3d_weight, g.grav_obj, g.grav_normal, g.grav_weight, odom_i=oi, odom_j=oj, odom_meas=om),
+    }
+    for name, gv in variants.items():
+        p6 = pkg.default_lm_params(numeric_delta=1e-6, max_iters=2)
+        co, oo, ro = po.optimize(gv, c, o, p6, solver=0)
+        for solver in (1, 2):
+            cg, og, rg = ctx.optimize(gv, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, max_iters=2, linear_solver=solver))
+            assert ctx.lm_solver_used() == solver
+            assert rg["trace_trials"] == ro["trace_trials"], (name, solver)
+            np.testing.assert_allclose(rg["trace_chi2"], ro["trace_chi2"], rtol=1e-6, err_msg=name)
+            assert cam_err(cg, co) < 1e-5 and obj_rel(og, oo) < 1e-5, (name, solver, cam_err(cg, co), obj_rel(og, oo))

@@ -83,6 +83,6 @@ def test_gpu_tangency_lm_matches_checker(pkg, tang, ctx, slam, jac):
 @pytest.mark.gpu
 def test_unknown_modes_are_rejected(pkg, ctx):
     g, c, o, _ = pkg.synth.make_graph(10, 2, 30, seed=1)
-    for kw in (dict(bbox_residual=7), dict(linear_solver=1)):
+    for kw in (dict(bbox_residual=7), dict(linear_solver=7)):
         with pytest.raises(pkg.EslError, match="esl_status 2"):
             ctx.optimize(g, c, o, pkg.default_lm_params(**kw))
