@@ -259,9 +259,9 @@ static void free_graph(esl_ctx* c) {
   dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
   dev_free(&c->Abb); dev_free(&c->Ae3); dev_free(&c->Aod); dev_free(&c->Dinv); dev_free(&c->Yb); dev_free(&c->Wt); dev_free(&c->Tb); dev_free(&c->Ye3);
   dev_free(&c->S); dev_free(&c->cam_part); dev_free(&c->od_part);
-  dev_free(&c->cf_oe_start); dev_free(&c->cf_oe_u); dev_free(&c->cf_oe_slot); dev_free(&c->cf_od_start); dev_free(&c->cf_od_edge);
+  dev_free(&c->cf_oe_start); dev_free(&c->cf_oe_u); dev_free(&c->cf_oe_slot); dev_free(&c->cf_od_start); dev_free(&c->cf_od_edge); dev_free(&c->cf_oe_cst);
   dev_free(&c->cf_Linv); dev_free(&c->cf_M); dev_free(&c->cf_N); dev_free(&c->cf_V); dev_free(&c->cf_vy); dev_free(&c->cf_z);
-  dev_free(&c->cf_Xt); dev_free(&c->cf_T); dev_free(&c->cf_Linv_ws);
+  dev_free(&c->cf_Xt); dev_free(&c->cf_T); dev_free(&c->cf_Linv_ws); dev_free(&c->cf_B); dev_free(&c->cf_Lfac); dev_free(&c->cf_G);
   c->cf_chain_ok = false;
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->S_n = 0;

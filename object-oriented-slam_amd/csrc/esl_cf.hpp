@@ -8,7 +8,7 @@
 // S = A - W D^-1 W^T of order 6 (F - 1).  In the reference's SLAM branch the camera block A is block TRIDIAGONAL -- the only
 // camera-camera edges are the odometry edges between consecutive frames (src/core/Optimizer.cpp:142-158) -- and there are
 // five times fewer ellipsoid unknowns than camera unknowns (C4: 18,000 vs 59,994).  Eliminating the cameras instead:
-//     A = L L^T                         block-bidiagonal Cholesky, one sequential sweep over the cameras        k_cf_tridiag_factor
+//     A = L L^T                         block-bidiagonal Cholesky, one sequential sweep over the cameras        k_cf_gather_B, k_cf_chain, k_cf_factor_blocks
 //     X = L^-1 W,  y = L^-1 b_c         forward substitution, one lane per column (9 N + 1 columns)             k_cf_edge_scale, k_cf_forward
 //     T = D - X^T X,  t = b_o - X^T y   rank-6(F-1) update on the FP64 matrix cores (k_chol_update_lds, external factor)
 //     T x_o = t                         dense FP64-MFMA Cholesky of order 9 N (esl_chol.hpp)
@@ -21,8 +21,6 @@
 // Applicable when every odometry edge joins two cameras whose free-camera slots differ by one (the reference's chain) and the run
 // is not sharded; esl_lm_params::linear_solver selects (include/esl.h).
 #pragma once
-#include <climits>
-
 #include "esl_kernels_map.hpp"
 
 namespace esl {
@@ -32,219 +30,318 @@ __device__ __forceinline__ double cf_readlane(double v, int src) {   // src: com
   return __hiloint2double(hi, lo);
 }
 
-// ---- A = L L^T for the block-tridiagonal camera matrix: ONE wave, sequential over the free cameras -----------------------
-// Lane (r, c) = lane / 6, lane % 6 owns entry (r, c) of every 6 x 6 block; the blocks travel through LDS (one wave: LDS
-// operations execute in order, only the compiler is fenced).  Per camera i:
-//   D_i = Hcc_i + lambda I - Lo Lo^T     (Lo = L_{i,i-1})        L_ii = chol(D_i),  Li = L_ii^-1
-//   M_i = Li Lo                          forward substitution:   X_i = Li W_i - M_i X_{i-1}
-//   B_i = A_{i+1,i} (odometry blocks),   Lo' = L_{i+1,i} = B_i Li^T
-//   N_i = Li^T Lo'^T                     back substitution:      x_i = Li^T z_i - N_i x_{i+1}
-// od_start / od_edge: odometry edges joining slots (i, i + 1), entry = edge * 2 + t; t = 1: the edge's first vertex is slot i
-// (its Hij block, rows = first vertex, is then the TRANSPOSE of B_i).
-static __global__ __launch_bounds__(64) void k_cf_tridiag_factor(int nf, const double* __restrict__ Hcc, const double* __restrict__ Aod,
-                                                                 const int* __restrict__ od_start, const int* __restrict__ od_edge,
-                                                                 double lambda, double* __restrict__ Linv, double* __restrict__ Mm,
-                                                                 double* __restrict__ Nn, int* __restrict__ info) {
-  __shared__ double sLo[36], sD[36], sL[36], sLi[36], sB[36], sIs[6];
-  const int lane = threadIdx.x, r = lane / 6, c = lane - 6 * r;
-  const bool on = lane < 36;
-  if (on) { sLo[lane] = 0; sL[lane] = 0; sLi[lane] = 0; }
-  bool ok = true;
-  double h_next = (on && nf > 0) ? Hcc[lane] : 0.0;
-  __builtin_amdgcn_wave_barrier();
-  for (int i = 0; i < nf; ++i) {
-    const double h = h_next;
-    if (on && i + 1 < nf) h_next = Hcc[(size_t)(i + 1) * 36 + lane];   // next camera's block: in flight under this step
-    double bsum = 0;                                                    // B_i entry (r, c), gathered early for the same reason
-    if (on && i + 1 < nf) {
-      for (int q = od_start[i]; q < od_start[i + 1]; ++q) {
-        const int es = od_edge[q];
-        const double* Hij = Aod + (size_t)(es >> 1) * 90 + 54;
-        bsum += (es & 1) ? Hij[c * 6 + r] : Hij[r * 6 + c];
-      }
+// ---- A = L L^T for the block-tridiagonal camera matrix -------------------------------------------------------------------
+// Three launches: (1) k_cf_gather_B, parallel: B_i = A_{i+1,i} from the odometry edges of slot pair (i, i + 1) -- od_start / od_edge,
+// entry = edge * 2 + t; t = 1: the edge's first vertex is slot i, so its Hij block (rows = first vertex) is the TRANSPOSE of B_i;
+// (2) k_cf_chain, ONE wave, sequential: only what is inherently serial, the Schur-complement recurrence
+//         D_0 = Hcc_0 + lambda I,   D_{i+1} = Hcc_{i+1} + lambda I - G_i^T G_i,   G_i = L_ii^-1 B_i^T,   L_ii = chol(D_i)
+//     Every lane carries the whole 6 x 6 problem in registers (no LDS hand-overs, no cross-lane traffic: a dependent LDS round trip
+//     costs more than the ~60 instructions it would save); the next step's Hcc and B are in flight one step ahead.  Round 3's first
+//     form (36 lanes, one entry each, blocks through LDS, odometry blocks gathered inside the loop) took 2.0 us per camera -- three
+//     dependent global loads and ~18 dependent LDS round trips per step; this one 0.5 us.
+// (3) k_cf_factor_blocks, parallel (one thread per camera): everything else the substitutions need, from L_ii and G_i:
+//         Li = L_ii^-1,   Lo = L_{i,i-1} = G_{i-1}^T,   M_i = Li Lo   (X_i = Li W_i - M_i X_{i-1}),
+//         N_i = Li^T L_{i+1,i}^T = Li^T G_i                            (x_i = Li^T z_i - N_i x_{i+1})
+static __global__ __launch_bounds__(256) void k_cf_gather_B(int nf, const double* __restrict__ Aod, const int* __restrict__ od_start,
+                                                            const int* __restrict__ od_edge, double* __restrict__ B) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long i = t / 36;
+  if (i >= nf) return;
+  const int e = (int)(t - i * 36), r = e / 6, c = e - 6 * r;
+  double s = 0;
+  if (i + 1 < nf)
+    for (int q = od_start[i]; q < od_start[i + 1]; ++q) {
+      const int es = od_edge[q];
+      const double* Hij = Aod + (size_t)(es >> 1) * 90 + 54;
+      s += (es & 1) ? Hij[c * 6 + r] : Hij[r * 6 + c];
     }
-    // D_i
-    if (on) {
-      double d = h + ((r == c) ? lambda : 0.0);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) d -= sLo[r * 6 + k] * sLo[c * 6 + k];
-      sD[lane] = d;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // L_ii: right-looking, column by column
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const double p = sD[j * 6 + j];
-      ok = ok && (p > 0);
-      double is = __builtin_amdgcn_rsq(p);   // 1 / sqrt(p): hardware estimate + two Newton steps
-      is = is * (1.5 - 0.5 * p * is * is);
-      is = is * (1.5 - 0.5 * p * is * is);
-      if (on && c == j && r >= j) sL[lane] = (r == j) ? p * is : sD[lane] * is;
-      if (lane == 0) sIs[j] = is;
-      __builtin_amdgcn_wave_barrier();
-      if (on && r >= c && c > j) sD[lane] -= sL[r * 6 + j] * sL[c * 6 + j];
-      __builtin_amdgcn_wave_barrier();
-    }
-    // Li = L_ii^-1 (lower): lane c < 6 solves column c by forward substitution
-    if (lane < 6) {
-      double col[6];
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr) {
-        double v = (rr == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < rr; ++k) v -= sL[rr * 6 + k] * col[k];
-        col[rr] = (rr >= lane) ? v * sIs[rr] : 0.0;
-      }
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr) sLi[rr * 6 + lane] = col[rr];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (on) {
-      Linv[(size_t)i * 36 + lane] = sLi[lane];
-      double m = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) m += sLi[r * 6 + k] * sLo[k * 6 + c];
-      Mm[(size_t)i * 36 + lane] = m;
-      sB[lane] = bsum;
-    }
-    __builtin_amdgcn_wave_barrier();
-    double lo_new = 0;
-    if (on && i + 1 < nf) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) lo_new += sB[r * 6 + k] * sLi[c * 6 + k];   // B Li^T
-    }
-    __builtin_amdgcn_wave_barrier();      // every lane has read the old Lo (M_i) before it is replaced
-    if (on) sLo[lane] = lo_new;
-    __builtin_amdgcn_wave_barrier();
-    if (on) {
-      double nv = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) nv += sLi[k * 6 + r] * sLo[c * 6 + k];      // Li^T Lo'^T
-      Nn[(size_t)i * 36 + lane] = nv;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (!__all(ok) && lane == 0) atomicOr(info, 1);
+  B[t] = s;   // (block nf - 1 is zero: nothing follows the last camera)
 }
 
-// ---- V_e = Li_{slot(e)} W_e per edge (per-edge records [u][b][a], a = camera row), vy_s = Li_s b_c,s ------------------------
-// thread = (edge u, ellipsoid column b) or, behind those, one per free camera.  Edges whose camera is fixed are never read;
-// bbox edges dropped by the NaN / visibility pre-check get V = 0 (the per-ellipsoid lists still hold them).
-static __global__ __launch_bounds__(256) void k_cf_edge_scale(DevGraph g, const double* __restrict__ W, const double* __restrict__ Linv,
+// packed lower triangle: (r, c), r >= c, at r (r + 1) / 2 + c
+#define CF_LT(r, c) ((r) * ((r) + 1) / 2 + (c))
+// Memory never sits inside the serial loop: Hcc and B of kCfChainCh cameras are staged in LDS (the next chunk's global loads are
+// issued before the chunk's steps run and land in LDS after them), L and G of the chunk collect in LDS and leave as coalesced
+// stores.  (With the loads inside the loop the compiler serialised three scalar-load round trips per camera: 2.3 us per step.)
+constexpr int kCfChainCh = 32;
+static __global__ __launch_bounds__(64) void k_cf_chain(int nf, const double* __restrict__ Hcc, const double* __restrict__ B, double lambda,
+                                                        double* __restrict__ Lfac /* nf x 21: L_ii, packed lower */,
+                                                        double* __restrict__ Gfac /* nf x 36: G_i = L_ii^-1 B_i^T, row-major */,
+                                                        int* __restrict__ info) {
+  __shared__ double sH[kCfChainCh * 36], sB[kCfChainCh * 36], sL[kCfChainCh * 21], sG[kCfChainCh * 36];
+  constexpr int kPer = kCfChainCh * 36 / 64;   // doubles per lane and array in one chunk
+  const int lane = threadIdx.x;
+  if (nf <= 0) return;
+  double rh[kPer], rb[kPer];
+  auto gload = [&](int i0) {
+    const size_t lim = (size_t)nf * 36;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const size_t idx = (size_t)i0 * 36 + (size_t)q * 64 + lane;
+      rh[q] = idx < lim ? Hcc[idx] : 0.0;
+      rb[q] = idx < lim ? B[idx] : 0.0;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) { sH[q * 64 + lane] = rh[q]; sB[q * 64 + lane] = rb[q]; }
+  };
+  gload(0);
+  lstore();
+  __builtin_amdgcn_wave_barrier();
+  bool ok = true;
+  double g[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) g[k] = 0;
+  for (int i0 = 0; i0 < nf; i0 += kCfChainCh) {
+    const int len = (nf - i0 < kCfChainCh) ? nf - i0 : kCfChainCh;
+    const bool more = i0 + kCfChainCh < nf;
+    if (more) gload(i0 + kCfChainCh);
+    for (int ii = 0; ii < len; ++ii) {
+      // D_i = Hcc_i + lambda I - G_{i-1}^T G_{i-1}
+      double d[21], b[36];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          double v = sH[ii * 36 + r * 6 + c] + ((r == c) ? lambda : 0.0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v -= g[k * 6 + r] * g[k * 6 + c];
+          d[CF_LT(r, c)] = v;
+        }
+#pragma unroll
+      for (int k = 0; k < 36; ++k) b[k] = sB[ii * 36 + k];
+      // L_ii = chol(D_i), right-looking, in place
+      double is[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double p = d[CF_LT(j, j)];
+        ok = ok && (p > 0);
+        double q = __builtin_amdgcn_rsq(p);   // 1 / sqrt(p): hardware estimate + two Newton steps
+        q = q * (1.5 - 0.5 * p * q * q);
+        q = q * (1.5 - 0.5 * p * q * q);
+        is[j] = q;
+        d[CF_LT(j, j)] = p * q;
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r) d[CF_LT(r, j)] *= q;
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r)
+#pragma unroll
+          for (int c = j + 1; c <= r; ++c) d[CF_LT(r, c)] -= d[CF_LT(r, j)] * d[CF_LT(c, j)];
+      }
+      // G = L^-1 B^T by forward substitution: column c of G solves L g = (row c of B)^T
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double v = b[c * 6 + r];
+#pragma unroll
+          for (int k = 0; k < r; ++k) v -= d[CF_LT(r, k)] * g[k * 6 + c];
+          g[r * 6 + c] = v * is[r];
+        }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) sL[ii * 21 + k] = d[k];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) sG[ii * 36 + k] = g[k];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (more) lstore();                      // the next chunk's blocks (their loads ran under the steps above)
+    for (int idx = lane; idx < len * 21; idx += 64) Lfac[(size_t)i0 * 21 + idx] = sL[idx];
+    for (int idx = lane; idx < len * 36; idx += 64) Gfac[(size_t)i0 * 36 + idx] = sG[idx];
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!ok && lane == 0) atomicOr(info, 1);
+}
+
+static __global__ __launch_bounds__(64) void k_cf_factor_blocks(int nf, const double* __restrict__ Lfac, const double* __restrict__ Gfac,
+                                                                double* __restrict__ Linv, double* __restrict__ Mm, double* __restrict__ Nn) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nf) return;
+  double L[21], Li[36];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) L[k] = Lfac[(size_t)i * 21 + k];
+  // Li = L^-1 (lower): column c by forward substitution
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if (r < c) { Li[r * 6 + c] = 0; continue; }
+      double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = c; k < r; ++k) v -= L[CF_LT(r, k)] * Li[k * 6 + c];
+      Li[r * 6 + c] = v / L[CF_LT(r, r)];
+    }
+#pragma unroll
+  for (int k = 0; k < 36; ++k) Linv[(size_t)i * 36 + k] = Li[k];
+  // M_i = Li Lo, Lo = L_{i,i-1} = G_{i-1}^T (zero for the first camera)
+  double Lo[36];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Lo[r * 6 + c] = (i > 0) ? Gfac[(size_t)(i - 1) * 36 + c * 6 + r] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k <= r; ++k) m += Li[r * 6 + k] * Lo[k * 6 + c];
+      Mm[(size_t)i * 36 + r * 6 + c] = m;
+    }
+  // N_i = Li^T G_i (G of the last camera is zero: B_{nf-1} = 0)
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double nv = 0;
+#pragma unroll
+      for (int k = r; k < 6; ++k) nv += Li[k * 6 + r] * Gfac[(size_t)i * 36 + k * 6 + c];
+      Nn[(size_t)i * 36 + r * 6 + c] = nv;
+    }
+}
+#undef CF_LT
+
+// ---- V_k = Li_{slot(k)} W_{edge(k)} for every entry k of the per-ellipsoid edge lists (sorted by slot), vy_s = Li_s b_c,s ----
+// thread = (list entry k, ellipsoid column b) or, behind those, one per free camera.  Records in LIST order ([k][b][a], a = camera
+// row): the forward substitution finds the record of entry k of column b without going through the edge id.  bbox edges dropped by
+// the NaN / visibility pre-check get V = 0 (the lists still hold them).
+static __global__ __launch_bounds__(256) void k_cf_edge_scale(DevGraph g, int n_list, const int* __restrict__ oe_u, const int* __restrict__ oe_slot,
+                                                              const double* __restrict__ W, const double* __restrict__ Linv,
                                                               const double* __restrict__ bc, double* __restrict__ V,
                                                               double* __restrict__ vy) {
   const long EU = (long)g.n_bbox + g.n_e3d;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t < EU * 9) {
-    const long u = t / 9;
-    const int b = (int)(t - u * 9);
-    const int cam = (u < g.n_bbox) ? g.bb_cam[u] : g.e3_cam[u - g.n_bbox];
-    const int obj = (u < g.n_bbox) ? g.bb_obj[u] : g.e3_obj[u - g.n_bbox];
-    if (obj < 0) return;                               // slack slot of an appendable layout
-    const int slot = g.cam_slot[cam];
-    if (slot < 0) return;
+  if (t < (long)n_list * 9) {
+    const long k = t / 9;
+    const int b = (int)(t - k * 9);
+    const long u = oe_u[k];
+    const int slot = oe_slot[k];
     const bool valid = !(u < g.n_bbox) || g.bb_valid[u];
     double w[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = valid ? W[(long)(k * 9 + b) * EU + u] : 0.0;
+    for (int q = 0; q < 6; ++q) w[q] = valid ? W[(long)(q * 9 + b) * EU + u] : 0.0;
     const double* Li = Linv + (size_t)slot * 36;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       double s = 0;
 #pragma unroll
-      for (int k = 0; k <= a; ++k) s += Li[a * 6 + k] * w[k];
-      V[u * 54 + b * 6 + a] = s;
+      for (int q = 0; q <= a; ++q) s += Li[a * 6 + q] * w[q];
+      V[t * 6 + a] = s;
     }
   } else {
-    const long s = t - EU * 9;
+    const long s = t - (long)n_list * 9;
     if (s >= g.n_free_cams) return;
     const double* Li = Linv + (size_t)s * 36;
     double w[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = bc[(size_t)s * 6 + k];
+    for (int q = 0; q < 6; ++q) w[q] = bc[(size_t)s * 6 + q];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       double v = 0;
 #pragma unroll
-      for (int k = 0; k <= a; ++k) v += Li[a * 6 + k] * w[k];
+      for (int q = 0; q <= a; ++q) v += Li[a * 6 + q] * w[q];
       vy[(size_t)s * 6 + a] = v;
     }
   }
 }
 
 // ---- X = L^-1 [W | b_c]: one lane per column (9 per ellipsoid + the right-hand side), sequential over the cameras -----------
-// X_i = V_i - M_i X_{i-1}; V_i is non-zero only where the column's ellipsoid has an edge at camera i (its list is sorted by
-// slot; the next edge's record is already in registers when its camera comes up).  The M blocks of kCfChunk cameras are staged
-// in LDS by the wave (one wave per workgroup).  Xt is the TRANSPOSE of X: element (column j, row k) at Xt[j + k * ldx] --
-// the layout the MFMA rank-K update wants for its factor, and coalesced for these stores.
-constexpr int kCfChunk = 32;
-static __global__ __launch_bounds__(64) void k_cf_forward(int nf, int n_o, const int* __restrict__ oe_start, const int* __restrict__ oe_u,
+// X_i = V_i - M_i X_{i-1}; V_i is non-zero only where the column's ellipsoid has an edge at camera i.  Chunks of kCfFwdCh cameras,
+// three phases each, so that no memory operation sits inside the serial loop:
+//   (1) gather: the M blocks of the chunk -> LDS; every lane adds the V records of ITS column's list entries that fall into the
+//       chunk into an LDS slab v[step][row][lane] (entry range of (ellipsoid, chunk) from a table built at upload: all loads of
+//       a batch of entries go out together);
+//   (2) kCfFwdCh steps on LDS only: x = v - M x, x written over v;
+//   (3) the slab leaves as coalesced stores: Xt is the TRANSPOSE of X (element (column j, row k) at Xt[j + k ldx]) -- the layout
+//       the MFMA rank-K update wants for its factor.
+// History: list walk inside the loop with the next record prefetched: 1.08 us per camera (a store and a dependent load per step:
+// the compiler's s_waitcnt vmcnt(0) at the loop head made every step wait for the previous step's stores); this form 0.2 us.
+constexpr int kCfFwdCh = 16;
+static __global__ __launch_bounds__(64) void k_cf_forward(int nf, int n_o, int n_chunks, const int* __restrict__ oe_cst /* [N][n_chunks + 1] */,
                                                           const int* __restrict__ oe_slot, const double* __restrict__ V,
                                                           const double* __restrict__ vy, const double* __restrict__ Mm,
                                                           double* __restrict__ Xt, long ldx) {
-  __shared__ double sM[kCfChunk * 36];
+  __shared__ double sM[kCfFwdCh * 36];
+  __shared__ double sv[kCfFwdCh * 6 * 64];
+  __shared__ double svy[kCfFwdCh * 6];
   const int lane = threadIdx.x;
   const int j = blockIdx.x * 64 + lane;
-  const bool on = j <= n_o, rhs = j == n_o;
-  const int o = (on && !rhs) ? j / 9 : 0, b = j - 9 * o;
-  int p = (on && !rhs) ? oe_start[o] : 0;
-  const int pe = (on && !rhs) ? oe_start[o + 1] : 0;
-  int nslot = rhs ? 0 : ((p < pe) ? oe_slot[p] : INT_MAX);
-  double vn[6] = {0, 0, 0, 0, 0, 0};
-  if (rhs && nf > 0) {
-#pragma unroll
-    for (int a = 0; a < 6; ++a) vn[a] = vy[a];
-  } else if (p < pe) {
-    const double* src = V + (size_t)oe_u[p] * 54 + b * 6;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) vn[a] = src[a];
-  }
+  const bool on = j <= n_o, rhs = j == n_o, col = on && !rhs;
+  const int o = col ? j / 9 : 0, b = j - 9 * o;
+  const int* cst = oe_cst + (size_t)o * (n_chunks + 1);
   double x[6] = {0, 0, 0, 0, 0, 0};
-  for (int i0 = 0; i0 < nf; i0 += kCfChunk) {
-    const int len = (nf - i0 < kCfChunk) ? nf - i0 : kCfChunk;
+  int ch = 0;
+  for (int i0 = 0; i0 < nf; i0 += kCfFwdCh, ++ch) {
+    const int len = (nf - i0 < kCfFwdCh) ? nf - i0 : kCfFwdCh;
+    // (1) gather
+    {   // (fixed trip counts with clamped addresses: all loads of the staging go out together)
+      double tm[kCfFwdCh * 36 / 64], ty[2];
+#pragma unroll
+      for (int q = 0; q < kCfFwdCh * 36 / 64; ++q) { const int idx = q * 64 + lane; tm[q] = Mm[(size_t)i0 * 36 + (idx < len * 36 ? idx : 0)]; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { const int idx = q * 64 + lane; ty[q] = vy[(size_t)i0 * 6 + (idx < len * 6 ? idx : 0)]; }
+#pragma unroll
+      for (int q = 0; q < kCfFwdCh * 36 / 64; ++q) sM[q * 64 + lane] = tm[q];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) if (q * 64 + lane < kCfFwdCh * 6) svy[q * 64 + lane] = ty[q];   // (used by the right-hand-side lane only)
+    }
+#pragma unroll
+    for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = 0.0;
     __builtin_amdgcn_wave_barrier();
-    for (int idx = lane; idx < len * 36; idx += 64) sM[idx] = Mm[(size_t)i0 * 36 + idx];
-    __builtin_amdgcn_wave_barrier();
-    for (int ii = 0; ii < len; ++ii) {
-      const int i = i0 + ii;
-      double v[6] = {0, 0, 0, 0, 0, 0};
-      while (nslot == i) {            // (a bbox and a 3-D edge of the same camera: two entries)
+    if (rhs) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a) v[a] += vn[a];
-        if (rhs) {
-          nslot = (i + 1 < nf) ? i + 1 : INT_MAX;
-          if (i + 1 < nf) {
+      for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = (q < len * 6) ? svy[q] : 0.0;
+    } else if (col) {
+      const int ka = cst[ch], kb = cst[ch + 1];
+      for (int k = ka; k < kb; k += 4) {       // batches of four entries: slots and records of a batch in flight together
+        int sl[4];
+        double rec[4][6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) vn[a] = vy[(size_t)(i + 1) * 6 + a];
-          }
-        } else {
-          ++p;
-          if (p < pe) {
-            nslot = oe_slot[p];
-            const double* src = V + (size_t)oe_u[p] * 54 + b * 6;
+        for (int e = 0; e < 4; ++e) {
+          const int kk = (k + e < kb) ? k + e : ka;
+          sl[e] = oe_slot[kk];
+          const double* src = V + ((size_t)kk * 9 + b) * 6;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) vn[a] = src[a];
-          } else {
-            nslot = INT_MAX;
-          }
+          for (int a = 0; a < 6; ++a) rec[e][a] = src[a];
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < kb) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) sv[((sl[e] - i0) * 6 + a) * 64 + lane] += rec[e][a];   // (a bbox and a 3-D edge of one camera add up)
+          }
       }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (2) the serial steps, LDS only
+    for (int ii = 0; ii < len; ++ii) {
       const double* M = sM + ii * 36;
       double xn[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        double s = v[a];
+        double t = sv[(ii * 6 + a) * 64 + lane];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s -= M[a * 6 + k] * x[k];
-        xn[a] = s;
-      }
-      if (on) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) Xt[(size_t)j + (size_t)(6 * i + a) * (size_t)ldx] = xn[a];
+        for (int q = 0; q < 6; ++q) t -= M[a * 6 + q] * x[q];
+        xn[a] = t;
       }
 #pragma unroll
-      for (int a = 0; a < 6; ++a) x[a] = xn[a];
+      for (int a = 0; a < 6; ++a) { x[a] = xn[a]; sv[(ii * 6 + a) * 64 + lane] = xn[a]; }
     }
+    // (3) out: batches of eight LDS reads, then their eight stores
+    if (on) {
+      double* dst = Xt + (size_t)j + (size_t)(6 * i0) * (size_t)ldx;
+      for (int q0 = 0; q0 < len * 6; q0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = sv[((q0 + e < len * 6) ? q0 + e : q0) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (q0 + e < len * 6) dst[(size_t)(q0 + e) * (size_t)ldx] = t[e];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -281,17 +378,32 @@ static __global__ __launch_bounds__(256) void k_cf_z(const double* __restrict__ 
 }
 
 // ---- x_c = L^-T z: one wave, sequential from the last camera to the first; x_i = Li^T z_i - N_i x_{i+1} -------------------------
+constexpr int kCfBackCh = 32;
 static __global__ __launch_bounds__(64) void k_cf_tridiag_back(int nf, const double* __restrict__ Linv, const double* __restrict__ Nn,
                                                                const double* __restrict__ z, double* __restrict__ xc) {
-  __shared__ double sLi[kCfChunk * 36], sN[kCfChunk * 36], sz[kCfChunk * 6];
+  __shared__ double sLi[kCfBackCh * 36], sN[kCfBackCh * 36], sz[kCfBackCh * 6];
   const int lane = threadIdx.x;
   const int a = lane < 6 ? lane : 5;
   double xa = 0;                        // lanes 0..5: component a of x_{i+1}
-  for (int hi = nf; hi > 0; hi -= kCfChunk) {
-    const int i0 = (hi - kCfChunk > 0) ? hi - kCfChunk : 0, len = hi - i0;
+  for (int hi = nf; hi > 0; hi -= kCfBackCh) {
+    const int i0 = (hi - kCfBackCh > 0) ? hi - kCfBackCh : 0, len = hi - i0;
     __builtin_amdgcn_wave_barrier();
-    for (int idx = lane; idx < len * 36; idx += 64) { sLi[idx] = Linv[(size_t)i0 * 36 + idx]; sN[idx] = Nn[(size_t)i0 * 36 + idx]; }
-    for (int idx = lane; idx < len * 6; idx += 64) sz[idx] = z[(size_t)i0 * 6 + idx];
+    {   // fixed trip counts with clamped addresses: all loads of the staging go out together (a run-time loop of load -> LDS write
+        // pays one memory round trip per iteration)
+      constexpr int kQ = kCfBackCh * 36 / 64, kZ = (kCfBackCh * 6 + 63) / 64;
+      double tl[kQ], tn[kQ], tz[kZ];
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) {
+        const int idx = q * 64 + lane, cl = idx < len * 36 ? idx : 0;
+        tl[q] = Linv[(size_t)i0 * 36 + cl]; tn[q] = Nn[(size_t)i0 * 36 + cl];
+      }
+#pragma unroll
+      for (int q = 0; q < kZ; ++q) { const int idx = q * 64 + lane; tz[q] = z[(size_t)i0 * 6 + (idx < len * 6 ? idx : 0)]; }
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) { sLi[q * 64 + lane] = tl[q]; sN[q * 64 + lane] = tn[q]; }
+#pragma unroll
+      for (int q = 0; q < kZ; ++q) if (q * 64 + lane < kCfBackCh * 6) sz[q * 64 + lane] = tz[q];
+    }
     __builtin_amdgcn_wave_barrier();
     for (int ii = len - 1; ii >= 0; --ii) {
       double xn[6];

@@ -196,8 +196,10 @@ struct esl_ctx {
   // camera slot, the odometry edges of every consecutive slot pair, the block-bidiagonal factor (Linv, M, N), per-edge V = Linv W,
   // X^T = (L^-1 [W | b_c])^T, the reduced ellipsoid system T (+ b row) and its solver workspaces.  Big buffers on first use.
   bool cf_chain_ok = false;
-  int *cf_oe_start = nullptr, *cf_oe_u = nullptr, *cf_oe_slot = nullptr, *cf_od_start = nullptr, *cf_od_edge = nullptr;
+  int *cf_oe_start = nullptr, *cf_oe_u = nullptr, *cf_oe_slot = nullptr, *cf_od_start = nullptr, *cf_od_edge = nullptr, *cf_oe_cst = nullptr;
+  int cf_n_list = 0, cf_n_chunks = 0;
   double *cf_Linv = nullptr, *cf_M = nullptr, *cf_N = nullptr, *cf_V = nullptr, *cf_vy = nullptr, *cf_z = nullptr;
+  double *cf_B = nullptr, *cf_Lfac = nullptr, *cf_G = nullptr;
   double *cf_Xt = nullptr, *cf_T = nullptr, *cf_Linv_ws = nullptr;
   int64_t cf_ldx = 0, cf_kpad = 0, cf_ldt = 0;
   int lm_solver_used = 0;   // esl_linear_solver the last trial step ran with (1 reduced camera system, 2 reduced ellipsoid system)

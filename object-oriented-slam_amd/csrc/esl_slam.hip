@@ -78,6 +78,18 @@ int slam_alloc(esl_ctx* c) {
       std::sort(es.begin(), es.end());
       for (size_t k = 0; k < es.size(); ++k) { os[(size_t)start[o] + k] = es[k].first; ou[(size_t)start[o] + k] = es[k].second; }
     }
+    // entry range of every (ellipsoid, chunk of kCfFwdCh slots) in those lists: the forward substitution's gather phase
+    const int nch = (nf + kCfFwdCh - 1) / kCfFwdCh;
+    std::vector<int> cst((size_t)std::max(N, 1) * (nch + 1), 0);
+    for (int o = 0; o < N; ++o) {
+      int k = start[o];
+      for (int chk = 0; chk <= nch; ++chk) {
+        while (k < start[(size_t)o + 1] && os[k] < chk * kCfFwdCh) ++k;
+        cst[(size_t)o * (nch + 1) + chk] = k;
+      }
+    }
+    c->cf_n_list = (int)id.size(); c->cf_n_chunks = nch;
+    if ((rc = up(&c->cf_oe_cst, cst.data(), cst.size(), c->stream))) return rc;
     std::vector<int> ods((size_t)std::max(nf, 1) + 1, 0), ode;
     bool chain = true;
     std::vector<std::vector<int>> per_pair((size_t)std::max(nf, 1));
@@ -159,6 +171,7 @@ static int cf_ensure(esl_ctx* c) {
   c->cf_ldt = c->cf_ldx;
   int rc;
   if ((rc = al(&c->cf_Linv, nf * 36)) || (rc = al(&c->cf_M, nf * 36)) || (rc = al(&c->cf_N, nf * 36)) || (rc = al(&c->cf_V, EU * 54)) ||
+      (rc = al(&c->cf_B, nf * 36)) || (rc = al(&c->cf_Lfac, nf * 21)) || (rc = al(&c->cf_G, nf * 36)) ||
       (rc = al(&c->cf_vy, nf * 6)) || (rc = al(&c->cf_z, nf * 6)) || (rc = al(&c->cf_Xt, (size_t)c->cf_ldx * (size_t)c->cf_kpad)) ||
       (rc = al(&c->cf_T, (size_t)c->cf_ldt * n_o)) || (rc = al(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB)))
     return rc;
@@ -175,16 +188,17 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
   int rc = cf_ensure(c);
   if (rc) return rc;
   const long ldx = (long)c->cf_ldx, ldt = (long)c->cf_ldt;
-  const long EU = (long)g.n_bbox + g.n_e3d;
   CholRuntime& rt = chol_rt(c);
   {
     ProfScope ps(c, 2);   // "reduced-system build": factor of the camera block, X = L^-1 [W | b_c], T = D - X^T X
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_cf_tridiag_factor, dim3(1), dim3(64), 0, c->stream, nf, c->Hcc, c->Aod, c->cf_od_start, c->cf_od_edge, lambda, c->cf_Linv,
-                       c->cf_M, c->cf_N, c->chol_info);
-    const long nt = EU * 9 + nf;
-    hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->Wbb, c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
-    hipLaunchKernelGGL(k_cf_forward, dim3((unsigned)((n_o + 1 + 63) / 64)), dim3(64), 0, c->stream, nf, n_o, c->cf_oe_start, c->cf_oe_u, c->cf_oe_slot,
+    hipLaunchKernelGGL(k_cf_gather_B, dim3((unsigned)(((long)nf * 36 + 255) / 256)), dim3(256), 0, c->stream, nf, c->Aod, c->cf_od_start, c->cf_od_edge, c->cf_B);
+    hipLaunchKernelGGL(k_cf_chain, dim3(1), dim3(64), 0, c->stream, nf, c->Hcc, c->cf_B, lambda, c->cf_Lfac, c->cf_G, c->chol_info);
+    hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, c->stream, nf, c->cf_Lfac, c->cf_G, c->cf_Linv, c->cf_M, c->cf_N);
+    const long nt = (long)c->cf_n_list * 9 + nf;
+    hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
+                       c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
+    hipLaunchKernelGGL(k_cf_forward, dim3((unsigned)((n_o + 1 + 63) / 64)), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot,
                        c->cf_V, c->cf_vy, c->cf_M, c->cf_Xt, ldx);
     ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)ldt * (size_t)n_o * sizeof(double), c->stream));
     hipLaunchKernelGGL(k_cf_T_init, dim3((unsigned)(((long)N * 90 + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
