@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -409,7 +410,8 @@ constexpr int kKC = 16;
 template <int BM, int BN, int WM = 4, int WN = 2>
 static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
                                                                            int kcol0, int K, long base, int ntJ, int rect,
-                                                                           const double* __restrict__ Pext, long ldp) {
+                                                                           const double* __restrict__ Pext, long ldp,
+                                                                           double* __restrict__ part, int kper) {
   static_assert((BM == 2 * BN || BM == BN) && BM % 64 == 0, "tile shape");
   constexpr int NT = 64 * WM * WN;                // threads per workgroup
   constexpr int RT = BM / BN;                     // tile row ti of the lower triangle holds RT (ti + 1) tiles
@@ -441,6 +443,17 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
   // matrix Pext with leading dimension ldp (C -= Pext Pext^T: the reduced ellipsoid system of the camera-first elimination, esl_cf.hpp)
   const double* P = Pext ? Pext : M + (long)kcol0 * lda;
   if (!Pext) ldp = lda;
+  // split-K (gridDim.y > 1; small outputs with a long K: a 450 x 450 system has 20 tiles): slice blockIdx.y takes K range
+  // [y kper, (y + 1) kper) and writes -acc into ITS copy of the output (part + y lda ncols; no read-modify-write); a reduction
+  // kernel adds the slices to C in slice order -- deterministic, unlike atomics
+  if (part) {
+    const int kbeg = (int)blockIdx.y * kper;
+    P += (long)kbeg * ldp;
+    K = (K - kbeg < kper) ? K - kbeg : kper;
+    M = part + (size_t)blockIdx.y * (size_t)lda * (size_t)ncols;
+    if (K <= 0) return;
+  }
+  const bool assign = part != nullptr;
   // global -> register staging: A chunk = BM x 16 doubles, B chunk = BN x 16 doubles, as double2
   typedef double double2_t __attribute__((ext_vector_type(2)));
   double2_t ra[QA], rb[QB];
@@ -544,7 +557,7 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cv[mi][g] = M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda];
+        for (int g = 0; g < 4; ++g) cv[mi][g] = assign ? 0.0 : M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -563,7 +576,7 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
       for (int g = 0; g < 4; ++g) {
         const long col = jw + nj * 16 + rq + 4 * g;   // D row  -> j
         const long row = iw + mi * 16 + r;            // D col  -> i (contiguous across lanes)
-        cv[mi][g] = M[(row < rows ? row : rows - 1) + (col < ncols ? col : ncols - 1) * lda];
+        cv[mi][g] = assign ? 0.0 : M[(row < rows ? row : rows - 1) + (col < ncols ? col : ncols - 1) * lda];
       }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -619,12 +632,26 @@ struct CholDist {
 };
 inline int chol_outer_panels(int n) { return (n >= 8192) ? 4 : 2; }   // inner 128-panels per outer panel
 
+// C += sum over the K slices of their partial products (slice order), lower triangle only
+static __global__ __launch_bounds__(256) void k_chol_splitk_reduce(double* __restrict__ M, long lda, long rows, long ncols,
+                                                                   const double* __restrict__ part, int nsplit) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long col = t / rows, row = t - col * rows;
+  if (col >= ncols || row < col) return;
+  double s = 0;
+  for (int y = 0; y < nsplit; ++y) s += part[(size_t)y * (size_t)lda * (size_t)ncols + row + col * lda];
+  M[row + col * lda] += s;
+}
+
 // C[base.., base..col_limit) -= P P^T on the lower triangle of the (rows x *) matrix M; P = columns [kcol0, kcol0 + K) of M, or
 // Pext (rows x K, leading dimension ldp) when given.  Needs chol_set_attributes() on the current device first.
+// part (optional, with Pext and base = 0): workspace of kCholMaxSplit x lda x col_limit doubles -- few tiles and a long K are split
+// over K (see the kernel).
 constexpr size_t kCholLdsBig = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
 constexpr size_t kCholLdsSmall = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
+constexpr int kCholMaxSplit = 16;
 inline void chol_launch_update(double* M, long lda, long rows, hipStream_t stream, int kcol0, int K, long base, long col_limit,
-                               const double* Pext = nullptr, long ldp = 0) {
+                               const double* Pext = nullptr, long ldp = 0, double* part = nullptr) {
   // trailing region: rows [base, rows), cols [base, col_limit)
   const long nrows = rows - base, nc = col_limit - base;
   if (nrows <= 0 || nc <= 0) return;
@@ -635,12 +662,24 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
     const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
     const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
     hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), kCholLdsBig, stream, M, lda, rows, col_limit, kcol0, K,
-                       base, (int)ntJ, whole ? 0 : 1, Pext, ldp);
+                       base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0);
   } else {
     const long ntI = (nrows + 127) / 128, ntJ = (nc + 63) / 64;
     const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;
-    hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), kCholLdsSmall, stream, M, lda, rows, col_limit, kcol0, K,
-                       base, (int)ntJ, whole ? 0 : 1, Pext, ldp);
+    int nsplit = 1, kper = K;
+    if (part && Pext && base == 0 && nblk < 128 && K >= 16 * kKC) {
+      nsplit = (int)std::min<long>(kCholMaxSplit, std::max<long>(1, 512 / nblk));
+      kper = ((K + nsplit - 1) / nsplit + kKC - 1) / kKC * kKC;
+      nsplit = (K + kper - 1) / kper;
+    }
+    if (nsplit > 1) {
+      hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk, (unsigned)nsplit), dim3(512), kCholLdsSmall, stream, M, lda, rows, col_limit,
+                         kcol0, K, base, (int)ntJ, whole ? 0 : 1, Pext, ldp, part, kper);
+      hipLaunchKernelGGL(k_chol_splitk_reduce, dim3((unsigned)((rows * col_limit + 255) / 256)), dim3(256), 0, stream, M, lda, rows, col_limit, part, nsplit);
+    } else {
+      hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), kCholLdsSmall, stream, M, lda, rows, col_limit, kcol0, K,
+                         base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0);
+    }
   }
 }
 

@@ -175,6 +175,7 @@ static int cf_ensure(esl_ctx* c) {
       (rc = al(&c->cf_vy, nf * 6)) || (rc = al(&c->cf_z, nf * 6)) || (rc = al(&c->cf_Xt, (size_t)c->cf_ldx * (size_t)c->cf_kpad)) ||
       (rc = al(&c->cf_T, (size_t)c->cf_ldt * n_o)) || (rc = al(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB)))
     return rc;
+  if (n_o <= 1024 && (rc = al(&c->cf_part, (size_t)kCholMaxSplit * (size_t)c->cf_ldt * n_o))) return rc;   // split-K workspace of small systems
   // rows 6 nf .. kpad of X (the K padding of the rank-K update) and the columns of never-written edges stay zero
   ESL_HIP_TRY(hipMemsetAsync(c->cf_Xt, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad * sizeof(double), c->stream));
   ESL_HIP_TRY(hipMemsetAsync(c->cf_V, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
@@ -206,7 +207,7 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     ESL_HIP_TRY(chol_set_attributes(rt));
     {
       ProfScope pk(c, 7);   // the rank-K update alone (nested in class 2): the MFMA roofline kernel of this form
-      chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, 0, (long)n_o, c->cf_Xt, ldx);
+      chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, 0, (long)n_o, c->cf_Xt, ldx, c->cf_part);
     }
     ESL_HIP_TRY(hipGetLastError());
   }
