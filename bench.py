@@ -230,8 +230,18 @@ def slam_roofline(prof, n_c, n_o, solver, trials):
         avg = rk["total_ms"] / max(rk["count"], 1)
         ach = fl["rank_k_update"] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
         ch_avg = ch["total_ms"] / max(ch["count"], 1)
-        return {"kernel": "k_chol_update_lds<256,128> as the rank-%d update T -= X^T X of the reduced ellipsoid system (order %d)" % (n_c, n_o),
-                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
+        traffic = None
+        if n_c == 59994 and n_o == 18000:   # HBM bytes per launch from the committed PMC passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE), not this run
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_c4_slam.json")))["kernels"]
+                traffic = [v for k, v in pmc.items() if "k_chol_update_lds<256, 128" in k][0]["traffic_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
+        tile = "256,128" if n_o >= 8192 else "128,64 (split-K)"
+        return {"kernel": "k_chol_update_lds<%s> as the rank-%d update T -= X^T X of the reduced ellipsoid system (order %d)" % (tile, n_c, n_o),
+                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": traffic,
+                "traffic_source": "profiles/r3_pmc_traffic_c4_slam.json (committed PMC passes of this workload; operand strips re-read per tile through L2 / MALL: "
+                                  "8.6 GB algorithmic)" if traffic else None,
                 "algorithmic_flops_per_launch": fl["rank_k_update"], "avg_launch_ms": avg, "launches": rk["count"], "measured_ceiling": ceiling,
                 "linear_solve_ms_per_trial": solve_ms, "cholesky_order_9N_ms_per_trial": ch_avg,
                 "cholesky_order_9N_tflops": (fl["cholesky"] / (ch_avg * 1e-3) / 1e12) if ch_avg > 0 else 0.0,
@@ -374,12 +384,12 @@ def mapping_bench(pkg, ctx, config="C4", jacobian="analytic", steps=20, warmup=1
     traffic = None
     try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) -- same workload only
         if config == "C4" and jacobian == "analytic":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_device_lm.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_device_lm.json")))["kernels"]
             traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, 0" in k or "k_chunk_linearize_both<1, false" in k][0]["traffic_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         traffic = None
     roof = {"kernel": "k_chunk_linearize_both (bbox + 3-D chunks, one launch)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r2_pmc_traffic_device_lm.json (committed PMC passes, not this run)",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r3_pmc_traffic_device_lm.json (committed PMC passes, not this run)",
             "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms, "launches": lin["count"],
             "sampling": "HIP events around ONE linearisation launch (the second trial's) of every FOURTH optimize() of the timed region: an event pair "
                         "splits two back-to-back dispatches and costs that trial ~20 us"}
