@@ -262,6 +262,8 @@ static void free_graph(esl_ctx* c) {
   dev_free(&c->cf_oe_start); dev_free(&c->cf_oe_u); dev_free(&c->cf_oe_slot); dev_free(&c->cf_od_start); dev_free(&c->cf_od_edge); dev_free(&c->cf_oe_cst);
   dev_free(&c->cf_Linv); dev_free(&c->cf_M); dev_free(&c->cf_N); dev_free(&c->cf_V); dev_free(&c->cf_vy); dev_free(&c->cf_z);
   dev_free(&c->cf_Xt); dev_free(&c->cf_T); dev_free(&c->cf_Linv_ws); dev_free(&c->cf_part); dev_free(&c->cf_B); dev_free(&c->cf_Lfac); dev_free(&c->cf_G);
+  dev_free(&c->cf_Zt); dev_free(&c->cf_Hs); dev_free(&c->cf_Bs); dev_free(&c->cf_LfacS); dev_free(&c->cf_GS); dev_free(&c->cf_LiS);
+  dev_free(&c->cf_MS); dev_free(&c->cf_NS); dev_free(&c->cf_R);
   c->cf_chain_ok = false;
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->S_n = 0;

@@ -64,17 +64,21 @@ static __global__ __launch_bounds__(256) void k_cf_gather_B(int nf, const double
 // issued before the chunk's steps run and land in LDS after them), L and G of the chunk collect in LDS and leave as coalesced
 // stores.  (With the loads inside the loop the compiler serialised three scalar-load round trips per camera: 2.3 us per step.)
 constexpr int kCfChainCh = 32;
-static __global__ __launch_bounds__(64) void k_cf_chain(int nf, const double* __restrict__ Hcc, const double* __restrict__ B, double lambda,
+// Nested dissection (see the file header): workgroup p runs the recurrence over segment p = cameras [p stride, p stride + seglen)
+// starting from D = Hcc (no incoming G); one segment covering everything (stride >= nf) is the plain chain.
+static __global__ __launch_bounds__(64) void k_cf_chain(int nf_all, const double* __restrict__ Hcc, const double* __restrict__ B, double lambda,
                                                         double* __restrict__ Lfac /* nf x 21: L_ii, packed lower */,
                                                         double* __restrict__ Gfac /* nf x 36: G_i = L_ii^-1 B_i^T, row-major */,
-                                                        int* __restrict__ info) {
+                                                        int* __restrict__ info, int stride, int seglen) {
   __shared__ double sH[kCfChainCh * 36], sB[kCfChainCh * 36], sL[kCfChainCh * 21], sG[kCfChainCh * 36];
   constexpr int kPer = kCfChainCh * 36 / 64;   // doubles per lane and array in one chunk
   const int lane = threadIdx.x;
-  if (nf <= 0) return;
+  const int beg = (int)blockIdx.x * stride;
+  const int nf = (beg + seglen < nf_all) ? beg + seglen : nf_all;   // end of this segment
+  if (beg >= nf) return;
   double rh[kPer], rb[kPer];
   auto gload = [&](int i0) {
-    const size_t lim = (size_t)nf * 36;
+    const size_t lim = (size_t)nf_all * 36;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
       const size_t idx = (size_t)i0 * 36 + (size_t)q * 64 + lane;
@@ -86,14 +90,14 @@ static __global__ __launch_bounds__(64) void k_cf_chain(int nf, const double* __
 #pragma unroll
     for (int q = 0; q < kPer; ++q) { sH[q * 64 + lane] = rh[q]; sB[q * 64 + lane] = rb[q]; }
   };
-  gload(0);
+  gload(beg);
   lstore();
   __builtin_amdgcn_wave_barrier();
   bool ok = true;
   double g[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) g[k] = 0;
-  for (int i0 = 0; i0 < nf; i0 += kCfChainCh) {
+  for (int i0 = beg; i0 < nf; i0 += kCfChainCh) {
     const int len = (nf - i0 < kCfChainCh) ? nf - i0 : kCfChainCh;
     const bool more = i0 + kCfChainCh < nf;
     if (more) gload(i0 + kCfChainCh);
@@ -155,10 +159,16 @@ static __global__ __launch_bounds__(64) void k_cf_chain(int nf, const double* __
   if (!ok && lane == 0) atomicOr(info, 1);
 }
 
+// stride > 0 (nested dissection): slots with i % stride == stride - 1 are separators (not touched here), the first camera of a
+// segment has no predecessor (M = 0) and the last none to hand its x to (N = 0; its G couples it to the separator instead)
 static __global__ __launch_bounds__(64) void k_cf_factor_blocks(int nf, const double* __restrict__ Lfac, const double* __restrict__ Gfac,
-                                                                double* __restrict__ Linv, double* __restrict__ Mm, double* __restrict__ Nn) {
+                                                                double* __restrict__ Linv, double* __restrict__ Mm, double* __restrict__ Nn,
+                                                                int stride) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= nf) return;
+  const int pos = stride > 0 ? i % stride : i;
+  if (stride > 0 && pos == stride - 1) return;
+  const bool first = pos == 0, last = (i == nf - 1) || (stride > 0 && pos == stride - 2);
   double L[21], Li[36];
 #pragma unroll
   for (int k = 0; k < 21; ++k) L[k] = Lfac[(size_t)i * 21 + k];
@@ -180,7 +190,7 @@ static __global__ __launch_bounds__(64) void k_cf_factor_blocks(int nf, const do
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) Lo[r * 6 + c] = (i > 0) ? Gfac[(size_t)(i - 1) * 36 + c * 6 + r] : 0.0;
+    for (int c = 0; c < 6; ++c) Lo[r * 6 + c] = first ? 0.0 : Gfac[(size_t)(i - 1) * 36 + c * 6 + r];
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -198,7 +208,7 @@ static __global__ __launch_bounds__(64) void k_cf_factor_blocks(int nf, const do
       double nv = 0;
 #pragma unroll
       for (int k = r; k < 6; ++k) nv += Li[k * 6 + r] * Gfac[(size_t)i * 36 + k * 6 + c];
-      Nn[(size_t)i * 36 + r * 6 + c] = nv;
+      Nn[(size_t)i * 36 + r * 6 + c] = last ? 0.0 : nv;
     }
 }
 #undef CF_LT
@@ -259,62 +269,86 @@ static __global__ __launch_bounds__(256) void k_cf_edge_scale(DevGraph g, int n_
 // History: list walk inside the loop with the next record prefetched: 1.08 us per camera (a store and a dependent load per step:
 // the compiler's s_waitcnt vmcnt(0) at the loop head made every step wait for the previous step's stores); this form 0.2 us.
 constexpr int kCfFwdCh = 16;
-static __global__ __launch_bounds__(64) void k_cf_forward(int nf, int n_o, int n_chunks, const int* __restrict__ oe_cst /* [N][n_chunks + 1] */,
+// SEP = false: blockIdx.y = segment p (cameras [p stride, p stride + seglen); one segment = the plain chain).  With nested
+//   dissection (Zt != null) the lane also accumulates acc = sum_j Zt_j^T X_j over its segment -- the segment's contribution to the
+//   right-hand side of the separator in FRONT of it -- into R[column + (6 (p - 1) + a) ldx]; list entries of separator slots are
+//   not this kernel's (they fall outside [beg, end)).
+// SEP = true: the same recurrence over the separators (nf = number of separators, M = the separator chain's blocks), V dense from
+//   R (k_cf_sep_rhs), rows written at the separators' slots k sep_stride + sep_stride - 1.
+template <bool SEP>
+static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, int n_chunks, const int* __restrict__ oe_cst /* [N][n_chunks + 1] */,
                                                           const int* __restrict__ oe_slot, const double* __restrict__ V,
                                                           const double* __restrict__ vy, const double* __restrict__ Mm,
-                                                          double* __restrict__ Xt, long ldx) {
+                                                          double* __restrict__ Xt, long ldx, int stride, int seglen,
+                                                          const double* __restrict__ Zt, double* __restrict__ R, int sep_stride) {
   __shared__ double sM[kCfFwdCh * 36];
+  __shared__ double sZ[kCfFwdCh * 36];
   __shared__ double sv[kCfFwdCh * 6 * 64];
   __shared__ double svy[kCfFwdCh * 6];
   const int lane = threadIdx.x;
   const int j = blockIdx.x * 64 + lane;
   const bool on = j <= n_o, rhs = j == n_o, col = on && !rhs;
   const int o = col ? j / 9 : 0, b = j - 9 * o;
+  const int seg = SEP ? 0 : (int)blockIdx.y;
+  const int beg = SEP ? 0 : seg * stride;
+  const int nf = SEP ? nf_all : ((beg + seglen < nf_all) ? beg + seglen : nf_all);
+  if (beg >= nf) return;
+  const bool use_z = !SEP && Zt != nullptr && seg >= 1;
   const int* cst = oe_cst + (size_t)o * (n_chunks + 1);
-  double x[6] = {0, 0, 0, 0, 0, 0};
-  int ch = 0;
-  for (int i0 = 0; i0 < nf; i0 += kCfFwdCh, ++ch) {
+  double x[6] = {0, 0, 0, 0, 0, 0}, acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int i0 = beg; i0 < nf; i0 += kCfFwdCh) {
+    const int ch = i0 / kCfFwdCh;
     const int len = (nf - i0 < kCfFwdCh) ? nf - i0 : kCfFwdCh;
     // (1) gather
     {   // (fixed trip counts with clamped addresses: all loads of the staging go out together)
-      double tm[kCfFwdCh * 36 / 64], ty[2];
+      double tm[kCfFwdCh * 36 / 64], tz[kCfFwdCh * 36 / 64], ty[2];
 #pragma unroll
-      for (int q = 0; q < kCfFwdCh * 36 / 64; ++q) { const int idx = q * 64 + lane; tm[q] = Mm[(size_t)i0 * 36 + (idx < len * 36 ? idx : 0)]; }
+      for (int q = 0; q < kCfFwdCh * 36 / 64; ++q) {
+        const int idx = q * 64 + lane, cl = idx < len * 36 ? idx : 0;
+        tm[q] = Mm[(size_t)i0 * 36 + cl];
+        tz[q] = use_z ? Zt[(size_t)i0 * 36 + cl] : 0.0;
+      }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) { const int idx = q * 64 + lane; ty[q] = vy[(size_t)i0 * 6 + (idx < len * 6 ? idx : 0)]; }
+      for (int q = 0; q < 2; ++q) { const int idx = q * 64 + lane; ty[q] = SEP ? 0.0 : vy[(size_t)i0 * 6 + (idx < len * 6 ? idx : 0)]; }
 #pragma unroll
-      for (int q = 0; q < kCfFwdCh * 36 / 64; ++q) sM[q * 64 + lane] = tm[q];
+      for (int q = 0; q < kCfFwdCh * 36 / 64; ++q) { sM[q * 64 + lane] = tm[q]; sZ[q * 64 + lane] = tz[q]; }
 #pragma unroll
       for (int q = 0; q < 2; ++q) if (q * 64 + lane < kCfFwdCh * 6) svy[q * 64 + lane] = ty[q];   // (used by the right-hand-side lane only)
     }
+    if (SEP) {   // dense right-hand sides of the separators: rows 6 i0 .. of R
 #pragma unroll
-    for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-    if (rhs) {
+      for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = (on && q < len * 6) ? R[(size_t)j + (size_t)(6 * i0 + q) * (size_t)ldx] : 0.0;
+      __builtin_amdgcn_wave_barrier();
+    } else {
 #pragma unroll
-      for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = (q < len * 6) ? svy[q] : 0.0;
-    } else if (col) {
-      const int ka = cst[ch], kb = cst[ch + 1];
-      for (int k = ka; k < kb; k += 4) {       // batches of four entries: slots and records of a batch in flight together
-        int sl[4];
-        double rec[4][6];
+      for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = 0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (rhs) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int kk = (k + e < kb) ? k + e : ka;
-          sl[e] = oe_slot[kk];
-          const double* src = V + ((size_t)kk * 9 + b) * 6;
+        for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = (q < len * 6) ? svy[q] : 0.0;
+      } else if (col) {
+        const int ka = cst[ch], kb = cst[ch + 1];
+        for (int k = ka; k < kb; k += 4) {       // batches of four entries: slots and records of a batch in flight together
+          int sl[4];
+          double rec[4][6];
 #pragma unroll
-          for (int a = 0; a < 6; ++a) rec[e][a] = src[a];
-        }
+          for (int e = 0; e < 4; ++e) {
+            const int kk = (k + e < kb) ? k + e : ka;
+            sl[e] = oe_slot[kk];
+            const double* src = V + ((size_t)kk * 9 + b) * 6;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < kb) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) sv[((sl[e] - i0) * 6 + a) * 64 + lane] += rec[e][a];   // (a bbox and a 3-D edge of one camera add up)
+            for (int a = 0; a < 6; ++a) rec[e][a] = src[a];
           }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kb && sl[e] - i0 < len) {   // (slots behind the segment's end in this chunk: the separator's entries)
+#pragma unroll
+              for (int a = 0; a < 6; ++a) sv[((sl[e] - i0) * 6 + a) * 64 + lane] += rec[e][a];   // (a bbox and a 3-D edge of one camera add up)
+            }
+        }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
     // (2) the serial steps, LDS only
     for (int ii = 0; ii < len; ++ii) {
       const double* M = sM + ii * 36;
@@ -328,21 +362,205 @@ static __global__ __launch_bounds__(64) void k_cf_forward(int nf, int n_o, int n
       }
 #pragma unroll
       for (int a = 0; a < 6; ++a) { x[a] = xn[a]; sv[(ii * 6 + a) * 64 + lane] = xn[a]; }
+      if (use_z) {
+        const double* Z = sZ + ii * 36;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int q = 0; q < 6; ++q) acc[a] += Z[q * 6 + a] * xn[q];
+      }
     }
     // (3) out: batches of eight LDS reads, then their eight stores
     if (on) {
-      double* dst = Xt + (size_t)j + (size_t)(6 * i0) * (size_t)ldx;
       for (int q0 = 0; q0 < len * 6; q0 += 8) {
         double t[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = sv[((q0 + e < len * 6) ? q0 + e : q0) * 64 + lane];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (q0 + e < len * 6) dst[(size_t)(q0 + e) * (size_t)ldx] = t[e];
+          if (q0 + e < len * 6) {
+            const int q = q0 + e;
+            // separator k = i0 + q / 6 sits at slot k sep_stride + sep_stride - 1
+            const size_t row = SEP ? (size_t)(6 * ((i0 + q / 6) * sep_stride + sep_stride - 1) + q % 6) : (size_t)(6 * i0 + q);
+            Xt[(size_t)j + row * (size_t)ldx] = t[e];
+          }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (use_z && on) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) R[(size_t)j + (size_t)(6 * (seg - 1) + a) * (size_t)ldx] = acc[a];
+  }
+}
+
+// ---- nested dissection of the camera chain (round 3) -------------------------------------------------------------------------------
+// The chain kernels above are serial over the cameras (C4: 10k steps).  Every stride-th camera (slot i with i % stride == stride - 1)
+// becomes a SEPARATOR; the segments between separators are independent chains (factor, forward and backward recurrences run one
+// workgroup per segment), and the separators form a short block-tridiagonal system of their own.  With the interiors I ordered
+// first and the separators S last, A = G G^T has
+//     G = [ L_II   0   ]     L_II  block diagonal over the segments (the plain chain factor of each),
+//         [ L_SI  L_SS ]     L_SI(s, j): for the LAST camera l of the segment in front of s the block G_l^T (what the chain computes
+//                            anyway); for every camera j of the segment BEHIND s the block Z_j with Z_j^T =: Zt_j = -M_j Zt_{j-1},
+//                            Zt_f = Li_f A(f, s) at the segment's first camera f (the forward recurrence applied to s's coupling),
+//     L_SS = chol of the separators' Schur complement: diagonal A(s, s) - G_l^T G_l - sum_j Zt_j^T Zt_j, sub-diagonal
+//            -G_e^T Zt_e (e = last camera of the segment between the two separators): block tridiagonal, factored by k_cf_chain.
+// X = G^-1 [W | b_c] : interior rows segment by segment; separator rows X_S = L_SS^-1 (W_S - L_SI X_I) (k_cf_sep_rhs + the forward
+// kernel on the separator chain).  T = D - X^T X does not care about the row order.  x_c = G^-T z : separators first (backward
+// chain), then z_j -= Zt_j x_s(front) + [j last] G_j x_s(behind) and the per-segment backward recurrences.
+// Serial length: stride - 1 + (F - 1) / stride steps instead of F - 1 (C4: 199 instead of 9,999; C3: 46 instead of 499).
+constexpr int kCfMaxStride = 128;
+// Zt of segment p >= 1 (workgroup p, lanes 0..5 = the six columns)
+static __global__ __launch_bounds__(64) void k_cf_zt(int nf, int stride, const double* __restrict__ Linv, const double* __restrict__ Mm,
+                                                     const double* __restrict__ B, double* __restrict__ Zt) {
+  __shared__ double sM[kCfMaxStride * 36];
+  const int p = blockIdx.x + 1, lane = threadIdx.x;
+  const int beg = p * stride, end = (beg + stride - 1 < nf) ? beg + stride - 1 : nf;
+  if (beg >= end) return;
+  const int len = end - beg;
+  {   // the segment's M blocks -> LDS (fixed trip count, clamped addresses: the loads go out together)
+    constexpr int kQ = kCfMaxStride * 36 / 64;
+    double t[kQ];
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) { const int idx = q * 64 + lane; t[q] = Mm[(size_t)beg * 36 + (idx < len * 36 ? idx : 0)]; }
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) sM[q * 64 + lane] = t[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int c = lane < 6 ? lane : 5;
+  double z[6];
+  {   // Zt_f = Li_f A(f, s), A(f, s) = B[s] (rows f, columns s), s = f - 1
+    const double* Li = Linv + (size_t)beg * 36;
+    const double* Bs = B + (size_t)(beg - 1) * 36;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double v = 0;
+#pragma unroll
+      for (int k = 0; k <= r; ++k) v += Li[r * 6 + k] * Bs[k * 6 + c];
+      z[r] = v;
+    }
+  }
+  for (int ii = 0; ii < len; ++ii) {
+    if (ii > 0) {
+      const double* M = sM + ii * 36;
+      double zn[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v -= M[r * 6 + k] * z[k];
+        zn[r] = v;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) z[r] = zn[r];
+    }
+    if (lane < 6) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Zt[(size_t)(beg + ii) * 36 + r * 6 + lane] = z[r];
+    }
+  }
+}
+
+// the separators' block-tridiagonal Schur complement: Hs[k] (diagonal, lambda included), Bs[k] = block (k + 1, k); thread = (k, entry)
+static __global__ __launch_bounds__(256) void k_cf_sep_assemble(int nf, int stride, int n_sep, const double* __restrict__ Hcc, double lambda,
+                                                                const double* __restrict__ Gfac, const double* __restrict__ Zt,
+                                                                double* __restrict__ Hs, double* __restrict__ Bs) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int k = t / 36;
+  if (k >= n_sep) return;
+  const int e = t - k * 36, r = e / 6, c = e - 6 * r;
+  const int s = k * stride + stride - 1, l = s - 1;
+  double v = Hcc[(size_t)s * 36 + e] + ((r == c) ? lambda : 0.0);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) v -= Gfac[(size_t)l * 36 + q * 6 + r] * Gfac[(size_t)l * 36 + q * 6 + c];
+  const int beg = (k + 1) * stride, end = (beg + stride - 1 < nf) ? beg + stride - 1 : nf;   // the segment behind s
+  for (int j = beg; j < end; ++j) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v -= Zt[(size_t)j * 36 + q * 6 + r] * Zt[(size_t)j * 36 + q * 6 + c];
+  }
+  Hs[t] = v;
+  double w = 0;
+  if (k + 1 < n_sep) {   // block (k + 1, k) = -G_e^T Zt_e, e = last camera of that segment
+    const int le = end - 1;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) w -= Gfac[(size_t)le * 36 + q * 6 + r] * Zt[(size_t)le * 36 + q * 6 + c];
+  }
+  Bs[t] = w;
+}
+// the separators' L_ii^-1 into the per-slot array the other kernels read
+static __global__ __launch_bounds__(256) void k_cf_sep_scatter(int stride, int n_sep, const double* __restrict__ LiS, double* __restrict__ Linv) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int k = t / 36;
+  if (k >= n_sep) return;
+  Linv[(size_t)(k * stride + stride - 1) * 36 + (t - k * 36)] = LiS[t];
+}
+
+// right-hand sides of the separator rows of X: R(k) <- V_s - LiS_k (G_l^T X_l + acc), acc = what the forward kernel left in R(k);
+// grid (column groups, separators), lane = column
+static __global__ __launch_bounds__(64) void k_cf_sep_rhs(int nf, int n_o, int stride, int n_chunks, const int* __restrict__ oe_cst,
+                                                          const int* __restrict__ oe_slot, const double* __restrict__ V,
+                                                          const double* __restrict__ vy, const double* __restrict__ Gfac,
+                                                          const double* __restrict__ LiS, const double* __restrict__ Xt, long ldx,
+                                                          double* __restrict__ R) {
+  const int j = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (j > n_o) return;
+  const bool rhs = j == n_o;
+  const int s = k * stride + stride - 1, l = s - 1;
+  double vs[6] = {0, 0, 0, 0, 0, 0};
+  if (rhs) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) vs[a] = vy[(size_t)s * 6 + a];
+  } else {
+    const int o = j / 9, b = j - 9 * o;
+    const int* cst = oe_cst + (size_t)o * (n_chunks + 1);
+    const int ch = s / kCfFwdCh;
+    for (int q = cst[ch]; q < cst[ch + 1]; ++q)
+      if (oe_slot[q] == s) {
+        const double* src = V + ((size_t)q * 9 + b) * 6;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) vs[a] += src[a];
+      }
+  }
+  const bool has_acc = (k + 1) * stride < nf;   // a segment behind s exists (else R(k) was never written)
+  double t[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) t[a] = has_acc ? R[(size_t)j + (size_t)(6 * k + a) * (size_t)ldx] : 0.0;
+  double xl[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) xl[r] = Xt[(size_t)j + (size_t)(6 * l + r) * (size_t)ldx];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) t[a] += Gfac[(size_t)l * 36 + r * 6 + a] * xl[r];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double v = vs[a];
+#pragma unroll
+    for (int q = 0; q <= a; ++q) v -= LiS[(size_t)k * 36 + a * 6 + q] * t[q];
+    R[(size_t)j + (size_t)(6 * k + a) * (size_t)ldx] = v;
+  }
+}
+
+// back-substitution, interior right-hand sides once the separators' x is known: z_j -= Zt_j x_s(front) + [j last in segment] G_j x_s(behind)
+static __global__ __launch_bounds__(256) void k_cf_back_prep(int nf, int stride, int n_sep, const double* __restrict__ Zt, const double* __restrict__ Gfac,
+                                                             const double* __restrict__ xc, double* __restrict__ z) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t / 6, a = t - 6 * i;
+  if (i >= nf) return;
+  const int p = i / stride, pos = i - p * stride;
+  if (pos == stride - 1) return;   // a separator
+  double v = 0;
+  if (p >= 1) {
+    const double* xs = xc + (size_t)(p * stride - 1) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v += Zt[(size_t)i * 36 + a * 6 + q] * xs[q];
+  }
+  if ((pos == stride - 2 || i == nf - 1) && p < n_sep) {
+    const double* xs = xc + (size_t)(p * stride + stride - 1) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v += Gfac[(size_t)i * 36 + a * 6 + q] * xs[q];
+  }
+  z[t] -= v;
 }
 
 // ---- T <- D (block diagonal, lower triangle) and row n_o <- b_o^T; the rest of T was cleared by a memset -----------------------
@@ -379,14 +597,20 @@ static __global__ __launch_bounds__(256) void k_cf_z(const double* __restrict__ 
 
 // ---- x_c = L^-T z: one wave, sequential from the last camera to the first; x_i = Li^T z_i - N_i x_{i+1} -------------------------
 constexpr int kCfBackCh = 32;
-static __global__ __launch_bounds__(64) void k_cf_tridiag_back(int nf, const double* __restrict__ Linv, const double* __restrict__ Nn,
-                                                               const double* __restrict__ z, double* __restrict__ xc) {
+// workgroup p: positions [p stride, p stride + seglen) of the chain (one segment = the plain chain).  map_stride > 0: position k
+// of the chain is the separator at slot k map_stride + map_stride - 1 (z read from / x_c written to that slot).
+static __global__ __launch_bounds__(64) void k_cf_tridiag_back(int nf_all, const double* __restrict__ Linv, const double* __restrict__ Nn,
+                                                               const double* __restrict__ z, double* __restrict__ xc, int stride, int seglen,
+                                                               int map_stride) {
   __shared__ double sLi[kCfBackCh * 36], sN[kCfBackCh * 36], sz[kCfBackCh * 6];
   const int lane = threadIdx.x;
   const int a = lane < 6 ? lane : 5;
+  const int beg = (int)blockIdx.x * stride;
+  const int nf = (beg + seglen < nf_all) ? beg + seglen : nf_all;
+  if (beg >= nf) return;
   double xa = 0;                        // lanes 0..5: component a of x_{i+1}
-  for (int hi = nf; hi > 0; hi -= kCfBackCh) {
-    const int i0 = (hi - kCfBackCh > 0) ? hi - kCfBackCh : 0, len = hi - i0;
+  for (int hi = nf; hi > beg; hi -= kCfBackCh) {
+    const int i0 = (hi - kCfBackCh > beg) ? hi - kCfBackCh : beg, len = hi - i0;
     __builtin_amdgcn_wave_barrier();
     {   // fixed trip counts with clamped addresses: all loads of the staging go out together (a run-time loop of load -> LDS write
         // pays one memory round trip per iteration)
@@ -398,7 +622,11 @@ static __global__ __launch_bounds__(64) void k_cf_tridiag_back(int nf, const dou
         tl[q] = Linv[(size_t)i0 * 36 + cl]; tn[q] = Nn[(size_t)i0 * 36 + cl];
       }
 #pragma unroll
-      for (int q = 0; q < kZ; ++q) { const int idx = q * 64 + lane; tz[q] = z[(size_t)i0 * 6 + (idx < len * 6 ? idx : 0)]; }
+      for (int q = 0; q < kZ; ++q) {
+        const int idx = q * 64 + lane, cl = idx < len * 6 ? idx : 0;
+        const size_t src = map_stride > 0 ? (size_t)((i0 + cl / 6) * map_stride + map_stride - 1) * 6 + cl % 6 : (size_t)i0 * 6 + cl;
+        tz[q] = z[src];
+      }
 #pragma unroll
       for (int q = 0; q < kQ; ++q) { sLi[q * 64 + lane] = tl[q]; sN[q * 64 + lane] = tn[q]; }
 #pragma unroll
@@ -413,7 +641,8 @@ static __global__ __launch_bounds__(64) void k_cf_tridiag_back(int nf, const dou
 #pragma unroll
       for (int k = 0; k < 6; ++k) s += sLi[ii * 36 + k * 6 + a] * sz[ii * 6 + k] - sN[ii * 36 + a * 6 + k] * xn[k];
       xa = s;
-      if (lane < 6) xc[(size_t)(i0 + ii) * 6 + lane] = s;
+      const size_t dst = map_stride > 0 ? (size_t)((i0 + ii) * map_stride + map_stride - 1) * 6 : (size_t)(i0 + ii) * 6;
+      if (lane < 6) xc[dst + lane] = s;
     }
   }
 }

@@ -200,6 +200,10 @@ struct esl_ctx {
   int cf_n_list = 0, cf_n_chunks = 0;
   double *cf_Linv = nullptr, *cf_M = nullptr, *cf_N = nullptr, *cf_V = nullptr, *cf_vy = nullptr, *cf_z = nullptr;
   double *cf_B = nullptr, *cf_Lfac = nullptr, *cf_G = nullptr;
+  // nested dissection of the camera chain (esl_cf.hpp): every cf_stride-th slot is a separator (0 = plain chain)
+  int cf_stride = 0, cf_n_sep = 0, cf_n_seg = 1;
+  double *cf_Zt = nullptr, *cf_Hs = nullptr, *cf_Bs = nullptr, *cf_LfacS = nullptr, *cf_GS = nullptr, *cf_LiS = nullptr, *cf_MS = nullptr,
+         *cf_NS = nullptr, *cf_R = nullptr;
   double *cf_Xt = nullptr, *cf_T = nullptr, *cf_Linv_ws = nullptr, *cf_part = nullptr;
   int64_t cf_ldx = 0, cf_kpad = 0, cf_ldt = 0;
   int lm_solver_used = 0;   // esl_linear_solver the last trial step ran with (1 reduced camera system, 2 reduced ellipsoid system)

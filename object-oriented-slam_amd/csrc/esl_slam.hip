@@ -4,6 +4,7 @@
 #include "esl_slam.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -176,6 +177,20 @@ static int cf_ensure(esl_ctx* c) {
       (rc = al(&c->cf_T, (size_t)c->cf_ldt * n_o)) || (rc = al(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB)))
     return rc;
   if (n_o <= 1024 && (rc = al(&c->cf_part, (size_t)kCholMaxSplit * (size_t)c->cf_ldt * n_o))) return rc;   // split-K workspace of small systems
+  // nested dissection of the camera chain from 128 free cameras on: stride = 16 x round(sqrt(nf) / 16) in [16, 128] (a multiple
+  // of the forward substitution's chunk, so that segments start on chunk boundaries); ESL_CF_NO_ND=1 keeps the plain chain (A/B)
+  c->cf_stride = 0; c->cf_n_sep = 0; c->cf_n_seg = 1;
+  if (nf >= 128 && !std::getenv("ESL_CF_NO_ND")) {
+    int st = 16 * (int)std::max(1.0, std::floor(std::sqrt((double)nf) / 16.0 + 0.5));
+    st = std::min(st, kCfMaxStride);
+    c->cf_stride = st; c->cf_n_sep = (int)(nf / st); c->cf_n_seg = (int)((nf + st - 1) / st);
+    const size_t ns = (size_t)std::max(c->cf_n_sep, 1);
+    if ((rc = al(&c->cf_Zt, nf * 36)) || (rc = al(&c->cf_Hs, ns * 36)) || (rc = al(&c->cf_Bs, ns * 36)) || (rc = al(&c->cf_LfacS, ns * 21)) ||
+        (rc = al(&c->cf_GS, ns * 36)) || (rc = al(&c->cf_LiS, ns * 36)) || (rc = al(&c->cf_MS, ns * 36)) || (rc = al(&c->cf_NS, ns * 36)) ||
+        (rc = al(&c->cf_R, ns * 6 * (size_t)c->cf_ldx)))
+      return rc;
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_Zt, 0, nf * 36 * sizeof(double), c->stream));
+  }
   // rows 6 nf .. kpad of X (the K padding of the rank-K update) and the columns of never-written edges stay zero
   ESL_HIP_TRY(hipMemsetAsync(c->cf_Xt, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad * sizeof(double), c->stream));
   ESL_HIP_TRY(hipMemsetAsync(c->cf_V, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
@@ -194,13 +209,35 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     ProfScope ps(c, 2);   // "reduced-system build": factor of the camera block, X = L^-1 [W | b_c], T = D - X^T X
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(k_cf_gather_B, dim3((unsigned)(((long)nf * 36 + 255) / 256)), dim3(256), 0, c->stream, nf, c->Aod, c->cf_od_start, c->cf_od_edge, c->cf_B);
-    hipLaunchKernelGGL(k_cf_chain, dim3(1), dim3(64), 0, c->stream, nf, c->Hcc, c->cf_B, lambda, c->cf_Lfac, c->cf_G, c->chol_info);
-    hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, c->stream, nf, c->cf_Lfac, c->cf_G, c->cf_Linv, c->cf_M, c->cf_N);
+    const int st = c->cf_stride, ns = c->cf_n_sep, nseg = c->cf_n_seg;
+    const bool nd = st > 0 && ns > 0;
+    const unsigned cg = (unsigned)((n_o + 1 + 63) / 64);
     const long nt = (long)c->cf_n_list * 9 + nf;
-    hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
-                       c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
-    hipLaunchKernelGGL(k_cf_forward, dim3((unsigned)((n_o + 1 + 63) / 64)), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot,
-                       c->cf_V, c->cf_vy, c->cf_M, c->cf_Xt, ldx);
+    if (!nd) {
+      hipLaunchKernelGGL(k_cf_chain, dim3(1), dim3(64), 0, c->stream, nf, c->Hcc, c->cf_B, lambda, c->cf_Lfac, c->cf_G, c->chol_info, nf, nf);
+      hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, c->stream, nf, c->cf_Lfac, c->cf_G, c->cf_Linv, c->cf_M, c->cf_N, 0);
+      hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
+                         c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
+      hipLaunchKernelGGL(k_cf_forward<false>, dim3(cg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                         c->cf_M, c->cf_Xt, ldx, nf, nf, (const double*)nullptr, (double*)nullptr, 0);
+    } else {   // nested dissection (esl_cf.hpp): segments in parallel, then the separators' own short chain
+      hipLaunchKernelGGL(k_cf_chain, dim3((unsigned)nseg), dim3(64), 0, c->stream, nf, c->Hcc, c->cf_B, lambda, c->cf_Lfac, c->cf_G, c->chol_info, st, st - 1);
+      hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, c->stream, nf, c->cf_Lfac, c->cf_G, c->cf_Linv, c->cf_M, c->cf_N, st);
+      if (nseg > 1) hipLaunchKernelGGL(k_cf_zt, dim3((unsigned)(nseg - 1)), dim3(64), 0, c->stream, nf, st, c->cf_Linv, c->cf_M, c->cf_B, c->cf_Zt);
+      hipLaunchKernelGGL(k_cf_sep_assemble, dim3((unsigned)((ns * 36 + 255) / 256)), dim3(256), 0, c->stream, nf, st, ns, c->Hcc, lambda, c->cf_G, c->cf_Zt,
+                         c->cf_Hs, c->cf_Bs);
+      hipLaunchKernelGGL(k_cf_chain, dim3(1), dim3(64), 0, c->stream, ns, c->cf_Hs, c->cf_Bs, 0.0, c->cf_LfacS, c->cf_GS, c->chol_info, ns, ns);
+      hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, c->stream, ns, c->cf_LfacS, c->cf_GS, c->cf_LiS, c->cf_MS, c->cf_NS, 0);
+      hipLaunchKernelGGL(k_cf_sep_scatter, dim3((unsigned)((ns * 36 + 255) / 256)), dim3(256), 0, c->stream, st, ns, c->cf_LiS, c->cf_Linv);
+      hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
+                         c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
+      hipLaunchKernelGGL(k_cf_forward<false>, dim3(cg, (unsigned)nseg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V,
+                         c->cf_vy, c->cf_M, c->cf_Xt, ldx, st, st - 1, (const double*)c->cf_Zt, c->cf_R, st);
+      hipLaunchKernelGGL(k_cf_sep_rhs, dim3(cg, (unsigned)ns), dim3(64), 0, c->stream, nf, n_o, st, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                         c->cf_G, c->cf_LiS, c->cf_Xt, ldx, c->cf_R);
+      hipLaunchKernelGGL(k_cf_forward<true>, dim3(cg), dim3(64), 0, c->stream, ns, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                         c->cf_MS, c->cf_Xt, ldx, ns, ns, (const double*)nullptr, c->cf_R, st);
+    }
     ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)ldt * (size_t)n_o * sizeof(double), c->stream));
     hipLaunchKernelGGL(k_cf_T_init, dim3((unsigned)(((long)N * 90 + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
     ESL_HIP_TRY(hipGetLastError());
@@ -215,7 +252,14 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     ProfScope ps(c, 3);   // dense Cholesky of the reduced ellipsoid system + the camera back-substitution
     ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
     hipLaunchKernelGGL(k_cf_z, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, c->cf_Xt, ldx, n_o, c->xo, c->cf_z);
-    hipLaunchKernelGGL(k_cf_tridiag_back, dim3(1), dim3(64), 0, c->stream, nf, c->cf_Linv, c->cf_N, c->cf_z, c->xc);
+    if (c->cf_stride > 0 && c->cf_n_sep > 0) {
+      const int st = c->cf_stride, ns = c->cf_n_sep;
+      hipLaunchKernelGGL(k_cf_tridiag_back, dim3(1), dim3(64), 0, c->stream, ns, c->cf_LiS, c->cf_NS, c->cf_z, c->xc, ns, ns, st);            // separators
+      hipLaunchKernelGGL(k_cf_back_prep, dim3((unsigned)((6 * nf + 255) / 256)), dim3(256), 0, c->stream, nf, st, ns, c->cf_Zt, c->cf_G, c->xc, c->cf_z);
+      hipLaunchKernelGGL(k_cf_tridiag_back, dim3((unsigned)c->cf_n_seg), dim3(64), 0, c->stream, nf, c->cf_Linv, c->cf_N, c->cf_z, c->xc, st, st - 1, 0);  // segments
+    } else {
+      hipLaunchKernelGGL(k_cf_tridiag_back, dim3(1), dim3(64), 0, c->stream, nf, c->cf_Linv, c->cf_N, c->cf_z, c->xc, nf, nf, 0);
+    }
     ESL_HIP_TRY(hipGetLastError());
   }
   {

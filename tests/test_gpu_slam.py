@@ -247,3 +247,47 @@ def test_camera_first_elimination_applicability(pkg, ctx):
             obj_rel(runs[1][1], runs[2][1])))
         np.testing.assert_allclose(runs[1][2]["trace_chi2"], runs[2][2]["trace_chi2"], rtol=1e-6, err_msg=name)
         assert cam_err(runs[1][0], runs[2][0]) < 1e-6 and obj_rel(runs[1][1], runs[2][1]) < 1e-6
+
+
+@pytest.mark.parametrize("n_cams", [129, 161, 200, 500])
+def test_nested_dissection_equals_plain_chain(pkg, monkeypatch, n_cams):
+    """Camera-first elimination with the camera chain cut into segments (nested dissection, from 128 free cameras on: every
+    stride-th camera a separator, segments factored / substituted in parallel, the separators' own block-tridiagonal system)
+    against the same elimination over the plain chain (ESL_CF_NO_ND=1) and against the reduced camera system: the same linear
+    systems, so x of the first trial to rounding and the whole LM run alike.  Sizes: 128 free cameras (the threshold, 8 segments
+    of stride 16), 160 (the last camera IS a separator), 199 (short last segment), 499 (C3's count, stride 16)."""
+    g, c, o, _ = pkg.synth.make_graph(n_cams, 12, 12 * n_cams, seed=31, slam=True)
+    nf = n_cams - 1
+    out = {}
+    for tag, env, solver in (("nd", None, 2), ("plain", "1", 2), ("camera", None, 1)):
+        if env:
+            monkeypatch.setenv("ESL_CF_NO_ND", env)
+        else:
+            monkeypatch.delenv("ESL_CF_NO_ND", raising=False)
+        cx = pkg.Context(0)
+        try:
+            cx.upload_graph(g); cx.upload_states(c, o)
+            cx.lm_begin(pkg.default_lm_params(jacobian_mode=1, linear_solver=solver))
+            part = cx.lm_linearize()
+            lam = 1e-5 * part.max_diag
+            tr = cx.lm_try_step(lam)
+            assert tr.solve_ok == 1 and cx.lm_solver_used() == solver
+            xc, xo = cx.lm_download(5, 6 * nf), cx.lm_download(2, 9 * g.n_objs)
+            res = cx.lm_reduced_residual()
+            cx.lm_commit(False)
+            cc, oo, rep = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1, linear_solver=solver))
+            out[tag] = (xc, xo, tr.chi2, res, cc, oo, rep)
+        finally:
+            cx.close()
+    monkeypatch.delenv("ESL_CF_NO_ND", raising=False)
+    ref = out["plain"]
+    for tag in ("nd", "camera"):
+        xc, xo, chi, res, cc, oo, rep = out[tag]
+        d_xc = float(np.abs(xc - ref[0]).max() / np.abs(ref[0]).max()); d_xo = float(np.abs(xo - ref[1]).max() / np.abs(ref[1]).max())
+        print("n_cams %d, %s vs plain chain: x_c %.2e x_o %.2e, |Sx-b|/|b| %.2e, run: chi2 rel %.2e cams %.2e" % (
+            n_cams, tag, d_xc, d_xo, res, abs(rep["chi2_final"] / ref[6]["chi2_final"] - 1), cam_err(cc, ref[4])))
+        assert res < 1e-10 and d_xc < 1e-8 and d_xo < 1e-8
+        assert chi == pytest.approx(ref[2], rel=1e-10)
+        assert rep["trace_trials"] == ref[6]["trace_trials"]
+        np.testing.assert_allclose(rep["trace_chi2"], ref[6]["trace_chi2"], rtol=1e-8)
+        assert cam_err(cc, ref[4]) < 1e-6 and obj_rel(oo, ref[5]) < 1e-6
