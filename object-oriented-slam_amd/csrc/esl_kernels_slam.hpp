@@ -9,11 +9,11 @@
 // which is the same solution as the dense LDLT of the whole system the shipped solver would compute.
 //
 // Work split:
-//   k_slam_linearize   one wave per ellipsoid (edges sorted by ellipsoid => coalesced): residuals,
-//                      Jacobians wrt ellipsoid AND camera, Hoo/b_o in registers + wave reduction,
-//                      per-edge W = Jc^T W Jo (6x9) and camera terms A = Jc^T W Jc, g = -Jc^T W r to HBM (SoA)
+//   k_slam_linearize_chunks  one wave per chunk (<= 64 bbox / <= 32 3-D edges of one ellipsoid): residuals, Jacobians wrt ellipsoid
+//                      AND camera, per-edge W = Jc^T W Jo (6x9, SoA) and camera terms A = Jc^T W Jc, g = -Jc^T W r (records) to
+//                      HBM, chunk partial of Hoo / b_o through the LDS transpose; k_slam_combine: Hoo, b_o, chi2 per ellipsoid
 //   k_slam_odom        one lane per odometry edge
-//   k_slam_cam_gather  one lane per free camera: Hcc, b_c from its edges (camera-side CSR; deterministic)
+//   k_slam_cam_gather  one wave per free camera: Hcc, b_c from its edges (camera-side CSR; deterministic)
 //   k_slam_prepare     one wave per ellipsoid: Dinv = (Hoo+lambda I)^-1, Y_e = W_e Dinv, b_s -= Y_e b_o
 //   k_slam_schur_pull  one lane per block (c1, c2) of S: intersects the two cameras' edge lists, S[c1,c2] -= sum Y_e1 W_e2^T in
 //                      list order (deterministic); the row camera's Y blocks, list and ellipsoid bitmap are staged in LDS per
@@ -23,7 +23,7 @@
 //   k_slam_cam_update  one lane per camera: retraction exp(x_c) * Tcw
 //   chi2 of the trial  k_slam_chi2_obj (wave per ellipsoid) + k_slam_chi2_odom
 #pragma once
-#include "esl_kernels_map.hpp"
+#include "esl_kernels_chunk.hpp"
 
 namespace esl {
 
@@ -43,7 +43,10 @@ __device__ __forceinline__ void numeric_jac_cam(const SE3& T, double delta, int 
   }
 }
 
-// per-edge camera-side products, written SoA (index k * EU + u); Y and the pull kernel's copy of W are per-edge records ([u][54])
+// per-edge camera-side products: W = Jc^T w Jo written SoA (index k * EU + u); the camera terms A = Jc^T w Jc (21 packed) and
+// g = -Jc^T w r (6) as a per-edge record ([u][27]: the camera gather reads a record as one coalesced row, lane = entry); Y and the
+// pull kernel's copy of W are per-edge records ([u][54])
+constexpr int kARec = 27;
 template <int D>
 __device__ __forceinline__ void store_cam_terms(const double* Jc, const double* Jo, const double* r, double w,
                                                 double* __restrict__ W, double* __restrict__ A, long EU, long u) {
@@ -64,99 +67,143 @@ __device__ __forceinline__ void store_cam_terms(const double* Jc, const double* 
       double s = 0;
 #pragma unroll
       for (int k = 0; k < D; ++k) s += Jc[k * 6 + a] * w * Jc[k * 6 + c];
-      A[(long)(p++) * EU + u] = s;
+      A[u * kARec + (p++)] = s;
     }
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     double s = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) s += Jc[k * 6 + a] * (w * r[k]);
-    A[(long)(21 + a) * EU + u] = -s;
+    A[u * kARec + 21 + a] = -s;
   }
 }
 
+// One wave per CHUNK (<= 64 bbox edges or <= 32 3-D edges of one ellipsoid: the decomposition of mapping mode, built at upload),
+// lane = edge: residual, Jacobians wrt ellipsoid AND camera, W / A of the edge to HBM, the 45 + 9 entries of the ellipsoid's
+// J^T w J / -J^T w r summed over the wave through the LDS transpose of esl_kernels_chunk.hpp into a chunk partial (row of
+// kChunkOut doubles: 45 packed H, 9 b, chi2).  One instantiation per edge type (very different register needs).
+// Round 2's form ran one wave per ELLIPSOID over all its edges: 50 waves at C3 (186 us), its tail set by the ellipsoid with the
+// most edges.
+template <int JAC, int TYPE>
+static __global__ __launch_bounds__(64 * kLinWaves) void k_slam_linearize_chunks(
+    DevGraph g, ChunkTable ct, const int* __restrict__ ids, int n_ids, const double* __restrict__ cams, const double* __restrict__ objs,
+    double delta, double* __restrict__ chunk_out, double* __restrict__ W, double* __restrict__ A) {
+  __shared__ double tr_all[kLinWaves * kTrDoubles];
+  double* tr = tr_all + (threadIdx.x >> 6) * kTrDoubles;
+  const int lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * kLinWaves + (threadIdx.x >> 6);
+  if (seg >= n_ids) return;
+  const int ch = ids[seg];
+  const int o = ct.obj[ch];
+  const int i = ct.begin[ch] + lane;
+  const bool in = i < ct.end[ch];
+  const long EU = (long)g.n_bbox + g.n_e3d;
+  const Ell e = ell_load(objs + 10 * o);
+  double* out = chunk_out + (size_t)ch * kChunkOut;
+  double chi = 0;
+  if (TYPE == 0) {
+    double r[4] = {0, 0, 0, 0}, Jo[36], w = 0;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Jo[k] = 0;
+    if (in && g.bb_valid[i]) {
+      const int ci = g.bb_cam[i];
+      const SE3 T = se3_load(cams + 7 * ci);
+      const bool cam_free = g.cam_slot[ci] >= 0;
+      double meas[4] = {g.bb_meas[4 * i], g.bb_meas[4 * i + 1], g.bb_meas[4 * i + 2], g.bb_meas[4 * i + 3]};
+      w = g.bb_w[i];
+      double Jc[24];
+      if (JAC == ESL_JAC_ANALYTIC) {
+        jac_box_edge(g.bbox_mode, T, e, g.K, meas, r, Jo, cam_free ? Jc : nullptr);
+      } else {
+        res_box_edge(g.bbox_mode, T, e, g.K, meas, r);
+        numeric_jac_obj(e, delta, 4, Jo, [&](const Ell& ep, double* o4) { res_box_edge(g.bbox_mode, T, ep, g.K, meas, o4); });
+        if (cam_free) numeric_jac_cam(T, delta, 4, Jc, [&](const SE3& Tp, double* o4) { res_box_edge(g.bbox_mode, Tp, e, g.K, meas, o4); });
+      }
+      chi = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+      if (cam_free) store_cam_terms<4>(Jc, Jo, r, w, W, A, EU, (long)i);
+    }
+    reduce_group_lds<4, 0>(Jo, r, w, lane, out, tr);
+    reduce_group_lds<4, 1>(Jo, r, w, lane, out, tr);
+    reduce_group_lds<4, 2>(Jo, r, w, lane, out, tr);
+  } else {
+    double r[9], Jo[81], w = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 81; ++k) Jo[k] = 0;
+    if (in) {
+      const int ci = g.e3_cam[i];
+      const SE3 T = se3_load(cams + 7 * ci);
+      const bool cam_free = g.cam_slot[ci] >= 0;
+      const Ell m = ell_load(g.e3_meas + 10 * i);
+      w = g.e3_w[i];
+      double Jc[54];
+      if (JAC == ESL_JAC_ANALYTIC) {
+        jac_e3d(T, e, m, g.yt, r, Jo, cam_free ? Jc : nullptr);
+      } else {
+        res_e3d(T, e, m, g.yt, r);
+        numeric_jac_obj(e, delta, 9, Jo, [&](const Ell& ep, double* o9) { res_e3d(T, ep, m, g.yt, o9); });
+        if (cam_free) numeric_jac_cam(T, delta, 9, Jc, [&](const SE3& Tp, double* o9) { res_e3d(Tp, e, m, g.yt, o9); });
+      }
+      double cc = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cc += r[k] * r[k];
+      chi = w * cc;
+      if (cam_free) store_cam_terms<9>(Jc, Jo, r, w, W, A, EU, (long)g.n_bbox + i);
+    }
+    reduce_group_lds<9, 0>(Jo, r, w, lane, out, tr);
+    reduce_group_lds<9, 1>(Jo, r, w, lane, out, tr);
+    reduce_group_lds<9, 2>(Jo, r, w, lane, out, tr);
+  }
+  chi = wave_sum(chi);
+  if (lane == 0) out[54] = chi;
+}
+
+// Hoo (45 packed), b_o (9), chi2 and max |H_kk| of every ellipsoid from its chunk partials (chunk order: deterministic) + its
+// gravity prior; one wave per ellipsoid, lane k < 55 = entry k
 template <int JAC>
-static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_linearize(
-    DevGraph g, const double* __restrict__ cams, const double* __restrict__ objs, double delta,
-    double* __restrict__ Hoo, double* __restrict__ bo, double* __restrict__ part, double* __restrict__ W,
-    double* __restrict__ A) {
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_combine(DevGraph g, ChunkTable ct, const double* __restrict__ chunk_out,
+                                                                         const double* __restrict__ objs, double delta,
+                                                                         double* __restrict__ Hoo, double* __restrict__ bo,
+                                                                         double* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int o = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (o >= g.n_objs) return;
-  const long EU = (long)g.n_bbox + g.n_e3d;
-  const Ell e = ell_load(objs + 10 * o);
-  double acc[54];
-#pragma unroll
-  for (int i = 0; i < 54; ++i) acc[i] = 0.0;
-  double chi = 0.0;
-  for (int i = g.bb_start[o] + lane; i < g.bb_start[o + 1]; i += 64) {
-    if (!g.bb_valid[i]) continue;
-    const int ci = g.bb_cam[i];
-    const SE3 T = se3_load(cams + 7 * ci);
-    const bool cam_free = g.cam_slot[ci] >= 0;
-    double meas[4] = {g.bb_meas[4 * i], g.bb_meas[4 * i + 1], g.bb_meas[4 * i + 2], g.bb_meas[4 * i + 3]};
-    const double w = g.bb_w[i];
-    double r[4], Jo[36], Jc[24];
-    if (JAC == ESL_JAC_ANALYTIC) {
-      jac_box_edge(g.bbox_mode, T, e, g.K, meas, r, Jo, cam_free ? Jc : nullptr);
-    } else {
-      res_box_edge(g.bbox_mode, T, e, g.K, meas, r);
-      numeric_jac_obj(e, delta, 4, Jo, [&](const Ell& ep, double* out) { res_box_edge(g.bbox_mode, T, ep, g.K, meas, out); });
-      if (cam_free) numeric_jac_cam(T, delta, 4, Jc, [&](const SE3& Tp, double* out) { res_box_edge(g.bbox_mode, Tp, e, g.K, meas, out); });
+  double v = 0;
+  if (lane < 55)
+    for (int ch = ct.ostart[o]; ch < ct.ostart[o + 1]; ++ch) v += chunk_out[(size_t)ch * kChunkOut + lane];
+  const int ng = g.gr_cnt[o];
+  if (ng > 0) {
+    const Ell e = ell_load(objs + 10 * o);
+    const double wg = g.grav_w * ng;
+    double Jg[9], rg;
+    if (JAC == ESL_JAC_ANALYTIC) rg = jac_grav(e, g.grav_n, Jg);
+    else {
+      rg = res_grav(e, g.grav_n);
+      numeric_jac_obj(e, delta, 1, Jg, [&](const Ell& ep, double* o1) { o1[0] = res_grav(ep, g.grav_n); });
     }
-    chi += w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-    accum_obj<4>(Jo, r, w, acc);
-    if (cam_free) store_cam_terms<4>(Jc, Jo, r, w, W, A, EU, (long)i);
-  }
-  for (int i = g.e3_start[o] + lane; i < g.e3_start[o + 1]; i += 64) {
-    const int ci = g.e3_cam[i];
-    const SE3 T = se3_load(cams + 7 * ci);
-    const bool cam_free = g.cam_slot[ci] >= 0;
-    const Ell m = ell_load(g.e3_meas + 10 * i);
-    const double w = g.e3_w[i];
-    double r[9], Jo[81], Jc[54];
-    if (JAC == ESL_JAC_ANALYTIC) {
-      jac_e3d(T, e, m, g.yt, r, Jo, cam_free ? Jc : nullptr);
-    } else {
-      res_e3d(T, e, m, g.yt, r);
-      numeric_jac_obj(e, delta, 9, Jo, [&](const Ell& ep, double* out) { res_e3d(T, ep, m, g.yt, out); });
-      if (cam_free) numeric_jac_cam(T, delta, 9, Jc, [&](const SE3& Tp, double* out) { res_e3d(Tp, e, m, g.yt, out); });
+    if (lane < 45) {
+      double ja = 0, jc = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { if (q == tri_a(lane)) ja = Jg[q]; if (q == tri_c(lane)) jc = Jg[q]; }
+      v += (wg * ja) * jc;
+    } else if (lane < 54) {
+      double ja = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) if (q == lane - 45) ja = Jg[q];
+      v -= ja * (wg * rg);
+    } else if (lane == 54) {
+      v += wg * rg * rg;
     }
-    double c = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) c += r[k] * r[k];
-    chi += w * c;
-    accum_obj<9>(Jo, r, w, acc);
-    if (cam_free) store_cam_terms<9>(Jc, Jo, r, w, W, A, EU, (long)g.n_bbox + i);
   }
-  if (lane < g.gr_cnt[o]) {
-    double J[9], r[1];
-    if (JAC == ESL_JAC_ANALYTIC) {
-      r[0] = jac_grav(e, g.grav_n, J);
-    } else {
-      r[0] = res_grav(e, g.grav_n);
-      numeric_jac_obj(e, delta, 1, J, [&](const Ell& ep, double* out) { out[0] = res_grav(ep, g.grav_n); });
-    }
-    chi += g.grav_w * r[0] * r[0];
-    accum_obj<1>(J, r, g.grav_w, acc);
-  }
+  if (lane < 45) Hoo[(size_t)o * 45 + lane] = v;
+  else if (lane < 54) bo[(size_t)o * 9 + (lane - 45)] = v;
+  bool diag = false;
 #pragma unroll
-  for (int i = 0; i < 54; ++i) acc[i] = wave_sum(acc[i]);
-  chi = wave_sum(chi);
-  if (lane == 0) {
-    double md = 0;
-    int p = 0;
-#pragma unroll
-    for (int a = 0; a < 9; ++a) { md = fmax(md, fabs(acc[p])); p += 9 - a; }
-#pragma unroll
-    for (int i = 0; i < 45; ++i) Hoo[(size_t)o * 45 + i] = acc[i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) bo[(size_t)o * 9 + i] = acc[45 + i];
-    part[o * 4 + 0] = chi;
-    part[o * 4 + 1] = md;
-    part[o * 4 + 2] = 0;
-    part[o * 4 + 3] = 1;
-  }
+  for (int a = 0, q = 0; a < 9; ++a) { if (lane == q) diag = true; q += 9 - a; }
+  const double md = wave_max(diag ? fabs(v) : 0.0);
+  const double chi = __shfl(v, 54, 64);
+  if (lane == 0) { part[o * 4 + 0] = chi; part[o * 4 + 1] = md; part[o * 4 + 2] = 0; part[o * 4 + 3] = 1; }
 }
 
 // odometry edges: Aod[e*90 ..] = Hii(21) bi(6) Hjj(21) bj(6) Hij(36, row-major i x j); od_part[e] = chi2
@@ -209,49 +256,48 @@ static __global__ void k_slam_odom(DevGraph g, const double* __restrict__ cams, 
     }
 }
 
-// one lane per camera: Hcc (36 full, row-major), bc (6); cam_part = {0, max diag, 0, 1}
-static __global__ void k_slam_cam_gather(DevGraph g, const double* __restrict__ A, const double* __restrict__ Aod,
-                                  double* __restrict__ Hcc, double* __restrict__ bc, double* __restrict__ cam_part) {
-  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per camera, lane k < 27 = entry k of {A (21 packed), g (6)}: the camera's edges are walked uniformly and every edge's
+// record is one coalesced row (round 2: one lane per camera over SoA planes, 64 us at C3 for 8 waves of dependent loads);
+// fixed edge order (bbox edges, 3-D edges, odometry) -> deterministic.  Hcc (36 full, row-major), bc (6); cam_part = {0, max diag, 0, 1}
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_cam_gather(DevGraph g, const double* __restrict__ A,
+                                                                            const double* __restrict__ Aod, double* __restrict__ Hcc,
+                                                                            double* __restrict__ bc, double* __restrict__ cam_part) {
+  const int lane = threadIdx.x & 63;
+  const int cidx = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (cidx >= g.n_cams) return;
   const int slot = g.cam_slot[cidx];
-  cam_part[cidx * 4 + 0] = 0; cam_part[cidx * 4 + 1] = 0; cam_part[cidx * 4 + 2] = 0; cam_part[cidx * 4 + 3] = 1;
-  if (slot < 0) return;
-  const long EU = (long)g.n_bbox + g.n_e3d;
-  double acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0;
+  if (slot < 0) {
+    if (lane == 0) { cam_part[cidx * 4 + 0] = 0; cam_part[cidx * 4 + 1] = 0; cam_part[cidx * 4 + 2] = 0; cam_part[cidx * 4 + 3] = 1; }
+    return;
+  }
+  const int k = lane < kARec ? lane : 0;
+  double acc = 0;
   for (int q = g.cbb_start[cidx]; q < g.cbb_start[cidx + 1]; ++q) {
     const int e = g.cbb_edge[q];
     if (!g.bb_valid[e]) continue;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] += A[(long)k * EU + e];
+    acc += A[(long)e * kARec + k];
   }
-  for (int q = g.ce3_start[cidx]; q < g.ce3_start[cidx + 1]; ++q) {
-    const long u = (long)g.n_bbox + g.ce3_edge[q];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] += A[(long)k * EU + u];
-  }
-  for (int q = g.cod_start[cidx]; q < g.cod_start[cidx + 1] && g.shard_rank == 0; ++q) {
-    const int es = g.cod_edge[q];
-    const double* src = Aod + (size_t)(es >> 1) * 90 + ((es & 1) ? 27 : 0);
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] += src[k];
-  }
-  double md = 0;
-  int p = 0;
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int c = a; c < 6; ++c) {
-      const double v = acc[p++];
-      Hcc[(size_t)slot * 36 + a * 6 + c] = v;
-      Hcc[(size_t)slot * 36 + c * 6 + a] = v;
-      if (a == c) md = fmax(md, fabs(v));
+  for (int q = g.ce3_start[cidx]; q < g.ce3_start[cidx + 1]; ++q) acc += A[((long)g.n_bbox + g.ce3_edge[q]) * kARec + k];
+  if (g.shard_rank == 0)
+    for (int q = g.cod_start[cidx]; q < g.cod_start[cidx + 1]; ++q) {
+      const int es = g.cod_edge[q];
+      acc += Aod[(size_t)(es >> 1) * 90 + ((es & 1) ? 27 : 0) + k];
     }
+  // packed (a, c), a <= c, index p: row a starts at a (13 - a) / 2
+  if (lane < 21) {
+    int a = 0, base = 0;
+    while (lane >= base + (6 - a)) { base += 6 - a; ++a; }
+    const int cc = a + (lane - base);
+    Hcc[(size_t)slot * 36 + a * 6 + cc] = acc;
+    Hcc[(size_t)slot * 36 + cc * 6 + a] = acc;
+  } else if (lane < 27) {
+    bc[(size_t)slot * 6 + (lane - 21)] = acc;
+  }
+  bool diag = false;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) bc[(size_t)slot * 6 + a] = acc[21 + a];
-  cam_part[cidx * 4 + 1] = md;
+  for (int a = 0, q = 0; a < 6; ++a) { if (lane == q) diag = true; q += 6 - a; }
+  const double md = wave_max(diag ? fabs(acc) : 0.0);
+  if (lane == 0) { cam_part[cidx * 4 + 0] = 0; cam_part[cidx * 4 + 1] = md; cam_part[cidx * 4 + 2] = 0; cam_part[cidx * 4 + 3] = 1; }
 }
 
 // max |Hcc_kk| per camera from the (possibly rank-summed) blocks

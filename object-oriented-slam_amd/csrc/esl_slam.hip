@@ -118,7 +118,7 @@ int slam_alloc(esl_ctx* c) {
   if ((rc = al(&c->Hcc, (size_t)nf * 36))) return rc;
   if ((rc = al(&c->bc, (size_t)nf * 6))) return rc;
   if ((rc = al(&c->Wbb, EU * 54))) return rc;   // unified W  [54][EU]
-  if ((rc = al(&c->Abb, EU * 27))) return rc;   // unified A  [27][EU]
+  if ((rc = al(&c->Abb, EU * 27))) return rc;   // unified A  [EU][27] (per-edge records)
   if ((rc = al(&c->Yb, EU * 54))) return rc;    // unified Y  [EU][54]
   if ((rc = al(&c->Wt, EU * 54))) return rc;    // W once more as per-edge records [EU][9][6]: what k_slam_schur_pull gathers
   if ((rc = al(&c->Tb, EU * 6))) return rc;     // Y_e b_o    [6][EU]
@@ -312,21 +312,34 @@ int slam_linearize(esl_ctx* c) {
   {
     ProfScope ps(c, 0);
     if (N > 0) {
-      const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-      if (an)
-        hipLaunchKernelGGL(k_slam_linearize<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, c->cams, c->objs, delta, c->Hoo,
-                           c->bo, c->obj_part, c->Wbb, c->Abb);
-      else
-        hipLaunchKernelGGL(k_slam_linearize<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, c->cams, c->objs, delta, c->Hoo,
-                           c->bo, c->obj_part, c->Wbb, c->Abb);
+      ChunkTable ct;
+      ct.n_chunks = c->n_chunks; ct.obj = c->ck_obj; ct.type = c->ck_type; ct.begin = c->ck_begin; ct.end = c->ck_end; ct.ostart = c->ck_ostart;
+      const dim3 block(64 * kLinWaves);
+      const int nb_e3 = (c->n_ids_e3 + kLinWaves - 1) / kLinWaves, nb_bb = (c->n_ids_bb + kLinWaves - 1) / kLinWaves;
+      // 3-D chunks first (the longer instruction stream), then the bbox chunks, then the per-ellipsoid sums
+      if (an) {
+        if (nb_e3) hipLaunchKernelGGL((k_slam_linearize_chunks<ESL_JAC_ANALYTIC, 1>), dim3(nb_e3), block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3, c->cams,
+                                      c->objs, delta, c->chunk_out, c->Wbb, c->Abb);
+        if (nb_bb) hipLaunchKernelGGL((k_slam_linearize_chunks<ESL_JAC_ANALYTIC, 0>), dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb, c->cams,
+                                      c->objs, delta, c->chunk_out, c->Wbb, c->Abb);
+        hipLaunchKernelGGL(k_slam_combine<ESL_JAC_ANALYTIC>, dim3((N + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kWave * kWavesPerBlock), 0, c->stream, g, ct,
+                           c->chunk_out, c->objs, delta, c->Hoo, c->bo, c->obj_part);
+      } else {
+        if (nb_e3) hipLaunchKernelGGL((k_slam_linearize_chunks<ESL_JAC_NUMERIC, 1>), dim3(nb_e3), block, 0, c->stream, g, ct, c->ck_ids_e3, c->n_ids_e3, c->cams,
+                                      c->objs, delta, c->chunk_out, c->Wbb, c->Abb);
+        if (nb_bb) hipLaunchKernelGGL((k_slam_linearize_chunks<ESL_JAC_NUMERIC, 0>), dim3(nb_bb), block, 0, c->stream, g, ct, c->ck_ids_bb, c->n_ids_bb, c->cams,
+                                      c->objs, delta, c->chunk_out, c->Wbb, c->Abb);
+        hipLaunchKernelGGL(k_slam_combine<ESL_JAC_NUMERIC>, dim3((N + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kWave * kWavesPerBlock), 0, c->stream, g, ct,
+                           c->chunk_out, c->objs, delta, c->Hoo, c->bo, c->obj_part);
+      }
     }
     if (g.n_odom) {
       const dim3 grid((g.n_odom + 127) / 128), block(128);
       if (an) hipLaunchKernelGGL(k_slam_odom<ESL_JAC_ANALYTIC>, grid, block, 0, c->stream, g, c->cams, delta, c->Aod, c->od_part);
       else hipLaunchKernelGGL(k_slam_odom<ESL_JAC_NUMERIC>, grid, block, 0, c->stream, g, c->cams, delta, c->Aod, c->od_part);
     }
-    hipLaunchKernelGGL(k_slam_cam_gather, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, c->Abb, c->Aod, c->Hcc, c->bc,
-                       c->cam_part);
+    hipLaunchKernelGGL(k_slam_cam_gather, dim3((F + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kWave * kWavesPerBlock), 0, c->stream, g, c->Abb, c->Aod,
+                       c->Hcc, c->bc, c->cam_part);
     if (c->comm) {   // camera blocks of all shards: every rank ends up with the TOTAL Hcc, b_c (3.4 MB at 10k cameras)
       int rc2 = comm_allreduce_sum(c, c->Hcc, (size_t)g.n_free_cams * 36);
       if (!rc2) rc2 = comm_allreduce_sum(c, c->bc, (size_t)g.n_free_cams * 6);
