@@ -267,6 +267,16 @@ int esl_comm_init(esl_ctx* ctx, int32_t n_ranks, int32_t rank, const char id[128
  * hosts without a GPU-aware transport and for tests; RCCL (esl_comm_init) is the fast path. */
 typedef int (*esl_host_allreduce_fn)(void* user, double* host_buf, int64_t count);
 int esl_comm_init_host(esl_ctx* ctx, int32_t n_ranks, int32_t rank, esl_host_allreduce_fn fn, void* user);
+/* REPLICATED-GRAPH mode of a communicator (round 3; call after esl_comm_init / esl_comm_init_host, on every rank): every rank has
+ * uploaded the WHOLE graph (the same esl_graph_upload everywhere: 15 MB at BASELINE configs[3]) instead of a shard of the
+ * ellipsoids.  Nothing is summed over ranks then (every rank linearises everything -- 0.4 ms at configs[3] -- and takes the same LM
+ * decisions by construction); the ranks divide the DENSE SOLVE of SLAM mode: the outer panels (512 columns) of the reduced system
+ * are dealt cyclically, a rank forms only its own panels (camera-first elimination: its share of the rank-6(F-1) MFMA update;
+ * reduced camera system: built everywhere, factored distributed), the owner factors a panel and ncclBroadcasts it, every rank
+ * updates its own later panels, the back-substitution runs replicated -- all ranks end with bit-identical states.  This is the
+ * multi-GPU form of ESL_SOLVER_REDUCED_ELLIPSOID (the sharded form below sums shard contributions and uses the reduced camera
+ * system).  Mapping-mode runs on such a communicator are simply replicated. */
+int esl_comm_set_replicated(esl_ctx* ctx, int replicated);
 int esl_comm_destroy(esl_ctx* ctx);
 
 /* host-only helper: balanced partition of ellipsoids (with all their edges) over n_parts shards.

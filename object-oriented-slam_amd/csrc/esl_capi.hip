@@ -1079,7 +1079,7 @@ int esl_lm_linearize(esl_ctx* c, esl_lm_partials* out) {
     int rc = slam_linearize(c);
     if (rc) return rc;
     double v[4];
-    rc = c->comm ? comm_reduce4(c, c->dev_part, v) : read_parts(c, v);
+    rc = (c->comm && !c->comm_replicated) ? comm_reduce4(c, c->dev_part, v) : read_parts(c, v);
     if (rc) return rc;
     out->chi2 = v[0]; out->max_diag = v[1]; out->scale = 0; out->solve_ok = 1; out->pad = 0;
     return ESL_OK;
@@ -1100,7 +1100,7 @@ int esl_lm_try_step(esl_ctx* c, double lambda, esl_lm_partials* out) {
     int rc = slam_try_step(c, lambda);
     if (rc) return rc;
     double v[4];
-    rc = c->comm ? comm_reduce4(c, c->dev_part, v) : read_parts(c, v);
+    rc = (c->comm && !c->comm_replicated) ? comm_reduce4(c, c->dev_part, v) : read_parts(c, v);
     if (rc) return rc;
     out->chi2 = v[0]; out->max_diag = 0; out->scale = v[2]; out->solve_ok = (c->g.n_objs == 0 || v[3] > 0.5) ? 1 : 0; out->pad = 0;
   } else {
@@ -1150,7 +1150,7 @@ static int optimize_mapping_device(esl_ctx* c, const esl_lm_params* p, esl_lm_re
   const DevGraph& g = c->g;
   LmHostView* hv = (LmHostView*)c->lm_host;
   LmCore* core = (LmCore*)c->lm_dev;   // [2]
-  const bool sharded = c->comm != nullptr;   // collective run: every rank issues the same sequence of all-gathers
+  const bool sharded = c->comm != nullptr && !c->comm_replicated;   // collective run: every rank issues the same sequence of all-gathers
   if (!sharded && (g.n_objs == 0 || (g.n_bbox == 0 && g.n_e3d == 0 && c->n_grav_edges == 0))) {   // empty graph
     out->stop_reason = 3;
     return ESL_OK;

@@ -209,12 +209,22 @@ int esl_comm_init_host(esl_ctx* c, int32_t n_ranks, int32_t rank, esl_host_allre
   return ESL_OK;
 }
 
+int esl_comm_set_replicated(esl_ctx* c, int replicated) {
+  if (!c) return ESL_ERR_INVALID;
+  if (!c->comm) { esl::set_error("esl_comm_set_replicated: no communicator"); return ESL_ERR_STATE; }
+  c->comm_replicated = replicated != 0;
+  // whole graph on every rank: odometry edges, lambda on the camera blocks and the camera part of the LM scale are counted by
+  // every rank for itself (shard_rank 0 = "contributes them"); sharded mode: rank 0 only
+  c->g.shard_rank = c->comm_replicated ? 0 : c->comm_rank;
+  return ESL_OK;
+}
+
 int esl_comm_destroy(esl_ctx* c) {
   if (!c) return ESL_ERR_INVALID;
   if (c->comm && !c->host_allreduce && g_rccl.destroy) { (void)hipStreamSynchronize(c->stream); g_rccl.destroy(c->comm); }
   c->host_allreduce = nullptr; c->host_user = nullptr;
   if (c->host_stage) { (void)hipHostFree(c->host_stage); c->host_stage = nullptr; }
-  c->comm = nullptr; c->comm_ranks = 1; c->comm_rank = 0;
+  c->comm = nullptr; c->comm_ranks = 1; c->comm_rank = 0; c->comm_replicated = false;
   c->g.shard_rank = 0;
   if (c->dev_gather) { (void)hipFree(c->dev_gather); c->dev_gather = nullptr; }
   if (c->host_gather) { (void)hipHostFree(c->host_gather); c->host_gather = nullptr; }

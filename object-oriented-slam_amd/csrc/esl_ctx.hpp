@@ -184,6 +184,7 @@ struct esl_ctx {
   // RCCL exchange (esl_comm.hip)
   void* comm = nullptr;          // ncclComm_t
   int comm_ranks = 1, comm_rank = 0;
+  bool comm_replicated = false;  // esl_comm_set_replicated: every rank holds the whole graph; only the dense solve is divided
   esl_host_allreduce_fn host_allreduce = nullptr;   // host-staged transport (esl_comm_init_host)
   void* host_user = nullptr;
   double* host_stage = nullptr;

@@ -143,6 +143,8 @@ int slam_alloc(esl_ctx* c) {
 }
 
 static CholRuntime& chol_rt(esl_ctx* c);
+static __global__ void k_info_to_double(const int* __restrict__ info, double* __restrict__ d) { d[0] = info[0] ? 1.0 : 0.0; }
+static __global__ void k_double_to_info(const double* __restrict__ d, int* __restrict__ info) { if (d[0] > 0.5) info[0] |= 1; }
 static int slam_ensure_S(esl_ctx* c) {
   if (c->S) return ESL_OK;
   int rc;
@@ -153,7 +155,13 @@ static int slam_ensure_S(esl_ctx* c) {
 }
 
 // ---- camera-first elimination: host side (kernels and the maths: esl_cf.hpp) ---------------------------------------------
-static bool cf_applicable(const esl_ctx* c) { return c->cf_chain_ok && !c->comm; }
+static bool cf_applicable(const esl_ctx* c) { return c->cf_chain_ok && (!c->comm || c->comm_replicated); }
+// replicated-graph communicator (esl_comm_set_replicated): the reduced ellipsoid system's outer panels are dealt to the ranks
+static bool cf_dist(const esl_ctx* c) {
+  if (!c->comm || !c->comm_replicated || c->comm_ranks < 2) return false;
+  if (c->sw_chol_dist >= 0) return c->sw_chol_dist == 1;
+  return 9L * c->g.n_objs >= 8192;
+}
 // esl_lm_params::linear_solver -> the form this trial runs with; < 0: the request cannot be served
 static int slam_pick_solver(const esl_ctx* c) {
   const int want = c->lm.p.linear_solver;
@@ -244,13 +252,28 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     ESL_HIP_TRY(chol_set_attributes(rt));
     {
       ProfScope pk(c, 7);   // the rank-K update alone (nested in class 2): the MFMA roofline kernel of this form
-      chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, 0, (long)n_o, c->cf_Xt, ldx, c->cf_part);
+      if (cf_dist(c)) {   // this rank's outer panels only (dealt cyclically, as the distributed factorisation below expects them)
+        const int Wp = chol_outer_panels(n_o), np = (n_o + kNB - 1) / kNB, n_outer = (np + Wp - 1) / Wp;
+        for (int op = c->comm_rank; op < n_outer; op += c->comm_ranks) {
+          const long c_begin = (long)op * Wp * kNB, c_end = std::min<long>((long)(op + 1) * Wp * kNB, (long)n_o);
+          chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, c_begin, c_end, c->cf_Xt, ldx);
+        }
+      } else {
+        chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, 0, (long)n_o, c->cf_Xt, ldx, c->cf_part);
+      }
     }
     ESL_HIP_TRY(hipGetLastError());
   }
   {
     ProfScope ps(c, 3);   // dense Cholesky of the reduced ellipsoid system + the camera back-substitution
-    ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
+    if (cf_dist(c)) {
+      CholDist d;
+      d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
+      d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
+      ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt, &d));
+    } else {
+      ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
+    }
     hipLaunchKernelGGL(k_cf_z, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, c->cf_Xt, ldx, n_o, c->xo, c->cf_z);
     if (c->cf_stride > 0 && c->cf_n_sep > 0) {
       const int st = c->cf_stride, ns = c->cf_n_sep;
@@ -340,7 +363,7 @@ int slam_linearize(esl_ctx* c) {
     }
     hipLaunchKernelGGL(k_slam_cam_gather, dim3((F + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kWave * kWavesPerBlock), 0, c->stream, g, c->Abb, c->Aod,
                        c->Hcc, c->bc, c->cam_part);
-    if (c->comm) {   // camera blocks of all shards: every rank ends up with the TOTAL Hcc, b_c (3.4 MB at 10k cameras)
+    if (c->comm && !c->comm_replicated) {   // camera blocks of all shards: every rank ends up with the TOTAL Hcc, b_c (3.4 MB at 10k cameras)
       int rc2 = comm_allreduce_sum(c, c->Hcc, (size_t)g.n_free_cams * 36);
       if (!rc2) rc2 = comm_allreduce_sum(c, c->bc, (size_t)g.n_free_cams * 6);
       if (rc2) return rc2;
@@ -383,7 +406,9 @@ int slam_build_reduced(esl_ctx* c, double lambda, bool full_sum, void** dev_ptr,
     }
   }
   ESL_HIP_TRY(hipGetLastError());
-  if (c->comm && !full_sum && slam_dist_chol(c)) {
+  if (c->comm && c->comm_replicated) {
+    // whole graph on every rank: S is complete everywhere, nothing to sum
+  } else if (c->comm && !full_sum && slam_dist_chol(c)) {
     // distributed factorisation: every outer panel of the summed system goes to its owner only (ncclReduce per panel)
     ProfScope ps(c, 6);
     const int W = chol_outer_panels((int)n), np = (int)((n + kNB - 1) / kNB), n_outer = (np + W - 1) / W;
@@ -446,6 +471,15 @@ int slam_try_step(esl_ctx* c, double lambda) {
   {
     ProfScope ps2(c, 4);
     if ((rc = reduce_all(c))) return rc;
+  }
+  if (c->comm && c->comm_replicated && c->comm_ranks > 1) {
+    // replicated-graph run: no LM scalars are exchanged, so the pivot check of the panels' OWNERS has to reach every rank here
+    // (one 8-byte all-reduce per trial) -- otherwise the owner would reject the step on its flag and the others on the NaNs that
+    // came with the broadcast panel, two different exits of the trial loop
+    hipLaunchKernelGGL(k_info_to_double, dim3(1), dim3(1), 0, c->stream, c->chol_info, c->dev_scal + 6);
+    if ((rc = comm_allreduce_sum(c, c->dev_scal + 6, 1))) return rc;
+    hipLaunchKernelGGL(k_double_to_info, dim3(1), dim3(1), 0, c->stream, c->dev_scal + 6, c->chol_info);
+    ESL_HIP_TRY(hipGetLastError());
   }
   // fold the Cholesky pivot check into the "ok" partial
   int info = 0;

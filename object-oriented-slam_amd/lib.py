@@ -22,7 +22,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_set_replicated", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
     "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane", "esl_extract_planes",
 ]
 
@@ -348,6 +348,10 @@ class Context:
                 return 1
         self._host_cb = HOST_ALLREDUCE_FN(_cb)   # keep alive as long as the context uses it
         _check(load().esl_comm_init_host(self._h, C.c_int32(n_ranks), C.c_int32(rank), self._host_cb, None), "esl_comm_init_host")
+
+    def comm_set_replicated(self, on=True):
+        """Every rank holds the whole graph; the ranks divide the dense solve of SLAM mode (esl_comm_set_replicated)."""
+        _check(load().esl_comm_set_replicated(self._h, C.c_int(1 if on else 0)), "esl_comm_set_replicated")
 
     def comm_destroy(self):
         _check(load().esl_comm_destroy(self._h), "esl_comm_destroy")

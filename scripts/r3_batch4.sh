@@ -1,5 +1,5 @@
 # round 3, GPU batch 4: camera-first chain kernels reworked -- SLAM parity tests, C3 / C4 timings, kernel traces
-R=gpurun_out/r3h; mkdir -p $R
+R=gpurun_out/r3i; mkdir -p $R
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -q -s --deselect tests/test_gpu_fullsize.py::test_c4_slam_schur_solve_full_size > $R/tests_a.log 2>&1; echo rc=$? >> $R/tests_a.log
 timeout 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -s -k slam > $R/tests_c4.log 2>&1; echo rc=$? >> $R/tests_c4.log
@@ -14,7 +14,7 @@ python - <<'PY'
 import json
 for f in ["c3_ellipsoid","c4_ellipsoid"]:
     try:
-        d=json.loads(open("gpurun_out/r3h/%s.json"%f).read().strip().splitlines()[-1])
+        d=json.loads(open("gpurun_out/r3i/%s.json"%f).read().strip().splitlines()[-1])
         r=d["roofline"]
         print(f, "%.3f it/s"%d["value"], "%.3f ms/step"%d["ms_per_step"], "|", "%.2f TF"%r["achieved"], "frac %.3f"%r["frac"], "avg %.3f ms"%r["avg_launch_ms"], "solve/trial %.3f ms"%r["linear_solve_ms_per_trial"])
         print("    ", {k:(round(v["total_ms"]/max(v["count"],1),4), v["count"]) for k,v in d["kernel_ms"].items()})

@@ -1,5 +1,6 @@
 """One rank of the two-GPU RCCL run of tests/test_gpu_sharded.py::test_rccl_two_ranks_on_two_gpus (one process per GPU; the
-128-byte communicator id travels through a file).  argv: rank, id file, output npz, slam flag."""
+128-byte communicator id travels through a file).  argv: rank, id file, output npz, mode: 0 mapping (sharded), 1 SLAM (sharded),
+2 SLAM with the whole graph on both ranks and the communicator in replicated-graph mode (the ranks divide the dense solve)."""
 import importlib
 import os
 import sys
@@ -9,10 +10,10 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("object-oriented-slam_amd")
-rank, id_file, out_file, slam = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4] == "1"
+rank, id_file, out_file, slam, repl = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4] in ("1", "2"), sys.argv[4] == "2"
 g, c, o, _ = pkg.synth.make_graph(120 if slam else 30, 10 if slam else 8, 1500 if slam else 300, seed=21, slam=slam)
 part = pkg.lib.partition_objects(g, 2)
-idx = np.nonzero(part == rank)[0]
+idx = np.arange(g.n_objs) if repl else np.nonzero(part == rank)[0]
 ctx = pkg.Context(rank)                       # one GPU per rank
 ctx.upload_graph(g.subset_objects(idx)); ctx.upload_states(c, o[idx])
 if rank == 0:
@@ -28,6 +29,8 @@ else:
         time.sleep(0.05)
     uid = open(id_file, "rb").read()
 ctx.comm_init(2, rank, uid)
+if repl:
+    ctx.comm_set_replicated(True)
 rep = ctx.optimize_resident(pkg.default_lm_params(jacobian_mode=1))
 cc, oo = ctx.download_states()
 ctx.comm_destroy(); ctx.close()

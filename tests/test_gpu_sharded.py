@@ -204,7 +204,7 @@ def test_rccl_single_rank_communicator_matches_plain_run(pkg, ctx, slam):
     np.testing.assert_allclose(cc, rc, rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize("slam", [False, True])
+@pytest.mark.parametrize("slam", [False, True, 2])
 def test_rccl_two_ranks_on_two_gpus(pkg, ctx, slam, tmp_path):
     """The real thing when the box has it: two processes, one GPU each, ncclAllGather / ncclAllReduce over the fabric between
     them (esl_comm_init with a 2-rank communicator).  Must take the single-context run's decisions on both ranks.  Skipped on
@@ -221,7 +221,7 @@ def test_rccl_two_ranks_on_two_gpus(pkg, ctx, slam, tmp_path):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_two_rank_worker.py")
     id_file = str(tmp_path / "nccl_id.bin")
     env = dict(os.environ, ESL_CHOL_DIST="1")      # SLAM: ncclReduce per outer panel + ncclBroadcast of the factored panels
-    procs = [subprocess.Popen([sys.executable, worker, str(r), id_file, str(tmp_path / f"rank{r}.npz"), "1" if slam else "0"], env=env)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), id_file, str(tmp_path / f"rank{r}.npz"), str(int(slam))], env=env)
              for r in range(2)]
     for pr in procs:
         assert pr.wait(timeout=180) == 0
@@ -267,3 +267,66 @@ def test_slam_distributed_factorisation_matches_replicated(pkg, ctx, monkeypatch
     np.testing.assert_allclose(objs_d, objs_r, atol=1e-9)
     np.testing.assert_allclose(cams_d[0], rc, atol=2e-6)
     np.testing.assert_allclose(objs_d, ro, atol=2e-5)
+
+
+def run_replicated(pkg, g, cams, objs, params, n_ranks=2):
+    """n contexts on one GPU, EVERY one with the whole graph, communicator in replicated-graph mode (esl_comm_set_replicated)"""
+    ar = ThreadAllreduce(n_ranks)
+    ctxs, reps, errs, used = [], [None] * n_ranks, [None] * n_ranks, [0] * n_ranks
+    for r in range(n_ranks):
+        c = pkg.Context(0)
+        c.upload_graph(g); c.upload_states(cams, objs)
+        c.comm_init_host(n_ranks, r, ar.make(r))
+        c.comm_set_replicated(True)
+        ctxs.append(c)
+
+    def work(r):
+        try:
+            reps[r] = ctxs[r].optimize_resident(params)
+            used[r] = ctxs[r].lm_solver_used()
+        except Exception as e:   # noqa: BLE001
+            errs[r] = e
+            ar.bar.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th), "replicated run hung"
+    assert errs == [None] * n_ranks, errs
+    states = [c.download_states() for c in ctxs]
+    for c in ctxs:
+        c.comm_destroy(); c.close()
+    return reps, states, used, ar
+
+
+@pytest.mark.parametrize("n_ranks,solver", [(2, 0), (3, 0), (2, 1)])
+def test_slam_replicated_graph_divides_the_dense_solve(pkg, ctx, monkeypatch, n_ranks, solver):
+    """esl_comm_set_replicated: every rank holds the whole graph, nothing is summed over ranks, the ranks divide the dense solve --
+    camera-first elimination (solver AUTO -> 2): each rank forms only the outer panels of the reduced ELLIPSOID system it owns,
+    the owner factors a panel and broadcasts it, own later panels updated, back-substitution replicated; reduced camera system
+    (solver 1): built everywhere, factored distributed.  ESL_CHOL_DIST=1 forces the distribution at this size (40 ellipsoids =
+    360 unknowns = 2 outer panels of 256; 720 camera unknowns = 3).  Must be the single-context run, identical on every rank."""
+    g, c, o, _ = pkg.synth.make_graph(121, 40, 2400, seed=37, slam=True)
+    p = pkg.default_lm_params(jacobian_mode=1, linear_solver=solver)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ref = ctx.optimize_resident(p)
+    used_ref = ctx.lm_solver_used()
+    rc, ro = ctx.download_states()
+    assert ref["chi2_final"] < 0.5 * ref["chi2_initial"] and used_ref == (1 if solver == 1 else 2)
+    monkeypatch.setenv("ESL_CHOL_DIST", "1")
+    reps, states, used, ar = run_replicated(pkg, g, c, o, p, n_ranks)
+    assert used == [used_ref] * n_ranks
+    n_tr = sum(ref["trace_trials"])
+    # per trial: one broadcast of the factored columns + one of the diagonal-block inverses per outer panel, and the 8-byte pivot flag
+    n_outer = 2 if used_ref == 2 else 3
+    assert ar.calls[0] == n_tr * (2 * n_outer + 1), (ar.calls[0], n_tr)
+    for r in range(n_ranks):
+        assert reps[r]["trace_trials"] == ref["trace_trials"] and reps[r]["stop_reason"] == ref["stop_reason"]
+        np.testing.assert_allclose(reps[r]["trace_chi2"], ref["trace_chi2"], rtol=1e-9)
+        assert reps[r]["trace_chi2"] == reps[0]["trace_chi2"] and reps[r]["trace_lambda"] == reps[0]["trace_lambda"]   # bit-identical ranks
+        np.testing.assert_array_equal(states[r][0], states[0][0])
+        np.testing.assert_array_equal(states[r][1], states[0][1])
+    print("replicated graph, %d ranks, solver %d: chi2 rel %.2e cams %.2e objs %.2e vs one context" % (
+        n_ranks, used_ref, float(np.abs(np.array(reps[0]["trace_chi2"]) / np.array(ref["trace_chi2"]) - 1).max()),
+        float(np.abs(states[0][0] - rc).max()), float(np.abs(states[0][1] - ro).max())))
+    np.testing.assert_allclose(states[0][0], rc, atol=1e-8)
+    np.testing.assert_allclose(states[0][1], ro, atol=1e-8)
