@@ -212,12 +212,13 @@ int esl_graph_sizes(esl_ctx* ctx, int32_t* n_cams, int32_t* n_objs, int32_t* n_b
  * kernel ids: 0 linearise, 1 LM trial (solve + retract + chi2), 2 reduced-system build (Schur complement / camera-first: factor of
  *             the camera block + X + the rank-K update), 3 dense Cholesky + solves, 4 reductions / misc, 5 single-frame fit,
  *             6 RCCL all-reduce of the reduced system (sharded SLAM), 7 the MFMA rank-K update T -= X^T X of the camera-first
- *             form alone (nested inside class 2).
+ *             form alone (nested inside class 2), 8 the block products of the sparse interior rows of X (k_cf_T_sparse, nested
+ *             inside class 2; with class 8 present class 7 is the dense update with the separators' rows only).
  * esl_profile_enable(ctx, 0) off; 1 = bracket only kernel class 0, and inside esl_optimize_resident's device-driven
  * mapping run only ONE linearisation launch per run (cheap enough to stay on inside a timed region: an event record
  * is a barrier packet between two otherwise back-to-back dispatches); 2 = bracket every launch of every class.
  * esl_profile_get drains the events: count[k] launches, total_ms[k] summed durations. */
-#define ESL_PROF_KINDS 8
+#define ESL_PROF_KINDS 9
 int esl_profile_enable(esl_ctx* ctx, int enable);
 int esl_profile_get(esl_ctx* ctx, int64_t count[ESL_PROF_KINDS], double total_ms[ESL_PROF_KINDS]);
 

@@ -269,27 +269,40 @@ static __global__ __launch_bounds__(256) void k_cf_edge_scale(DevGraph g, int n_
 // History: list walk inside the loop with the next record prefetched: 1.08 us per camera (a store and a dependent load per step:
 // the compiler's s_waitcnt vmcnt(0) at the loop head made every step wait for the previous step's stores); this form 0.2 us.
 constexpr int kCfFwdCh = 16;
-// SEP = false: blockIdx.y = segment p (cameras [p stride, p stride + seglen); one segment = the plain chain).  With nested
+// MODE 0: blockIdx.y = segment p (cameras [p stride, p stride + seglen); one segment = the plain chain).  With nested
 //   dissection (Zt != null) the lane also accumulates acc = sum_j Zt_j^T X_j over its segment -- the segment's contribution to the
 //   right-hand side of the separator in FRONT of it -- into R[column + (6 (p - 1) + a) ldx]; list entries of separator slots are
 //   not this kernel's (they fall outside [beg, end)).
-// SEP = true: the same recurrence over the separators (nf = number of separators, M = the separator chain's blocks), V dense from
-//   R (k_cf_sep_rhs), rows written at the separators' slots k sep_stride + sep_stride - 1.
-template <bool SEP>
+// MODE 1 (SEP): the same recurrence over the separators (nf = number of separators, M = the separator chain's blocks), V dense from
+//   R (k_cf_sep_rhs), rows written at the separators' slots k sep_stride + sep_stride - 1 (sep_stride = 0: at row block k).
+// MODE 2 (X is sparse, see "sparse interior rows" below): segments of kCfFwdCh slots, workgroup = entry of the work list
+//   (segment p, group of 64 COMPACT columns); compact column 9 i + b = column b of the i-th ellipsoid of the segment's list, the
+//   column after the last one = the right-hand side; rows go to the segment's slab Xc (xoff / xld), acc to R at the T column.
+constexpr int kCfSyT = 128;     // tile of the per-segment product kernel (compact columns)
+constexpr int kCfSegRows = 96;   // rows of a slab: 6 (kCfFwdCh - 1) = 90, padded with zero rows to a multiple of the T kernel's row batch
+struct CfSegs {
+  const int* fwork; const int* seg_start; const int* seg_obj; const long long* xoff; const int* xld;
+};
+template <int MODE>
 static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, int n_chunks, const int* __restrict__ oe_cst /* [N][n_chunks + 1] */,
                                                           const int* __restrict__ oe_slot, const double* __restrict__ V,
                                                           const double* __restrict__ vy, const double* __restrict__ Mm,
                                                           double* __restrict__ Xt, long ldx, int stride, int seglen,
-                                                          const double* __restrict__ Zt, double* __restrict__ R, int sep_stride) {
+                                                          const double* __restrict__ Zt, double* __restrict__ R, int sep_stride, CfSegs sg) {
+  constexpr bool SEP = MODE == 1;
   __shared__ double sM[kCfFwdCh * 36];
   __shared__ double sZ[kCfFwdCh * 36];
   __shared__ double sv[kCfFwdCh * 6 * 64];
   __shared__ double svy[kCfFwdCh * 6];
   const int lane = threadIdx.x;
-  const int j = blockIdx.x * 64 + lane;
-  const bool on = j <= n_o, rhs = j == n_o, col = on && !rhs;
-  const int o = col ? j / 9 : 0, b = j - 9 * o;
-  const int seg = SEP ? 0 : (int)blockIdx.y;
+  const int seg = SEP ? 0 : (MODE == 2 ? sg.fwork[2 * blockIdx.x] : (int)blockIdx.y);
+  const int j = (MODE == 2 ? sg.fwork[2 * blockIdx.x + 1] : (int)blockIdx.x) * 64 + lane;
+  const int ob = MODE == 2 ? sg.seg_start[seg] : 0;
+  const int jr = MODE == 2 ? 9 * (sg.seg_start[seg + 1] - ob) : n_o;   // the right-hand side's column
+  const bool on = j <= jr, rhs = j == jr, col = on && !rhs;
+  const int oi = col ? j / 9 : 0, b = j - 9 * oi;
+  const int o = (MODE == 2 && col) ? sg.seg_obj[ob + oi] : oi;
+  const long tcol = MODE == 2 ? (rhs ? (long)n_o : 9L * o + b) : (long)j;   // this lane's column of T / R
   const int beg = SEP ? 0 : seg * stride;
   const int nf = SEP ? nf_all : ((beg + seglen < nf_all) ? beg + seglen : nf_all);
   if (beg >= nf) return;
@@ -381,8 +394,12 @@ static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, i
           if (q0 + e < len * 6) {
             const int q = q0 + e;
             // separator k = i0 + q / 6 sits at slot k sep_stride + sep_stride - 1
-            const size_t row = SEP ? (size_t)(6 * ((i0 + q / 6) * sep_stride + sep_stride - 1) + q % 6) : (size_t)(6 * i0 + q);
-            Xt[(size_t)j + row * (size_t)ldx] = t[e];
+            if (MODE == 2) {
+              Xt[(size_t)sg.xoff[seg] + (size_t)(6 * (i0 - beg) + q) * (size_t)sg.xld[seg] + (size_t)j] = t[e];
+            } else {
+              const size_t row = (SEP && sep_stride > 0) ? (size_t)(6 * ((i0 + q / 6) * sep_stride + sep_stride - 1) + q % 6) : (size_t)(6 * i0 + q);
+              Xt[(size_t)j + row * (size_t)ldx] = t[e];
+            }
           }
       }
     }
@@ -390,7 +407,7 @@ static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, i
   }
   if (use_z && on) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a) R[(size_t)j + (size_t)(6 * (seg - 1) + a) * (size_t)ldx] = acc[a];
+    for (int a = 0; a < 6; ++a) R[(size_t)tcol + (size_t)(6 * (seg - 1) + a) * (size_t)ldx] = acc[a];
   }
 }
 
@@ -501,10 +518,12 @@ static __global__ __launch_bounds__(64) void k_cf_sep_rhs(int nf, int n_o, int s
                                                           const int* __restrict__ oe_slot, const double* __restrict__ V,
                                                           const double* __restrict__ vy, const double* __restrict__ Gfac,
                                                           const double* __restrict__ LiS, const double* __restrict__ Xt, long ldx,
-                                                          double* __restrict__ R) {
+                                                          double* __restrict__ R, const int* __restrict__ cmap /* null: X dense in Xt */,
+                                                          CfSegs sg) {
   const int j = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
   if (j > n_o) return;
   const bool rhs = j == n_o;
+  const int N1 = n_o / 9 + 1;
   const int s = k * stride + stride - 1, l = s - 1;
   double vs[6] = {0, 0, 0, 0, 0, 0};
   if (rhs) {
@@ -521,13 +540,25 @@ static __global__ __launch_bounds__(64) void k_cf_sep_rhs(int nf, int n_o, int s
         for (int a = 0; a < 6; ++a) vs[a] += src[a];
       }
   }
-  const bool has_acc = (k + 1) * stride < nf;   // a segment behind s exists (else R(k) was never written)
+  bool has_acc = (k + 1) * stride < nf;   // a segment behind s exists (else R(k) was never written)
+  double xl[6] = {0, 0, 0, 0, 0, 0};
+  if (cmap) {   // X sparse: column j is zero over a segment unless its ellipsoid is in the segment's list
+    const int ob = rhs ? N1 - 1 : j / 9, bb = rhs ? 0 : j - 9 * ob;
+    has_acc = has_acc && cmap[(size_t)(k + 1) * N1 + ob] >= 0;
+    const int e = cmap[(size_t)k * N1 + ob];
+    if (e >= 0) {
+      const double* src = Xt + (size_t)sg.xoff[k] + (size_t)(9 * (e & 0xFFFFFF) + bb);
+      const size_t ld = (size_t)sg.xld[k];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) xl[r] = src[(size_t)(6 * (stride - 2) + r) * ld];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) xl[r] = Xt[(size_t)j + (size_t)(6 * l + r) * (size_t)ldx];
+  }
   double t[6];
 #pragma unroll
   for (int a = 0; a < 6; ++a) t[a] = has_acc ? R[(size_t)j + (size_t)(6 * k + a) * (size_t)ldx] : 0.0;
-  double xl[6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) xl[r] = Xt[(size_t)j + (size_t)(6 * l + r) * (size_t)ldx];
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -666,6 +697,245 @@ static __global__ __launch_bounds__(256) void k_cf_obj_update(DevGraph g, double
   for (int i = 0; i < 9; ++i) { x[i] = xo[(size_t)o * 9 + i]; scale += x[i] * (lambda * x[i] + bo[(size_t)o * 9 + i]); }
   ell_store(ell_oplus(e, x), objs_trial + 10 * o);
   part[o * 4 + 2] = scale;
+}
+
+// ---- sparse interior rows of X (round 3) ---------------------------------------------------------------------------------------------
+// Column o of X = G^-1 W is zero over segment p unless a camera INSIDE p sees ellipsoid o (the recurrence X_j = V_j - M_j X_{j-1}
+// starts from zero at every segment), and non-zero only from the first such camera on.  A camera sees ~20 ellipsoids (the
+// reference adds one bbox edge per detection, Optimizer.cpp:166-245), so over a 15-camera segment ~13 % of the C4 columns are
+// live: the dense rank-6(F-1) update T -= X^T X spends 98 % of its 1.9e13 flops on zeros.  With the dissection stride fixed at
+// kCfFwdCh = 16:
+//   interior rows: compact slabs Xc_p [kCfSegRows][xld_p], columns = the segment's list (k_cf_forward<2>);
+//   T(o1, o2) = D(o1) [o1 == o2] - sum over the segments p that list BOTH (bitmap AND), rows from the later first camera on, of
+//               Xc_p(:, o1)^T Xc_p(:, o2)                                   k_cf_T_sparse: output stationary, one wave per 9 x 9 block,
+//               v_mfma_f64_16x16x4 with 9 of the 16 rows / columns used; segments in ascending order -> bit-reproducible, no atomics;
+//   separator rows (dense: the separator chain couples everything): Xs [6 n_sep][ldx], T -= Xs^T Xs on the MFMA update kernel
+//               (k_chol_update_lds, external factor) -- 6 F / 16 rows instead of 6 F;
+//   z = y - X x_o reads the slabs (k_cf_z_sparse).
+// C4: 2.7e8 (block pair, camera) triples instead of 4e10; per LM trial 299 ms -> the dense separator update (K = 3,750) + this kernel.
+typedef double cf_d4 __attribute__((ext_vector_type(4)));
+constexpr int kCfTPer = 16;
+constexpr int kCfTBatch = 8; // k-steps (of four rows) per batch of loads in k_cf_T_sparse   // ellipsoids o2 per workgroup of k_cf_T_sparse (4 waves x 4)
+static __global__ __launch_bounds__(256) void k_cf_T_sparse(int N, int nw, const unsigned long long* __restrict__ mask, const int* __restrict__ cmap,
+                                                            const long long* __restrict__ xoff, const int* __restrict__ xld,
+                                                            const double* __restrict__ Xc, const double* __restrict__ Hoo,
+                                                            const double* __restrict__ bo, double lambda, double* __restrict__ T, long ldt,
+                                                            int o2_begin, int o2_end) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int o1 = blockIdx.x;                    // N = the right-hand side (row 9 N of T)
+  const int r = lane & 15, kq = lane >> 4;
+  const int N1 = N + 1;
+  const long n_o = 9L * N;
+  for (int q = wave; q < kCfTPer; q += 4) {
+    const int o2 = o2_begin + (int)blockIdx.y * kCfTPer + q;
+    if (o2 >= o2_end || o2 > o1 || o2 >= N) continue;
+    cf_d4 acc = {0, 0, 0, 0};
+    for (int wd = 0; wd < nw; ++wd) {
+      unsigned long long m = mask[(size_t)o1 * nw + wd] & mask[(size_t)o2 * nw + wd];
+      if (!m) continue;
+      // lane = bit: the column-map entries of all 64 segments of this word in one round trip
+      const int pl = wd * 64 + lane;
+      const bool mine = (m >> lane) & 1ull;
+      const int e1l = mine ? cmap[(size_t)pl * N1 + o1] : 0, e2l = mine ? cmap[(size_t)pl * N1 + o2] : 0;
+      const long long xol = mine ? xoff[pl] : 0;
+      const int ldl = mine ? xld[pl] : 0;
+      while (m) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1;
+        const int e1 = __builtin_amdgcn_readlane(e1l, bit), e2 = __builtin_amdgcn_readlane(e2l, bit);
+        const int ld = __builtin_amdgcn_readlane(ldl, bit);
+        const long long xo = ((long long)__builtin_amdgcn_readlane((int)(xol >> 32), bit) << 32) | (unsigned)__builtin_amdgcn_readlane((int)xol, bit);
+        const int f1 = e1 >> 24, f2 = e2 >> 24, f = f1 > f2 ? f1 : f2;
+        const double* pa = Xc + xo + 9 * (e1 & 0xFFFFFF) + r;
+        const double* pb = Xc + xo + 9 * (e2 & 0xFFFFFF) + r;
+        for (int k = (6 * f) & ~3; k < 6 * (kCfFwdCh - 1); k += 4 * kCfTBatch) {   // batches of k-steps: all loads of a batch in flight, then its MFMAs
+          double av[kCfTBatch], bv[kCfTBatch];
+#pragma unroll
+          for (int u = 0; u < kCfTBatch; ++u) {
+            int row = k + 4 * u + kq;
+            row = row < kCfSegRows ? row : kCfSegRows - 1;              // (rows 90 .. 95 are zero)
+            av[u] = pa[(long)row * ld];
+            bv[u] = pb[(long)row * ld];
+          }
+#pragma unroll
+          for (int u = 0; u < kCfTBatch; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+      }
+    }
+    // D: acc[g] = C(i = kq + 4 g, j = r); block (o1, o2) of T (column major), rows 9 o1 + i, columns 9 o2 + j
+    if (r < 9) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = kq + 4 * g;
+        if (o1 == N) {
+          if (i == 0) T[n_o + (9L * o2 + r) * ldt] = bo[(size_t)o2 * 9 + r] - acc[g];
+        } else if (i < 9) {
+          double base = 0;
+          if (o1 == o2) {   // packed upper triangle of the symmetric block: (c, r) with c <= r at c * 9 - c (c - 1) / 2 + (r - c)
+            const int lo = i < r ? i : r, hi = i < r ? r : i;
+            base = Hoo[(size_t)o1 * 45 + lo * 9 - (lo * (lo - 1)) / 2 + (hi - lo)] + ((i == r) ? lambda : 0.0);
+          }
+          T[(9L * o1 + i) + (9L * o2 + r) * ldt] = base - acc[g];
+        }
+      }
+    }
+  }
+}
+
+// z = y - X x_o with the interior rows in the slabs: one workgroup per row (slot i, component a)
+static __global__ __launch_bounds__(256) void k_cf_z_sparse(int n_o, const double* __restrict__ Xs, long ldx, CfSegs sg, const double* __restrict__ Xc,
+                                                            const double* __restrict__ xo, double* __restrict__ z) {
+  __shared__ double red[4];
+  const int t = blockIdx.x, i = t / 6, a = t - 6 * i;
+  const int p = i / kCfFwdCh, pos = i - p * kCfFwdCh;
+  double s = 0, y;
+  if (pos == kCfFwdCh - 1) {   // separator p: a dense row
+    const double* row = Xs + (size_t)(6 * p + a) * (size_t)ldx;
+    for (int o = threadIdx.x; o < n_o; o += 256) s += row[o] * xo[o];
+    y = row[n_o];
+  } else {
+    const int ob = sg.seg_start[p], m = 9 * (sg.seg_start[p + 1] - ob);
+    const double* row = Xc + (size_t)sg.xoff[p] + (size_t)(6 * pos + a) * (size_t)sg.xld[p];
+    for (int cc = threadIdx.x; cc < m; cc += 256) {
+      const int ci = cc / 9;
+      s += row[cc] * xo[(size_t)9 * sg.seg_obj[ob + ci] + (cc - 9 * ci)];
+    }
+    y = row[m];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) z[t] = y - (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+// ---- stored products (the default form of the sparse path) ---------------------------------------------------------------------------
+// k_cf_T_sparse reads every slab column once per PARTNER column: ~450 GB of cache-line traffic at C4 (57 ms).  Blocking needs a
+// dense tile, and the dense thing here is ONE segment's product P_p = Xc_p^T Xc_p over its compact columns:
+//   k_cf_seg_syrk   one workgroup per 128 x 128 tile of one segment's product (work list of all (segment, tile) on and below the
+//                   diagonal), four waves of 64 x 64, operands straight from the slab in MFMA layout (a slab is L2 resident while
+//                   its tiles run), K = 96; the tile leaves as 9 x 9 BLOCKS (81 contiguous doubles per ellipsoid pair; column
+//                   major inside) at boff[p] + i1 (i1 + 1) / 2 + i2, the right-hand side's row to Prhs;
+//   k_cf_T_gather   T(o1, o2) = D [o1 == o2] - sum over the shared segments, ascending, of their stored block: 648 contiguous
+//                   bytes per (pair, segment), every stored block read exactly once.
+// C4: 14 GB of products written and read once, 3.7e11 flops of dense MFMA tiles.
+static __global__ __launch_bounds__(256) void k_cf_seg_syrk(const int* __restrict__ twork, const int* __restrict__ seg_start,
+                                                            const long long* __restrict__ xoff, const int* __restrict__ xld,
+                                                            const double* __restrict__ Xc, const long long* __restrict__ boff,
+                                                            const long long* __restrict__ roff, double* __restrict__ P, double* __restrict__ Prhs) {
+  const int p = twork[3 * blockIdx.x], ti = twork[3 * blockIdx.x + 1], tj = twork[3 * blockIdx.x + 2];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, kq = lane >> 4;
+  const int m = 9 * (seg_start[p + 1] - seg_start[p]);           // compact column m = the right-hand side
+  const int c1b = ti * kCfSyT + (wave >> 1) * 64, c2b = tj * kCfSyT + (wave & 1) * 64;
+  if (c1b + 63 < c2b || c1b > m || c2b >= m) return;             // above the diagonal / past the last column
+  const long ld = xld[p];
+  const double* X = Xc + xoff[p];
+  cf_d4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = cf_d4{0, 0, 0, 0};
+  const double* pa = X + c1b + r;
+  const double* pb = X + c2b + r;
+  constexpr int kB = 3;   // k-steps per batch: 24 loads in flight, then 48 MFMAs
+  for (int k = 0; k < kCfSegRows; k += 4 * kB) {
+    double a[kB][4], b[kB][4];
+#pragma unroll
+    for (int u = 0; u < kB; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[u][q] = pa[(long)(k + 4 * u + kq) * ld + 16 * q];
+        b[u][q] = pb[(long)(k + 4 * u + kq) * ld + 16 * q];
+      }
+#pragma unroll
+    for (int u = 0; u < kB; ++u)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][mi], b[u][nj], acc[mi][nj], 0, 0, 0);
+  }
+  // acc[mi][nj][g] = P(c1 = c1b + 16 mi + kq + 4 g, c2 = c2b + 16 nj + r)
+  double* Pp = P + (size_t)boff[p] * 81;
+  double* Pr = Prhs + roff[p];
+#pragma unroll
+  for (int nj = 0; nj < 4; ++nj) {
+    const int c2 = c2b + 16 * nj + r;
+    if (c2 >= m) continue;
+    const int i2 = c2 / 9, j = c2 - 9 * i2;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c1 = c1b + 16 * mi + kq + 4 * g;
+        if (c1 < c2 || c1 > m) continue;
+        if (c1 == m) { Pr[c2] = acc[mi][nj][g]; continue; }
+        const int i1 = c1 / 9, i = c1 - 9 * i1;
+        Pp[((size_t)i1 * (i1 + 1) / 2 + i2) * 81 + j * 9 + i] = acc[mi][nj][g];
+      }
+  }
+}
+
+static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const unsigned long long* __restrict__ mask, const int* __restrict__ cmap,
+                                                            const long long* __restrict__ boff, const long long* __restrict__ roff,
+                                                            const double* __restrict__ P, const double* __restrict__ Prhs,
+                                                            const double* __restrict__ Hoo, const double* __restrict__ bo, double lambda,
+                                                            double* __restrict__ T, long ldt, int o2_begin, int o2_end) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int o1 = blockIdx.x;                    // N = the right-hand side (row 9 N of T)
+  const int N1 = N + 1;
+  const long n_o = 9L * N;
+  const bool rhs = o1 == N;
+  for (int q = wave; q < kCfTPer; q += 4) {
+    const int o2 = o2_begin + (int)blockIdx.y * kCfTPer + q;
+    if (o2 >= o2_end || o2 > o1 || o2 >= N) continue;
+    double s0 = 0, s1 = 0;                      // entries lane and 64 + lane of the 81 (column major: entry = 9 j + i)
+    for (int wd = 0; wd < nw; ++wd) {
+      unsigned long long mk = mask[(size_t)o1 * nw + wd] & mask[(size_t)o2 * nw + wd];
+      if (!mk) continue;
+      // lane = bit: where this segment keeps the pair's block (one round trip for the word's 64 segments)
+      const int pl = wd * 64 + lane;
+      long long offl = 0;
+      if ((mk >> lane) & 1ull) {
+        const long long i2 = cmap[(size_t)pl * N1 + o2] & 0xFFFFFF;
+        if (rhs) offl = roff[pl] + 9 * i2;
+        else { const long long i1 = cmap[(size_t)pl * N1 + o1] & 0xFFFFFF; offl = (boff[pl] + i1 * (i1 + 1) / 2 + i2) * 81; }
+      }
+      while (mk) {   // four segments' blocks in flight, added in ascending segment order
+        long long off[4];
+        bool have[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          have[u] = mk != 0;
+          const int bit = have[u] ? __builtin_ctzll(mk) : 0;
+          if (have[u]) mk &= mk - 1;
+          off[u] = ((long long)__builtin_amdgcn_readlane((int)(offl >> 32), bit) << 32) | (unsigned)__builtin_amdgcn_readlane((int)offl, bit);
+        }
+        double v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* src = (rhs ? Prhs : P) + off[u];
+          v0[u] = (have[u] && (!rhs || lane < 9)) ? src[lane] : 0.0;
+          v1[u] = (have[u] && !rhs && lane < 17) ? src[64 + lane] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += v0[u]; s1 += v1[u]; }
+      }
+    }
+    if (rhs) {
+      if (lane < 9) T[n_o + (9L * o2 + lane) * ldt] = bo[(size_t)o2 * 9 + lane] - s0;
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = h * 64 + lane;
+        if (e >= 81) continue;
+        const int j = e / 9, i = e - 9 * j;
+        if (o1 == o2 && i < j) continue;        // (above the diagonal: never stored, never read)
+        double base = 0;
+        if (o1 == o2) base = Hoo[(size_t)o1 * 45 + j * 9 - (j * (j - 1)) / 2 + (i - j)] + ((i == j) ? lambda : 0.0);
+        T[(9L * o1 + i) + (9L * o2 + j) * ldt] = base - (h ? s1 : s0);
+      }
+    }
+  }
 }
 
 }  // namespace esl

@@ -207,6 +207,27 @@ struct esl_ctx {
          *cf_NS = nullptr, *cf_R = nullptr;
   double *cf_Xt = nullptr, *cf_T = nullptr, *cf_Linv_ws = nullptr, *cf_part = nullptr;
   int64_t cf_ldx = 0, cf_kpad = 0, cf_ldt = 0;
+  // sparse interior rows of X (esl_cf.hpp, "X is sparse"): segments of kCfFwdCh slots; per segment the sorted list of ellipsoids
+  // with an edge at one of its interior cameras (seg_start / seg_obj), the column map cmap[p (N + 1) + o] = first << 24 | index
+  // (-1: column o of X is zero over segment p; entry N = the right-hand side), per ellipsoid the bitmap of its segments, the
+  // compact slabs Xc (xoff / xld) and the separators' dense rows Xs
+  bool cf_sp_built = false, cf_sparse = false;
+  int cf_sp_nseg = 0, cf_sp_nw = 0, cf_n_fwork = 0;
+  double cf_sp_flops = 0;   // sum over the segments of (9 |O_p|)^2 x rows
+  int *cf_seg_start = nullptr, *cf_seg_obj = nullptr, *cf_cmap = nullptr, *cf_xld = nullptr, *cf_fwork = nullptr;
+  unsigned long long* cf_mask = nullptr;
+  long long* cf_xoff = nullptr;
+  size_t cf_xc_len = 0;
+  double *cf_Xc = nullptr, *cf_Xs = nullptr;
+  int64_t cf_kpad_s = 0;
+  // per-segment products P_p = Xc_p^T Xc_p in 9 x 9 blocks (block (i1, i2), i1 >= i2, of segment p at boff[p] + i1 (i1 + 1) / 2 + i2),
+  // the right-hand side's row of every product (roff), the tile list of the product kernel; cf_sp_form: 1 = products stored and
+  // gathered (k_cf_seg_syrk + k_cf_T_gather), 2 = blocks of T computed from the slabs directly (k_cf_T_sparse: no P, more traffic)
+  int cf_sp_form = 0, cf_n_twork = 0;
+  long long *cf_boff = nullptr, *cf_roff = nullptr;
+  int* cf_twork = nullptr;
+  size_t cf_p_blocks = 0, cf_prhs_len = 0;
+  double *cf_P = nullptr, *cf_Prhs = nullptr;
   int lm_solver_used = 0;   // esl_linear_solver the last trial step ran with (1 reduced camera system, 2 reduced ellipsoid system)
   // per-context runtime of the dense solver (esl_chol.hpp CholRuntime: look-ahead stream + events on THIS device, one-time
   // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context

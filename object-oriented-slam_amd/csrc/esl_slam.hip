@@ -108,6 +108,58 @@ int slam_alloc(esl_ctx* c) {
     if ((rc = up(&c->cf_oe_slot, os.data(), os.size(), c->stream))) return rc;
     if ((rc = up(&c->cf_od_start, ods.data(), ods.size(), c->stream))) return rc;
     if ((rc = up(&c->cf_od_edge, ode.data(), ode.size(), c->stream))) return rc;
+    // X = L^-1 W is SPARSE over a short run of cameras (esl_cf.hpp): per segment of kCfFwdCh slots (the last one the separator) the
+    // ellipsoids seen by its interior cameras, where each one's column starts, and per ellipsoid the bitmap of its segments
+    c->cf_sp_built = false;
+    if (chain && nf >= 256 && N > 0) {
+      const int nseg = (nf + kCfFwdCh - 1) / kCfFwdCh, nw = (nseg + 63) / 64, N1 = N + 1;
+      std::vector<int> cmap((size_t)nseg * N1, -1), seg_start((size_t)nseg + 1, 0), seg_obj, xld((size_t)nseg), fwork;
+      std::vector<unsigned long long> mask((size_t)N1 * nw, 0ull);
+      std::vector<long long> xoff((size_t)nseg + 1, 0), boff((size_t)nseg + 1, 0), roff((size_t)nseg + 1, 0);
+      std::vector<int> twork;
+      for (int o = 0; o < N; ++o)
+        for (int k = start[o]; k < start[(size_t)o + 1]; ++k) {
+          const int sl = os[k], p = sl / kCfFwdCh, pos = sl - p * kCfFwdCh;
+          if (pos == kCfFwdCh - 1) continue;                       // the separator's own edges
+          int& e = cmap[(size_t)p * N1 + o];
+          if (e < 0) e = pos << 24;                                // (lists sorted by slot: the first hit is the first camera)
+          mask[(size_t)o * nw + p / 64] |= 1ull << (p & 63);
+        }
+      double fl = 0;
+      for (int p = 0; p < nseg; ++p) {
+        int cnt = 0;
+        for (int o = 0; o < N; ++o) {
+          int& e = cmap[(size_t)p * N1 + o];
+          if (e >= 0) { e |= cnt++; seg_obj.push_back(o); }
+        }
+        cmap[(size_t)p * N1 + N] = cnt;                            // the right-hand side: the column after the last ellipsoid's
+        mask[(size_t)N * nw + p / 64] |= 1ull << (p & 63);
+        seg_start[(size_t)p + 1] = seg_start[p] + cnt;
+        const int m = 9 * cnt + 1;
+        xld[p] = (m + 15) / 16 * 16 + 16;                          // + 16: the T kernel reads 16 columns from any column start
+        xoff[(size_t)p + 1] = xoff[p] + (long long)kCfSegRows * xld[p];
+        for (int q = 0; q < (m + 63) / 64; ++q) { fwork.push_back(p); fwork.push_back(q); }
+        boff[(size_t)p + 1] = boff[p] + (long long)cnt * (cnt + 1) / 2;
+        roff[(size_t)p + 1] = roff[p] + 9LL * cnt;
+        for (int ti = 0; ti < (m + kCfSyT - 1) / kCfSyT; ++ti)   // tiles of the product on and below the diagonal
+          for (int tj = 0; tj <= ti; ++tj) { twork.push_back(p); twork.push_back(ti); twork.push_back(tj); }
+        fl += (double)(9 * cnt) * (9 * cnt) * (6 * (kCfFwdCh - 1));
+      }
+      c->cf_sp_nseg = nseg; c->cf_sp_nw = nw; c->cf_n_fwork = (int)(fwork.size() / 2); c->cf_sp_flops = fl; c->cf_xc_len = (size_t)xoff[nseg] + 2 * kCfSyT;   // (+: the product kernel's last tile reads past the last slab's columns)
+      if ((rc = up(&c->cf_cmap, cmap.data(), cmap.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_mask, mask.data(), mask.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_seg_start, seg_start.data(), seg_start.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_seg_obj, seg_obj.data(), seg_obj.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_xld, xld.data(), xld.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_xoff, xoff.data(), xoff.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_fwork, fwork.data(), fwork.size(), c->stream))) return rc;
+      c->cf_n_twork = (int)(twork.size() / 3); c->cf_p_blocks = (size_t)boff[nseg]; c->cf_prhs_len = (size_t)roff[nseg];
+      if ((rc = up(&c->cf_boff, boff.data(), boff.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_roff, roff.data(), roff.size(), c->stream))) return rc;
+      if ((rc = up(&c->cf_twork, twork.data(), twork.size(), c->stream))) return rc;
+      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+      c->cf_sp_built = true;
+    }
     ESL_HIP_TRY(hipStreamSynchronize(c->stream));           // the host vectors go out of scope
   }
   if ((rc = up(&g.ue_start, start.data(), start.size(), c->stream))) return rc;
@@ -172,25 +224,42 @@ static int slam_pick_solver(const esl_ctx* c) {
   return (no * no * nc + no * no * no / 3.0 < nc * nc * nc / 3.0) ? ESL_SOLVER_REDUCED_ELLIPSOID : ESL_SOLVER_REDUCED_CAMERA;
 }
 static int cf_ensure(esl_ctx* c) {
-  if (c->cf_Xt) return ESL_OK;
+  if (c->cf_T) return ESL_OK;
   const DevGraph& g = c->g;
   const size_t nf = (size_t)g.n_free_cams, EU = (size_t)g.n_bbox + g.n_e3d, n_o = (size_t)9 * g.n_objs;
   c->cf_ldx = (int64_t)((n_o + 1 + 15) / 16 * 16);
   c->cf_kpad = (int64_t)((6 * nf + kKC - 1) / kKC * kKC);
   c->cf_ldt = c->cf_ldx;
+  // X sparse or dense (esl_cf.hpp, "sparse interior rows"): flops of the dense rank-6 nf update against the separators' dense rows
+  // plus the per-segment products at a quarter of the MFMA rate; ESL_CF_SPARSE=1 / 0 forces it (A/B and the parity tests)
+  c->cf_sparse = false;
+  if (c->cf_sp_built && !std::getenv("ESL_CF_NO_ND")) {
+    const double dense = (double)n_o * (double)n_o * 6.0 * (double)nf;
+    const double sparse = (double)n_o * (double)n_o * 6.0 * (double)(nf / kCfFwdCh) + 4.0 * c->cf_sp_flops;
+    const char* sw = std::getenv("ESL_CF_SPARSE");
+    c->cf_sparse = sw ? sw[0] != '0' : (n_o >= 2048 && sparse < 0.5 * dense);
+    // the per-segment products are stored when they fit beside everything else (C4: 14 GB); else (or ESL_CF_SPARSE=2) the blocks
+    // of T come straight from the slabs (k_cf_T_sparse)
+    size_t free_b = 0, total_b = 0;
+    ESL_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const double need = 8.0 * (81.0 * (double)c->cf_p_blocks + (double)c->cf_xc_len + 2.0 * (double)c->cf_ldt * (double)n_o);
+    c->cf_sp_form = (sw && sw[0] == '2') || need > 0.5 * (double)free_b ? 2 : 1;
+  }
   int rc;
   if ((rc = al(&c->cf_Linv, nf * 36)) || (rc = al(&c->cf_M, nf * 36)) || (rc = al(&c->cf_N, nf * 36)) || (rc = al(&c->cf_V, EU * 54)) ||
       (rc = al(&c->cf_B, nf * 36)) || (rc = al(&c->cf_Lfac, nf * 21)) || (rc = al(&c->cf_G, nf * 36)) ||
-      (rc = al(&c->cf_vy, nf * 6)) || (rc = al(&c->cf_z, nf * 6)) || (rc = al(&c->cf_Xt, (size_t)c->cf_ldx * (size_t)c->cf_kpad)) ||
+      (rc = al(&c->cf_vy, nf * 6)) || (rc = al(&c->cf_z, nf * 6)) ||
       (rc = al(&c->cf_T, (size_t)c->cf_ldt * n_o)) || (rc = al(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB)))
     return rc;
   if (n_o <= 1024 && (rc = al(&c->cf_part, (size_t)kCholMaxSplit * (size_t)c->cf_ldt * n_o))) return rc;   // split-K workspace of small systems
   // nested dissection of the camera chain from 128 free cameras on: stride = 16 x round(sqrt(nf) / 16) in [16, 128] (a multiple
-  // of the forward substitution's chunk, so that segments start on chunk boundaries); ESL_CF_NO_ND=1 keeps the plain chain (A/B)
+  // of the forward substitution's chunk, so that segments start on chunk boundaries), kCfFwdCh when X is kept sparse;
+  // ESL_CF_NO_ND=1 keeps the plain chain (A/B)
   c->cf_stride = 0; c->cf_n_sep = 0; c->cf_n_seg = 1;
   if (nf >= 128 && !std::getenv("ESL_CF_NO_ND")) {
     int st = 16 * (int)std::max(1.0, std::floor(std::sqrt((double)nf) / 16.0 + 0.5));
     st = std::min(st, kCfMaxStride);
+    if (c->cf_sparse) st = kCfFwdCh;
     c->cf_stride = st; c->cf_n_sep = (int)(nf / st); c->cf_n_seg = (int)((nf + st - 1) / st);
     const size_t ns = (size_t)std::max(c->cf_n_sep, 1);
     if ((rc = al(&c->cf_Zt, nf * 36)) || (rc = al(&c->cf_Hs, ns * 36)) || (rc = al(&c->cf_Bs, ns * 36)) || (rc = al(&c->cf_LfacS, ns * 21)) ||
@@ -199,8 +268,20 @@ static int cf_ensure(esl_ctx* c) {
       return rc;
     ESL_HIP_TRY(hipMemsetAsync(c->cf_Zt, 0, nf * 36 * sizeof(double), c->stream));
   }
-  // rows 6 nf .. kpad of X (the K padding of the rank-K update) and the columns of never-written edges stay zero
-  ESL_HIP_TRY(hipMemsetAsync(c->cf_Xt, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad * sizeof(double), c->stream));
+  if (c->cf_sparse) {
+    // slabs: pad columns and rows 90 .. 95 stay zero; Xs: rows 6 n_sep .. kpad_s (the K padding of the rank-K update) stay zero;
+    // T: the blocks above the diagonal are never written
+    c->cf_kpad_s = (int64_t)((6 * (size_t)c->cf_n_sep + kKC - 1) / kKC * kKC);
+    if ((rc = al(&c->cf_Xc, c->cf_xc_len)) || (rc = al(&c->cf_Xs, (size_t)c->cf_ldx * (size_t)c->cf_kpad_s))) return rc;
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_Xc, 0, std::max<size_t>(c->cf_xc_len, 1) * sizeof(double), c->stream));
+    if (c->cf_sp_form == 1 && ((rc = al(&c->cf_P, c->cf_p_blocks * 81)) || (rc = al(&c->cf_Prhs, c->cf_prhs_len)))) return rc;
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_Xs, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad_s * sizeof(double), c->stream));
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)c->cf_ldt * n_o * sizeof(double), c->stream));
+  } else {
+    // rows 6 nf .. kpad of X (the K padding of the rank-K update) and the columns of never-written edges stay zero
+    if ((rc = al(&c->cf_Xt, (size_t)c->cf_ldx * (size_t)c->cf_kpad))) return rc;
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_Xt, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad * sizeof(double), c->stream));
+  }
   ESL_HIP_TRY(hipMemsetAsync(c->cf_V, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
   return ESL_OK;
 }
@@ -226,8 +307,8 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
       hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, c->stream, nf, c->cf_Lfac, c->cf_G, c->cf_Linv, c->cf_M, c->cf_N, 0);
       hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
                          c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
-      hipLaunchKernelGGL(k_cf_forward<false>, dim3(cg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
-                         c->cf_M, c->cf_Xt, ldx, nf, nf, (const double*)nullptr, (double*)nullptr, 0);
+      hipLaunchKernelGGL(k_cf_forward<0>, dim3(cg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                         c->cf_M, c->cf_Xt, ldx, nf, nf, (const double*)nullptr, (double*)nullptr, 0, CfSegs{});
     } else {   // nested dissection (esl_cf.hpp): segments in parallel, then the separators' own short chain
       hipLaunchKernelGGL(k_cf_chain, dim3((unsigned)nseg), dim3(64), 0, c->stream, nf, c->Hcc, c->cf_B, lambda, c->cf_Lfac, c->cf_G, c->chol_info, st, st - 1);
       hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, c->stream, nf, c->cf_Lfac, c->cf_G, c->cf_Linv, c->cf_M, c->cf_N, st);
@@ -239,27 +320,60 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
       hipLaunchKernelGGL(k_cf_sep_scatter, dim3((unsigned)((ns * 36 + 255) / 256)), dim3(256), 0, c->stream, st, ns, c->cf_LiS, c->cf_Linv);
       hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
                          c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
-      hipLaunchKernelGGL(k_cf_forward<false>, dim3(cg, (unsigned)nseg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V,
-                         c->cf_vy, c->cf_M, c->cf_Xt, ldx, st, st - 1, (const double*)c->cf_Zt, c->cf_R, st);
-      hipLaunchKernelGGL(k_cf_sep_rhs, dim3(cg, (unsigned)ns), dim3(64), 0, c->stream, nf, n_o, st, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
-                         c->cf_G, c->cf_LiS, c->cf_Xt, ldx, c->cf_R);
-      hipLaunchKernelGGL(k_cf_forward<true>, dim3(cg), dim3(64), 0, c->stream, ns, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
-                         c->cf_MS, c->cf_Xt, ldx, ns, ns, (const double*)nullptr, c->cf_R, st);
+      if (!c->cf_sparse) {
+        hipLaunchKernelGGL(k_cf_forward<0>, dim3(cg, (unsigned)nseg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V,
+                           c->cf_vy, c->cf_M, c->cf_Xt, ldx, st, st - 1, (const double*)c->cf_Zt, c->cf_R, st, CfSegs{});
+        hipLaunchKernelGGL(k_cf_sep_rhs, dim3(cg, (unsigned)ns), dim3(64), 0, c->stream, nf, n_o, st, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                           c->cf_G, c->cf_LiS, c->cf_Xt, ldx, c->cf_R, (const int*)nullptr, CfSegs{});
+        hipLaunchKernelGGL(k_cf_forward<1>, dim3(cg), dim3(64), 0, c->stream, ns, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                           c->cf_MS, c->cf_Xt, ldx, ns, ns, (const double*)nullptr, c->cf_R, st, CfSegs{});
+      } else {   // interior rows into the segments' compact slabs, the separators' dense rows into Xs (row block k = separator k)
+        const CfSegs sg{c->cf_fwork, c->cf_seg_start, c->cf_seg_obj, c->cf_xoff, c->cf_xld};
+        hipLaunchKernelGGL(k_cf_forward<2>, dim3((unsigned)c->cf_n_fwork), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V,
+                           c->cf_vy, c->cf_M, c->cf_Xc, ldx, st, st - 1, (const double*)c->cf_Zt, c->cf_R, st, sg);
+        hipLaunchKernelGGL(k_cf_sep_rhs, dim3(cg, (unsigned)ns), dim3(64), 0, c->stream, nf, n_o, st, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                           c->cf_G, c->cf_LiS, c->cf_Xc, ldx, c->cf_R, (const int*)c->cf_cmap, sg);
+        hipLaunchKernelGGL(k_cf_forward<1>, dim3(cg), dim3(64), 0, c->stream, ns, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
+                           c->cf_MS, c->cf_Xs, ldx, ns, ns, (const double*)nullptr, c->cf_R, 0, CfSegs{});
+      }
     }
-    ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)ldt * (size_t)n_o * sizeof(double), c->stream));
-    hipLaunchKernelGGL(k_cf_T_init, dim3((unsigned)(((long)N * 90 + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
+    // this rank's columns of T: everything, or with the replicated-graph communicator its outer panels (dealt cyclically, as the
+    // distributed factorisation below expects them)
+    const int Wp = chol_outer_panels(n_o), n_outer = ((n_o + kNB - 1) / kNB + Wp - 1) / Wp;
+    const bool dist = cf_dist(c);
+    if (!c->cf_sparse) {
+      ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)ldt * (size_t)n_o * sizeof(double), c->stream));
+      hipLaunchKernelGGL(k_cf_T_init, dim3((unsigned)(((long)N * 90 + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
+    } else {   // T = D - (interior rows)^T (interior rows), block by block (every block on and below the diagonal is written)
+      ProfScope pk(c, 8);
+      if (c->cf_sp_form == 1)   // the segments' products (all of them on every rank: 3 % of a trial)
+        hipLaunchKernelGGL(k_cf_seg_syrk, dim3((unsigned)c->cf_n_twork), dim3(256), 0, c->stream, c->cf_twork, c->cf_seg_start, c->cf_xoff, c->cf_xld, c->cf_Xc,
+                           c->cf_boff, c->cf_roff, c->cf_P, c->cf_Prhs);
+      for (int op = dist ? c->comm_rank : 0; op < (dist ? n_outer : 1); op += dist ? c->comm_ranks : 1) {
+        const long c_begin = dist ? (long)op * Wp * kNB : 0, c_end = dist ? std::min<long>((long)(op + 1) * Wp * kNB, (long)n_o) : (long)n_o;
+        const int o2b = (int)(c_begin / 9), o2e = (int)((c_end + 8) / 9);   // (a block that straddles a panel boundary: on both sides)
+        const dim3 grid((unsigned)(N + 1), (unsigned)((o2e - o2b + kCfTPer - 1) / kCfTPer));
+        if (c->cf_sp_form == 1)
+          hipLaunchKernelGGL(k_cf_T_gather, grid, dim3(256), 0, c->stream, N, c->cf_sp_nw, c->cf_mask, c->cf_cmap, c->cf_boff, c->cf_roff, c->cf_P, c->cf_Prhs,
+                             c->Hoo, c->bo, lambda, c->cf_T, ldt, o2b, o2e);
+        else
+          hipLaunchKernelGGL(k_cf_T_sparse, grid, dim3(256), 0, c->stream, N, c->cf_sp_nw, c->cf_mask, c->cf_cmap, c->cf_xoff, c->cf_xld, c->cf_Xc, c->Hoo, c->bo,
+                             lambda, c->cf_T, ldt, o2b, o2e);
+      }
+    }
     ESL_HIP_TRY(hipGetLastError());
     ESL_HIP_TRY(chol_set_attributes(rt));
     {
       ProfScope pk(c, 7);   // the rank-K update alone (nested in class 2): the MFMA roofline kernel of this form
-      if (cf_dist(c)) {   // this rank's outer panels only (dealt cyclically, as the distributed factorisation below expects them)
-        const int Wp = chol_outer_panels(n_o), np = (n_o + kNB - 1) / kNB, n_outer = (np + Wp - 1) / Wp;
+      const double* Xf = c->cf_sparse ? c->cf_Xs : c->cf_Xt;
+      const int K = (int)(c->cf_sparse ? c->cf_kpad_s : c->cf_kpad);
+      if (dist) {
         for (int op = c->comm_rank; op < n_outer; op += c->comm_ranks) {
           const long c_begin = (long)op * Wp * kNB, c_end = std::min<long>((long)(op + 1) * Wp * kNB, (long)n_o);
-          chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, c_begin, c_end, c->cf_Xt, ldx);
+          chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, K, c_begin, c_end, Xf, ldx);
         }
-      } else {
-        chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, (int)c->cf_kpad, 0, (long)n_o, c->cf_Xt, ldx, c->cf_part);
+      } else if (K > 0) {
+        chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, K, 0, (long)n_o, Xf, ldx, c->cf_part);
       }
     }
     ESL_HIP_TRY(hipGetLastError());
@@ -274,7 +388,11 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     } else {
       ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
     }
-    hipLaunchKernelGGL(k_cf_z, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, c->cf_Xt, ldx, n_o, c->xo, c->cf_z);
+    if (c->cf_sparse)
+      hipLaunchKernelGGL(k_cf_z_sparse, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, n_o, c->cf_Xs, ldx,
+                         CfSegs{c->cf_fwork, c->cf_seg_start, c->cf_seg_obj, c->cf_xoff, c->cf_xld}, c->cf_Xc, c->xo, c->cf_z);
+    else
+      hipLaunchKernelGGL(k_cf_z, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, c->cf_Xt, ldx, n_o, c->xo, c->cf_z);
     if (c->cf_stride > 0 && c->cf_n_sep > 0) {
       const int st = c->cf_stride, ns = c->cf_n_sep;
       hipLaunchKernelGGL(k_cf_tridiag_back, dim3(1), dim3(64), 0, c->stream, ns, c->cf_LiS, c->cf_NS, c->cf_z, c->xc, ns, ns, st);            // separators

@@ -212,10 +212,10 @@ class Context:
         _check(load().esl_profile_enable(self._h, C.c_int(lv)), "esl_profile_enable")
 
     def profile_get(self):
-        cnt = (C.c_int64 * 8)()
-        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 9)()
+        ms = (C.c_double * 9)()
         _check(load().esl_profile_get(self._h, cnt, ms), "esl_profile_get")
-        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "shard_allreduce", "rank_k_update"]
+        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "shard_allreduce", "rank_k_update", "sparse_block_products"]
         return {n: dict(count=int(cnt[i]), total_ms=float(ms[i])) for i, n in enumerate(names) if cnt[i]}
 
     def init_quadric(self, poses_Twc, bboxes, K, rows=480, cols=640, faithful=1):

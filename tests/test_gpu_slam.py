@@ -292,3 +292,51 @@ def test_nested_dissection_equals_plain_chain(pkg, monkeypatch, n_cams):
         assert rep["trace_trials"] == ref[6]["trace_trials"]
         np.testing.assert_allclose(rep["trace_chi2"], ref[6]["trace_chi2"], rtol=1e-11)
         assert cam_err(cc, ref[4]) < 1e-9 and obj_rel(oo, ref[5]) < 1e-9
+
+
+@pytest.mark.parametrize("n_cams,n_objs,per_cam", [(257, 40, 6), (300, 80, 10), (500, 50, 10), (1000, 300, 8)])
+def test_sparse_interior_rows_equal_dense_rows(pkg, monkeypatch, n_cams, n_objs, per_cam):
+    """Camera-first elimination with X = G^-1 W kept SPARSE (esl_cf.hpp: segments of 16 slots, compact slabs of the columns a
+    segment's cameras see, T assembled block by block from the segments two ellipsoids share -- from the stored per-segment
+    products (ESL_CF_SPARSE=1) or straight from the slabs (=2) --, the separators' dense rows on the MFMA update) against the dense X of the same elimination (ESL_CF_SPARSE=0) and the reduced camera system: one linear system,
+    so x of the first trial to rounding and the LM run alike.  Sizes: 256 free cameras (the last one IS a separator), 299 (short
+    last segment), 499 (C3's count), 999 with 300 ellipsoids (most columns dead in most segments)."""
+    g, c, o, _ = pkg.synth.make_graph(n_cams, n_objs, per_cam * n_cams, seed=41, slam=True)
+    nf = n_cams - 1
+    out = {}
+    for tag, env, solver in (("sparse", "1", 2), ("sparse_direct", "2", 2), ("dense", "0", 2), ("camera", None, 1)):
+        if env:
+            monkeypatch.setenv("ESL_CF_SPARSE", env)
+        else:
+            monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
+        cx = pkg.Context(0)
+        try:
+            cx.upload_graph(g); cx.upload_states(c, o)
+            cx.lm_begin(pkg.default_lm_params(jacobian_mode=1, linear_solver=solver))
+            part = cx.lm_linearize()
+            tr = cx.lm_try_step(1e-5 * part.max_diag)
+            assert tr.solve_ok == 1 and cx.lm_solver_used() == solver
+            xc, xo = cx.lm_download(5, 6 * nf), cx.lm_download(2, 9 * g.n_objs)
+            res = cx.lm_reduced_residual()
+            prof_classes = None
+            cx.lm_commit(False)
+            cx.profile_enable(2)
+            cc, oo, rep = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1, linear_solver=solver))
+            prof_classes = set(cx.profile_get())
+            out[tag] = (xc, xo, tr.chi2, res, cc, oo, rep, prof_classes)
+        finally:
+            cx.close()
+    monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
+    assert "sparse_block_products" in out["sparse"][7] and "sparse_block_products" not in out["dense"][7]   # the form under test ran
+    ref = out["dense"]
+    assert "sparse_block_products" in out["sparse_direct"][7]
+    for tag in ("sparse", "sparse_direct", "camera"):
+        xc, xo, chi, res, cc, oo, rep, _ = out[tag]
+        d_xc = float(np.abs(xc - ref[0]).max() / np.abs(ref[0]).max()); d_xo = float(np.abs(xo - ref[1]).max() / np.abs(ref[1]).max())
+        print("n_cams %d, %s vs dense X: x_c %.2e x_o %.2e, |Sx-b|/|b| %.2e, run: chi2 rel %.2e cams %.2e" % (
+            n_cams, tag, d_xc, d_xo, res, abs(rep["chi2_final"] / ref[6]["chi2_final"] - 1), cam_err(cc, ref[4])))
+        assert res < 1e-13 and d_xc < 1e-10 and d_xo < 1e-10
+        assert chi == pytest.approx(ref[2], rel=1e-12)
+        assert rep["trace_trials"] == ref[6]["trace_trials"]
+        np.testing.assert_allclose(rep["trace_chi2"], ref[6]["trace_chi2"], rtol=1e-11)
+        assert cam_err(cc, ref[4]) < 1e-9 and obj_rel(oo, ref[5]) < 1e-9
