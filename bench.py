@@ -204,20 +204,25 @@ SOLVER_NAMES = {1: "reduced camera system (ellipsoids eliminated, dense Cholesky
                 2: "reduced ellipsoid system (cameras eliminated first: block-bidiagonal factor, rank-6(F-1) MFMA update, dense Cholesky of order 9N)"}
 
 
-def slam_flops(n_c, n_o, solver):
+def slam_flops(n_c, n_o, solver, stats=None):
     """algorithmic flops of one damped solve (SURVEY.md section 8 d): the dense figure n_c^3/3 + 2 n_c^2 of the reduced camera
-    system, and what the camera-first elimination actually executes"""
+    system, and what the camera-first elimination actually executes (stats = esl_lm_solver_stats: with X kept sparse the MFMA
+    update only carries the separators' rows and the interior rows go through the per-segment products)"""
     dense = n_c ** 3 / 3.0 + 2.0 * n_c * n_c
     if solver == 2:
-        rank_k = float(n_o) * (n_o + 1) * n_c                    # lower triangle of X^T X: n_o (n_o + 1) / 2 entries x 2 n_c
+        sparse = bool(stats and stats.get("x_form", 0) > 0)
+        k = 6.0 * stats["separators"] if sparse else float(n_c)   # rows of X in the dense update
+        rank_k = float(n_o) * (n_o + 1) * k                       # lower triangle of X^T X: n_o (n_o + 1) / 2 entries x 2 k
         chol = n_o ** 3 / 3.0 + 2.0 * n_o * n_o
-        return {"dense_figure": dense, "rank_k_update": rank_k, "cholesky": chol, "actual": rank_k + chol + 2.0 * n_o * n_c}
+        prod = stats["product_flops"] / 2.0 if sparse else 0.0   # (lower triangle of every segment's product)
+        return {"dense_figure": dense, "rank_k_update": rank_k, "rank_k_rows": k, "segment_products": prod, "cholesky": chol,
+                "actual": rank_k + prod + chol + 2.0 * n_o * n_c}
     return {"dense_figure": dense, "cholesky": dense, "actual": dense}
 
 
-def slam_roofline(prof, n_c, n_o, solver, trials):
+def slam_roofline(prof, n_c, n_o, solver, trials, stats=None):
     """MFMA roofline of the dominant kernel of a SLAM-mode run from the HIP-event classes of esl_profile_get."""
-    fl = slam_flops(n_c, n_o, solver)
+    fl = slam_flops(n_c, n_o, solver, stats)
     ch = prof.get("cholesky_solve", dict(count=0, total_ms=0.0))
     bd = prof.get("schur_build", dict(count=0, total_ms=0.0))
     ceiling = {"value": FP64_MFMA_MEASURED_TF, "unit": "TFLOP/s",
@@ -230,26 +235,40 @@ def slam_roofline(prof, n_c, n_o, solver, trials):
         avg = rk["total_ms"] / max(rk["count"], 1)
         ach = fl["rank_k_update"] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
         ch_avg = ch["total_ms"] / max(ch["count"], 1)
+        sparse = bool(stats and stats.get("x_form", 0) > 0)
         traffic = None
         if n_c == 59994 and n_o == 18000:   # HBM bytes per launch from the committed PMC passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE), not this run
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_c4_slam.json")))["kernels"]
-                traffic = [v for k, v in pmc.items() if "k_chol_update_lds<256, 128" in k][0]["traffic_bytes_per_launch"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_c4_slam.json")))
+                if bool(pmc.get("x_sparse")) == sparse:
+                    traffic = pmc["rank_k_update_launch"]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
                 traffic = None
         tile = "256,128" if n_o >= 8192 else "128,64 (split-K)"
-        return {"kernel": "k_chol_update_lds<%s> as the rank-%d update T -= X^T X of the reduced ellipsoid system (order %d)" % (tile, n_c, n_o),
-                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": traffic,
-                "traffic_source": "profiles/r3_pmc_traffic_c4_slam.json (committed PMC passes of this workload; operand strips re-read per tile through L2 / MALL: "
-                                  "8.6 GB algorithmic)" if traffic else None,
-                "algorithmic_flops_per_launch": fl["rank_k_update"], "avg_launch_ms": avg, "launches": rk["count"], "measured_ceiling": ceiling,
-                "linear_solve_ms_per_trial": solve_ms, "cholesky_order_9N_ms_per_trial": ch_avg,
-                "cholesky_order_9N_tflops": (fl["cholesky"] / (ch_avg * 1e-3) / 1e12) if ch_avg > 0 else 0.0,
-                "actual_flops_per_trial": fl["actual"],
-                "dense_figure": {"flops_per_trial": fl["dense_figure"], "equivalent_tflops": dense_equiv, "frac_of_peak": dense_equiv / FP64_MFMA_PEAK_TF,
-                                 "note": "SURVEY.md section 8 d: a cheaper exact solve is reported against the dense reduced-camera figure AND its own "
-                                         "operation count; equivalent = n_c^3/3 flops / the time of the whole linear solve of a trial (it can exceed "
-                                         "the peak: the flops were not executed)"}}
+        k_rows = int(fl["rank_k_rows"])
+        sp = prof.get("sparse_block_products", dict(count=0, total_ms=0.0))
+        sp_avg = sp["total_ms"] / max(sp["count"], 1)
+        out = {"kernel": "k_chol_update_lds<%s>, the launch that carries the rank-%d update T -= X^T X of the reduced ellipsoid system (order %d)%s" % (
+                   tile, k_rows, n_o, "; X kept sparse: these are the separators' rows, the interior rows go through the per-segment products"
+                   if sparse else ""),
+               "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": traffic,
+               "traffic_source": "profiles/r3_pmc_traffic_c4_slam.json (committed PMC passes of this workload)" if traffic else None,
+               "algorithmic_flops_per_launch": fl["rank_k_update"], "avg_launch_ms": avg, "launches": rk["count"], "measured_ceiling": ceiling,
+               "linear_solve_ms_per_trial": solve_ms, "cholesky_order_9N_ms_per_trial": ch_avg,
+               "cholesky_order_9N_tflops": (fl["cholesky"] / (ch_avg * 1e-3) / 1e12) if ch_avg > 0 else 0.0,
+               "actual_flops_per_trial": fl["actual"],
+               "dense_figure": {"flops_per_trial": fl["dense_figure"], "equivalent_tflops": dense_equiv, "frac_of_peak": dense_equiv / FP64_MFMA_PEAK_TF,
+                                "note": "SURVEY.md section 8 d: a cheaper exact solve is reported against the dense reduced-camera figure AND its own "
+                                        "operation count; equivalent = n_c^3/3 flops / the time of the whole linear solve of a trial (it can exceed "
+                                        "the peak: the flops were not executed)"}}
+        if sparse:
+            out["x_sparse"] = {"form": int(stats["x_form"]), "stride": int(stats["stride"]), "separators": int(stats["separators"]),
+                               "segments": int(stats["segments"]), "segment_product_flops": fl["segment_products"],
+                               "segment_products_ms_per_trial": sp_avg,
+                               "segment_products_tflops": fl["segment_products"] / (sp_avg * 1e-3) / 1e12 if sp_avg > 0 else 0.0,
+                               "stored_products_bytes": stats["product_bytes"], "slab_bytes": stats["slab_bytes"],
+                               "dense_X_update_flops_avoided": float(n_o) * (n_o + 1) * (n_c - fl["rank_k_rows"])}
+        return out
     avg = ch["total_ms"] / max(ch["count"], 1)
     ach = fl["cholesky"] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
     return {"kernel": "dense_cholesky_f64 of the reduced camera system (k_chol_potrf2 + k_chol_panel + k_chol_update_lds + triangular solves)",
@@ -283,7 +302,7 @@ def slam_run(pkg, ctx, g, c, o, solver, steps, warmup, jacobian=1, barrier=None)
             "lm_iterations_per_step": its / steps, "lm_trials_per_step": trials / steps, "linear_solver": used,
             "linear_solver_name": SOLVER_NAMES.get(used, "?"), "unknowns": {"cameras": n_c, "ellipsoids": n_o},
             "chi2": {"initial": rep["chi2_initial"], "final": rep["chi2_final"]}, "kernel_ms": prof,
-            "roofline": slam_roofline(prof, n_c, n_o, used, trials), "_dt": dt, "_its": its, "_trials": trials}
+            "roofline": slam_roofline(prof, n_c, n_o, used, trials, ctx.lm_solver_stats()), "_dt": dt, "_its": its, "_trials": trials}
 
 
 def slam_workload(name, g):
@@ -698,11 +717,12 @@ def main():
             if slam:
                 n_c, n_o = 6 * int((~g_full.cam_fixed.astype(bool)).sum()), 9 * g_full.n_objs
                 used = ctx.lm_solver_used()
-                roof = slam_roofline(prof, n_c, n_o, used, trials)
+                st = ctx.lm_solver_stats()
+                roof = slam_roofline(prof, n_c, n_o, used, trials, st)
                 if used == 2:   # rank 0 ran its share of the update (one launch per owned outer panel): price it at 1 / n_gpus of the flops
                     rk = prof.get("rank_k_update", dict(count=0, total_ms=0.0))
                     avg = rk["total_ms"] / max(rk["count"], 1)
-                    fl = slam_flops(n_c, n_o, 2)["rank_k_update"] / world
+                    fl = slam_flops(n_c, n_o, 2, st)["rank_k_update"] / world
                     roof.update({"achieved": fl / (avg * 1e-3) / 1e12 if avg > 0 else 0.0, "algorithmic_flops_per_launch": fl})
                     roof["frac"] = roof["achieved"] / FP64_MFMA_PEAK_TF
                 roof["note"] = "rank 0's launches; every rank executes 1 / n_gpus of the update flops (its own outer panels) and the factorisation is distributed"

@@ -40,7 +40,8 @@ extern "C" {
 #endif
 
 #define ESL_ABI_VERSION 3   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append
-                             * 3: esl_linear_solver gains ESL_SOLVER_REDUCED_CAMERA / ESL_SOLVER_REDUCED_ELLIPSOID, esl_lm_solver_used */
+                             * 3: esl_linear_solver gains ESL_SOLVER_REDUCED_CAMERA / ESL_SOLVER_REDUCED_ELLIPSOID, esl_lm_solver_used,
+                             *    esl_lm_solver_stats, esl_comm_set_replicated, ESL_PROF_KINDS 9 */
 #define ESL_MAX_TRACE 32
 
 typedef enum {
@@ -240,6 +241,12 @@ int esl_lm_commit(esl_ctx* ctx, int accept);
 /* which esl_linear_solver the last SLAM-mode trial step of this context ran with (ESL_SOLVER_REDUCED_CAMERA or
  * ESL_SOLVER_REDUCED_ELLIPSOID: what ESL_SOLVER_AUTO resolved to); 0 before any SLAM-mode step */
 int esl_lm_solver_used(esl_ctx* ctx, int32_t* solver_out);
+/* shape of the camera-first elimination of the resident graph as the last trial step ran it (zeros when it did not):
+ * stats[0] form of X: 0 dense rows, 1 sparse with stored per-segment products, 2 sparse, blocks of T straight from the slabs;
+ * [1] dissection stride (0: plain chain), [2] separators, [3] segments, [4] flops of the per-segment products (2 x sum (9 |O_p|)^2 x 90),
+ * [5] bytes of the stored products, [6] bytes of the compact slabs, [7] rows of the dense MFMA update (K, padded). */
+#define ESL_SOLVER_STATS 8
+int esl_lm_solver_stats(esl_ctx* ctx, double stats[ESL_SOLVER_STATS]);
 
 /* inspection (tests, debugging): copy one device array of the current linearisation to the host.
  * which: 0 Hoo (n_objs x 45 packed upper 9x9), 1 bo (n_objs x 9), 2 xo (n_objs x 9, last trial),

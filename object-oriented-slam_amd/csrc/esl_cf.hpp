@@ -329,8 +329,18 @@ static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, i
       for (int q = 0; q < 2; ++q) if (q * 64 + lane < kCfFwdCh * 6) svy[q * 64 + lane] = ty[q];   // (used by the right-hand-side lane only)
     }
     if (SEP) {   // dense right-hand sides of the separators: rows 6 i0 .. of R
+      // clamped addresses + selects, ALL 96 loads of the chunk in flight together: the grid is one wave per 64 columns (282 waves
+      // at C4), so the bytes in flight per wave set the bandwidth -- a guarded load per element (96 dependent round trips per chunk)
+      // and batches of 16 both took 2.2 ms per trial at C4's 625 separators
+      const size_t jc = on ? (size_t)j : 0;
+      {
+        constexpr int kQ = kCfFwdCh * 6;
+        double t[kQ];
 #pragma unroll
-      for (int q = 0; q < kCfFwdCh * 6; ++q) sv[q * 64 + lane] = (on && q < len * 6) ? R[(size_t)j + (size_t)(6 * i0 + q) * (size_t)ldx] : 0.0;
+        for (int q = 0; q < kQ; ++q) t[q] = R[jc + (size_t)(6 * i0 + (q < len * 6 ? q : 0)) * (size_t)ldx];
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) sv[q * 64 + lane] = (on && q < len * 6) ? t[q] : 0.0;
+      }
       __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
@@ -837,40 +847,51 @@ static __global__ __launch_bounds__(256) void k_cf_seg_syrk(const int* __restric
     for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = cf_d4{0, 0, 0, 0};
   const double* pa = X + c1b + r;
   const double* pb = X + c2b + r;
-  constexpr int kB = 3;   // k-steps per batch: 24 loads in flight, then 48 MFMAs
-  for (int k = 0; k < kCfSegRows; k += 4 * kB) {
-    double a[kB][4], b[kB][4];
+  constexpr int kB = 3;   // k-steps per batch: the 24 loads of batch i + 1 are in flight while the 48 MFMAs of batch i issue
+  constexpr int kNBatch = kCfSegRows / (4 * kB);
+  static_assert(kNBatch * 4 * kB == kCfSegRows, "slab rows = whole batches");
+  double a[2][kB][4], b[2][kB][4];
+  auto load = [&](int buf, int k) {
 #pragma unroll
     for (int u = 0; u < kB; ++u)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        a[u][q] = pa[(long)(k + 4 * u + kq) * ld + 16 * q];
-        b[u][q] = pb[(long)(k + 4 * u + kq) * ld + 16 * q];
+        a[buf][u][q] = pa[(long)(k + 4 * u + kq) * ld + 16 * q];
+        b[buf][u][q] = pb[(long)(k + 4 * u + kq) * ld + 16 * q];
       }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int it = 0; it < kNBatch; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < kNBatch) load(cur ^ 1, (it + 1) * 4 * kB);
 #pragma unroll
     for (int u = 0; u < kB; ++u)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][mi], b[u][nj], acc[mi][nj], 0, 0, 0);
+        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[cur][u][nj], a[cur][u][mi], acc[mi][nj], 0, 0, 0);
   }
-  // acc[mi][nj][g] = P(c1 = c1b + 16 mi + kq + 4 g, c2 = c2b + 16 nj + r)
+  // The product is formed TRANSPOSED (the c2 fragment as the MFMA A operand): acc[mi][nj][g] = P(c1 = c1b + 16 mi + r, c2 = c2b + 16 nj +
+  // kq + 4 g), so 16 lanes of a store walk down c1 = the contiguous direction of a stored block (with c2 on the lanes every
+  // lane of a store hit a different 64-byte segment)
   double* Pp = P + (size_t)boff[p] * 81;
   double* Pr = Prhs + roff[p];
 #pragma unroll
-  for (int nj = 0; nj < 4; ++nj) {
-    const int c2 = c2b + 16 * nj + r;
-    if (c2 >= m) continue;
-    const int i2 = c2 / 9, j = c2 - 9 * i2;
+  for (int mi = 0; mi < 4; ++mi) {
+    const int c1 = c1b + 16 * mi + r;
+    if (c1 > m) continue;
+    const int i1 = c1 / 9, i = c1 - 9 * i1;
+    const size_t row_off = (size_t)i1 * (i1 + 1) / 2;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c1 = c1b + 16 * mi + kq + 4 * g;
-        if (c1 < c2 || c1 > m) continue;
+        const int c2 = c2b + 16 * nj + kq + 4 * g;
+        if (c2 > c1 || c2 >= m) continue;
         if (c1 == m) { Pr[c2] = acc[mi][nj][g]; continue; }
-        const int i1 = c1 / 9, i = c1 - 9 * i1;
-        Pp[((size_t)i1 * (i1 + 1) / 2 + i2) * 81 + j * 9 + i] = acc[mi][nj][g];
+        const int i2 = c2 / 9, j = c2 - 9 * i2;
+        Pp[(row_off + i2) * 81 + j * 9 + i] = acc[mi][nj][g];
       }
   }
 }

@@ -770,6 +770,20 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
 }
 
 
+extern "C" int esl_lm_solver_stats(esl_ctx* c, double* st) {
+  if (!c || !st) return ESL_ERR_INVALID;
+  for (int k = 0; k < ESL_SOLVER_STATS; ++k) st[k] = 0;
+  if (c->lm_solver_used != ESL_SOLVER_REDUCED_ELLIPSOID || !c->cf_T) return ESL_OK;
+  st[0] = c->cf_sparse ? c->cf_sp_form : 0;
+  st[1] = c->cf_stride; st[2] = c->cf_n_sep; st[3] = c->cf_n_seg;
+  if (c->cf_sparse) {
+    st[4] = 2.0 * c->cf_sp_flops;
+    st[5] = c->cf_sp_form == 1 ? 8.0 * 81.0 * (double)c->cf_p_blocks : 0.0;
+    st[6] = 8.0 * (double)c->cf_xc_len;
+  }
+  st[7] = (double)(c->cf_sparse ? c->cf_kpad_s : c->cf_kpad);
+  return ESL_OK;
+}
 extern "C" int esl_lm_solver_used(esl_ctx* c, int32_t* solver_out) {
   if (!c || !solver_out) return ESL_ERR_INVALID;
   *solver_out = c->lm_solver_used;

@@ -22,7 +22,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_set_replicated", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_solver_stats", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_set_replicated", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
     "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane", "esl_extract_planes",
 ]
 
@@ -181,6 +181,13 @@ class Context:
         v = C.c_int32(0)
         _check(load().esl_lm_solver_used(self._h, C.byref(v)), "esl_lm_solver_used")
         return v.value
+
+    def lm_solver_stats(self):
+        """Shape of the camera-first elimination as the last trial ran it (esl_lm_solver_stats)."""
+        st = (C.c_double * 8)()
+        _check(load().esl_lm_solver_stats(self._h, st), "esl_lm_solver_stats")
+        names = ["x_form", "stride", "separators", "segments", "product_flops", "product_bytes", "slab_bytes", "dense_update_rows"]
+        return {n: float(st[i]) for i, n in enumerate(names)}
 
     def lm_reduced_system(self, lam):
         ptr, n, lda = C.c_void_p(), C.c_int64(0), C.c_int64(0)

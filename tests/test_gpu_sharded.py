@@ -298,14 +298,18 @@ def run_replicated(pkg, g, cams, objs, params, n_ranks=2):
     return reps, states, used, ar
 
 
-@pytest.mark.parametrize("n_ranks,solver", [(2, 0), (3, 0), (2, 1)])
-def test_slam_replicated_graph_divides_the_dense_solve(pkg, ctx, monkeypatch, n_ranks, solver):
+@pytest.mark.parametrize("n_ranks,solver,sparse", [(2, 0, False), (3, 0, False), (2, 1, False), (2, 2, True), (3, 2, True)])
+def test_slam_replicated_graph_divides_the_dense_solve(pkg, ctx, monkeypatch, n_ranks, solver, sparse):
     """esl_comm_set_replicated: every rank holds the whole graph, nothing is summed over ranks, the ranks divide the dense solve --
     camera-first elimination (solver AUTO -> 2): each rank forms only the outer panels of the reduced ELLIPSOID system it owns,
     the owner factors a panel and broadcasts it, own later panels updated, back-substitution replicated; reduced camera system
     (solver 1): built everywhere, factored distributed.  ESL_CHOL_DIST=1 forces the distribution at this size (40 ellipsoids =
-    360 unknowns = 2 outer panels of 256; 720 camera unknowns = 3).  Must be the single-context run, identical on every rank."""
-    g, c, o, _ = pkg.synth.make_graph(121, 40, 2400, seed=37, slam=True)
+    360 unknowns = 2 outer panels of 256; 720 camera unknowns = 3).  Must be the single-context run, identical on every rank.
+    sparse: 300 cameras with X kept sparse (ESL_CF_SPARSE=1, esl_cf.hpp): the per-segment products on every rank, the blocks of T
+    gathered and the separators' rows applied for a rank's own panels only."""
+    if sparse:
+        monkeypatch.setenv("ESL_CF_SPARSE", "1")
+    g, c, o, _ = pkg.synth.make_graph(300 if sparse else 121, 40, 2400, seed=37, slam=True)
     p = pkg.default_lm_params(jacobian_mode=1, linear_solver=solver)
     ctx.upload_graph(g); ctx.upload_states(c, o)
     ref = ctx.optimize_resident(p)
@@ -315,6 +319,7 @@ def test_slam_replicated_graph_divides_the_dense_solve(pkg, ctx, monkeypatch, n_
     monkeypatch.setenv("ESL_CHOL_DIST", "1")
     reps, states, used, ar = run_replicated(pkg, g, c, o, p, n_ranks)
     assert used == [used_ref] * n_ranks
+    assert (ctx.lm_solver_stats()["x_form"] > 0) == sparse
     n_tr = sum(ref["trace_trials"])
     # per trial: one broadcast of the factored columns + one of the diagonal-block inverses per outer panel, and the 8-byte pivot flag
     n_outer = 2 if used_ref == 2 else 3

@@ -170,12 +170,14 @@ def test_c3_slam_full_run_vs_faithful_dense_delta_1e9(pkg, po, ctx, c3_dense):
     assert cam_err(cg, c6) < 1e-4 and obj_rel(og, o6) < 1e-4
 
 
-@pytest.mark.parametrize("n", [1, 7, 130, 777, 3000, 8192, 9001])
+@pytest.mark.parametrize("n", [1, 7, 130, 777, 3000, 8192, 8704, 9001, 18000])
 def test_dense_cholesky_selftest_residual(ctx, n):
     """Known-answer test of the MFMA Cholesky on a generated diagonally dominant system (sizes straddle the 128-wide
     inner panels and the outer panels of 2 / 4 of them; from 8,192 on the factorisation runs with the look-ahead split on two
-    streams, rectangular head updates and both tile sizes): |A x - b| / |b| at fp64 round-off."""
+    streams, rectangular head updates and both tile sizes -- 8,704: the last outer panel is full and only the right-hand side's row
+    is below it; 18,000: the reduced ellipsoid system of C4): |A x - b| / |b| at fp64 round-off."""
     ms, res = ctx.selftest_cholesky(n)
+    print("dense Cholesky self test n = %d: %.3f ms, residual %.2e" % (n, ms, res))
     assert res < 1e-12, (n, res)
     assert ms >= 0
 
