@@ -214,7 +214,7 @@ def slam_flops(n_c, n_o, solver, stats=None):
         k = 6.0 * stats["separators"] if sparse else float(n_c)   # rows of X in the dense update
         rank_k = float(n_o) * (n_o + 1) * k                       # lower triangle of X^T X: n_o (n_o + 1) / 2 entries x 2 k
         chol = n_o ** 3 / 3.0 + 2.0 * n_o * n_o
-        prod = stats["product_flops"] / 2.0 if sparse else 0.0   # (lower triangle of every segment's product)
+        prod = stats["product_flops"] if sparse else 0.0         # (lower block triangle of every segment's product, live rows only)
         return {"dense_figure": dense, "rank_k_update": rank_k, "rank_k_rows": k, "segment_products": prod, "cholesky": chol,
                 "actual": rank_k + prod + chol + 2.0 * n_o * n_c}
     return {"dense_figure": dense, "cholesky": dense, "actual": dense}

@@ -264,7 +264,7 @@ static void free_graph(esl_ctx* c) {
   dev_free(&c->cf_Xt); dev_free(&c->cf_T); dev_free(&c->cf_Linv_ws); dev_free(&c->cf_part); dev_free(&c->cf_B); dev_free(&c->cf_Lfac); dev_free(&c->cf_G);
   dev_free(&c->cf_Zt); dev_free(&c->cf_Hs); dev_free(&c->cf_Bs); dev_free(&c->cf_LfacS); dev_free(&c->cf_GS); dev_free(&c->cf_LiS);
   dev_free(&c->cf_MS); dev_free(&c->cf_NS); dev_free(&c->cf_R);
-  dev_free(&c->cf_seg_start); dev_free(&c->cf_seg_obj); dev_free(&c->cf_cmap); dev_free(&c->cf_xld); dev_free(&c->cf_fwork);
+  dev_free(&c->cf_seg_start); dev_free(&c->cf_seg_obj); dev_free(&c->cf_seg_first); dev_free(&c->cf_cmap); dev_free(&c->cf_xld); dev_free(&c->cf_fwork);
   dev_free(&c->cf_mask); dev_free(&c->cf_xoff); dev_free(&c->cf_Xc); dev_free(&c->cf_Xs);
   dev_free(&c->cf_boff); dev_free(&c->cf_roff); dev_free(&c->cf_twork); dev_free(&c->cf_P); dev_free(&c->cf_Prhs);
   c->cf_sp_built = c->cf_sparse = false;

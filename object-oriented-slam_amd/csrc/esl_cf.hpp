@@ -393,12 +393,15 @@ static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, i
           for (int q = 0; q < 6; ++q) acc[a] += Z[q * 6 + a] * xn[q];
       }
     }
-    // (3) out: batches of eight LDS reads, then their eight stores
+    // (3) out: batches of eight LDS reads, then their eight stores.  Straight-line code (fixed trip count, predicated stores): as a
+    // run-time loop every batch waited for the previous batch's stores (the s_waitcnt vmcnt(0) at the loop head) -- hidden where
+    // thousands of waves run, 18 us per chunk over the separators, where the grid is one wave per 64 columns
     if (on) {
-      for (int q0 = 0; q0 < len * 6; q0 += 8) {
+#pragma unroll
+      for (int q0 = 0; q0 < kCfFwdCh * 6; q0 += 8) {
         double t[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = sv[((q0 + e < len * 6) ? q0 + e : q0) * 64 + lane];
+        for (int e = 0; e < 8; ++e) t[e] = sv[((q0 + e < len * 6) ? q0 + e : 0) * 64 + lane];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (q0 + e < len * 6) {
@@ -829,15 +832,15 @@ static __global__ __launch_bounds__(256) void k_cf_z_sparse(int n_o, const doubl
 //                   bytes per (pair, segment), every stored block read exactly once.
 // C4: 14 GB of products written and read once, 3.7e11 flops of dense MFMA tiles.
 static __global__ __launch_bounds__(256) void k_cf_seg_syrk(const int* __restrict__ twork, const int* __restrict__ seg_start,
-                                                            const long long* __restrict__ xoff, const int* __restrict__ xld,
-                                                            const double* __restrict__ Xc, const long long* __restrict__ boff,
-                                                            const long long* __restrict__ roff, double* __restrict__ P, double* __restrict__ Prhs) {
+                                                            const int* __restrict__ seg_first, const long long* __restrict__ xoff,
+                                                            const int* __restrict__ xld, const double* __restrict__ Xc,
+                                                            const long long* __restrict__ boff, double* __restrict__ P) {
   const int p = twork[3 * blockIdx.x], ti = twork[3 * blockIdx.x + 1], tj = twork[3 * blockIdx.x + 2];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, kq = lane >> 4;
-  const int m = 9 * (seg_start[p + 1] - seg_start[p]);           // compact column m = the right-hand side
+  const int ob = seg_start[p], m = 9 * (seg_start[p + 1] - ob);   // the ellipsoids' compact columns (the right-hand side: k_cf_seg_rhs)
   const int c1b = ti * kCfSyT + (wave >> 1) * 64, c2b = tj * kCfSyT + (wave & 1) * 64;
-  if (c1b + 63 < c2b || c1b > m || c2b >= m) return;             // above the diagonal / past the last column
+  if (c1b + 63 < c2b || c1b >= m || c2b >= m) return;            // above the diagonal / past the last column
   const long ld = xld[p];
   const double* X = Xc + xoff[p];
   cf_d4 acc[4][4];
@@ -850,37 +853,43 @@ static __global__ __launch_bounds__(256) void k_cf_seg_syrk(const int* __restric
   constexpr int kB = 3;   // k-steps per batch: the 24 loads of batch i + 1 are in flight while the 48 MFMAs of batch i issue
   constexpr int kNBatch = kCfSegRows / (4 * kB);
   static_assert(kNBatch * 4 * kB == kCfSegRows, "slab rows = whole batches");
-  double a[2][kB][4], b[2][kB][4];
-  auto load = [&](int buf, int k) {
+  double a0[kB][4], b0[kB][4], a1[kB][4], b1[kB][4];
+  auto load = [&](double (&a)[kB][4], double (&b)[kB][4], int it) {
+    const int k = it * 4 * kB;
 #pragma unroll
     for (int u = 0; u < kB; ++u)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        a[buf][u][q] = pa[(long)(k + 4 * u + kq) * ld + 16 * q];
-        b[buf][u][q] = pb[(long)(k + 4 * u + kq) * ld + 16 * q];
+        a[u][q] = pa[(long)(k + 4 * u + kq) * ld + 16 * q];
+        b[u][q] = pb[(long)(k + 4 * u + kq) * ld + 16 * q];
       }
   };
-  load(0, 0);
-#pragma unroll
-  for (int it = 0; it < kNBatch; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < kNBatch) load(cur ^ 1, (it + 1) * 4 * kB);
+  auto mac = [&](double (&a)[kB][4], double (&b)[kB][4]) {
 #pragma unroll
     for (int u = 0; u < kB; ++u)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[cur][u][nj], a[cur][u][mi], acc[mi][nj], 0, 0, 0);
+        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][nj], a[u][mi], acc[mi][nj], 0, 0, 0);
+  };
+  // the columns are ordered by first camera: everything above row 6 first(c1b) is zero in all of this wave's c1 columns
+  const int it0 = (6 * seg_first[ob + c1b / 9]) / (4 * kB);
+  load(a0, b0, it0);
+  for (int it = it0; it < kNBatch; it += 2) {
+    if (it + 1 < kNBatch) load(a1, b1, it + 1);
+    mac(a0, b0);
+    if (it + 1 < kNBatch) {
+      if (it + 2 < kNBatch) load(a0, b0, it + 2);
+      mac(a1, b1);
+    }
   }
   // The product is formed TRANSPOSED (the c2 fragment as the MFMA A operand): acc[mi][nj][g] = P(c1 = c1b + 16 mi + r, c2 = c2b + 16 nj +
-  // kq + 4 g), so 16 lanes of a store walk down c1 = the contiguous direction of a stored block (with c2 on the lanes every
-  // lane of a store hit a different 64-byte segment)
+  // kq + 4 g), so 16 lanes of a store walk down c1 = the contiguous direction of a stored block
   double* Pp = P + (size_t)boff[p] * 81;
-  double* Pr = Prhs + roff[p];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int c1 = c1b + 16 * mi + r;
-    if (c1 > m) continue;
+    if (c1 >= m) continue;
     const int i1 = c1 / 9, i = c1 - 9 * i1;
     const size_t row_off = (size_t)i1 * (i1 + 1) / 2;
 #pragma unroll
@@ -888,12 +897,28 @@ static __global__ __launch_bounds__(256) void k_cf_seg_syrk(const int* __restric
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c2 = c2b + 16 * nj + kq + 4 * g;
-        if (c2 > c1 || c2 >= m) continue;
-        if (c1 == m) { Pr[c2] = acc[mi][nj][g]; continue; }
+        if (c2 > c1) continue;
         const int i2 = c2 / 9, j = c2 - 9 * i2;
         Pp[(row_off + i2) * 81 + j * 9 + i] = acc[mi][nj][g];
       }
   }
+}
+
+// the right-hand side's row of every product: Prhs_p(c) = sum over the rows of Xc_p(row, c) Xc_p(row, m); workgroup = entry of the
+// forward kernel's work list (segment, group of 64 compact columns), lane = column
+static __global__ __launch_bounds__(64) void k_cf_seg_rhs(const int* __restrict__ fwork, const int* __restrict__ seg_start,
+                                                          const long long* __restrict__ xoff, const int* __restrict__ xld,
+                                                          const double* __restrict__ Xc, const long long* __restrict__ roff,
+                                                          double* __restrict__ Prhs) {
+  const int p = fwork[2 * blockIdx.x], c = fwork[2 * blockIdx.x + 1] * 64 + (int)threadIdx.x;
+  const int m = 9 * (seg_start[p + 1] - seg_start[p]);
+  const long ld = xld[p];
+  const double* X = Xc + xoff[p];
+  const int cc = c < m ? c : 0;
+  double s = 0;
+#pragma unroll 6
+  for (int row = 0; row < 6 * (kCfFwdCh - 1); ++row) s += X[(long)row * ld + cc] * X[(long)row * ld + m];
+  if (c < m) Prhs[roff[p] + c] = s;
 }
 
 static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const unsigned long long* __restrict__ mask, const int* __restrict__ cmap,
@@ -910,33 +935,42 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
     const int o2 = o2_begin + (int)blockIdx.y * kCfTPer + q;
     if (o2 >= o2_end || o2 > o1 || o2 >= N) continue;
     double s0 = 0, s1 = 0;                      // entries lane and 64 + lane of the 81 (column major: entry = 9 j + i)
+    const int eT0 = (lane % 9) * 9 + lane / 9, eT1 = lane < 17 ? ((64 + lane) % 9) * 9 + (64 + lane) / 9 : 0;   // the same entries of the transposed block
     for (int wd = 0; wd < nw; ++wd) {
       unsigned long long mk = mask[(size_t)o1 * nw + wd] & mask[(size_t)o2 * nw + wd];
       if (!mk) continue;
       // lane = bit: where this segment keeps the pair's block (one round trip for the word's 64 segments)
+      // (the compact order of a segment is by first camera, not by ellipsoid: where o2 comes after o1 the stored block is the
+      //  transpose of the one wanted)
       const int pl = wd * 64 + lane;
       long long offl = 0;
+      int swl = 0;
       if ((mk >> lane) & 1ull) {
         const long long i2 = cmap[(size_t)pl * N1 + o2] & 0xFFFFFF;
         if (rhs) offl = roff[pl] + 9 * i2;
-        else { const long long i1 = cmap[(size_t)pl * N1 + o1] & 0xFFFFFF; offl = (boff[pl] + i1 * (i1 + 1) / 2 + i2) * 81; }
+        else {
+          const long long i1 = cmap[(size_t)pl * N1 + o1] & 0xFFFFFF;
+          swl = i2 > i1;
+          offl = (boff[pl] + (swl ? i2 * (i2 + 1) / 2 + i1 : i1 * (i1 + 1) / 2 + i2)) * 81;
+        }
       }
       while (mk) {   // four segments' blocks in flight, added in ascending segment order
         long long off[4];
-        bool have[4];
+        bool have[4], sw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           have[u] = mk != 0;
           const int bit = have[u] ? __builtin_ctzll(mk) : 0;
           if (have[u]) mk &= mk - 1;
           off[u] = ((long long)__builtin_amdgcn_readlane((int)(offl >> 32), bit) << 32) | (unsigned)__builtin_amdgcn_readlane((int)offl, bit);
+          sw[u] = __builtin_amdgcn_readlane(swl, bit) != 0;
         }
         double v0[4], v1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const double* src = (rhs ? Prhs : P) + off[u];
-          v0[u] = (have[u] && (!rhs || lane < 9)) ? src[lane] : 0.0;
-          v1[u] = (have[u] && !rhs && lane < 17) ? src[64 + lane] : 0.0;
+          v0[u] = (have[u] && (!rhs || lane < 9)) ? src[sw[u] ? eT0 : lane] : 0.0;
+          v1[u] = (have[u] && !rhs && lane < 17) ? src[sw[u] ? eT1 : 64 + lane] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { s0 += v0[u]; s1 += v1[u]; }

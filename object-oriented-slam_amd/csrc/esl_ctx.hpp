@@ -213,8 +213,8 @@ struct esl_ctx {
   // compact slabs Xc (xoff / xld) and the separators' dense rows Xs
   bool cf_sp_built = false, cf_sparse = false;
   int cf_sp_nseg = 0, cf_sp_nw = 0, cf_n_fwork = 0;
-  double cf_sp_flops = 0;   // sum over the segments of (9 |O_p|)^2 x rows
-  int *cf_seg_start = nullptr, *cf_seg_obj = nullptr, *cf_cmap = nullptr, *cf_xld = nullptr, *cf_fwork = nullptr;
+  double cf_sp_flops = 0;   // FMAs of the per-segment products: block lower triangles, rows from each block row's first camera on
+  int *cf_seg_start = nullptr, *cf_seg_obj = nullptr, *cf_seg_first = nullptr, *cf_cmap = nullptr, *cf_xld = nullptr, *cf_fwork = nullptr;
   unsigned long long* cf_mask = nullptr;
   long long* cf_xoff = nullptr;
   size_t cf_xc_len = 0;

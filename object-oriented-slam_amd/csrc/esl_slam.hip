@@ -125,12 +125,23 @@ int slam_alloc(esl_ctx* c) {
           if (e < 0) e = pos << 24;                                // (lists sorted by slot: the first hit is the first camera)
           mask[(size_t)o * nw + p / 64] |= 1ull << (p & 63);
         }
+      // compact order inside a segment: by FIRST camera, then by ellipsoid -- the slab is then upper-trapezoidal (column c is zero
+      // above row 6 first(c)), and a tile of the segment's product starts at the first camera of its first column
       double fl = 0;
+      std::vector<int> seg_first;
+      std::vector<std::pair<int, int>> ord;
       for (int p = 0; p < nseg; ++p) {
-        int cnt = 0;
+        ord.clear();
         for (int o = 0; o < N; ++o) {
-          int& e = cmap[(size_t)p * N1 + o];
-          if (e >= 0) { e |= cnt++; seg_obj.push_back(o); }
+          const int e = cmap[(size_t)p * N1 + o];
+          if (e >= 0) ord.push_back({e >> 24, o});
+        }
+        std::sort(ord.begin(), ord.end());
+        const int cnt = (int)ord.size();
+        for (int k = 0; k < cnt; ++k) {
+          cmap[(size_t)p * N1 + ord[k].second] = (ord[k].first << 24) | k;
+          seg_obj.push_back(ord[k].second); seg_first.push_back(ord[k].first);
+          fl += 81.0 * (k + 1) * (6 * (kCfFwdCh - 1 - ord[k].first));   // block row k of the product: k + 1 blocks, rows from its first camera on
         }
         cmap[(size_t)p * N1 + N] = cnt;                            // the right-hand side: the column after the last ellipsoid's
         mask[(size_t)N * nw + p / 64] |= 1ull << (p & 63);
@@ -141,10 +152,10 @@ int slam_alloc(esl_ctx* c) {
         for (int q = 0; q < (m + 63) / 64; ++q) { fwork.push_back(p); fwork.push_back(q); }
         boff[(size_t)p + 1] = boff[p] + (long long)cnt * (cnt + 1) / 2;
         roff[(size_t)p + 1] = roff[p] + 9LL * cnt;
-        for (int ti = 0; ti < (m + kCfSyT - 1) / kCfSyT; ++ti)   // tiles of the product on and below the diagonal
+        for (int ti = 0; ti < (9 * cnt + kCfSyT - 1) / kCfSyT; ++ti)   // tiles of the product on and below the diagonal (ellipsoid columns only)
           for (int tj = 0; tj <= ti; ++tj) { twork.push_back(p); twork.push_back(ti); twork.push_back(tj); }
-        fl += (double)(9 * cnt) * (9 * cnt) * (6 * (kCfFwdCh - 1));
       }
+      if ((rc = up(&c->cf_seg_first, seg_first.data(), seg_first.size(), c->stream))) return rc;
       c->cf_sp_nseg = nseg; c->cf_sp_nw = nw; c->cf_n_fwork = (int)(fwork.size() / 2); c->cf_sp_flops = fl; c->cf_xc_len = (size_t)xoff[nseg] + 2 * kCfSyT;   // (+: the product kernel's last tile reads past the last slab's columns)
       if ((rc = up(&c->cf_cmap, cmap.data(), cmap.size(), c->stream))) return rc;
       if ((rc = up(&c->cf_mask, mask.data(), mask.size(), c->stream))) return rc;
@@ -235,7 +246,7 @@ static int cf_ensure(esl_ctx* c) {
   c->cf_sparse = false;
   if (c->cf_sp_built && !std::getenv("ESL_CF_NO_ND")) {
     const double dense = (double)n_o * (double)n_o * 6.0 * (double)nf;
-    const double sparse = (double)n_o * (double)n_o * 6.0 * (double)(nf / kCfFwdCh) + 4.0 * c->cf_sp_flops;
+    const double sparse = (double)n_o * (double)n_o * 6.0 * (double)(nf / kCfFwdCh) + 24.0 * c->cf_sp_flops;   // (cf_sp_flops: FMAs of the products' lower triangles)
     const char* sw = std::getenv("ESL_CF_SPARSE");
     c->cf_sparse = sw ? sw[0] != '0' : (n_o >= 2048 && sparse < 0.5 * dense);
     // the per-segment products are stored when they fit beside everything else (C4: 14 GB); else (or ESL_CF_SPARSE=2) the blocks
@@ -347,8 +358,12 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     } else {   // T = D - (interior rows)^T (interior rows), block by block (every block on and below the diagonal is written)
       ProfScope pk(c, 8);
       if (c->cf_sp_form == 1)   // the segments' products (all of them on every rank: 3 % of a trial)
-        hipLaunchKernelGGL(k_cf_seg_syrk, dim3((unsigned)c->cf_n_twork), dim3(256), 0, c->stream, c->cf_twork, c->cf_seg_start, c->cf_xoff, c->cf_xld, c->cf_Xc,
-                           c->cf_boff, c->cf_roff, c->cf_P, c->cf_Prhs);
+      {
+        hipLaunchKernelGGL(k_cf_seg_syrk, dim3((unsigned)c->cf_n_twork), dim3(256), 0, c->stream, c->cf_twork, c->cf_seg_start, c->cf_seg_first, c->cf_xoff,
+                           c->cf_xld, c->cf_Xc, c->cf_boff, c->cf_P);
+        hipLaunchKernelGGL(k_cf_seg_rhs, dim3((unsigned)c->cf_n_fwork), dim3(64), 0, c->stream, c->cf_fwork, c->cf_seg_start, c->cf_xoff, c->cf_xld, c->cf_Xc,
+                           c->cf_roff, c->cf_Prhs);
+      }
       for (int op = dist ? c->comm_rank : 0; op < (dist ? n_outer : 1); op += dist ? c->comm_ranks : 1) {
         const long c_begin = dist ? (long)op * Wp * kNB : 0, c_end = dist ? std::min<long>((long)(op + 1) * Wp * kNB, (long)n_o) : (long)n_o;
         const int o2b = (int)(c_begin / 9), o2e = (int)((c_end + 8) / 9);   // (a block that straddles a panel boundary: on both sides)
@@ -777,7 +792,7 @@ extern "C" int esl_lm_solver_stats(esl_ctx* c, double* st) {
   st[0] = c->cf_sparse ? c->cf_sp_form : 0;
   st[1] = c->cf_stride; st[2] = c->cf_n_sep; st[3] = c->cf_n_seg;
   if (c->cf_sparse) {
-    st[4] = 2.0 * c->cf_sp_flops;
+    st[4] = 2.0 * c->cf_sp_flops;   // (FMAs of the block lower triangles, rows from each block row's first camera on)
     st[5] = c->cf_sp_form == 1 ? 8.0 * 81.0 * (double)c->cf_p_blocks : 0.0;
     st[6] = 8.0 * (double)c->cf_xc_len;
   }

@@ -45,7 +45,22 @@ def main():
         res["kernels"][k] = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "dispatches": len(fv), "live_dispatches": len(live_f),
                              "fetch_bytes_corrected": 2 * f_kib * 1024, "write_bytes": w_kib * 1024,
                              "traffic_bytes_per_launch": 2 * f_kib * 1024 + w_kib * 1024}
+    # the launch the bench line's roofline is quoted on: the rank-K update T -= X^T X of the camera-first elimination = the
+    # dispatch of the 256 x 128 update kernel with the LARGEST grid (the whole lower triangle of T; the trailing updates of the
+    # factorisation that follows cover less and less of it)
+    big = [k for k in fetch if "k_chol_update_lds<256" in k and k in write]
+    if big:
+        k = big[0]
+        gmax = max(g for _, g in fetch[k])
+        fv = [v for v, g in fetch[k] if g == gmax]; wv = [v for v, g in write[k] if g == gmax]
+        f_kib, w_kib = statistics.median(fv), statistics.median(wv)
+        res["rank_k_update_launch"] = {"kernel": k, "grid_threads": gmax, "dispatches": len(fv), "fetch_bytes_corrected": 2 * f_kib * 1024,
+                                       "write_bytes": w_kib * 1024, "traffic_bytes_per_launch": 2 * f_kib * 1024 + w_kib * 1024}
+    res["x_sparse"] = any("k_cf_T_gather" in k or "k_cf_T_sparse" in k for k in fetch)
     json.dump(res, open(dst, "w"), indent=1)
+    if "rank_k_update_launch" in res:
+        v = res["rank_k_update_launch"]
+        print(f"rank-K update launch (grid {v['grid_threads']}): fetch {v['fetch_bytes_corrected']/1e6:.2f} MB write {v['write_bytes']/1e6:.2f} MB, X sparse: {res['x_sparse']}")
     for k, v in res["kernels"].items():
         print(f"{k:60s} fetch {v['fetch_bytes_corrected']/1e6:8.2f} MB  write {v['write_bytes']/1e6:7.2f} MB  ({v['live_dispatches']}/{v['dispatches']} live)")
 
