@@ -629,7 +629,20 @@ struct CholDist {
   int rank = 0, n_ranks = 1;
   void* user = nullptr;
   int (*bcast)(void* user, double* dev, size_t count, int root) = nullptr;   // on the factorisation's stream
+  // staging buffer of chol_pack_len(n) doubles: a factored outer panel travels as ONE message holding its rows from the diagonal
+  // down (+ the right-hand side's row) and the inverses of its diagonal blocks -- half of the whole-column volume on average.
+  // Null: whole columns and the inverses in two messages.
+  double* pack = nullptr;
 };
+inline int chol_outer_panels(int n);
+inline size_t chol_pack_len(int n) { const size_t w = (size_t)chol_outer_panels(n) * kNB; return ((size_t)n + 1) * w + w * kNB; }
+// pack / unpack of rows [r0, rows) x columns [c0, c0 + w) of M (dir 0: M -> buf, 1: buf -> M); buf column-major, height rows - r0
+static __global__ __launch_bounds__(256) void k_chol_pack(double* __restrict__ M, long lda, long rows, long r0, long c0, double* __restrict__ buf, int dir) {
+  const long h = rows - r0, i = (long)blockIdx.x * 256 + threadIdx.x, cidx = blockIdx.y;
+  if (i >= h) return;
+  if (dir == 0) buf[i + cidx * h] = M[(r0 + i) + (c0 + cidx) * lda];
+  else M[(r0 + i) + (c0 + cidx) * lda] = buf[i + cidx * h];
+}
 inline int chol_outer_panels(int n) { return (n >= 8192) ? 4 : 2; }   // inner 128-panels per outer panel
 
 // C += sum over the K slices of their partial products (slice order), lower triangle only
@@ -758,9 +771,26 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
         }
         hipError_t e = hipGetLastError(); if (e != hipSuccess) return e;
       }
-      // the factored columns (whole columns: the rows above the diagonal travel along, unused) and the diagonal blocks' inverses
-      if (dist->bcast(dist->user, M + (size_t)c_begin * lda, (size_t)lda * (size_t)(c_end - c_begin), owner)) return hipErrorUnknown;
-      if (dist->bcast(dist->user, Linv_ws + (size_t)p0 * kNB * kNB, (size_t)(p1 - p0) * kNB * kNB, owner)) return hipErrorUnknown;
+      if (dist->pack) {   // one message: the panel from its diagonal down, then the diagonal blocks' inverses
+        const long h = rows - c_begin, w = c_end - c_begin;
+        const size_t n_inv = (size_t)(p1 - p0) * kNB * kNB;
+        const dim3 grid((unsigned)((h + 255) / 256), (unsigned)w);
+        if (owner == dist->rank) {
+          hipLaunchKernelGGL(k_chol_pack, grid, dim3(256), 0, st, M, lda, rows, (long)c_begin, (long)c_begin, dist->pack, 0);
+          hipError_t e = hipMemcpyAsync(dist->pack + (size_t)h * w, Linv_ws + (size_t)p0 * kNB * kNB, n_inv * sizeof(double), hipMemcpyDeviceToDevice, st);
+          if (e != hipSuccess) return e;
+        }
+        if (dist->bcast(dist->user, dist->pack, (size_t)h * w + n_inv, owner)) return hipErrorUnknown;
+        if (owner != dist->rank) {
+          hipLaunchKernelGGL(k_chol_pack, grid, dim3(256), 0, st, M, lda, rows, (long)c_begin, (long)c_begin, dist->pack, 1);
+          hipError_t e = hipMemcpyAsync(Linv_ws + (size_t)p0 * kNB * kNB, dist->pack + (size_t)h * w, n_inv * sizeof(double), hipMemcpyDeviceToDevice, st);
+          if (e != hipSuccess) return e;
+        }
+      } else {
+        // the factored columns (whole columns: the rows above the diagonal travel along, unused) and the diagonal blocks' inverses
+        if (dist->bcast(dist->user, M + (size_t)c_begin * lda, (size_t)lda * (size_t)(c_end - c_begin), owner)) return hipErrorUnknown;
+        if (dist->bcast(dist->user, Linv_ws + (size_t)p0 * kNB * kNB, (size_t)(p1 - p0) * kNB * kNB, owner)) return hipErrorUnknown;
+      }
       // this rank's later outer panels
       for (int o2 = o + 1; o2 < n_outer; ++o2) {
         if (o2 % dist->n_ranks != dist->rank) continue;

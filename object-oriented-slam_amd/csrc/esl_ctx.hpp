@@ -232,6 +232,8 @@ struct esl_ctx {
   // per-context runtime of the dense solver (esl_chol.hpp CholRuntime: look-ahead stream + events on THIS device, one-time
   // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context
   void* chol_rt = nullptr;
+  double* chol_pack = nullptr;   // staging buffer of the distributed factorisation's panel messages (esl_chol.hpp CholDist::pack)
+  size_t chol_pack_len = 0;
   bool schur_attr_set = false;
   // switches resolved ONCE when the communicator is created (every rank must take the same collective sequence for the whole
   // run; an environment read per trial could change mid-run): ESL_CHOL_DIST = 1 / 0 forces the distributed factorisation

@@ -218,6 +218,15 @@ static int slam_ensure_S(esl_ctx* c) {
 }
 
 // ---- camera-first elimination: host side (kernels and the maths: esl_cf.hpp) ---------------------------------------------
+// staging buffer of the distributed factorisation (one message per outer panel: esl_chol.hpp CholDist::pack)
+static int chol_pack_ensure(esl_ctx* c, int n) {
+  const size_t need = chol_pack_len(n);
+  if (c->chol_pack && c->chol_pack_len >= need) return ESL_OK;
+  int rc = al(&c->chol_pack, need);
+  if (rc) return rc;
+  c->chol_pack_len = need;
+  return ESL_OK;
+}
 static bool cf_applicable(const esl_ctx* c) { return c->cf_chain_ok && (!c->comm || c->comm_replicated); }
 // replicated-graph communicator (esl_comm_set_replicated): the reduced ellipsoid system's outer panels are dealt to the ranks
 static bool cf_dist(const esl_ctx* c) {
@@ -399,6 +408,8 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
       CholDist d;
       d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
       d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
+      if ((rc = chol_pack_ensure(c, n_o))) return rc;
+      d.pack = c->chol_pack;
       ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt, &d));
     } else {
       ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
@@ -582,6 +593,8 @@ int slam_try_step(esl_ctx* c, double lambda) {
       CholDist d;
       d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
       d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
+      { const int rcp = chol_pack_ensure(c, (int)c->S_n); if (rcp) return rcp; }
+      d.pack = c->chol_pack;
       ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, chol_rt(c), &d));
     } else {
       ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, chol_rt(c)));

@@ -1,7 +1,7 @@
 # round 3, GPU batch 5: X kept sparse in the camera-first elimination -- parity of the sparse form, C4 timing, kernel trace
 R=gpurun_out/${1:-r3j}; mkdir -p $R
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_slam.py tests/test_gpu_sharded.py -m gpu -q -s -x -k "sparse_interior or nested_dissection or applicab or selftest or replicated" > $R/tests_sparse.log 2>&1; echo rc=$? >> $R/tests_sparse.log
+timeout 600 python -m pytest tests/test_gpu_slam.py tests/test_gpu_sharded.py -m gpu -q -s -x -k "sparse_interior or nested_dissection or applicab or replicated or distributed or sharded" > $R/tests_sparse.log 2>&1; echo rc=$? >> $R/tests_sparse.log
 timeout 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -s -k slam > $R/tests_c4.log 2>&1; echo rc=$? >> $R/tests_c4.log
 timeout 600 python bench.py --config C4 --solver ellipsoid --no-extras --no-cpu-baseline --steps 3 --warmup 1 > $R/c4_ellipsoid.json 2> $R/c4_ellipsoid.err
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$R/prof_c4 -- python $GRAFT_REPO_ROOT/bench.py --config C4 --solver ellipsoid --no-extras --no-cpu-baseline --steps 1 --warmup 0 > $GRAFT_REPO_ROOT/$R/prof_c4.log 2>&1)
