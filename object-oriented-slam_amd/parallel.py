@@ -114,7 +114,8 @@ class ShardedSlamLM:
       trial       every rank: partial reduced camera system  S_r = - sum_{o in shard} W_o (Hoo_o + lambda I)^-1 W_o^T
                   (+ on rank 0: the summed Hcc + lambda I and the odometry off-diagonal blocks), b_s likewise
                   the outer panels (`panel` columns) are dealt cyclically: REDUCE of panel p to its owner p mod R [1 per panel]
-                  right-looking loop: the owner factors its panel, BROADCAST of the factored columns        [1 per panel]
+                  right-looking loop: the owner factors its panel, BROADCAST of ONE packed message -- the panel's rows
+                  from its diagonal down + the inverse of its diagonal block                                  [1 per panel]
                   every rank applies the rank-`panel` update to ITS OWN later panels only
                   back-substitution replicated: all ranks hold the whole factor -> bit-identical x_c everywhere
                   x_o local; ALL-GATHER of {chi2, scale, ok}, reduced in rank order -> identical decisions  [1 collective]
@@ -218,8 +219,12 @@ class ShardedSlamLM:
                     L11 = np.eye(c1 - c0)
                 M[c0:c1, c0:c1] = L11
                 M[c1:, c0:c1] = np.linalg.solve(L11, M[c1:, c0:c1].T).T
-            if self.dfac:
-                M[:, c0:c1] = self._bcast(M[:, c0:c1], src=owner)
+            if self.dfac:      # ONE packed message: the panel's rows from its diagonal down (+ the rhs row), then the inverse of its diagonal block
+                w = c1 - c0
+                Linv = np.linalg.inv(M[c0:c1, c0:c1]) if owner == self.rank else np.zeros((w, w))
+                msg = self._bcast(np.concatenate([M[c0:, c0:c1].ravel(), Linv.ravel()]), src=owner)
+                M[c0:, c0:c1] = msg[:(nc + 1 - c0) * w].reshape(nc + 1 - c0, w)
+                self.last_Linv = msg[(nc + 1 - c0) * w:].reshape(w, w)       # (csrc: the back-substitution's Linv blocks)
             for q in range(p + 1, n_pan):            # trailing update: own later panels only (all of them when replicated)
                 if self.dfac and q % self.world != self.rank:
                     continue
@@ -275,3 +280,74 @@ class ShardedSlamLM:
                     ok_outer = False; rep["stop_reason"] = 2
         rep["iterations"] = it; rep["chi2_final"] = cur; rep["lambda_final"] = lam
         return rep
+
+
+class ReplicatedSlamLM(ShardedSlamLM):
+    """SLAM mode with the REPLICATED graph (esl_comm_set_replicated, csrc/esl_slam.hip): every rank holds the whole graph and
+    linearises it (bit-identically, nothing is summed over ranks); the cameras are eliminated first -- A = Hcc + lambda I is block
+    tridiagonal along the odometry chain, X = L^-1 [W | b_c] -- and the ranks divide the reduced ELLIPSOID system
+    T = D - X^T X by outer panels: a rank forms only the columns of ITS panels, the owner factors a panel and broadcasts one packed
+    message (rows from the diagonal down + the inverse of the diagonal block), every rank updates its own later panels, the
+    back-substitution is replicated; the pivot flag is all-reduced (one double) so that every rank rejects the same trials.
+    Per trial: one broadcast per panel + one all-reduce.  `engine` as for ShardedSlamLM, over the WHOLE graph."""
+
+    def _linearize(self):
+        import numpy as np
+        H, b, chi2 = self.e.linearize()
+        nc = 6 * self.e.n_free_cams
+        self.sys = dict(H=H, b=b, nc=nc)
+        return chi2, float(np.abs(np.diag(H)).max())
+
+    def _gather(self, vals):       # nothing to gather: every rank holds every term
+        return [list(vals)]
+
+    def _solve(self, lam):
+        import numpy as np
+        s = self.sys
+        H, b, nc = s["H"], s["b"], s["nc"]
+        no = H.shape[0] - nc
+        ok = 1.0
+        A = H[:nc, :nc] + lam * np.eye(nc)
+        try:
+            L = np.linalg.cholesky(A)                         # (csrc: the block-bidiagonal chain + its dissection; same factor)
+        except np.linalg.LinAlgError:
+            ok, L = 0.0, np.eye(nc)
+        X = np.linalg.solve(L, H[:nc, nc:])                  # nc x no
+        y = np.linalg.solve(L, b[:nc])
+        D = H[nc:, nc:] + lam * np.eye(no)
+        P = self.panel
+        n_pan = (no + P - 1) // P
+        M = np.zeros((no + 1, no))                            # lower triangle of T, the rhs row rides along
+        for p in range(n_pan):                                # this rank's panels only
+            if p % self.world != self.rank:
+                continue
+            c0, c1 = p * P, min((p + 1) * P, no)
+            M[c0:no, c0:c1] = D[c0:, c0:c1] - X[:, c0:].T @ X[:, c0:c1]
+            M[no, c0:c1] = b[nc + c0:nc + c1] - X[:, c0:c1].T @ y
+        for p in range(n_pan):
+            c0, c1 = p * P, min((p + 1) * P, no)
+            w, owner = c1 - c0, p % self.world
+            if owner == self.rank:
+                try:
+                    L11 = np.linalg.cholesky(M[c0:c1, c0:c1])
+                except np.linalg.LinAlgError:
+                    ok, L11 = 0.0, np.eye(w)
+                M[c0:c1, c0:c1] = L11
+                M[c1:, c0:c1] = np.linalg.solve(L11, M[c1:, c0:c1].T).T
+                Linv = np.linalg.inv(L11)
+            else:
+                Linv = np.zeros((w, w))
+            msg = self._bcast(np.concatenate([M[c0:, c0:c1].ravel(), Linv.ravel()]), src=owner)
+            M[c0:, c0:c1] = msg[:(no + 1 - c0) * w].reshape(no + 1 - c0, w)
+            for q in range(p + 1, n_pan):                     # own later panels only
+                if q % self.world != self.rank:
+                    continue
+                d0, d1 = q * P, min((q + 1) * P, no)
+                M[d0:, d0:d1] -= M[d0:, c0:c1] @ M[d0:d1, c0:c1].T
+        ok = 1.0 if float(self._allreduce(np.array([1.0 - ok]))[0]) < 0.5 else 0.0     # a non-positive pivot anywhere rejects the trial everywhere
+        Lt = np.tril(M[:no, :no])
+        xo = np.linalg.solve(Lt.T, M[no, :no]) if no else np.zeros(0)
+        xc = np.linalg.solve(L.T, y - X @ xo) if nc else np.zeros(0)
+        scale = float(xo @ (lam * xo + b[nc:])) + float(xc @ (lam * xc + b[:nc]))
+        return xc, xo, scale, ok
+

@@ -146,4 +146,71 @@ def test_sharded_slam_world2_matches_unsharded(pkg, po, dfac):
         owners = [int(name.split("->")[1]) for name, _ in log0 if name.startswith("reduce")]
         assert owners[:n_pan] == [p % world for p in range(n_pan)]              # panels dealt cyclically
         sizes = [n for name, n in log0 if name.startswith("broadcast")][:n_pan]
-        assert sizes == [(nc + 1) * min(12, nc - 12 * p) for p in range(n_pan)]  # whole columns + the rhs row travel
+        # one packed message per panel: its rows from the diagonal down + the rhs row, then the inverse of its diagonal block
+        assert sizes == [(nc + 1 - 12 * p) * min(12, nc - 12 * p) + min(12, nc - 12 * p) ** 2 for p in range(n_pan)]
+
+
+def _worker_replicated(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("object-oriented-slam_amd")
+        par = importlib.import_module("object-oriented-slam_amd.parallel")
+        from oracle import pyoracle as po
+        g, c, o, _ = pkg.synth.make_graph(14, 6, 120, seed=23, slam=True)
+        eng = OracleSlamShardEngine(po, pkg, g, c, o)          # the WHOLE graph on every rank
+        lm = par.ReplicatedSlamLM(eng, dist, panel=18)
+        rep = lm.optimize(pkg.default_lm_params(numeric_delta=1e-6, max_iters=4))
+        q.put((rank, eng.cams.tolist(), eng.objs.tolist(), rep, lm.log, [x.tolist() for x in lm.xc_log]))
+    except Exception:   # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicated_slam_world2_divides_the_dense_solve(pkg, po):
+    """The N > 1 default of SLAM mode (esl_comm_set_replicated) restated over gloo: every rank holds the whole graph,
+    the cameras are eliminated first, the ranks divide the reduced ELLIPSOID system by outer panels (own panels assembled, owner
+    factors + one packed broadcast per panel, own later panels updated, replicated back-substitution), the pivot flag is
+    all-reduced.  Asserted: the run IS the dense checker's LM run; both ranks end with the same bits; the collective sequence is
+    one broadcast per panel with the expected owners and message sizes + one all-reduce of one double per trial, nothing else."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_replicated, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    for _ in range(world):
+        r = q.get(timeout=180)
+        if len(r) == 3 and r[1] == "error":
+            for p in procs:
+                p.kill()
+            pytest.fail("rank %d: %s" % (r[0], r[2]))
+        results.append(r)
+    results.sort(key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g, c, o, _ = pkg.synth.make_graph(14, 6, 120, seed=23, slam=True)
+    params = pkg.default_lm_params(numeric_delta=1e-6, max_iters=4)
+    co, oo, ro = po.optimize(g, c, o, params, solver=po.ORACLE_DENSE)
+    (_, cams0, objs0, rep0, log0, xc0), (_, cams1, objs1, rep1, log1, xc1) = results
+    assert rep0["trace_trials"] == ro["trace_trials"]
+    np.testing.assert_allclose(rep0["trace_chi2"], ro["trace_chi2"], rtol=1e-5)
+    np.testing.assert_allclose(np.asarray(cams0), co, atol=1e-4)
+    np.testing.assert_allclose(np.asarray(objs0), oo, atol=1e-4)
+    assert rep0 == rep1 and cams0 == cams1 and objs0 == objs1 and xc0 == xc1     # the same bits on both ranks
+    assert log0 == log1
+    no = 9 * 6
+    n_pan = (no + 17) // 18
+    assert len(log0) == rep0["total_trials"] * (n_pan + 1)                       # nothing per linearisation, no scalar gather
+    per = log0[:n_pan + 1]
+    assert [name for name, _ in per] == ["broadcast<-%d" % (p % world) for p in range(n_pan)] + ["all_reduce"]
+    assert [n for _, n in per] == [(no + 1 - 18 * p) * min(18, no - 18 * p) + min(18, no - 18 * p) ** 2 for p in range(n_pan)] + [1]
+
