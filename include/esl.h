@@ -118,8 +118,11 @@ typedef enum {
   /* Cameras first (round 3): in the reference's SLAM branch the camera block is block TRIDIAGONAL (odometry edges join
    * consecutive frames only, Optimizer.cpp:142-158), so it has a block-bidiagonal Cholesky factor L; the reduced system
    * T = (Hoo + lambda I) - (L^-1 W)^T (L^-1 W) over the ELLIPSOIDS (order 9 N) is formed with an FP64-MFMA rank-6(F-1) update and
-   * factored densely.  (9N)^2 6F + (9N)^3/3 flops instead of (6F)^3/3 (C4: 2.1e13 vs 7.2e13).  Needs every odometry edge to join
-   * two free cameras that are neighbours in free-camera order, and a single-GPU run; ESL_ERR_INVALID otherwise. */
+   * factored densely.  (9N)^2 6F + (9N)^3/3 flops instead of (6F)^3/3 (C4: 2.1e13 vs 7.2e13); for long chains the camera chain is
+   * dissected into 16-camera segments and X = L^-1 W kept sparse (per-segment MFMA products, the dense update only for the
+   * separator cameras' rows: C4 3.3e12 flops; esl_lm_solver_stats reports the shape).  Needs every odometry edge to join two free
+   * cameras that are neighbours in free-camera order, and either one GPU or the replicated-graph communicator
+   * (esl_comm_set_replicated); ESL_ERR_INVALID otherwise. */
   ESL_SOLVER_REDUCED_ELLIPSOID = 2
 } esl_linear_solver;
 

@@ -13,13 +13,21 @@
 //     T = D - X^T X,  t = b_o - X^T y   rank-6(F-1) update on the FP64 matrix cores (k_chol_update_lds, external factor)
 //     T x_o = t                         dense FP64-MFMA Cholesky of order 9 N (esl_chol.hpp)
 //     x_c = L^-T (y - X x_o)            k_cf_z, k_cf_tridiag_back
-// Flops per LM trial: (9N)^2 6F + (9N)^3 / 3 instead of (6F)^3 / 3 -- C4: 2.1e13 instead of 7.2e13, C3: 6.4e8 instead of 8.9e9;
-// memory: X 8.6 GB + T 2.6 GB instead of S 28.8 GB.  Same x up to rounding (it is the same linear system), so every parity
+// Flops per LM trial with X dense: (9N)^2 6F + (9N)^3 / 3 instead of (6F)^3 / 3 -- C4: 2.1e13 instead of 7.2e13, C3: 6.4e8 instead of
+// 8.9e9; memory: X 8.6 GB + T 2.6 GB instead of S 28.8 GB.  Same x up to rounding (it is the same linear system), so every parity
 // test of SLAM mode applies unchanged.  Positive-definiteness ("ok" of LinearSolverDense, solvers/linear_solver_dense.h:107-112)
 // = all pivots of A and of T positive.
 //
-// Applicable when every odometry edge joins two cameras whose free-camera slots differ by one (the reference's chain) and the run
-// is not sharded; esl_lm_params::linear_solver selects (include/esl.h).
+// Two refinements (both further down in this file), each the same factorisation in another order:
+//   nested dissection of the camera chain  every stride-th camera a separator, the segments between them factored / substituted in
+//                                          parallel: serial length F -> stride + F / stride;
+//   X kept sparse                          (long chains, large T: C4) stride 16, the interior rows of X as compact per-segment
+//                                          slabs, T assembled from per-segment MFMA products, the dense MFMA update only for the
+//                                          separators' 6 F / 16 rows: C4 3.3e12 flops per trial instead of 2.1e13.
+//
+// Applicable when every odometry edge joins two cameras whose free-camera slots differ by one (the reference's chain); across GPUs
+// with the replicated-graph communicator (esl_comm_set_replicated: the ranks divide T by outer panels); esl_lm_params::linear_solver
+// selects (include/esl.h).
 #pragma once
 #include "esl_kernels_map.hpp"
 
