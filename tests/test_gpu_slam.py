@@ -342,3 +342,68 @@ def test_sparse_interior_rows_equal_dense_rows(pkg, monkeypatch, n_cams, n_objs,
         assert rep["trace_trials"] == ref[6]["trace_trials"]
         np.testing.assert_allclose(rep["trace_chi2"], ref[6]["trace_chi2"], rtol=1e-11)
         assert cam_err(cc, ref[4]) < 1e-9 and obj_rel(oo, ref[5]) < 1e-9
+
+
+def test_sparse_interior_rows_on_awkward_structures(pkg, monkeypatch):
+    """The sparse form's tables on structures a synthetic trajectory does not produce: an ellipsoid seen only by SEPARATOR cameras (in
+    no segment's list: its column of X lives in the separators' rows alone), one seen only by the fixed camera 0 (no column of X at
+    all), one seen inside a single segment, a segment none of whose interior cameras sees anything (an empty slab), and the last
+    segment short.  Stored products (=1) and blocks straight from the slabs (=2) against dense X and the reduced camera system."""
+    g0, c, o, _ = pkg.synth.make_graph(330, 14, 3300, seed=43, slam=True)
+
+    def keep(cam, obj):
+        k = np.ones(len(cam), bool)
+        k &= ~((obj == 0) & ~((cam % 16 == 0) & (cam > 0)))          # ellipsoid 0: separator cameras only (slot = cam - 1, separators at slot % 16 == 15)
+        k &= ~((obj == 1) & (cam != 0))                              # ellipsoid 1: the fixed camera only
+        k &= ~((obj == 2) & ~((cam >= 17) & (cam <= 30)))            # ellipsoid 2: inside segment 1
+        k &= ~((cam >= 81) & (cam <= 95))                            # segment 5: no interior observation
+        return k
+    kb, k3 = keep(g0.bbox_cam, g0.bbox_obj), keep(g0.e3d_cam, g0.e3d_obj)
+    # make sure the special ellipsoids still have what they need
+    extra_cam = np.array([16, 32, 48, 0, 0, 20, 25], np.int32); extra_obj = np.array([0, 0, 0, 1, 1, 2, 2], np.int32)
+    bb, _, _ = pkg.synth.project_bboxes(c, o, g0.K, extra_cam, extra_obj)
+    okb = np.isfinite(bb).all(1)
+    g = pkg.Graph(g0.K, g0.n_cams, g0.n_objs, g0.cam_fixed,
+                  np.concatenate([g0.bbox_cam[kb], extra_cam[okb]]), np.concatenate([g0.bbox_obj[kb], extra_obj[okb]]),
+                  np.concatenate([g0.bbox_meas.reshape(-1, 4)[kb], bb[okb]]), np.concatenate([g0.bbox_weight[kb], np.full(okb.sum(), 0.7)]),
+                  g0.e3d_cam[k3], g0.e3d_obj[k3], g0.e3d_meas.reshape(-1, 10)[k3], g0.e3d_weight[k3],
+                  g0.grav_obj, g0.grav_normal, g0.grav_weight, g0.odom_i, g0.odom_j, g0.odom_meas, g0.odom_info)
+    cams_of = lambda ob: set(np.concatenate([g.bbox_cam[g.bbox_obj == ob], g.e3d_cam[g.e3d_obj == ob]]).tolist())
+    assert cams_of(0) and all(cm % 16 == 0 and cm > 0 for cm in cams_of(0)) and cams_of(1) == {0} and cams_of(2) <= set(range(17, 31))
+    assert not (set(range(81, 96)) & set(np.concatenate([g.bbox_cam, g.e3d_cam]).tolist()))
+    nf = g.n_cams - 1
+    out = {}
+    for tag, env, solver in (("stored", "1", 2), ("direct", "2", 2), ("dense", "0", 2), ("camera", None, 1)):
+        if env:
+            monkeypatch.setenv("ESL_CF_SPARSE", env)
+        else:
+            monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
+        cx = pkg.Context(0)
+        try:
+            cx.upload_graph(g); cx.upload_states(c, o)
+            cx.lm_begin(pkg.default_lm_params(jacobian_mode=1, linear_solver=solver))
+            part = cx.lm_linearize()
+            tr = cx.lm_try_step(1e-5 * part.max_diag)
+            assert cx.lm_solver_used() == solver
+            st = cx.lm_solver_stats()
+            xc, xo = cx.lm_download(5, 6 * nf), cx.lm_download(2, 9 * g.n_objs)
+            res = cx.lm_reduced_residual() if tr.solve_ok == 1 else float("nan")
+            cx.lm_commit(False)
+            cc, oo, rep = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1, linear_solver=solver))
+            out[tag] = (xc, xo, tr.chi2, tr.solve_ok, res, cc, oo, rep, st)
+        finally:
+            cx.close()
+    monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
+    assert out["stored"][8]["x_form"] == 1 and out["direct"][8]["x_form"] == 2 and out["dense"][8]["x_form"] == 0
+    assert out["stored"][8]["separators"] == nf // 16 and out["stored"][8]["segments"] == (nf + 15) // 16
+    ref = out["dense"]
+    for tag in ("stored", "direct", "camera"):
+        xc, xo, chi, ok, res, cc, oo, rep, _ = out[tag]
+        assert ok == ref[3]
+        d_xc = float(np.abs(xc - ref[0]).max() / np.abs(ref[0]).max()); d_xo = float(np.abs(xo - ref[1]).max() / np.abs(ref[1]).max())
+        print("awkward structures, %s vs dense X: x_c %.2e x_o %.2e, |Sx-b|/|b| %.2e, run: chi2 rel %.2e cams %.2e" % (
+            tag, d_xc, d_xo, res, abs(rep["chi2_final"] / ref[7]["chi2_final"] - 1), cam_err(cc, ref[5])))
+        assert d_xc < 1e-9 and d_xo < 1e-9 and chi == pytest.approx(ref[2], rel=1e-11)
+        assert rep["trace_trials"] == ref[7]["trace_trials"]
+        np.testing.assert_allclose(rep["trace_chi2"], ref[7]["trace_chi2"], rtol=1e-10)
+        assert cam_err(cc, ref[5]) < 1e-8 and obj_rel(oo, ref[6]) < 1e-8
