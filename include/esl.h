@@ -284,7 +284,8 @@ int esl_comm_init_host(esl_ctx* ctx, int32_t n_ranks, int32_t rank, esl_host_all
  * decisions by construction); the ranks divide the DENSE SOLVE of SLAM mode: the outer panels (512 columns) of the reduced system
  * are dealt cyclically, a rank forms only its own panels (camera-first elimination: its share of the rank-6(F-1) MFMA update;
  * reduced camera system: built everywhere, factored distributed), the owner factors a panel and ncclBroadcasts it, every rank
- * updates its own later panels, the back-substitution runs replicated -- all ranks end with bit-identical states.  This is the
+ * updates its own later panels (the broadcasts run on their own stream under those updates; ESL_CHOL_DIST_OVERLAP=0 puts them
+ * back on the compute stream), the back-substitution runs replicated -- all ranks end with bit-identical states.  This is the
  * multi-GPU form of ESL_SOLVER_REDUCED_ELLIPSOID (the sharded form below sums shard contributions and uses the reduced camera
  * system).  Mapping-mode runs on such a communicator are simply replicated. */
 int esl_comm_set_replicated(esl_ctx* ctx, int replicated);

@@ -266,7 +266,7 @@ static void free_graph(esl_ctx* c) {
   dev_free(&c->cf_MS); dev_free(&c->cf_NS); dev_free(&c->cf_R);
   dev_free(&c->cf_seg_start); dev_free(&c->cf_seg_obj); dev_free(&c->cf_seg_first); dev_free(&c->cf_cmap); dev_free(&c->cf_xld); dev_free(&c->cf_fwork);
   dev_free(&c->cf_mask); dev_free(&c->cf_xoff); dev_free(&c->cf_Xc); dev_free(&c->cf_Xs);
-  dev_free(&c->chol_pack); c->chol_pack_len = 0;
+  dev_free(&c->chol_pack); dev_free(&c->chol_pack2); c->chol_pack_len = 0;
   dev_free(&c->cf_boff); dev_free(&c->cf_roff); dev_free(&c->cf_twork); dev_free(&c->cf_P); dev_free(&c->cf_Prhs);
   c->cf_sp_built = c->cf_sparse = false;
   c->cf_chain_ok = false;

@@ -633,6 +633,11 @@ struct CholDist {
   // down (+ the right-hand side's row) and the inverses of its diagonal blocks -- half of the whole-column volume on average.
   // Null: whole columns and the inverses in two messages.
   double* pack = nullptr;
+  // OVERLAPPED form (round 3): a second staging buffer and a broadcast that takes the stream to run on.  The messages then travel
+  // on their own stream: the owner of panel o + 1 brings it up to date with panel o FIRST, factors and packs it, and its message is
+  // on the wire while every rank is still applying panel o to the rest of its panels (the single-GPU look-ahead carried over).
+  double* pack2 = nullptr;
+  int (*bcast_on)(void* user, double* dev, size_t count, int root, hipStream_t stream) = nullptr;
 };
 inline int chol_outer_panels(int n);
 inline size_t chol_pack_len(int n) { const size_t w = (size_t)chol_outer_panels(n) * kNB; return ((size_t)n + 1) * w + w * kNB; }
@@ -701,12 +706,20 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
 struct CholRuntime {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ev_panel, ev_trail;
+  hipStream_t comm = nullptr;                               // the distributed factorisation's message stream
+  hipEvent_t ev_begin = nullptr;                            // everything the caller's stream held when the factorisation began
+  std::vector<hipEvent_t> ev_packed, ev_recv, ev_unpacked;  // per outer panel: message staged / received / copied out of its staging buffer
   bool attr_set = false;
   void release() {
     for (hipEvent_t e : ev_panel) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_trail) (void)hipEventDestroy(e);
-    ev_panel.clear(); ev_trail.clear();
+    for (hipEvent_t e : ev_packed) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_recv) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_unpacked) (void)hipEventDestroy(e);
+    ev_panel.clear(); ev_trail.clear(); ev_packed.clear(); ev_recv.clear(); ev_unpacked.clear();
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
+    if (comm) { (void)hipStreamDestroy(comm); comm = nullptr; }
+    if (ev_begin) { (void)hipEventDestroy(ev_begin); ev_begin = nullptr; }
     attr_set = false;
   }
 };
@@ -755,7 +768,86 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   // below ~8k unknowns the chain of single-workgroup potrf launches is the critical path whatever runs beside it (measured:
   // n = 2994 4.55 ms without, 4.75 ms with look-ahead), from 16k on it buys 12-15 %
   const bool lookahead = n >= 8192;
-  if (dist && dist->n_ranks > 1) {
+  if (dist && dist->n_ranks > 1 && dist->pack && dist->pack2 && dist->bcast_on) {
+    // ---- distributed, messages overlapped with the trailing updates --------------------------------------------------------------
+    // Streams: st (the caller's: all arithmetic), rt.comm (the broadcasts, in panel order -- the same order on every rank).
+    // Buffers: panel o travels in pack (o even) / pack2 (o odd).  Events per panel o: ev_packed (owner: factored + staged, on st),
+    // ev_recv (message complete, on comm), ev_unpacked (non-owners: copied out into M / Linv_ws, on st).  Ordering that keeps the two
+    // buffers safe: the broadcast of panel o waits for ev_packed[o] on the owner and for ev_unpacked[o - 2] on the others (the last
+    // reader of that buffer); the owner stages panel o on st after st has waited for ev_recv[o - 1], and comm runs in order, so the
+    // broadcast of panel o - 2 (the last sender from that buffer) is over by then.
+    // Every panel still receives the updates of panels 0, 1, 2, .. in that order: same bits as the form below.
+    const int R = dist->n_ranks, me = dist->rank;
+    if (!rt.comm) { hipError_t e = hipStreamCreateWithFlags(&rt.comm, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+    if (!rt.ev_begin) { hipError_t e = hipEventCreateWithFlags(&rt.ev_begin, hipEventDisableTiming); if (e != hipSuccess) return e; }
+    {   // the message stream starts behind everything the caller's stream already holds (its earlier collectives on this communicator
+        // among it: two collectives of one communicator must not run side by side)
+      hipError_t e = hipEventRecord(rt.ev_begin, st); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(rt.comm, rt.ev_begin, 0); if (e != hipSuccess) return e;
+    }
+    while ((int)rt.ev_packed.size() < n_outer) {
+      hipEvent_t a, b, c3;
+      hipError_t e = hipEventCreateWithFlags(&a, hipEventDisableTiming); if (e != hipSuccess) return e;
+      e = hipEventCreateWithFlags(&b, hipEventDisableTiming); if (e != hipSuccess) return e;
+      e = hipEventCreateWithFlags(&c3, hipEventDisableTiming); if (e != hipSuccess) return e;
+      rt.ev_packed.push_back(a); rt.ev_recv.push_back(b); rt.ev_unpacked.push_back(c3);
+    }
+    struct Geo { int p0, p1, c_begin, c_end; long h, w; size_t n_inv; double* buf; };
+    auto geo = [&](int o) {
+      Geo g;
+      g.p0 = o * W; g.p1 = (g.p0 + W < np) ? g.p0 + W : np;
+      g.c_begin = g.p0 * kNB; g.c_end = (g.p1 * kNB < n) ? g.p1 * kNB : n;
+      g.h = rows - g.c_begin; g.w = g.c_end - g.c_begin; g.n_inv = (size_t)(g.p1 - g.p0) * kNB * kNB;
+      g.buf = (o & 1) ? dist->pack2 : dist->pack;
+      return g;
+    };
+    auto factor_and_stage = [&](int o) -> hipError_t {   // this rank owns panel o; everything on st
+      const Geo g = geo(o);
+      for (int p = g.p0; p < g.p1; ++p) {
+        const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+        double* Linv = Linv_ws + (size_t)p * kNB * kNB;
+        hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
+        const long below = rows - (k0 + nb);
+        if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb, Linv);
+        if (p + 1 < g.p1) launch_update(st, k0, nb, (long)k0 + nb, (long)g.c_end);
+      }
+      hipLaunchKernelGGL(k_chol_pack, dim3((unsigned)((g.h + 255) / 256), (unsigned)g.w), dim3(256), 0, st, M, lda, rows, (long)g.c_begin, (long)g.c_begin, g.buf, 0);
+      hipError_t e = hipMemcpyAsync(g.buf + (size_t)g.h * g.w, Linv_ws + (size_t)g.p0 * kNB * kNB, g.n_inv * sizeof(double), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return e;
+      e = hipGetLastError(); if (e != hipSuccess) return e;
+      return hipEventRecord(rt.ev_packed[o], st);
+    };
+    auto update_with = [&](int o, int o2) {   // panel o2 -= (its rows of panel o) (panel o's rows of panel o2's columns)^T
+      const Geo g = geo(o), q = geo(o2);
+      launch_update(st, g.c_begin, g.c_end - g.c_begin, (long)q.c_begin, (long)q.c_end);
+    };
+    if (0 % R == me) { hipError_t e = factor_and_stage(0); if (e != hipSuccess) return e; }
+    for (int o = 0; o < n_outer; ++o) {
+      const int owner = o % R;
+      const Geo g = geo(o);
+      hipError_t e;
+      if (owner == me) e = hipStreamWaitEvent(rt.comm, rt.ev_packed[o], 0);
+      else e = (o >= 2) ? hipStreamWaitEvent(rt.comm, rt.ev_unpacked[o - 2], 0) : hipSuccess;
+      if (e != hipSuccess) return e;
+      if (dist->bcast_on(dist->user, g.buf, (size_t)g.h * g.w + g.n_inv, owner, rt.comm)) return hipErrorUnknown;
+      e = hipEventRecord(rt.ev_recv[o], rt.comm); if (e != hipSuccess) return e;
+      e = hipStreamWaitEvent(st, rt.ev_recv[o], 0); if (e != hipSuccess) return e;
+      if (owner != me) {
+        hipLaunchKernelGGL(k_chol_pack, dim3((unsigned)((g.h + 255) / 256), (unsigned)g.w), dim3(256), 0, st, M, lda, rows, (long)g.c_begin, (long)g.c_begin, g.buf, 1);
+        e = hipMemcpyAsync(Linv_ws + (size_t)g.p0 * kNB * kNB, g.buf + (size_t)g.h * g.w, g.n_inv * sizeof(double), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+      }
+      e = hipEventRecord(rt.ev_unpacked[o], st); if (e != hipSuccess) return e;
+      // look-ahead: the next panel, if it is this rank's, before anything else
+      const bool next_mine = o + 1 < n_outer && (o + 1) % R == me;
+      if (next_mine) {
+        update_with(o, o + 1);
+        e = factor_and_stage(o + 1); if (e != hipSuccess) return e;
+      }
+      for (int o2 = o + 1 + (next_mine ? 1 : 0); o2 < n_outer; ++o2)
+        if (o2 % R == me) update_with(o, o2);
+    }
+  } else if (dist && dist->n_ranks > 1) {
     for (int o = 0; o < n_outer; ++o) {
       const int owner = o % dist->n_ranks;
       const int p0 = o * W, p1 = (p0 + W < np) ? p0 + W : np;

@@ -58,6 +58,8 @@ namespace esl {
 static void resolve_switches(esl_ctx* c) {
   const char* e = std::getenv("ESL_CHOL_DIST");
   c->sw_chol_dist = e ? (e[0] == '1' ? 1 : 0) : -1;
+  const char* ov = std::getenv("ESL_CHOL_DIST_OVERLAP");   // 0: the panels' messages on the compute stream, one after the other (A/B)
+  c->sw_chol_overlap = !(ov && ov[0] == '0');
 }
 // host-staged transport (esl_comm_init_host): the caller's callback sums a host buffer over the ranks
 static int host_fail(int rc) {
@@ -96,23 +98,24 @@ int comm_gather_scalars_device(esl_ctx* c) {
   if (rc != 0) return nccl_fail(rc, "ncclAllGather");
   return ESL_OK;
 }
-int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count) {
+int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count, hipStream_t st) {
   if (!c->comm || count == 0) return ESL_OK;
+  if (!st) st = c->stream;
   if (c->host_allreduce) {
     constexpr size_t kStage = (size_t)8 << 20;   // doubles per staging chunk (64 MiB pinned)
     if (!c->host_stage) ESL_HIP_TRY(hipHostMalloc((void**)&c->host_stage, kStage * sizeof(double), hipHostMallocDefault));
     for (size_t off = 0; off < count; off += kStage) {
       const size_t m = count - off < kStage ? count - off : kStage;
-      ESL_HIP_TRY(hipMemcpyAsync(c->host_stage, dev_buf + off, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+      ESL_HIP_TRY(hipMemcpyAsync(c->host_stage, dev_buf + off, m * sizeof(double), hipMemcpyDeviceToHost, st));
+      ESL_HIP_TRY(hipStreamSynchronize(st));
       const int rc = c->host_allreduce(c->host_user, c->host_stage, (int64_t)m);
       if (rc) return host_fail(rc);
-      ESL_HIP_TRY(hipMemcpyAsync(dev_buf + off, c->host_stage, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+      ESL_HIP_TRY(hipMemcpyAsync(dev_buf + off, c->host_stage, m * sizeof(double), hipMemcpyHostToDevice, st));
+      ESL_HIP_TRY(hipStreamSynchronize(st));
     }
     return ESL_OK;
   }
-  const int rc = g_rccl.allreduce(dev_buf, dev_buf, count, kNcclDouble, /*ncclSum*/ 0, c->comm, c->stream);
+  const int rc = g_rccl.allreduce(dev_buf, dev_buf, count, kNcclDouble, /*ncclSum*/ 0, c->comm, st);
   if (rc != 0) return nccl_fail(rc, "ncclAllReduce");
   return ESL_OK;
 }
@@ -129,16 +132,17 @@ int comm_reduce_sum_root(esl_ctx* c, double* dev_buf, size_t count, int root) {
 static __global__ void k_zero_fill(double* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
 }
-int comm_bcast(esl_ctx* c, double* dev_buf, size_t count, int root) {
+int comm_bcast(esl_ctx* c, double* dev_buf, size_t count, int root, hipStream_t st) {   // st: the stream to run on (null: the context's)
   if (!c->comm || count == 0) return ESL_OK;
+  if (!st) st = c->stream;
   if (c->host_allreduce || !g_rccl.bcast) {
     if (c->comm_rank != root) {
-      hipLaunchKernelGGL(k_zero_fill, dim3(256), dim3(256), 0, c->stream, dev_buf, count);
+      hipLaunchKernelGGL(k_zero_fill, dim3(256), dim3(256), 0, st, dev_buf, count);
       ESL_HIP_TRY(hipGetLastError());
     }
-    return comm_allreduce_sum(c, dev_buf, count);
+    return comm_allreduce_sum(c, dev_buf, count, st);
   }
-  const int rc = g_rccl.bcast(dev_buf, dev_buf, count, kNcclDouble, root, c->comm, c->stream);
+  const int rc = g_rccl.bcast(dev_buf, dev_buf, count, kNcclDouble, root, c->comm, st);
   if (rc != 0) return nccl_fail(rc, "ncclBroadcast");
   return ESL_OK;
 }

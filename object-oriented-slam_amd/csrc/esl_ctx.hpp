@@ -90,9 +90,9 @@ void plane_release(esl_ctx* c);
 // all-gather the 8-double dev_scal block of every rank into c->dev_gather (device), ordered on the context's stream
 int comm_gather_scalars_device(esl_ctx* c);
 // SLAM mode: in-place sum over ranks of a device buffer (RCCL all-reduce); no-op without a communicator
-int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count);
+int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count, hipStream_t st = nullptr);
 int comm_reduce_sum_root(esl_ctx* c, double* dev_buf, size_t count, int root);   // sum over the ranks, delivered to root
-int comm_bcast(esl_ctx* c, double* dev_buf, size_t count, int root);
+int comm_bcast(esl_ctx* c, double* dev_buf, size_t count, int root, hipStream_t st = nullptr);
 // {sum, max, sum, min} of 4 device scalars over ranks -> host
 int comm_reduce4(esl_ctx* c, const double* dev_src4, double out[4]);
 }  // namespace esl
@@ -232,11 +232,12 @@ struct esl_ctx {
   // per-context runtime of the dense solver (esl_chol.hpp CholRuntime: look-ahead stream + events on THIS device, one-time
   // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context
   void* chol_rt = nullptr;
-  double* chol_pack = nullptr;   // staging buffer of the distributed factorisation's panel messages (esl_chol.hpp CholDist::pack)
+  double *chol_pack = nullptr, *chol_pack2 = nullptr;   // staging buffers of the distributed factorisation's panel messages (esl_chol.hpp CholDist)
   size_t chol_pack_len = 0;
   bool schur_attr_set = false;
   // switches resolved ONCE when the communicator is created (every rank must take the same collective sequence for the whole
   // run; an environment read per trial could change mid-run): ESL_CHOL_DIST = 1 / 0 forces the distributed factorisation
   // on / off, unset = by size
   int sw_chol_dist = -1;
+  bool sw_chol_overlap = true;   // the distributed factorisation's messages on their own stream under the trailing updates
 };

@@ -221,10 +221,24 @@ static int slam_ensure_S(esl_ctx* c) {
 // staging buffer of the distributed factorisation (one message per outer panel: esl_chol.hpp CholDist::pack)
 static int chol_pack_ensure(esl_ctx* c, int n) {
   const size_t need = chol_pack_len(n);
-  if (c->chol_pack && c->chol_pack_len >= need) return ESL_OK;
+  if (c->chol_pack && c->chol_pack2 && c->chol_pack_len >= need) return ESL_OK;
   int rc = al(&c->chol_pack, need);
   if (rc) return rc;
+  if ((rc = al(&c->chol_pack2, need))) return rc;
   c->chol_pack_len = need;
+  return ESL_OK;
+}
+// CholDist of this context: one packed message per outer panel, on its own stream unless switched off (ESL_CHOL_DIST_OVERLAP=0)
+static int chol_dist_fill(esl_ctx* c, int n, CholDist& d) {
+  d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
+  d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
+  const int rc = chol_pack_ensure(c, n);
+  if (rc) return rc;
+  d.pack = c->chol_pack;
+  if (c->sw_chol_overlap) {
+    d.pack2 = c->chol_pack2;
+    d.bcast_on = [](void* u, double* dev, size_t count, int root, hipStream_t st) { return comm_bcast((esl_ctx*)u, dev, count, root, st); };
+  }
   return ESL_OK;
 }
 static bool cf_applicable(const esl_ctx* c) { return c->cf_chain_ok && (!c->comm || c->comm_replicated); }
@@ -406,10 +420,7 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     ProfScope ps(c, 3);   // dense Cholesky of the reduced ellipsoid system + the camera back-substitution
     if (cf_dist(c)) {
       CholDist d;
-      d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
-      d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
-      if ((rc = chol_pack_ensure(c, n_o))) return rc;
-      d.pack = c->chol_pack;
+      if ((rc = chol_dist_fill(c, n_o, d))) return rc;
       ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt, &d));
     } else {
       ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
@@ -591,10 +602,7 @@ int slam_try_step(esl_ctx* c, double lambda) {
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
     if (c->comm && slam_dist_chol(c)) {
       CholDist d;
-      d.rank = c->comm_rank; d.n_ranks = c->comm_ranks; d.user = c;
-      d.bcast = [](void* u, double* dev, size_t count, int root) { return comm_bcast((esl_ctx*)u, dev, count, root); };
-      { const int rcp = chol_pack_ensure(c, (int)c->S_n); if (rcp) return rcp; }
-      d.pack = c->chol_pack;
+      { const int rcp = chol_dist_fill(c, (int)c->S_n, d); if (rcp) return rcp; }
       ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, chol_rt(c), &d));
     } else {
       ESL_HIP_TRY(chol_factor_solve(c->S, (long)c->S_lda, (int)c->S_n, c->Linv_ws, c->z_ws, c->xc, c->chol_info, c->stream, chol_rt(c)));

@@ -336,3 +336,34 @@ def test_slam_replicated_graph_divides_the_dense_solve(pkg, ctx, monkeypatch, n_
         float(np.abs(states[0][0] - rc).max()), float(np.abs(states[0][1] - ro).max())))
     np.testing.assert_allclose(states[0][0], rc, atol=1e-8)
     np.testing.assert_allclose(states[0][1], ro, atol=1e-8)
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_distributed_factorisation_overlapped_messages_same_bits(pkg, ctx, monkeypatch, n_ranks):
+    """The distributed factorisation with its messages on their own stream (the owner of panel o + 1 updates, factors and stages it
+    before anything else; two staging buffers; esl_chol.hpp) against the same factorisation with the messages on the compute stream
+    (ESL_CHOL_DIST_OVERLAP=0): every panel still receives the updates of panels 0, 1, 2, .. in that order, so the two must agree BIT
+    FOR BIT -- on a system of 1,350 ellipsoid unknowns = 6 outer panels (both staging buffers reused, look-ahead on every rank)."""
+    g, c, o, _ = pkg.synth.make_graph(121, 150, 6000, seed=39, slam=True)
+    p = pkg.default_lm_params(jacobian_mode=1, linear_solver=2)
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ref = ctx.optimize_resident(p)
+    rc, ro = ctx.download_states()
+    monkeypatch.setenv("ESL_CHOL_DIST", "1")
+    runs = {}
+    for ov in ("1", "0"):
+        monkeypatch.setenv("ESL_CHOL_DIST_OVERLAP", ov)
+        reps, states, used, ar = run_replicated(pkg, g, c, o, p, n_ranks)
+        assert used == [2] * n_ranks
+        n_outer = (9 * 150 + 255) // 256
+        assert ar.calls[0] == sum(ref["trace_trials"]) * (n_outer + 1)
+        for r in range(1, n_ranks):
+            np.testing.assert_array_equal(states[r][0], states[0][0]); np.testing.assert_array_equal(states[r][1], states[0][1])
+        runs[ov] = (reps[0], states[0])
+    monkeypatch.delenv("ESL_CHOL_DIST_OVERLAP", raising=False)
+    assert runs["1"][0]["trace_chi2"] == runs["0"][0]["trace_chi2"] and runs["1"][0]["trace_lambda"] == runs["0"][0]["trace_lambda"]
+    np.testing.assert_array_equal(runs["1"][1][0], runs["0"][1][0])
+    np.testing.assert_array_equal(runs["1"][1][1], runs["0"][1][1])
+    assert runs["1"][0]["trace_trials"] == ref["trace_trials"]
+    np.testing.assert_allclose(runs["1"][1][0], rc, atol=1e-8)
+    np.testing.assert_allclose(runs["1"][1][1], ro, atol=1e-8)
