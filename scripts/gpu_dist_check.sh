@@ -1,3 +1,5 @@
+# quick GPU check of the distributed factorisation on ONE GPU (host transport + a 1-rank RCCL communicator): the sharded / replicated
+# tests with the panel messages on their own stream and on the compute stream, then the forced-dist bench both ways
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r3y
 timeout 900 python -m pytest tests/test_gpu_sharded.py -m gpu -q -s > gpurun_out/r3y/sharded_overlap.log 2>&1; echo rc=$? >> gpurun_out/r3y/sharded_overlap.log

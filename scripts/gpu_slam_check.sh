@@ -1,4 +1,5 @@
-# round 3, GPU batch 5: X kept sparse in the camera-first elimination -- parity of the sparse form, C4 timing, kernel trace
+# quick GPU check of SLAM mode's camera-first elimination (gpurun -- bash scripts/gpu_slam_check.sh <tag>): the parity tests of the
+# sparse / dissected / replicated forms, the C4 full-size test, a short C4 bench and its kernel trace -> gpurun_out/<tag>/
 R=gpurun_out/${1:-r3j}; mkdir -p $R
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_slam.py tests/test_gpu_sharded.py -m gpu -q -s -x -k "sparse_interior or nested_dissection or applicab or replicated or distributed or sharded" > $R/tests_sparse.log 2>&1; echo rc=$? >> $R/tests_sparse.log
