@@ -111,7 +111,8 @@ int slam_alloc(esl_ctx* c) {
     // X = L^-1 W is SPARSE over a short run of cameras (esl_cf.hpp): per segment of kCfFwdCh slots (the last one the separator) the
     // ellipsoids seen by its interior cameras, where each one's column starts, and per ellipsoid the bitmap of its segments
     c->cf_sp_built = false;
-    if (chain && nf >= 256 && N > 0) {
+    // (the column map is nseg x (N + 1) ints: not built beyond 1 GB of it -- such a graph runs the dense-X form or the reduced camera system)
+    if (chain && nf >= 256 && N > 0 && (size_t)((nf + kCfFwdCh - 1) / kCfFwdCh) * (size_t)(N + 1) <= ((size_t)1 << 28)) {
       const int nseg = (nf + kCfFwdCh - 1) / kCfFwdCh, nw = (nseg + 63) / 64, N1 = N + 1;
       std::vector<int> cmap((size_t)nseg * N1, -1), seg_start((size_t)nseg + 1, 0), seg_obj, xld((size_t)nseg), fwork;
       std::vector<unsigned long long> mask((size_t)N1 * nw, 0ull);
