@@ -81,7 +81,7 @@ constexpr int kSymLds = 1024;
 // One raw LDS buffer, carved per stage (the stages are separated by barriers):
 //   clustering (M <= kClLds points):  cell keys u32[kClCells] | cell heads i32[kClCells] | next i32[kClLds] | parent i32[kClLds]
 //                       afterwards:   min centre distance u64[kClLds] | min voxel key u64[kClLds] | size i32[kClLds] | parent
-//   symmetry:                         candidate points float[3 * kSymLds]
+//   symmetry:                         candidate points float4[kSymLds]
 constexpr int kClLds = 2048, kClCells = 4096;
 constexpr unsigned int kEmpty32 = 0xFFFFFFFFu;
 __shared__ __attribute__((aligned(16))) unsigned char g_fit_lds[(kClCells * 2 + kClLds * 2) * 4];
@@ -392,61 +392,6 @@ __device__ bool ldlt_small(double* A, int n, const double* b, double* x) {
   return positive;
 }
 
-// the 1-edge LM of SymmetrySolver::OptimizeSymmetry(Dual)Plane, run redundantly by all lanes of one wave
-__device__ double sym_optimize_wave(const SymCtx& c, PlaneT& pl, bool dual, int iters) {
-  const int dim = dual ? 3 : 2;
-  const double delta = 1e-9;
-  double lambda = 0, ni = 2;
-  int nbad = 0;
-  double e_last = sym_error_wave(c, pl, dual);
-  for (int it = 0; it < iters; ++it) {
-    const double e0 = sym_error_wave(c, pl, dual);
-    e_last = e0;
-    double cur = e0 * e0;
-    const double ini = cur;
-    double J[3] = {0, 0, 0}, H[9], b[3];
-    for (int d = 0; d < dim; ++d) {
-      double u[3] = {0, 0, 0};
-      PlaneT pp = pl, pm = pl;
-      u[d] = delta; plane_update(pp, u, dual);
-      u[d] = -delta; plane_update(pm, u, dual);
-      J[d] = (1.0 / (2 * delta)) * (sym_error_wave(c, pp, dual) - sym_error_wave(c, pm, dual));
-    }
-    for (int a = 0; a < dim; ++a) { b[a] = J[a] * (-(1.0 * e0)); for (int k = 0; k < dim; ++k) H[a * dim + k] = J[a] * 1.0 * J[k]; }
-    if (it == 0) {
-      double md = 0;
-      for (int a = 0; a < dim; ++a) md = fmax(md, fabs(H[a * dim + a]));
-      lambda = 1e-5 * md; ni = 2; nbad = 0;
-    }
-    double rho = 0;
-    int q = 0;
-    do {
-      const PlaneT bak = pl;
-      double M[9], x[3] = {0, 0, 0};
-      for (int a = 0; a < dim * dim; ++a) M[a] = H[a];
-      for (int a = 0; a < dim; ++a) M[a * dim + a] += lambda;
-      const bool ok = ldlt_small(M, dim, b, x);
-      plane_update(pl, x, dual);
-      const double et = sym_error_wave(c, pl, dual);
-      e_last = et;
-      const double tmp = ok ? et * et : 1.7976931348623157e308;
-      double scale = 0;
-      for (int a = 0; a < dim; ++a) scale += x[a] * (lambda * x[a] + b[a]);
-      rho = (cur - tmp) / (scale + 1e-3);
-      if (rho > 0 && isfinite(tmp)) {
-        double alpha = 1. - pow((2 * rho - 1), 3);
-        alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
-        lambda *= (1. / 3. > alpha ? 1. / 3. : alpha);
-        ni = 2; cur = tmp;
-      } else { lambda *= ni; ni *= 2; pl = bak; }
-      q++;
-    } while (rho < 0 && q < 10);
-    if (q == 10 || rho == 0) break;
-    if ((ini - cur) * 1e3 < ini) nbad++; else nbad = 0;
-    if (nbad >= 3) break;
-  }
-  return e_last;
-}
 
 __device__ __forceinline__ int symmetry_type(int label) {  // EllipsoidExtractor::LoadSymmetryPrior (:52-79)
   switch (label) {
