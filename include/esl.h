@@ -255,7 +255,10 @@ int esl_lm_solver_stats(esl_ctx* ctx, double stats[ESL_SOLVER_STATS]);
  * which: 0 Hoo (n_objs x 45 packed upper 9x9), 1 bo (n_objs x 9), 2 xo (n_objs x 9, last trial),
  *        3 Hcc (n_free_cams x 36), 4 bc (n_free_cams x 6), 5 xc (n_free_cams x 6, last trial),
  *        6 reduced system ((n+1) x n column-major, lda = round_up(n+1,16): lda*n doubles), 7 trial ellipsoids (n_objs x 10),
- *        8 trial cameras (n_cams x 7).  count = number of doubles the caller's buffer holds. */
+ *        8 trial cameras (n_cams x 7), 9 (SLAM mode) the per-edge camera-ellipsoid blocks W = Jc^T Omega Jo as [54][n_bbox + n_e3d]:
+ *        entry (a, b) of edge u at [(a * 9 + b) * (n_bbox + n_e3d) + u], u = position of the edge after the stable sort by
+ *        ellipsoid (bbox edges first, 3-D edges from n_bbox on); zero for edges of fixed cameras.
+ *        count = number of doubles the caller's buffer holds. */
 int esl_lm_download(esl_ctx* ctx, int32_t which, double* dst, int64_t count);
 
 /* ---- multi-GPU exchange inside the library (RCCL over xGMI) ---------------------------------------------------
@@ -287,7 +290,9 @@ int esl_comm_init_host(esl_ctx* ctx, int32_t n_ranks, int32_t rank, esl_host_all
  * updates its own later panels (the broadcasts run on their own stream under those updates; ESL_CHOL_DIST_OVERLAP=0 puts them
  * back on the compute stream), the back-substitution runs replicated -- all ranks end with bit-identical states.  This is the
  * multi-GPU form of ESL_SOLVER_REDUCED_ELLIPSOID (the sharded form below sums shard contributions and uses the reduced camera
- * system).  Mapping-mode runs on such a communicator are simply replicated. */
+ * system).  Mapping-mode runs on such a communicator are simply replicated.
+ * CONTRACT: the library cannot tell a shard from a whole graph -- the caller asserts that the graph resident on EVERY rank is the
+ * same whole graph (switching the mode on over ellipsoid shards would leave every rank with its own partial sums, silently). */
 int esl_comm_set_replicated(esl_ctx* ctx, int replicated);
 int esl_comm_destroy(esl_ctx* ctx);
 

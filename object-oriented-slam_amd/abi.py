@@ -195,3 +195,22 @@ class Graph:
                      self.e3d_meas.reshape(-1, 10)[me], self.e3d_weight[me],
                      remap[self.grav_obj[mg]] if mg.any() else (), self.grav_normal, self.grav_weight,
                      self.odom_i, self.odom_j, self.odom_meas, self.odom_info, self.check_visibility, self.image_rows, self.image_cols)
+
+    def subset(self, cams, objs):
+        """Sub-graph on the cameras `cams` and the ellipsoids `objs` (both ascending, re-indexed in that order): the edges whose
+        two ends are both kept.  Used by the full-size parity tests (a sample of BASELINE configs[3] the CPU checker can hold)."""
+        cams = np.asarray(cams, dtype=np.int64); objs = np.asarray(objs, dtype=np.int64)
+        rc = -np.ones(self.n_cams, dtype=np.int64); rc[cams] = np.arange(len(cams))
+        ro = -np.ones(self.n_objs, dtype=np.int64); ro[objs] = np.arange(len(objs))
+        mb = (rc[self.bbox_cam] >= 0) & (ro[self.bbox_obj] >= 0) if len(self.bbox_cam) else np.zeros(0, bool)
+        me = (rc[self.e3d_cam] >= 0) & (ro[self.e3d_obj] >= 0) if len(self.e3d_cam) else np.zeros(0, bool)
+        mg = ro[self.grav_obj] >= 0 if len(self.grav_obj) else np.zeros(0, bool)
+        mo = (rc[self.odom_i] >= 0) & (rc[self.odom_j] >= 0) if len(self.odom_i) else np.zeros(0, bool)
+        fixed = None if self.cam_fixed is None else self.cam_fixed[cams]
+        return Graph(self.K, len(cams), len(objs), fixed,
+                     rc[self.bbox_cam[mb]], ro[self.bbox_obj[mb]], self.bbox_meas.reshape(-1, 4)[mb], self.bbox_weight[mb],
+                     rc[self.e3d_cam[me]], ro[self.e3d_obj[me]], self.e3d_meas.reshape(-1, 10)[me], self.e3d_weight[me],
+                     ro[self.grav_obj[mg]], self.grav_normal, self.grav_weight,
+                     rc[self.odom_i[mo]], rc[self.odom_j[mo]], self.odom_meas.reshape(-1, 7)[mo],
+                     None if self.odom_info is None else self.odom_info.reshape(-1, 6)[mo],
+                     self.check_visibility, self.image_rows, self.image_cols)

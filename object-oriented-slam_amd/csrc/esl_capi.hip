@@ -270,6 +270,7 @@ static void free_graph(esl_ctx* c) {
   dev_free(&c->cf_boff); dev_free(&c->cf_roff); dev_free(&c->cf_twork); dev_free(&c->cf_P); dev_free(&c->cf_Prhs);
   c->cf_sp_built = c->cf_sparse = false;
   c->cf_chain_ok = false;
+  c->cf_ready = false; c->cf_unavailable = false;
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->S_n = 0;
   c->graph_loaded = false;
@@ -1425,6 +1426,7 @@ int esl_lm_download(esl_ctx* c, int32_t which, double* dst, int64_t count) {
     case 6: src = c->S; n = c->S_lda * c->S_n; break;
     case 7: src = c->objs_trial; n = (int64_t)g.n_objs * 10; break;
     case 8: src = c->cams_trial; n = (int64_t)g.n_cams * 7; break;
+    case 9: src = c->lm.slam ? c->Wbb : nullptr; n = ((int64_t)g.n_bbox + g.n_e3d) * 54; break;
     default: set_error("esl_lm_download: unknown array"); return ESL_ERR_INVALID;
   }
   if (!src || count < n) { set_error("esl_lm_download: array not available or buffer too small"); return ESL_ERR_INVALID; }

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -619,6 +620,118 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
   if (lane == 0) x[k0 + r] = s;
 }
 
+// ---- backward substitution L^T x = y in ONE launch (round 4) ---------------------------------------------------------------
+// The launch-per-panel form above is 2 x ceil(n / 128) dependent launches whose kernels are each a few microseconds of work
+// (n = 18,000: 282 launches, ~6 ms of a 46 ms solve).  Here panel p belongs to workgroup (np - 1 - p) mod G; the workgroup streams
+// the blocks L[panel r, panel p] for r = np - 1 .. p + 1 in the order the x_r appear, keeps per-lane partial sums of
+// z_p = y_p - sum_r L_rp^T x_r in registers (ONE cross-lane reduction at the end, fixed order => bit-reproducible), then
+// x_p = Linv_p^T z_p from an LDS copy of Linv_p staged at the start, and publishes x_p.  Block r - 1 is fetched before the
+// flag of x_{r-1} is polled, so the only things on the chain per panel are: flag -> 1 KB of x -> 32 FMAs -> reduction -> the
+// 128 x 128 product from LDS -> publish.
+// Hand-off (guide G16, recipe R1): x_p is stored write-through (relaxed agent-scope atomic stores = sc1), every storing wave
+// drains its stores, one lane stores the flag; the consumer polls the flag relaxed from ONE lane and reads x_r with sc1 loads
+// (L1 bypassed: no acquire fence on the chain).  Flags are zeroed by a memset in front of every launch.  Every spin is bounded:
+// on a timeout bit 1 of info is set and every waiter gives up (the host reports an error instead of hanging the device).
+// Workgroup b only ever waits for panels owned by workgroups that were dispatched before it or for its own earlier panels;
+// with G <= 256 workgroups of one per CU (128 KB of LDS each) all of them are resident anyway.
+constexpr int kBsThreads = 512;
+constexpr int kBsMaxGrid = 256;
+constexpr size_t kBsLds = (size_t)(kNB * kNB + kNB) * sizeof(double);
+// sum over the 64 lanes of 16 per-lane values in 17 shuffles: after the four halving steps lane l holds the partial of value
+// 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of l) summed over the lanes that agree with it in bits 1..0; two plain butterflies finish.
+// The total of value v ends up in every lane of the quad { l : bits 5..2 of l spell v }.
+__device__ __forceinline__ double bs_reduce16(double (&a)[16], int lane) {
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+  double b[8], c[4], d[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const double mine = h5 ? a[8 + i] : a[i], send = h5 ? a[i] : a[8 + i]; b[i] = mine + __shfl_xor(send, 32, 64); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const double mine = h4 ? b[4 + i] : b[i], send = h4 ? b[i] : b[4 + i]; c[i] = mine + __shfl_xor(send, 16, 64); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const double mine = h3 ? c[2 + i] : c[i], send = h3 ? c[i] : c[2 + i]; d[i] = mine + __shfl_xor(send, 8, 64); }
+  double e = (h2 ? d[1] : d[0]) + __shfl_xor(h2 ? d[0] : d[1], 4, 64);
+  e += __shfl_xor(e, 2, 64);
+  e += __shfl_xor(e, 1, 64);
+  return e;
+}
+static __global__ __launch_bounds__(kBsThreads) void k_chol_backsub(const double* __restrict__ M, long lda, int n, int np,
+                                                                    const double* __restrict__ Linv_ws, double* x,
+                                                                    int* flags, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  double* Li = sm;                 // Linv_p, 128 x 128 column-major
+  double* zs = sm + kNB * kNB;     // z_p
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  bool aborted = false;            // (thread 0 only; no static __shared__ here: it would shift the 16-byte alignment of sm, guide G17)
+  const int c0 = 16 * wave;                                                   // this wave's 16 columns of the panel
+  const int vcol = c0 + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);   // bs_reduce16: whose total this lane ends up with
+  for (int p = np - 1 - (int)blockIdx.x; p >= 0; p -= (int)gridDim.x) {
+    const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+    __syncthreads();                                                           // the previous panel's readers of Li / zs are done
+    {
+      const double2_t* src = reinterpret_cast<const double2_t*>(Linv_ws + (size_t)p * kNB * kNB);
+      double2_t* dst = reinterpret_cast<double2_t*>(Li);
+#pragma unroll 4
+      for (int e = t; e < kNB * kNB / 2; e += kBsThreads) dst[e] = src[e];
+    }
+    const double yv = (vcol < nb) ? M[(long)n + (long)(k0 + vcol) * lda] : 0.0;   // row n of the factored matrix: y = L^-1 b
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    double2_t blk[16];
+    auto load_blk = [&](int r) {   // rows r 128 + 2 lane, + 1 of this wave's 16 columns
+      const long row = (long)r * kNB + 2 * lane;
+      const double* src = M + row + (long)(k0 + c0) * lda;
+      if ((long)r * kNB + kNB <= (long)n) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) blk[i] = *reinterpret_cast<const double2_t*>(src + (long)i * lda);
+      } else {                      // the last panel's partial block: rows >= n hold y^T and padding
+        const bool v0 = row < n, v1 = row + 1 < n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { blk[i].x = v0 ? src[(long)i * lda] : 0.0; blk[i].y = v1 ? src[(long)i * lda + 1] : 0.0; }
+      }
+    };
+    if (np - 1 > p) load_blk(np - 1);
+    for (int r = np - 1; r > p; --r) {
+      if (t == 0 && !aborted) {
+        const long long t0 = (long long)wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if ((++spins & 1023u) == 0) {
+            if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) { aborted = true; break; }
+            if ((long long)wall_clock64() - t0 > 300000000LL) { atomicOr(info, 2); aborted = true; break; }   // 3 s at 100 MHz
+          }
+        }
+      }
+      __syncthreads();
+      const long xr = (long)r * kNB + 2 * lane;
+      const double x0 = (xr < n) ? __hip_atomic_load(x + xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      const double x1 = (xr + 1 < n) ? __hip_atomic_load(x + xr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] += blk[i].x * x0 + blk[i].y * x1;
+      if (r - 1 > p) load_blk(r - 1);
+    }
+    const double tot = bs_reduce16(acc, lane);
+    if ((lane & 3) == 0) zs[vcol] = yv - tot;
+    __syncthreads();                                                           // z_p complete (and Li staged long ago)
+    {
+      const double z0 = zs[2 * lane], z1 = zs[2 * lane + 1];
+      double o[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                                           // x[r] = sum_c Linv(c, r) z[c]: column r of Linv is contiguous in c
+        const double2_t v = *reinterpret_cast<const double2_t*>(Li + 2 * lane + (c0 + i) * kNB);
+        o[i] = v.x * z0 + v.y * z1;
+      }
+      const double xo = bs_reduce16(o, lane);
+      if ((lane & 3) == 0 && vcol < nb) __hip_atomic_store(x + k0 + vcol, xo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // every storing wave drains its stores ...
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&flags[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then ONE lane publishes
+  }
+}
+
 // Distributed form (one process per GPU; SURVEY.md section 8 e).  Outer panel o (W x 128 columns) belongs to rank o mod R.
 // Every rank holds the full-size matrix, but only the columns of ITS outer panels are kept up to date: the owner factors
 // its panel (diagonal blocks, panel solves, inner updates), broadcasts the factored columns (+ the inverses of the diagonal
@@ -710,7 +823,10 @@ struct CholRuntime {
   hipEvent_t ev_begin = nullptr;                            // everything the caller's stream held when the factorisation began
   std::vector<hipEvent_t> ev_packed, ev_recv, ev_unpacked;  // per outer panel: message staged / received / copied out of its staging buffer
   bool attr_set = false;
+  int* bs_flags = nullptr; int bs_flags_cap = 0;            // one "x_p published" word per 128-panel of k_chol_backsub
+  int sw_backsub = -1;                                      // ESL_CHOL_BACKSUB_LAUNCHES=1 keeps the launch-per-panel form (A/B)
   void release() {
+    if (bs_flags) { (void)hipFree(bs_flags); bs_flags = nullptr; bs_flags_cap = 0; }
     for (hipEvent_t e : ev_panel) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_trail) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_packed) (void)hipEventDestroy(e);
@@ -730,6 +846,8 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
   hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBig);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBsLds);
   if (e != hipSuccess) return e;
   rt.attr_set = true;
   return hipSuccess;
@@ -924,6 +1042,19 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     trail_pending = true;
   }
   if (trail_pending) { hipError_t e = hipStreamWaitEvent(st, ev_trail[n_outer - 2], 0); if (e != hipSuccess) return e; }
+  }
+  if (rt.sw_backsub < 0) { const char* sw = std::getenv("ESL_CHOL_BACKSUB_LAUNCHES"); rt.sw_backsub = (sw && sw[0] == '1') ? 1 : 0; }
+  // the one-launch form reads the factor as 16-byte pairs: even leading dimension, 16-byte aligned base
+  if (rt.sw_backsub == 0 && (lda & 1) == 0 && ((uintptr_t)M & 15) == 0 && ((uintptr_t)Linv_ws & 15) == 0) {
+    if (rt.bs_flags_cap < np) {
+      if (rt.bs_flags) { (void)hipFree(rt.bs_flags); rt.bs_flags = nullptr; rt.bs_flags_cap = 0; }
+      const int cap = std::max(np, 512);
+      hipError_t e = hipMalloc((void**)&rt.bs_flags, (size_t)cap * sizeof(int)); if (e != hipSuccess) return e;
+      rt.bs_flags_cap = cap;
+    }
+    hipError_t e = hipMemsetAsync(rt.bs_flags, 0, (size_t)np * sizeof(int), st); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_chol_backsub, dim3((unsigned)std::min(np, kBsMaxGrid)), dim3(kBsThreads), kBsLds, st, M, lda, n, np, Linv_ws, x, rt.bs_flags, info);
+    return hipGetLastError();
   }
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;

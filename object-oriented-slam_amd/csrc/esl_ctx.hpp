@@ -197,6 +197,8 @@ struct esl_ctx {
   // camera slot, the odometry edges of every consecutive slot pair, the block-bidiagonal factor (Linv, M, N), per-edge V = Linv W,
   // X^T = (L^-1 [W | b_c])^T, the reduced ellipsoid system T (+ b row) and its solver workspaces.  Big buffers on first use.
   bool cf_chain_ok = false;
+  bool cf_ready = false;         // every buffer of cf_ensure exists and is initialised (esl_slam.hip)
+  bool cf_unavailable = false;   // ESL_SOLVER_AUTO: the camera-first buffers did not fit; this graph runs the reduced camera system
   int *cf_oe_start = nullptr, *cf_oe_u = nullptr, *cf_oe_slot = nullptr, *cf_od_start = nullptr, *cf_od_edge = nullptr, *cf_oe_cst = nullptr;
   int cf_n_list = 0, cf_n_chunks = 0;
   double *cf_Linv = nullptr, *cf_M = nullptr, *cf_N = nullptr, *cf_V = nullptr, *cf_vy = nullptr, *cf_z = nullptr;

@@ -254,12 +254,32 @@ static int slam_pick_solver(const esl_ctx* c) {
   const int want = c->lm.p.linear_solver;
   if (want == ESL_SOLVER_REDUCED_CAMERA) return ESL_SOLVER_REDUCED_CAMERA;
   if (want == ESL_SOLVER_REDUCED_ELLIPSOID) return cf_applicable(c) ? ESL_SOLVER_REDUCED_ELLIPSOID : -1;
-  if (!cf_applicable(c)) return ESL_SOLVER_REDUCED_CAMERA;
+  if (!cf_applicable(c) || c->cf_unavailable) return ESL_SOLVER_REDUCED_CAMERA;
   const double nc = (double)c->S_n, no = 9.0 * c->g.n_objs;
   return (no * no * nc + no * no * no / 3.0 < nc * nc * nc / 3.0) ? ESL_SOLVER_REDUCED_ELLIPSOID : ESL_SOLVER_REDUCED_CAMERA;
 }
+template <class T>
+static void fr(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+// everything cf_ensure allocates (the tables slam_alloc builds at upload stay)
+static void cf_free_work(esl_ctx* c) {
+  fr(&c->cf_Linv); fr(&c->cf_M); fr(&c->cf_N); fr(&c->cf_V); fr(&c->cf_B); fr(&c->cf_Lfac); fr(&c->cf_G); fr(&c->cf_vy); fr(&c->cf_z);
+  fr(&c->cf_T); fr(&c->cf_Linv_ws); fr(&c->cf_part);
+  fr(&c->cf_Zt); fr(&c->cf_Hs); fr(&c->cf_Bs); fr(&c->cf_LfacS); fr(&c->cf_GS); fr(&c->cf_LiS); fr(&c->cf_MS); fr(&c->cf_NS); fr(&c->cf_R);
+  fr(&c->cf_Xc); fr(&c->cf_Xs); fr(&c->cf_P); fr(&c->cf_Prhs); fr(&c->cf_Xt);
+  c->cf_ready = false;
+}
+static int cf_ensure_impl(esl_ctx* c);
+// The buffers of the camera-first form exist and are initialised <=> cf_ready.  A failed allocation half-way (cf_Xt alone is 8.6 GB
+// at BASELINE configs[3] with dense X) frees the partial set again: the next trial step starts from scratch instead of launching
+// on null pointers.
 static int cf_ensure(esl_ctx* c) {
-  if (c->cf_T) return ESL_OK;
+  if (c->cf_ready) return ESL_OK;
+  const int rc = cf_ensure_impl(c);
+  if (rc) { cf_free_work(c); (void)hipGetLastError(); return rc; }
+  c->cf_ready = true;
+  return ESL_OK;
+}
+static int cf_ensure_impl(esl_ctx* c) {
   const DevGraph& g = c->g;
   const size_t nf = (size_t)g.n_free_cams, EU = (size_t)g.n_bbox + g.n_e3d, n_o = (size_t)9 * g.n_objs;
   c->cf_ldx = (int64_t)((n_o + 1 + 15) / 16 * 16);
@@ -275,10 +295,15 @@ static int cf_ensure(esl_ctx* c) {
     c->cf_sparse = sw ? sw[0] != '0' : (n_o >= 2048 && sparse < 0.5 * dense);
     // the per-segment products are stored when they fit beside everything else (C4: 14 GB); else (or ESL_CF_SPARSE=2) the blocks
     // of T come straight from the slabs (k_cf_T_sparse)
+    // decided from the graph's size against the device's TOTAL memory, not from what happens to be free at the first trial: the two
+    // forms add in different orders, so the bits of T must not depend on what else occupies the GPU; every rank of a
+    // replicated run takes the same decision by construction.  esl_lm_solver_stats reports the form.
     size_t free_b = 0, total_b = 0;
     ESL_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const double need = 8.0 * (81.0 * (double)c->cf_p_blocks + (double)c->cf_xc_len + 2.0 * (double)c->cf_ldt * (double)n_o);
-    c->cf_sp_form = (sw && sw[0] == '2') || need > 0.5 * (double)free_b ? 2 : 1;
+    const double n_sep = (double)(nf / kCfFwdCh);
+    const double need = 8.0 * (81.0 * (double)c->cf_p_blocks + (double)c->cf_xc_len + 2.0 * (double)c->cf_ldt * (double)n_o +
+                               2.0 * 6.0 * n_sep * (double)c->cf_ldx /* Xs, R */ + 54.0 * (double)EU /* V */);
+    c->cf_sp_form = (sw && sw[0] == '2') || need > 0.4 * (double)total_b ? 2 : 1;
   }
   int rc;
   if ((rc = al(&c->cf_Linv, nf * 36)) || (rc = al(&c->cf_M, nf * 36)) || (rc = al(&c->cf_N, nf * 36)) || (rc = al(&c->cf_V, EU * 54)) ||
@@ -587,13 +612,20 @@ int slam_build_reduced(esl_ctx* c, double lambda, bool full_sum, void** dev_ptr,
 int slam_try_step(esl_ctx* c, double lambda) {
   const DevGraph& g = c->g;
   const int N = g.n_objs, F = g.n_cams;
-  const int solver = slam_pick_solver(c);
+  int solver = slam_pick_solver(c);
   if (solver < 0) {
-    set_error("ESL_SOLVER_REDUCED_ELLIPSOID needs a single-GPU run whose odometry edges join neighbouring free cameras only");
+    set_error("ESL_SOLVER_REDUCED_ELLIPSOID needs odometry edges that join neighbouring free cameras only and, across GPUs, the "
+              "replicated-graph communicator (esl_comm_set_replicated); a single GPU always qualifies");
     return ESL_ERR_INVALID;
   }
-  c->lm_solver_used = solver;
   int rc;
+  if (solver == ESL_SOLVER_REDUCED_ELLIPSOID && c->lm.p.linear_solver == ESL_SOLVER_AUTO && (rc = cf_ensure(c)) != ESL_OK) {
+    // AUTO: the camera-first form does not fit beside what else lives on the device -> the reduced camera system for this graph
+    if (c->comm && c->comm_ranks > 1) return rc;   // (every rank must take the same form: no unilateral fall-back)
+    c->cf_unavailable = true;
+    solver = ESL_SOLVER_REDUCED_CAMERA;
+  }
+  c->lm_solver_used = solver;
   if (solver == ESL_SOLVER_REDUCED_ELLIPSOID) {
     if ((rc = slam_try_step_cf(c, lambda))) return rc;
   } else {
@@ -640,6 +672,7 @@ int slam_try_step(esl_ctx* c, double lambda) {
   int info = 0;
   ESL_HIP_TRY(hipMemcpyAsync(&info, c->chol_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (info & 2) { set_error("dense solver: a device-side hand-off timed out (k_chol_backsub / persistent panel kernel)"); return ESL_ERR_HIP; }
   if (info) {
     const double zero = 0.0;
     ESL_HIP_TRY(hipMemcpyAsync(c->dev_part + 3, &zero, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -810,7 +843,7 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
 extern "C" int esl_lm_solver_stats(esl_ctx* c, double* st) {
   if (!c || !st) return ESL_ERR_INVALID;
   for (int k = 0; k < ESL_SOLVER_STATS; ++k) st[k] = 0;
-  if (c->lm_solver_used != ESL_SOLVER_REDUCED_ELLIPSOID || !c->cf_T) return ESL_OK;
+  if (c->lm_solver_used != ESL_SOLVER_REDUCED_ELLIPSOID || !c->cf_ready) return ESL_OK;
   st[0] = c->cf_sparse ? c->cf_sp_form : 0;
   st[1] = c->cf_stride; st[2] = c->cf_n_sep; st[3] = c->cf_n_seg;
   if (c->cf_sparse) {

@@ -955,6 +955,125 @@ static int solve_schur(const ograph* G, const double* H, const double* b, double
   return ok;
 }
 
+/* Camera-first elimination for SLAM mode: the SAME damped system (H + lambda I) x = b with the OTHER block marginalised
+ * (block_solver.hpp:367-486 eliminates whichever vertices carry the marginalised flag; x does not depend on the choice).
+ * In the reference's SLAM branch the camera block is block TRIDIAGONAL -- odometry edges join consecutive frames only
+ * (Optimizer.cpp:142-158) -- so A = Hpp + lambda I = L L^T with L block bidiagonal, Y = L^-1 [Hpl | b_p] by a forward
+ * recurrence, T = Hll + lambda I - Y^T Y (order 9 N), x_l from the pivoted LDLT of T, x_p = L^-T (y - Y x_l).
+ * Written as the plain chain (no dissection, Y dense): the independent CPU check of csrc/esl_cf.hpp's nested-dissection /
+ * sparse-X form, and the measured CPU time of the GPU's own elimination order in bench.py.
+ * Returns 1 ok, 0 not positive, -1 not applicable (camera block not block tridiagonal). */
+static void chol6(const double* A, double* L, int* ok) { /* lower Cholesky of a 6 x 6 row-major block */
+  for (int i = 0; i < 36; ++i) L[i] = 0;
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j * 6 + j];
+    for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
+    if (!(d > 0)) { *ok = 0; d = 1; }
+    double r = sqrt(d);
+    L[j * 6 + j] = r;
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[i * 6 + j];
+      for (int k = 0; k < j; ++k) v -= L[i * 6 + k] * L[j * 6 + k];
+      L[i * 6 + j] = v / r;
+    }
+  }
+}
+static void fwd6(const double* L, double* v) { /* v <- L^-1 v */
+  for (int i = 0; i < 6; ++i) { double s = v[i]; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * v[k]; v[i] = s / L[i * 6 + i]; }
+}
+static void bwd6(const double* L, double* v) { /* v <- L^-T v */
+  for (int i = 5; i >= 0; --i) { double s = v[i]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * v[k]; v[i] = s / L[i * 6 + i]; }
+}
+__attribute__((optimize("O3")))
+static int solve_camfirst(const ograph* G, const double* H, const double* b, double lambda, double* x) {
+  const int n = G->n;
+  int np = 0;
+  for (int k = 0; k < G->n_free_v; ++k) if (G->order[k] < G->F) np += 6;
+  const int nl = n - np, nc = np / 6, m = nl + 1;
+  if (nc == 0 || nl == 0) return -1;
+  for (int i = 0; i < nc; ++i)          /* band check: blocks (i, j), j < i - 1, must vanish */
+    for (int j = 0; j + 1 < i; ++j)
+      for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c)
+        if (H[(size_t)(6 * i + a) * n + 6 * j + c] != 0.0) return -1;
+  int ok = 1;
+  double* Ld = (double*)malloc(sizeof(double) * 36 * (size_t)nc);   /* L_ii */
+  double* Lo = (double*)calloc(36 * (size_t)nc, sizeof(double));    /* L_{i,i-1} */
+  double* Y = (double*)malloc(sizeof(double) * (size_t)np * (size_t)m);
+  for (int i = 0; i < nc; ++i) {
+    double A[36];
+    for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) A[a * 6 + c] = H[(size_t)(6 * i + a) * n + 6 * i + c] + (a == c ? lambda : 0.0);
+    if (i > 0) {   /* L_{i,i-1} = A_{i,i-1} L_{i-1,i-1}^-T: row a of it solves L_{i-1,i-1} w = (row a of A_{i,i-1})^T */
+      for (int a = 0; a < 6; ++a) {
+        double w[6];
+        for (int c = 0; c < 6; ++c) w[c] = H[(size_t)(6 * i + a) * n + 6 * (i - 1) + c];
+        fwd6(&Ld[36 * (size_t)(i - 1)], w);
+        for (int c = 0; c < 6; ++c) Lo[36 * (size_t)i + a * 6 + c] = w[c];
+      }
+      for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) {
+        double sum = 0;
+        for (int k = 0; k < 6; ++k) sum += Lo[36 * (size_t)i + a * 6 + k] * Lo[36 * (size_t)i + c * 6 + k];
+        A[a * 6 + c] -= sum;
+      }
+    }
+    chol6(A, &Ld[36 * (size_t)i], &ok);
+    /* Y_i = L_ii^-1 (R_i - L_{i,i-1} Y_{i-1}), R = [Hpl | b_p] */
+    double* Yi = Y + (size_t)(6 * i) * m;
+    for (int a = 0; a < 6; ++a) {
+      for (int j = 0; j < nl; ++j) Yi[(size_t)a * m + j] = H[(size_t)(6 * i + a) * n + np + j];
+      Yi[(size_t)a * m + nl] = b[6 * i + a];
+    }
+    if (i > 0) {
+      const double* Yp = Y + (size_t)(6 * (i - 1)) * m;
+      for (int a = 0; a < 6; ++a) for (int k = 0; k < 6; ++k) {
+        const double l = Lo[36 * (size_t)i + a * 6 + k];
+        if (l == 0.0) continue;
+        for (int j = 0; j < m; ++j) Yi[(size_t)a * m + j] -= l * Yp[(size_t)k * m + j];
+      }
+    }
+    const double* L = &Ld[36 * (size_t)i];
+    for (int a = 0; a < 6; ++a) {
+      for (int k = 0; k < a; ++k) { const double l = L[a * 6 + k]; for (int j = 0; j < m; ++j) Yi[(size_t)a * m + j] -= l * Yi[(size_t)k * m + j]; }
+      const double d = L[a * 6 + a];
+      for (int j = 0; j < m; ++j) Yi[(size_t)a * m + j] /= d;
+    }
+  }
+  /* T = Hll + lambda I - Y^T Y (lower triangle, then mirrored), t = b_l - Y^T y */
+  double* T = (double*)malloc(sizeof(double) * (size_t)nl * (size_t)nl);
+  double* t = (double*)malloc(sizeof(double) * (size_t)nl);
+  for (int i = 0; i < nl; ++i) {
+    for (int j = 0; j <= i; ++j) T[(size_t)i * nl + j] = H[(size_t)(np + i) * n + np + j];
+    T[(size_t)i * nl + i] += lambda;
+    t[i] = b[np + i];
+  }
+  for (int k = 0; k < np; ++k) {
+    const double* yk = Y + (size_t)k * m;
+    const double yy = yk[nl];
+    for (int i = 0; i < nl; ++i) {
+      const double a = yk[i];
+      if (a == 0.0) continue;
+      double* Ti = T + (size_t)i * nl;
+      for (int j = 0; j <= i; ++j) Ti[j] -= a * yk[j];
+      t[i] -= a * yy;
+    }
+  }
+  for (int i = 0; i < nl; ++i) for (int j = i + 1; j < nl; ++j) T[(size_t)i * nl + j] = T[(size_t)j * nl + i];
+  if (!esl_oracle_ldlt_solve(T, nl, t, &x[np])) ok = 0;
+  /* z = y - Y x_l, x_p = L^-T z (backward along the chain) */
+  for (int k = 0; k < np; ++k) {
+    const double* yk = Y + (size_t)k * m;
+    double sum = yk[nl];
+    for (int j = 0; j < nl; ++j) sum -= yk[j] * x[np + j];
+    x[k] = sum;
+  }
+  for (int i = nc - 1; i >= 0; --i) {
+    double* xi = &x[6 * i];
+    if (i + 1 < nc) for (int a = 0; a < 6; ++a) { double sum = 0; for (int k = 0; k < 6; ++k) sum += Lo[36 * (size_t)(i + 1) + k * 6 + a] * x[6 * (i + 1) + k]; xi[a] -= sum; }
+    bwd6(&Ld[36 * (size_t)i], xi);
+  }
+  free(Ld); free(Lo); free(Y); free(T); free(t);
+  return ok;
+}
+
 int esl_oracle_optimize(const esl_graph* g, double* cams_io, double* objs_io, const esl_lm_params* p,
                         int solver, esl_lm_report* out) {
   ograph G;
@@ -983,7 +1102,7 @@ int esl_oracle_optimize(const esl_graph* g, double* cams_io, double* objs_io, co
     S.b = b;
   } else {
     H = (double*)malloc(sizeof(double) * (size_t)n * (size_t)n);
-    Hwork = (double*)malloc(sizeof(double) * (size_t)n * (size_t)n);
+    if (solver == ESL_ORACLE_DENSE) Hwork = (double*)malloc(sizeof(double) * (size_t)n * (size_t)n);
   }
   /* map vertex -> position in order (for block storage) */
   int* vpos = (int*)malloc(sizeof(int) * (size_t)(G.F + G.N + 1));
@@ -1049,6 +1168,10 @@ int esl_oracle_optimize(const esl_graph* g, double* cams_io, double* objs_io, co
       int ok2;
       if (use_blockdiag) ok2 = solve_blockdiag(&G, NULL, &S, lambda, x);
       else if (solver == ESL_ORACLE_BLOCK) ok2 = solve_schur(&G, H, b, lambda, x);
+      else if (solver == ESL_ORACLE_CAMFIRST) {
+        ok2 = solve_camfirst(&G, H, b, lambda, x);
+        if (ok2 < 0) ok2 = solve_schur(&G, H, b, lambda, x);   /* camera block not a chain: the other elimination */
+      }
       else {
         memcpy(Hwork, H, sizeof(double) * (size_t)n * (size_t)n);
         for (int j = 0; j < n; ++j) Hwork[(size_t)j * n + j] += lambda; /* setLambda */

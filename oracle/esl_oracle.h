@@ -24,6 +24,9 @@ extern "C" {
 /* linear-solver choice of the oracle LM */
 #define ESL_ORACLE_DENSE 0  /* faithful: dense pivoted LDLT of the whole free system (linear_solver_dense.h:65-113) */
 #define ESL_ORACLE_BLOCK 1  /* "CPU, improved over reference": per-ellipsoid 9x9 (mapping) / Schur + dense (SLAM) */
+#define ESL_ORACLE_CAMFIRST 2 /* SLAM mode, cameras eliminated first along the odometry chain (plain block-bidiagonal factor, dense Y,
+                               * pivoted LDLT of the reduced ELLIPSOID system): the same x as the other two; falls back to BLOCK when
+                               * the camera block is not block tridiagonal.  The CPU counterpart of csrc/esl_cf.hpp. */
 
 /* --- SE3 / ellipsoid primitives (g2o types/se3quat.h, src/core/Ellipsoid.cpp) ------------------*/
 void esl_oracle_se3_exp(const double upd[6], double out[7]);

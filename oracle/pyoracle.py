@@ -15,6 +15,7 @@ _lib = None
 
 ORACLE_DENSE = 0
 ORACLE_BLOCK = 1
+ORACLE_CAMFIRST = 2   # SLAM mode: cameras eliminated first along the odometry chain (esl_oracle.h)
 
 
 def build():

@@ -115,6 +115,82 @@ def test_c4_sharding_invariance_of_chi2(pkg, ctx, c4):
     assert md == whole.max_diag
 
 
+@pytest.fixture(scope="module")
+def c4_slam(pkg):
+    return pkg.synth.make_config("C4", seed=0, slam=True)
+
+
+def test_c4_slam_sampled_linearisation_matches_oracle(pkg, po, ctx, c4_slam):
+    """SLAM-mode twin of test_c4_sampled_linearisation_matches_oracle: BASELINE configs[3] AS NAMED (9,999 free cameras) is far
+    beyond the checker's dense H (77,994^2), but every block of the linearisation is a sum over the edges of ONE vertex or ONE
+    (camera, ellipsoid) pair, so samples of it are checked against the checker's linearisation of sub-graphs that hold exactly
+    those edges:
+      (A) a sample of ellipsoids with ALL the cameras that see them: H_oo, b_o and the camera-ellipsoid blocks W (summed per pair:
+          the checker's H holds one block per vertex pair, base_binary_edge.hpp:55-120);
+      (B) a sample of free cameras with ALL the ellipsoids they see and both odometry neighbours: H_cc, b_c."""
+    g, c, o, _ = c4_slam
+    nf = int((~g.cam_fixed.astype(bool)).sum())
+    assert g.n_cams == 10000 and g.n_objs == 2000 and len(g.bbox_cam) == 200000 and nf == 9999 and g.cam_fixed[0] == 1
+    ctx.upload_graph(g); ctx.upload_states(c, o)
+    ctx.lm_begin(pkg.default_lm_params(jacobian_mode=1))
+    part = ctx.lm_linearize()
+    EU = len(g.bbox_cam) + len(g.e3d_cam)
+    Hoo = ctx.lm_download(0, g.n_objs * 45).reshape(-1, 45)
+    bo = ctx.lm_download(1, g.n_objs * 9).reshape(-1, 9)
+    Hcc = ctx.lm_download(3, nf * 36).reshape(nf, 6, 6)
+    bc = ctx.lm_download(4, nf * 6).reshape(nf, 6)
+    W = ctx.lm_download(9, EU * 54).reshape(54, EU)
+    # the library's edge order: stable sort by ellipsoid, bbox edges first (include/esl.h, esl_lm_download)
+    ob, oe = np.argsort(g.bbox_obj, kind="stable"), np.argsort(g.e3d_obj, kind="stable")
+    ucam = np.concatenate([g.bbox_cam[ob], g.e3d_cam[oe]]); uobj = np.concatenate([g.bbox_obj[ob], g.e3d_obj[oe]])
+    rng = np.random.default_rng(5)
+    tol = 3e-6      # analytic Jacobians against the checker's delta = 1e-6 differences (the mapping twin's figure)
+    # (A)
+    ids = np.sort(rng.choice(g.n_objs, size=10, replace=False))
+    cams_a = np.unique(ucam[np.isin(uobj, ids)])
+    sub = g.subset(cams_a, ids)
+    assert len(sub.bbox_cam) == int(np.isin(g.bbox_obj, ids).sum()) and len(sub.odom_i) > 0
+    H, b, fidx, _ = po.build_system(sub, c[cams_a], o[ids], delta=1e-6)
+    worst = dict(Hoo=0.0, bo=0.0, W=0.0)
+    n_pairs = 0
+    for k, oid in enumerate(ids):
+        i = fidx[len(cams_a) + k]
+        Href = H[i:i + 9, i:i + 9]
+        worst["Hoo"] = max(worst["Hoo"], np.abs(unpack45(Hoo[oid]) - Href).max() / np.abs(Href).max())
+        worst["bo"] = max(worst["bo"], np.abs(bo[oid] - b[i:i + 9]).max() / np.abs(b[i:i + 9]).max())
+        np.testing.assert_allclose(unpack45(Hoo[oid]), Href, atol=tol * np.abs(Href).max())
+        np.testing.assert_allclose(bo[oid], b[i:i + 9], atol=tol * np.abs(b[i:i + 9]).max())
+        us = np.nonzero(uobj == oid)[0]
+        scale = max(np.abs(H[fidx[np.searchsorted(cams_a, cam)]:fidx[np.searchsorted(cams_a, cam)] + 6, i:i + 9]).max()
+                    for cam in np.unique(ucam[us]) if not g.cam_fixed[cam])
+        for cam in np.unique(ucam[us]):
+            Wsum = W[:, us[ucam[us] == cam]].sum(axis=1).reshape(6, 9)
+            if g.cam_fixed[cam]:
+                assert not Wsum.any()
+                continue
+            j = fidx[np.searchsorted(cams_a, cam)]
+            worst["W"] = max(worst["W"], np.abs(Wsum - H[j:j + 6, i:i + 9]).max() / scale)
+            np.testing.assert_allclose(Wsum, H[j:j + 6, i:i + 9], atol=tol * scale)
+            n_pairs += 1
+    # (B)
+    cs = np.sort(rng.choice(np.arange(1, g.n_cams), size=24, replace=False))
+    cams_b = np.unique(np.clip(np.concatenate([cs - 1, cs, cs + 1]), 0, g.n_cams - 1))
+    objs_b = np.unique(uobj[np.isin(ucam, cs)])
+    subb = g.subset(cams_b, objs_b)
+    Hb, bb, fb, _ = po.build_system(subb, c[cams_b], o[objs_b], delta=1e-6)
+    worst["Hcc"] = worst["bc"] = 0.0
+    for cam in cs:
+        j = fb[np.searchsorted(cams_b, cam)]
+        Href = Hb[j:j + 6, j:j + 6]
+        worst["Hcc"] = max(worst["Hcc"], np.abs(Hcc[cam - 1] - Href).max() / np.abs(Href).max())      # slot = camera - 1 (camera 0 is the fixed one)
+        worst["bc"] = max(worst["bc"], np.abs(bc[cam - 1] - bb[j:j + 6]).max() / max(np.abs(bb[j:j + 6]).max(), 1.0))
+        np.testing.assert_allclose(Hcc[cam - 1], Href, atol=tol * np.abs(Href).max())
+        np.testing.assert_allclose(bc[cam - 1], bb[j:j + 6], atol=tol * max(np.abs(bb[j:j + 6]).max(), 1.0))
+    print("C4 SLAM sampled linearisation vs checker: %d ellipsoids / %d cameras / %d (camera, ellipsoid) blocks; %d cameras with %d ellipsoids; worst relative %s"
+          % (len(ids), len(cams_a), n_pairs, len(cs), len(objs_b), {k: "%.1e" % v for k, v in worst.items()}))
+    assert n_pairs > 500 and part.chi2 > 0
+
+
 def test_c4_slam_schur_solve_full_size(pkg, ctx):
     """BASELINE.json configs[3] as it is named — "Schur solve": 10k free cameras (cam 0 fixed), 2k ellipsoids, 200k bbox +
     40k 3-D + 9,999 odometry edges; reduced camera system n = 59,994 (28.8 GB of lower triangle in HBM), dense FP64-MFMA

@@ -407,3 +407,30 @@ def test_sparse_interior_rows_on_awkward_structures(pkg, monkeypatch):
         assert rep["trace_trials"] == ref[7]["trace_trials"]
         np.testing.assert_allclose(rep["trace_chi2"], ref[7]["trace_chi2"], rtol=1e-10)
         assert cam_err(cc, ref[5]) < 1e-8 and obj_rel(oo, ref[6]) < 1e-8
+
+
+def test_sparse_camera_first_trial_matches_cpu_camera_first_checker(pkg, po, monkeypatch):
+    """The sparse camera-first path (nested dissection of a 2,047-camera chain into 128 segments of 16 slots, X kept sparse,
+    per-segment products, separators' rows on the MFMA update: every piece of esl_cf.hpp live, as at BASELINE configs[3]) against the
+    CPU checker at a size the checker reaches: ONE LM iteration from the same start, numeric Jacobians at delta = 1e-6 on both
+    sides.  The checker eliminates the cameras first too, but as the PLAIN chain with a dense Y and a pivoted LDLT
+    (oracle/esl_oracle.c solve_camfirst; tests/test_oracle_cross.py holds it to the faithful dense LDLT of the whole system) --
+    none of the dissection / sparsity machinery."""
+    g, c, o, _ = pkg.synth.make_graph(2048, 150, 8 * 2048, seed=43, slam=True)
+    p1 = pkg.default_lm_params(numeric_delta=1e-6, max_iters=1)
+    co, oo, ro = po.optimize(g, c, o, p1, solver=po.ORACLE_CAMFIRST)
+    monkeypatch.setenv("ESL_CF_SPARSE", "1")
+    cx = pkg.Context(0)
+    try:
+        for jac in (0, 1):
+            cg, og, rg = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6, max_iters=1, linear_solver=2))
+            st = cx.lm_solver_stats()
+            assert cx.lm_solver_used() == 2 and st["x_form"] == 1 and st["stride"] == 16 and st["separators"] == 127
+            print("2,048-camera chain, sparse camera-first trial (jac %d) vs CPU camera-first checker: chi2 rel %.2e, cameras %.2e, ellipsoids %.2e, trials %s / %s"
+                  % (jac, abs(rg["chi2_final"] / ro["chi2_final"] - 1), cam_err(cg, co), obj_rel(og, oo), rg["trace_trials"], ro["trace_trials"]))
+            assert rg["trace_trials"] == ro["trace_trials"]
+            assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-6)
+            assert cam_err(cg, co) < 1e-5 and obj_rel(og, oo) < 1e-5
+    finally:
+        cx.close()
+        monkeypatch.delenv("ESL_CF_SPARSE", raising=False)

@@ -34,6 +34,50 @@ def graph_upto(pkg, g, f):
                      g.e3d_cam[me], g.e3d_obj[me], g.e3d_meas.reshape(-1, 10)[me], g.e3d_weight[me], g.grav_obj, g.grav_normal, g.grav_weight)
 
 
+def per_obj_err(a, b):
+    """the north-star metric per ellipsoid: max of |dt| / |t|, |dq|, |ds| / |s|"""
+    a, b = np.asarray(a).reshape(-1, 10), np.asarray(b).reshape(-1, 10)
+    et = np.linalg.norm(a[:, :3] - b[:, :3], axis=1) / np.linalg.norm(b[:, :3], axis=1)
+    eq = np.linalg.norm(a[:, 3:7] - b[:, 3:7], axis=1)
+    es = np.linalg.norm(a[:, 7:] - b[:, 7:], axis=1) / np.linalg.norm(b[:, 7:], axis=1)
+    return np.maximum(np.maximum(et, eq), es)
+
+
+def yaw_hypothesis_gap(cam7, obj10, meas10):
+    """relative gap between the two smallest of the four yaw-hypothesis residual norms of a 3-D edge (Ellipsoid.cpp:92-117);
+    a gap near 0 is a kink of the min() the edge's residual takes"""
+    from oracle import np_oracle as npo
+    Tcw = npo.T_from7(cam7); To, s = npo.obj_from10(obj10); Tm, sm = npo.obj_from10(meas10)
+    Tmw = npo.T_inv(Tcw) @ Tm
+    norms = []
+    for k in (-1, 0, 1, 2):
+        a = k * np.pi / 2
+        Rz = np.eye(4); Rz[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        sk = sm.copy()
+        if k in (-1, 1):
+            sk[0], sk[1] = sm[1], sm[0]
+        with np.errstate(all="ignore"):
+            norms.append(np.linalg.norm(np.concatenate([npo.se3_log(npo.T_inv(Tmw @ Rz) @ To), s - sk])))
+    norms = np.sort(np.nan_to_num(norms, nan=np.inf))
+    return float((norms[1] - norms[0]) / norms[0])
+
+
+def constraint_of(po, gf, cams, objs, oid):
+    """how well the graph pins ellipsoid oid at the state `objs`: (bbox edges, 3-D edges, condition number of its 9 x 9 block of
+    the checker's normal equations, smallest yaw-hypothesis gap of its 3-D edges)"""
+    sub = gf.subset_objects([oid])
+    H, b, fidx, _ = po.build_system(sub, cams, objs[oid:oid + 1], delta=1e-6)
+    w = np.linalg.eigvalsh(H)
+    cond = float(w[-1] / max(w[0], 1e-300)) if w[0] > 0 else float("inf")
+    gaps = [yaw_hypothesis_gap(cams[sub.e3d_cam[k]], objs[oid], sub.e3d_meas.reshape(-1, 10)[k]) for k in range(len(sub.e3d_cam))]
+    return len(sub.bbox_cam), len(sub.e3d_cam), cond, (min(gaps) if gaps else float("inf"))
+
+
+def weak_constraint_report(po, gf, cams, objs, oid):
+    nb, ne, cond, gap = constraint_of(po, gf, cams, objs, oid)
+    return "ellipsoid %d: %d bbox + %d 3-D edges, cond(H_oo) %.1e, yaw-hypothesis gap %.2e" % (oid, nb, ne, cond, gap)
+
+
 def test_streaming_sequence_append_equals_rebuild_and_checker(pkg, po, ctx):
     n_frames = 60
     g, c, o, _ = pkg.synth.make_graph(n_frames, 20, 20 * n_frames, seed=3)

@@ -78,3 +78,40 @@ def test_schur_matches_dense_in_slam_mode(po, pkg):
     assert r1["trace_trials"] == r2["trace_trials"]
     np.testing.assert_allclose(o1, o2, atol=1e-5)
     np.testing.assert_allclose(c1, c2, atol=1e-5)
+
+
+@pytest.mark.parametrize("n_cams,n_objs,seed", [(30, 6, 3), (120, 12, 9)])
+def test_camera_first_checker_matches_dense_in_slam_mode(po, pkg, n_cams, n_objs, seed):
+    """solver 2 of the checker (cameras eliminated first along the odometry chain, oracle/esl_oracle.c solve_camfirst: block-
+    bidiagonal factor, dense Y, pivoted LDLT of the reduced ELLIPSOID system) solves the same damped system as the faithful dense
+    pivoted LDLT (linear_solver_dense.h:65-113) and as the Schur complement onto the cameras: the same LM run.  It is what
+    tests/test_gpu_slam.py holds the GPU's sparse camera-first form to at 2,048 cameras."""
+    g, c, o, _ = pkg.synth.make_graph(n_cams, n_objs, 8 * n_cams, seed=seed, slam=True)
+    p = pkg.default_lm_params(numeric_delta=1e-6, max_iters=3)
+    c0, o0, r0 = po.optimize(g, c, o, p, solver=po.ORACLE_DENSE)
+    for solver in (po.ORACLE_BLOCK, po.ORACLE_CAMFIRST):
+        c2, o2, r2 = po.optimize(g, c, o, p, solver=solver)
+        assert r2["trace_trials"] == r0["trace_trials"]
+        # (three exact solvers of one ill-conditioned system: measured 1e-7 on the objective, the figure the existing Schur test has)
+        np.testing.assert_allclose(r2["trace_chi2"], r0["trace_chi2"], rtol=1e-6)
+        np.testing.assert_allclose(o2, o0, atol=1e-5)
+        np.testing.assert_allclose(c2, c0, atol=1e-5)
+
+
+def test_camera_first_checker_falls_back_when_the_cameras_are_no_chain(po, pkg):
+    """a loop-closure odometry edge (first to last camera) breaks the block-tridiagonal structure: solver 2 must take the other
+    elimination and still return the dense checker's run"""
+    g, c, o, _ = pkg.synth.make_graph(24, 5, 160, seed=6, slam=True)
+    oi, oj = np.append(g.odom_i, 1), np.append(g.odom_j, 23)
+    om = np.vstack([g.odom_meas.reshape(-1, 7), g.odom_meas.reshape(-1, 7)[:1]])
+    gl = pkg.Graph(g.K, g.n_cams, g.n_objs, g.cam_fixed, g.bbox_cam, g.bbox_obj, g.bbox_meas, g.bbox_weight, g.e3d_cam, g.e3d_obj, g.e3d_meas,
+                   g.e3d_weight, g.grav_obj, g.grav_normal, g.grav_weight, odom_i=oi, odom_j=oj, odom_meas=om)
+    p = pkg.default_lm_params(numeric_delta=1e-6, max_iters=2)
+    c1, o1, r1 = po.optimize(gl, c, o, p, solver=po.ORACLE_BLOCK)
+    c2, o2, r2 = po.optimize(gl, c, o, p, solver=po.ORACLE_CAMFIRST)
+    assert r2["trace_chi2"] == r1["trace_chi2"] and np.array_equal(o2, o1) and np.array_equal(c2, c1)   # the very same code path
+    c0, o0, r0 = po.optimize(gl, c, o, pkg.default_lm_params(numeric_delta=1e-6, max_iters=1), solver=po.ORACLE_DENSE)
+    c3, o3, r3 = po.optimize(gl, c, o, pkg.default_lm_params(numeric_delta=1e-6, max_iters=1), solver=po.ORACLE_CAMFIRST)
+    assert r3["trace_trials"] == r0["trace_trials"]
+    np.testing.assert_allclose(o3, o0, atol=1e-6)
+    np.testing.assert_allclose(c3, c0, atol=1e-6)
