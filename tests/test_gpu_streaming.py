@@ -9,6 +9,10 @@ from test_gpu_optimizer import group_rel_err
 
 pytestmark = pytest.mark.gpu
 
+# lock-step tolerances (lockstep_frame): both sides difference numerically at delta = 1e-6, so H and b carry ~1e-7 of differencing
+# noise each (per-block tolerance inside lockstep_frame); the other pieces are plain fp64 arithmetic
+LOCK_TOL = dict(lin_chi2=1e-9, H=1.0, b=1.0, solve_own=1e-12, solve_ref=1.0, retract=1e-9, trial_chi2=1e-9, scale=1e-9)   # H, b, solve_ref: multiples of the per-block tolerance
+
 
 def frame_slices(g, f):
     """edges of frame f (camera index f), bbox edges only once their ellipsoid has > 2 observations (Optimizer.cpp:201): the
@@ -78,6 +82,110 @@ def weak_constraint_report(po, gf, cams, objs, oid):
     return "ellipsoid %d: %d bbox + %d 3-D edges, cond(H_oo) %.1e, yaw-hypothesis gap %.2e" % (oid, nb, ne, cond, gap)
 
 
+def unpack45(Hp):
+    H = np.zeros((9, 9))
+    H[np.triu_indices(9)] = Hp
+    return H + np.triu(H, 1).T
+
+
+def lockstep_frame(pkg, po, cx, gf, cams, objs0, params):
+    """One frame's LM run driven through the step API with g2o's control flow (optimization_algorithm_levenberg.cpp:61-164) and,
+    at EVERY linearisation and EVERY trial, the checker put on the GPU's own current state.  No LM run is compared with another
+    LM run here -- nothing can amplify a last-bit difference into another accept/reject sequence -- and every piece is compared in
+    the form in which it is WELL CONDITIONED (a weakly observed ellipsoid's 9 x 9 block has a condition number of 1e7 .. 1e12, so
+    the solution of its damped system moves by 1e-2 when the Jacobians move by 1e-7: the checker against itself does):
+      linearise   chi2; every ellipsoid's H_oo block and b_o against the checker's, relative to the block's largest entry.  The
+                  tolerance of a block is 5e-6 + 3 x the checker's OWN spread of that block between delta and 0.9 delta.  Blocks
+                  the checker does not reproduce itself to 1e-5 are counted (`noisy`) and not compared: the reference's gravity
+                  prior acos(z . n) (BasicEllipsoidEdges.cpp:129-152) is not differentiable where LM drives it -- angle 0 -- and
+                  while the angle is of the order of delta its central difference is anything between -1 and 1 (measured: the
+                  checker's H moves by 23 % between delta = 1e-6 and 0.9e-6 on frame 0; SURVEY.md section 7 calls the edge
+                  "numerically degenerate"); once acos returns exactly 0 the term drops out and the blocks are stable again;
+      solve       the GPU's step x as a solution of its OWN system, |(H + lambda I) x - b| / (|H + lambda I| |x| + |b|) per
+                  ellipsoid (normwise backward error: LinearSolverDense's job, linear_solver_dense.h:65-113), and of the checker's
+                  system with the tolerance above;
+      retract     the GPU's trial state against the checker's ellipsoid::exp_update (Ellipsoid.cpp:38-47) of the GPU's x;
+      errors      the checker's chi2 AT the GPU's trial state against the GPU's (computeActiveErrors / activeRobustChi2);
+      scale       computeScale (optimization_algorithm_levenberg.cpp:182-189) from the GPU's own x and b.
+    Mapping mode (all cameras fixed).  Returns the worst figures (H / b / solve_ref as multiples of their tolerance) and the run's
+    decisions."""
+    F, N = gf.n_cams, gf.n_objs
+    cx.upload_graph(gf); cx.upload_states(cams, objs0)
+    cx.lm_begin(params)
+    worst = dict(lin_chi2=0.0, H=0.0, b=0.0, solve_own=0.0, solve_ref=0.0, retract=0.0, trial_chi2=0.0, scale=0.0, blocks=0, noisy=0)
+    lam, ni, nbad, it, ok_outer, trials = -1.0, 2.0, 0, 0, True, []
+    nrm = lambda M: max(float(np.abs(M).max()), 1e-300)
+    while it < params.max_iters and ok_outer:
+        _, cur_objs = cx.download_states()
+        lin = cx.lm_linearize()
+        H, b, fidx, chi = po.build_system(gf, cams, cur_objs, delta=params.numeric_delta)
+        H2, b2, _, _ = po.build_system(gf, cams, cur_objs, delta=0.9 * params.numeric_delta)
+        Hg = cx.lm_download(0, N * 45).reshape(N, 45); bg = cx.lm_download(1, N * 9).reshape(N, 9)
+        worst["lin_chi2"] = max(worst["lin_chi2"], abs(lin.chi2 / chi - 1))
+        tol = np.zeros(N)
+        for k in range(N):
+            i = fidx[F + k]
+            if i < 0:
+                assert not Hg[k].any()
+                continue
+            Hr, br = H[i:i + 9, i:i + 9], b[i:i + 9]
+            # b = -sum J^T Omega r cancels to ~0 at a minimum: its differencing noise scales with sqrt(H_ii chi2) (Cauchy-Schwarz), not with b
+            sb = nrm(br) + np.sqrt(nrm(np.diag(Hr)) * chi)
+            spread = max(np.abs(H2[i:i + 9, i:i + 9] - Hr).max() / nrm(Hr), np.abs(b2[i:i + 9] - br).max() / sb)
+            worst["blocks"] += 1
+            if spread > 1e-5:     # the checker does not reproduce this block itself (the gravity prior at its kink): counted, not compared
+                worst["noisy"] += 1
+                tol[k] = np.inf
+                continue
+            tol[k] = 5e-6 + 3 * spread
+            worst["H"] = max(worst["H"], np.abs(unpack45(Hg[k]) - Hr).max() / nrm(Hr) / tol[k])
+            worst["b"] = max(worst["b"], np.abs(bg[k] - br).max() / sb / tol[k])
+        cur = ini = lin.chi2
+        if it == 0:
+            lam, ni, nbad = params.tau * lin.max_diag, 2.0, 0
+            assert lin.max_diag == pytest.approx(np.abs(np.diag(H)).max(), rel=1e-5 if np.isfinite(tol).all() else 0.5)
+        q, rho = 0, 0.0
+        while True:
+            tr = cx.lm_try_step(lam)
+            xg = cx.lm_download(2, N * 9).reshape(N, 9)
+            trial_gpu = cx.lm_download(7, N * 10).reshape(N, 10)
+            trial_ref, sc_terms = cur_objs.copy(), []
+            for k in range(N):
+                i = fidx[F + k]
+                if i < 0:
+                    continue
+                A = H[i:i + 9, i:i + 9] + lam * np.eye(9); Ag = unpack45(Hg[k]) + lam * np.eye(9)
+                berr = lambda M, r: np.linalg.norm(M @ xg[k] - r) / (np.linalg.norm(M) * np.linalg.norm(xg[k]) + np.linalg.norm(r) + 1e-300)
+                worst["solve_own"] = max(worst["solve_own"], berr(Ag, bg[k]))
+                worst["solve_ref"] = max(worst["solve_ref"], berr(A, b[i:i + 9]) / tol[k])
+                trial_ref[k] = po.obj_oplus(cur_objs[k], xg[k])
+                sc_terms.append(xg[k] * (lam * xg[k] + bg[k]))
+            worst["retract"] = max(worst["retract"], float(per_obj_err(trial_gpu, trial_ref).max()))
+            chi_ref = po.build_system(gf, cams, trial_gpu, delta=params.numeric_delta)[3]
+            worst["trial_chi2"] = max(worst["trial_chi2"], abs(tr.chi2 / chi_ref - 1))
+            sc = np.concatenate(sc_terms) if sc_terms else np.zeros(1)
+            worst["scale"] = max(worst["scale"], abs(tr.scale - sc.sum()) / max(np.abs(sc).sum(), 1e-300))
+            tmp = tr.chi2 if tr.solve_ok else 1.7976931348623157e308
+            rho = (cur - tmp) / (tr.scale + 1e-3)
+            if rho > 0 and np.isfinite(tmp):
+                lam *= max(1. / 3., min(1. - (2 * rho - 1) ** 3, 2. / 3.)); ni = 2.0; cur = tmp
+                cx.lm_commit(True)
+            else:
+                lam *= ni; ni *= 2
+                cx.lm_commit(False)
+            q += 1
+            if not (rho < 0 and q < params.max_trials):
+                break
+        trials.append(q)
+        it += 1
+        if q == params.max_trials or rho == 0:
+            ok_outer = False
+        else:
+            nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0
+            ok_outer = nbad < 3
+    return worst, dict(iterations=it, trace_trials=trials, chi2_final=cur)
+
+
 def test_streaming_sequence_append_equals_rebuild_and_checker(pkg, po, ctx):
     n_frames = 60
     g, c, o, _ = pkg.synth.make_graph(n_frames, 20, 20 * n_frames, seed=3)
@@ -88,6 +196,9 @@ def test_streaming_sequence_append_equals_rebuild_and_checker(pkg, po, ctx):
     objs_inc = o.copy(); objs_reb = o.copy()
     e_fit_ref, p_fit_ref, st_ref, _ = po.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"])
     relayouts = 0
+    lock_worst = dict(lin_chi2=0.0, H=0.0, b=0.0, solve_own=0.0, solve_ref=0.0, retract=0.0, trial_chi2=0.0, scale=0.0)
+    lock_blocks = lock_noisy = 0
+    n_reproducible = 0
     for f in range(n_frames):
         # the frame's single-frame fits (20 boxes) ...
         e_fit, p_fit, st, _ = ctx_inc.fit_frame(sc["depth"], sc["bboxes"], sc["labels"], sc["Twc"], sc["intr"], sc["ground"], P)
@@ -113,22 +224,45 @@ def test_streaming_sequence_append_equals_rebuild_and_checker(pkg, po, ctx):
         assert rep_inc["trace_chi2"] == rep_reb["trace_chi2"] and rep_inc["trace_trials"] == rep_reb["trace_trials"], f
         np.testing.assert_array_equal(objs_inc, objs_reb)
         relayouts = sizes["relayouts"]
-        # (c) the checker on this frame's problem (same start state, like for like: numeric Jacobians at delta = 1e-6 -- the 3-D
-        #     edge takes the minimum over four yaw hypotheses, so analytic and numeric LM paths may part at a kink)
-        # Checked frames: 0, 6 and every sixth from 30 on (+ the last).  Frames 12 .. 24 are left out on purpose (SURVEY.md section 7:
-        # keep parity fixtures away from yaw kinks): there most ellipsoids still hang on 3-D edges alone, whose residual is a minimum
-        # over four yaw hypotheses, and the two implementations' central differences across such a kink differ in the last bits, so
-        # the two LM runs can leave a kink on different sides (measured: states 7.7e-3 / 1.8e-4 apart at frames 12 / 24 with chi2
-        # equal to 3e-5 / 5e-7).  Everything checked holds the north star's 1e-4 outright (measured 8e-10 .. 2.2e-6).
-        if f in (0, 6) or (f >= 30 and f % 6 == 0) or f == n_frames - 1:
-            pn = pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6)
-            _, o_orc, r_orc = po.optimize(gf, c[:f + 1], objs_before, pn, solver=1)
-            _, o_gpu, r_gpu = ctx.optimize(gf, c[:f + 1], objs_before, pn)
-            assert r_gpu["chi2_final"] == pytest.approx(r_orc["chi2_final"], rel=1e-7), f     # measured 3e-10 .. 9e-9
-            assert r_gpu["n_bbox_valid"] == r_orc["n_bbox_valid"]
-            err = group_rel_err(o_gpu, o_orc)
-            print("streaming frame %d: GPU vs checker chi2 rel %.2e, states %.2e" % (f, abs(r_gpu["chi2_final"] / r_orc["chi2_final"] - 1), err))
+        # (c) the checker, on EVERY frame (round 4: none is left out), numeric Jacobians at delta = 1e-6 on both sides:
+        #   (c1) LOCK-STEP: every linearisation and every trial step of the GPU's own LM run against the checker at the same state
+        #        (lockstep_frame) -- the parity statement proper, immune to the chaos of (c2);
+        #   (c2) FREE-RUNNING: the two complete LM runs from the same start.  Evaluation parity always (the checker's chi2 at the
+        #        GPU's end state).  End states to the north star's 1e-4 wherever the reference's OWN result is reproducible: its
+        #        run converged before the 10-iteration cap and moves < 1e-5 when only its differencing step changes by 10 %.
+        #        In the first ~27 frames it often is not: ellipsoids with three or four bbox edges from one viewpoint, or a single
+        #        3-D edge, sit in flat valleys, LM's lambda and accept/reject are GLOBAL (one weak ellipsoid redirects the run of
+        #        all), and the runs stop at the iteration cap mid-way -- measured on the GPU box, the checker against ITSELF at
+        #        delta 0.9e-6 / 1.1e-6: up to 2e-2 (frame 11), 3e-3 (frames 10, 19).  The yaw-hypothesis explanation of round 3
+        #        did not survive measurement: the two best hypotheses of every offending 3-D edge are 20x .. 190x apart.
+        pn = pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6)
+        worst, r_lock = lockstep_frame(pkg, po, ctx, gf, c[:f + 1], objs_before, pn)
+        for k in lock_worst:
+            lock_worst[k] = max(lock_worst[k], worst[k])
+        lock_blocks += worst["blocks"]; lock_noisy += worst["noisy"]
+        assert all(worst[k] < LOCK_TOL[k] for k in LOCK_TOL), (f, worst)
+        _, o_orc, r_orc = po.optimize(gf, c[:f + 1], objs_before, pn, solver=1)
+        _, o_gpu, r_gpu = ctx.optimize(gf, c[:f + 1], objs_before, pn)
+        assert r_gpu["n_bbox_valid"] == r_orc["n_bbox_valid"]
+        assert r_gpu["trace_trials"] == r_lock["trace_trials"]                  # the step API and the device-driven loop are one LM
+        chi_at_gpu = po.build_system(gf, c[:f + 1], o_gpu, delta=1e-6)[3]
+        assert r_gpu["chi2_final"] == pytest.approx(chi_at_gpu, rel=1e-9), f
+        self_err = 0.0
+        for d in (0.9e-6, 1.1e-6):
+            _, o_alt, _ = po.optimize(gf, c[:f + 1], objs_before, pkg.default_lm_params(jacobian_mode=0, numeric_delta=d), solver=1)
+            self_err = max(self_err, float(per_obj_err(o_alt, o_orc).max()))
+        err = float(per_obj_err(o_gpu, o_orc).max())
+        reproducible = self_err < 1e-5 and r_orc["iterations"] < pn.max_iters and r_gpu["iterations"] < pn.max_iters
+        n_reproducible += reproducible
+        print("streaming frame %2d: lock-step H %.2f b %.2f solve %.2f of tolerance (%d of %d blocks noisy) | free-running GPU vs checker chi2 rel %.2e states %.2e, checker vs itself %.2e, iterations %d / %d%s"
+              % (f, worst["H"], worst["b"], worst["solve_ref"], worst["noisy"], worst["blocks"], abs(r_gpu["chi2_final"] / r_orc["chi2_final"] - 1), err, self_err, r_gpu["iterations"],
+                 r_orc["iterations"], "" if reproducible else "  (reference not reproducible here)"))
+        if reproducible:
             assert err < 1e-4, (f, err)
+            assert r_gpu["chi2_final"] == pytest.approx(r_orc["chi2_final"], rel=1e-6), f
+    print("streaming, all %d frames in lock-step: worst %s; %d of %d linearised blocks the checker does not reproduce itself to 1e-5 (gravity prior at its kink); %d frames where the reference's LM run reproduces itself"
+          % (n_frames, {k: "%.1e" % v for k, v in lock_worst.items()}, lock_noisy, lock_blocks, n_reproducible))
+    assert n_reproducible >= 30 and lock_noisy < 0.5 * lock_blocks
     assert 1 <= relayouts <= 4, relayouts      # 60 appends, a handful of re-layouts (slack doubles)
     ctx_inc.close()
 
