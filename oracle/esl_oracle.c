@@ -29,6 +29,10 @@ static double now_s(void) {
 }
 static double g_timing[3];
 void esl_oracle_last_timing(double t[3]) { t[0] = g_timing[0]; t[1] = g_timing[1]; t[2] = g_timing[2]; }
+/* split of the solve time of ESL_ORACLE_CAMFIRST: band check + chain factor + forward substitution (Y) | T = D - Y^T Y | pivoted
+ * LDLT of T | back-substitution; summed over the trials of the last esl_oracle_optimize */
+static double g_cf_timing[4];
+void esl_oracle_last_camfirst_timing(double t[4]) { for (int k = 0; k < 4; ++k) t[k] = g_cf_timing[k]; }
 
 /* Eigen QuaternionBase::operator* */
 static quat q_mul(quat a, quat b) {
@@ -991,6 +995,7 @@ static int solve_camfirst(const ograph* G, const double* H, const double* b, dou
   for (int k = 0; k < G->n_free_v; ++k) if (G->order[k] < G->F) np += 6;
   const int nl = n - np, nc = np / 6, m = nl + 1;
   if (nc == 0 || nl == 0) return -1;
+  double tm0 = now_s();
   for (int i = 0; i < nc; ++i)          /* band check: blocks (i, j), j < i - 1, must vanish */
     for (int j = 0; j + 1 < i; ++j)
       for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c)
@@ -1037,6 +1042,7 @@ static int solve_camfirst(const ograph* G, const double* H, const double* b, dou
       for (int j = 0; j < m; ++j) Yi[(size_t)a * m + j] /= d;
     }
   }
+  g_cf_timing[0] += now_s() - tm0; tm0 = now_s();
   /* T = Hll + lambda I - Y^T Y (lower triangle, then mirrored), t = b_l - Y^T y */
   double* T = (double*)malloc(sizeof(double) * (size_t)nl * (size_t)nl);
   double* t = (double*)malloc(sizeof(double) * (size_t)nl);
@@ -1057,7 +1063,9 @@ static int solve_camfirst(const ograph* G, const double* H, const double* b, dou
     }
   }
   for (int i = 0; i < nl; ++i) for (int j = i + 1; j < nl; ++j) T[(size_t)i * nl + j] = T[(size_t)j * nl + i];
+  g_cf_timing[1] += now_s() - tm0; tm0 = now_s();
   if (!esl_oracle_ldlt_solve(T, nl, t, &x[np])) ok = 0;
+  g_cf_timing[2] += now_s() - tm0; tm0 = now_s();
   /* z = y - Y x_l, x_p = L^-T z (backward along the chain) */
   for (int k = 0; k < np; ++k) {
     const double* yk = Y + (size_t)k * m;
@@ -1070,6 +1078,7 @@ static int solve_camfirst(const ograph* G, const double* H, const double* b, dou
     if (i + 1 < nc) for (int a = 0; a < 6; ++a) { double sum = 0; for (int k = 0; k < 6; ++k) sum += Lo[36 * (size_t)(i + 1) + k * 6 + a] * x[6 * (i + 1) + k]; xi[a] -= sum; }
     bwd6(&Ld[36 * (size_t)i], xi);
   }
+  g_cf_timing[3] += now_s() - tm0;
   free(Ld); free(Lo); free(Y); free(T); free(t);
   return ok;
 }
@@ -1081,6 +1090,7 @@ int esl_oracle_optimize(const esl_graph* g, double* cams_io, double* objs_io, co
   ograph_build(&G, g, cams_io, objs_io, p->drop_nan_bbox);
   memset(out, 0, sizeof(*out));
   g_timing[0] = g_timing[1] = g_timing[2] = 0;
+  g_cf_timing[0] = g_cf_timing[1] = g_cf_timing[2] = g_cf_timing[3] = 0;
   int nb = 0;
   for (int i = 0; i < G.n_edges; ++i) if (G.edges[i].type == 0) nb++;
   out->n_bbox_valid = nb; out->n_bbox_dropped = G.n_dropped;

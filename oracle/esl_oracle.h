@@ -104,6 +104,9 @@ void esl_oracle_set_bbox_residual(int mode);
 /* timing helper for bench.py's cpu_baseline: seconds spent in linearise / solve / error evaluation
  * of the last esl_oracle_optimize call */
 void esl_oracle_last_timing(double t[3]);
+/* solver ESL_ORACLE_CAMFIRST, summed over the trials of the last run: chain factor + forward substitution | T = D - Y^T Y | pivoted
+ * LDLT of T | back-substitution */
+void esl_oracle_last_camfirst_timing(double t[4]);
 
 #ifdef __cplusplus
 }

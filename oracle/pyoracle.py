@@ -261,3 +261,10 @@ def last_timing():
     t = (C.c_double * 3)()
     lib().esl_oracle_last_timing(t)
     return dict(linearize_s=t[0], solve_s=t[1], errors_s=t[2])
+
+
+def last_camfirst_timing():
+    """split of the solve time of the last optimize(solver=ORACLE_CAMFIRST), summed over its trials"""
+    t = (C.c_double * 4)()
+    lib().esl_oracle_last_camfirst_timing(t)
+    return dict(chain_forward_s=t[0], syrk_s=t[1], ldlt_s=t[2], back_s=t[3])

@@ -1,0 +1,62 @@
+"""bench.py's N-rank branch across REAL process boundaries on a box with one GPU ("make the N > 1 path executable
+before a node ever sees it"): `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` with
+ESL_BENCH_HOST_TRANSPORT=1 -- both ranks on device 0, the library's collectives over esl_comm_init_host with a gloo all-reduce
+behind the callback.  What runs is what the driver's 8-GPU launch runs except for the wire: rank / world from the environment,
+the replicated-graph communicator (esl_comm_set_replicated), the distributed factorisation with its panel messages on their own
+stream, the ellipsoid-sharded forms, the max-over-ranks timing and the single JSON line from rank 0.  Every mode must take the
+LM run of `--gpus 1` (same accept / reject sequence, same chi2 trace up to the summation order of the sharded sums)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "1", "--warmup", "0", "--config", "C3", "--no-cpu-baseline", "--no-extras"]
+
+
+def run_bench(extra_args, n_ranks, env_extra, port):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    if n_ranks == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON + extra_args
+    else:
+        env["ESL_BENCH_HOST_TRANSPORT"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks)] + COMMON + extra_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])      # rank 0 prints ONE line, the other ranks nothing
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def single():
+    return {mode: run_bench(["--mode", mode], 1, {}, 0) for mode in ("slam", "mapping")}
+
+
+@pytest.mark.parametrize("mode,env,tol", [
+    ("slam", {"ESL_CHOL_DIST": "1"}, 1e-9),                                   # replicated graph, reduced ELLIPSOID system divided over the ranks, overlapped panel messages
+    ("slam", {"ESL_CHOL_DIST": "1", "ESL_CHOL_DIST_OVERLAP": "0"}, 1e-9),     # ... with the messages on the compute stream
+    ("slam", {"ESL_BENCH_SHARDED_SLAM": "1", "ESL_CHOL_DIST": "1"}, 1e-7),    # ellipsoid shards: all-reduce of the camera blocks, per-panel reduce, distributed factorisation of S
+    ("slam", {"ESL_BENCH_SHARDED_SLAM": "1", "ESL_CHOL_DIST": "0"}, 1e-7),    # ... with the all-reduced S factored on every rank
+    ("mapping", {}, 1e-11),                                                   # ellipsoid shards, one 64-byte all-gather per trial
+])
+def test_two_processes_on_one_gpu_take_the_single_gpu_run(single, mode, env, tol):
+    port = 29600 + (os.getpid() % 300) + 7 * len(env)
+    multi = run_bench(["--mode", mode], 2, env, port)
+    ref = single[mode]
+    assert multi["n_gpus"] == 2 and multi["steps"] == 1 and multi["scaling"] == "strong" and multi["value"] > 0
+    assert "host transport" in multi["config"]["lm_scalar_exchange"]
+    print("bench.py --gpus 2 (%s, %s): %s | chi2 %s" % (mode, env, multi["config"]["parallelism"], multi["chi2"]["trace"]))
+    assert multi["chi2"]["trials"] == ref["chi2"]["trials"]
+    np.testing.assert_allclose(multi["chi2"]["trace"], ref["chi2"]["trace"], rtol=tol)
+    assert multi["chi2"]["initial"] == pytest.approx(ref["chi2"]["initial"], rel=1e-12)
+    if mode == "slam" and "ESL_BENCH_SHARDED_SLAM" not in env:
+        assert "replicated graph" in multi["config"]["parallelism"]
