@@ -403,6 +403,11 @@ int esl_init_plane_error(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, cons
  * strictly diagonally dominant n x n system; returns the time of factor + solve (HIP events) and |A x - b| / |b|.
  * A known-answer test of the solver and the micro-benchmark behind the "mfma" roofline numbers. */
 int esl_selftest_cholesky(esl_ctx* ctx, int32_t n, double* ms_out, double* rel_residual_out);
+/* test / debug: the static task list of the persistent dense factorisation for an order-n system (outer panels of W 128-panels,
+ * `filler` far-update tasks between the chain-dependent groups): 4 int32 per task {type, a, b, c} -- 0: S(panel a, strip b),
+ * 1: u(panel a, row tile b, column tile c), 2: U(outer panel a, row tile b, column tile c) --, ns[np][nR] = strips of row tile R that
+ * panel k solves, meta = {np, n_outer, nR, n_tasks, W}.  Pure host code (no device needed); call with null buffers for the sizes. */
+int esl_debug_chol_plan(int32_t n, int32_t W, int32_t filler, int32_t* tasks_out, int64_t cap_tasks, int32_t* ns_out, int64_t cap_ns, int32_t meta_out[5]);
 
 #ifdef __cplusplus
 }

@@ -56,14 +56,23 @@ __device__ long long g_potrf_clk[16];
 // overlapped -- slower, 4.9 ms: at two waves per SIMD and 244 registers the wave-synchronous column steps went 12 -> 17 us.
 // Round 1's kernel itself was deleted in round 3 after its equivalence runs.)
 constexpr int kP2Threads = 640;
-static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __restrict__ M, long lda, int k0, int nb,
-                                                            double* __restrict__ Linv /* kNB x kNB col-major */,
-                                                            int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+// WT: L and Linv leave with write-through (sc1) stores -- the persistent factorisation hands them to other workgroups inside the launch
+template <bool WT>
+__device__ __forceinline__ void chol_store(double* p, double v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+// NT = 640: every one of the 528 blocks has its own thread (the stand-alone kernel).  NT = 512 (the persistent kernel's workgroup
+// shape): threads 0..15 own TWO blocks one after the other -- their first one lies in block column 0 and is final after step 0, so
+// they store it there and then (global memory + the LDS copy) and take over blocks 512..527 (block columns 26..31, which only see
+// work at the very end) in time for step 0's rank-4 update.
+template <bool WT, int NT = kP2Threads>
+__device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double* __restrict__ M, long lda, int k0, int nb,
+                                                 double* __restrict__ Linv /* kNB x kNB col-major */, int* __restrict__ info) {
+  static_assert(NT == 640 || NT == 512, "potrf2: 640 or 512 threads");
   double* L = sm;                          // kNB x kNB, column stride kLdsPad: the factor, later its inverse
   double* T = sm + kNB * kLdsPad;          // 96 x 32 temporary of the inverse; the column buffers of the factorisation before that
   double* dinv = T + 96 * kSB;             // kNB reciprocals of the diagonal
-  constexpr int NT = kP2Threads, NW = kP2Threads / 64;
+  constexpr int NW = NT / 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #define LL(i, j) L[(i) + (j) * kLdsPad]
   POTRF_MARK(0);
@@ -71,11 +80,12 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
   // block columns are finished first, so whole waves drop out of the update as the factorisation moves right
   const bool own = t < 528;
   int bi = 0, bj = 0;
-  if (own) {
-    int off = 0;
-    while (off + (32 - bj) <= t) { off += 32 - bj; ++bj; }
-    bi = bj + (t - off);
-  }
+  auto block_of = [](int idx, int& obi, int& obj) {
+    int off = 0; obj = 0;
+    while (off + (32 - obj) <= idx) { off += 32 - obj; ++obj; }
+    obi = obj + (idx - off);
+  };
+  if (own) block_of(t, bi, bj);
   double a[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -158,6 +168,28 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
         for (int r = 0; r < 4; ++r) colbuf[c * kNB + 4 * bi + r] = a[r][c];
     }
     __syncthreads();                                    // barrier B
+    if constexpr (NT == 512) {
+      if (J == 0 && t < 16) {   // first block (t, 0) is final: store it, take over block 512 + t (original values; step 0's update follows)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 4 * bi + r, j = c;
+            if (i >= j) {
+              if (i < nb && j < nb) chol_store<WT>(&M[(long)(k0 + i) + (long)(k0 + j) * lda], a[r][c]);
+              LL(i, j) = (bi == 0) ? xd[r][c] : a[r][c];
+            }
+          }
+        block_of(512 + t, bi, bj);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 4 * bi + r, j = 4 * bj + c;
+            a[r][c] = (i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);
+          }
+      }
+    }
     if (own && bj > J) {                                // (c) rank-4 update
       double rv[4][4], cv[4][4];                        // [k][r]: entries of column k of the block column in this block's rows / columns
 #pragma unroll
@@ -187,7 +219,7 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
       for (int r = 0; r < 4; ++r) {
         const int i = 4 * bi + r, j = 4 * bj + c;
         if (i >= j) {
-          if (i < nb && j < nb) M[(long)(k0 + i) + (long)(k0 + j) * lda] = a[r][c];
+          if (i < nb && j < nb) chol_store<WT>(&M[(long)(k0 + i) + (long)(k0 + j) * lda], a[r][c]);
           LL(i, j) = (bi == bj) ? xd[r][c] : a[r][c];
         }
       }
@@ -258,10 +290,16 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
   POTRF_MARK(8);
   for (int idx = t; idx < kNB * kNB; idx += NT) {
     const int i = idx % kNB, j = idx / kNB;
-    Linv[idx] = (i < nb && j < nb && i >= j) ? LL(i, j) : 0.0;
+    chol_store<WT>(&Linv[idx], (i < nb && j < nb && i >= j) ? LL(i, j) : 0.0);
   }
   POTRF_MARK(9);
 #undef LL
+}
+static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __restrict__ M, long lda, int k0, int nb,
+                                                            double* __restrict__ Linv /* kNB x kNB col-major */,
+                                                            int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  chol_potrf2_body<false, kP2Threads>(sm, M, lda, k0, nb, Linv, info);
 }
 
 // ---- MFMA micro-kernel: acc(64x64 per wave) += X[i0.., 0..K) * Y[j0.., 0..K)^T ------------------------------
@@ -311,11 +349,12 @@ __device__ __forceinline__ void mfma_xyT_64x64(const double* __restrict__ X, lon
 // wave's dependent chain is 128 MFMAs, not the 1,024 of the first version (one wave per 64 rows x 128 columns: 86 us per
 // launch whatever the height of the panel).  The rows are updated in place: every wave reads all K input columns of its
 // rows, the barrier makes sure all of the workgroup's reads are done before anybody writes.
-static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ M, long lda, long rows, int k0, int nb,
-                                                    const double* __restrict__ Linv) {
+template <bool WT>
+__device__ __forceinline__ void chol_panel_body(double* __restrict__ M, long lda, long rows, int k0, int nb,
+                                                const double* __restrict__ Linv, long strip) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, kq = lane >> 4;
-  const long r0 = (long)k0 + nb + (long)blockIdx.x * 64 + (wave >> 2) * 32;
+  const long r0 = (long)k0 + nb + strip * 64 + (wave >> 2) * 32;
   const int cg = (wave & 3) * 32;
   const double* P = M + (long)k0 * lda;
   double4_t acc[2][2];
@@ -392,8 +431,12 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
         // store 128 contiguous bytes of a column (row-major-in-lanes stores touched 64 different cache lines per instruction)
         const long row = r0 + mi * 16 + r;
         const int col = cg + nj * 16 + kq + 4 * g;
-        if (row < rows && col < nb) M[row + (long)(k0 + col) * lda] = acc[mi][nj][g];
+        if (row < rows && col < nb) chol_store<WT>(&M[row + (long)(k0 + col) * lda], acc[mi][nj][g]);
       }
+}
+static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ M, long lda, long rows, int k0, int nb,
+                                                    const double* __restrict__ Linv) {
+  chol_panel_body<false>(M, lda, rows, k0, nb, Linv, (long)blockIdx.x);
 }
 
 // ---- trailing update, LDS-staged: C[base.., base..) -= P P^T with P = columns [kcol0, kcol0 + K) -------------------
@@ -408,53 +451,21 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 // chain of one wave is then 4 MFMAs per k-step instead of 16 and a trailing matrix of 1,500 rows still spreads over ~140
 // workgroups; with the big tile it occupied 20 CUs for 86 us whatever its size.
 constexpr int kKC = 16;
-template <int BM, int BN, int WM = 4, int WN = 2>
-static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
-                                                                           int kcol0, int K, long base, int ntJ, int rect,
-                                                                           const double* __restrict__ Pext, long ldp,
-                                                                           double* __restrict__ part, int kper) {
-  static_assert((BM == 2 * BN || BM == BN) && BM % 64 == 0, "tile shape");
+// One tile of C -= P P^T: rows [i0, i0 + BM) x columns [j0, j0 + BN) of M (lower triangle only), P = (rows x K) column-major with
+// leading dimension ldp; `assign`: C = -P P^T (split-K slices).  WT: C leaves with write-through stores (persistent factorisation).
+template <int BM, int BN, int WM, int WN, bool WT>
+__device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double* __restrict__ M, long lda, long rows, long ncols,
+                                                 const double* __restrict__ P, long ldp, int K, long i0, long j0, bool assign) {
   constexpr int NT = 64 * WM * WN;                // threads per workgroup
-  constexpr int RT = BM / BN;                     // tile row ti of the lower triangle holds RT (ti + 1) tiles
   constexpr int kLdA = BM + 16, kLdB = BN + 16;   // +16: the 4 k-groups of a fragment read land in different banks
   constexpr int SM = BM / WM, SN = BN / WN;       // rows x columns of one wave's sub-tile
   constexpr int MI = SM / 16, NJ = SN / 16;
   constexpr int QA = BM * kKC / 2 / NT, QB = BN * kKC / 2 / NT;   // double2 per thread per chunk
   static_assert(QA >= 1 && QB >= 1, "chunk smaller than the workgroup");
-  extern __shared__ __attribute__((aligned(16))) double sm[];
   double* As = sm;                               // [2][kKC][kLdA]
   double* Bs = sm + 2 * kKC * kLdA;              // [2][kKC][kLdB]
-  const long b = blockIdx.x;
-  long ti, tj;
-  if (rect) {                                    // a few tile columns of a tall region: ntJ tiles per tile row
-    ti = b / ntJ; tj = b - ti * ntJ;
-    if (tj > RT * ti + RT - 1) return;           // above the diagonal
-  } else {                                       // the whole lower triangle: rows 0 .. ti-1 hold RT ti (ti + 1) / 2 tiles
-    ti = (long)((sqrt(1.0 + 8.0 * (double)b / RT) - 1.0) * 0.5);
-    while (RT * ti * (ti + 1) / 2 > b) --ti;
-    while (RT * (ti + 1) * (ti + 2) / 2 <= b) ++ti;
-    tj = b - RT * ti * (ti + 1) / 2;             // 0 .. RT (ti + 1) - 1
-    if (tj >= ntJ) return;
-  }
-  const long i0 = base + ti * BM, j0 = base + tj * BN;
-  if (i0 >= rows || j0 >= ncols) return;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int wi = wave / WN, wj = wave % WN;
-  // the rank-K factor: columns [kcol0, kcol0 + K) of M itself (Cholesky trailing update), or an external (rows x K) column-major
-  // matrix Pext with leading dimension ldp (C -= Pext Pext^T: the reduced ellipsoid system of the camera-first elimination, esl_cf.hpp)
-  const double* P = Pext ? Pext : M + (long)kcol0 * lda;
-  if (!Pext) ldp = lda;
-  // split-K (gridDim.y > 1; small outputs with a long K: a 450 x 450 system has 20 tiles): slice blockIdx.y takes K range
-  // [y kper, (y + 1) kper) and writes -acc into ITS copy of the output (part + y lda ncols; no read-modify-write); a reduction
-  // kernel adds the slices to C in slice order -- deterministic, unlike atomics
-  if (part) {
-    const int kbeg = (int)blockIdx.y * kper;
-    P += (long)kbeg * ldp;
-    K = (K - kbeg < kper) ? K - kbeg : kper;
-    M = part + (size_t)blockIdx.y * (size_t)lda * (size_t)ncols;
-    if (K <= 0) return;
-  }
-  const bool assign = part != nullptr;
   // global -> register staging: A chunk = BM x 16 doubles, B chunk = BN x 16 doubles, as double2
   typedef double double2_t __attribute__((ext_vector_type(2)));
   double2_t ra[QA], rb[QB];
@@ -562,7 +573,7 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda] = cv[mi][g] - acc[nj][mi][g];
+        for (int g = 0; g < 4; ++g) chol_store<WT>(&M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda], cv[mi][g] - acc[nj][mi][g]);
     }
     return;
   }
@@ -585,9 +596,48 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
       for (int g = 0; g < 4; ++g) {
         const long col = jw + nj * 16 + rq + 4 * g;
         const long row = iw + mi * 16 + r;
-        if (row < rows && col < ncols && row >= col) M[row + col * lda] = cv[mi][g] - acc[nj][mi][g];
+        if (row < rows && col < ncols && row >= col) chol_store<WT>(&M[row + col * lda], cv[mi][g] - acc[nj][mi][g]);
       }
   }
+}
+
+template <int BM, int BN, int WM = 4, int WN = 2>
+static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
+                                                                           int kcol0, int K, long base, int ntJ, int rect,
+                                                                           const double* __restrict__ Pext, long ldp,
+                                                                           double* __restrict__ part, int kper) {
+  static_assert((BM == 2 * BN || BM == BN) && BM % 64 == 0, "tile shape");
+  constexpr int RT = BM / BN;                     // tile row ti of the lower triangle holds RT (ti + 1) tiles
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const long b = blockIdx.x;
+  long ti, tj;
+  if (rect) {                                    // a few tile columns of a tall region: ntJ tiles per tile row
+    ti = b / ntJ; tj = b - ti * ntJ;
+    if (tj > RT * ti + RT - 1) return;           // above the diagonal
+  } else {                                       // the whole lower triangle: rows 0 .. ti-1 hold RT ti (ti + 1) / 2 tiles
+    ti = (long)((sqrt(1.0 + 8.0 * (double)b / RT) - 1.0) * 0.5);
+    while (RT * ti * (ti + 1) / 2 > b) --ti;
+    while (RT * (ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    tj = b - RT * ti * (ti + 1) / 2;             // 0 .. RT (ti + 1) - 1
+    if (tj >= ntJ) return;
+  }
+  const long i0 = base + ti * BM, j0 = base + tj * BN;
+  if (i0 >= rows || j0 >= ncols) return;
+  // the rank-K factor: columns [kcol0, kcol0 + K) of M itself (Cholesky trailing update), or an external (rows x K) column-major
+  // matrix Pext with leading dimension ldp (C -= Pext Pext^T: the reduced ellipsoid system of the camera-first elimination, esl_cf.hpp)
+  const double* P = Pext ? Pext : M + (long)kcol0 * lda;
+  if (!Pext) ldp = lda;
+  // split-K (gridDim.y > 1; small outputs with a long K: a 450 x 450 system has 20 tiles): slice blockIdx.y takes K range
+  // [y kper, (y + 1) kper) and writes -acc into ITS copy of the output (part + y lda ncols; no read-modify-write); a reduction
+  // kernel adds the slices to C in slice order -- deterministic, unlike atomics
+  if (part) {
+    const int kbeg = (int)blockIdx.y * kper;
+    P += (long)kbeg * ldp;
+    K = (K - kbeg < kper) ? K - kbeg : kper;
+    M = part + (size_t)blockIdx.y * (size_t)lda * (size_t)ncols;
+    if (K <= 0) return;
+  }
+  chol_update_tile<BM, BN, WM, WN, false>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, part != nullptr);
 }
 
 // ---- backward substitution L^T x = y, panel by panel from the last ------------------------------------------
@@ -634,6 +684,18 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
 // on a timeout bit 1 of info is set and every waiter gives up (the host reports an error instead of hanging the device).
 // Workgroup b only ever waits for panels owned by workgroups that were dispatched before it or for its own earlier panels;
 // with G <= 256 workgroups of one per CU (128 KB of LDS each) all of them are resident anyway.
+// Read a word other workgroups of the SAME launch write: a device-scope atomic ADD OF ZERO, written as inline assembly.
+// Measured on MI355X (round 4): an agent-scope (sc1) LOAD in a poll loop -- and every atomic the compiler or the L2 can treat as a
+// read: fetch_or 0 is folded into a load, a compare-and-swap that fails writes nothing -- can keep returning the value the line had
+// when the poller's XCD first fetched it, for as long as nothing evicts the line: with all 256 workgroups waiting (nobody streams
+// data) the chain sat on "3" for 300 ms while a copy from another stream showed 4.  An atomic that WRITES has to own the line, and
+// the task counter of these very kernels shows those are coherent across the XCDs.  ~1-3 us per poll; pollers sleep in between.
+__device__ __forceinline__ int chol_peek(int* word) {
+  int seen;
+  const int zero = 0;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(word), "v"(zero) : "memory");
+  return seen;
+}
 constexpr int kBsThreads = 512;
 constexpr int kBsMaxGrid = 256;
 constexpr size_t kBsLds = (size_t)(kNB * kNB + kNB) * sizeof(double);
@@ -696,10 +758,10 @@ static __global__ __launch_bounds__(kBsThreads) void k_chol_backsub(const double
       if (t == 0 && !aborted) {
         const long long t0 = (long long)wall_clock64();
         unsigned spins = 0;
-        while (__hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 1023u) == 0) {
-            if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) { aborted = true; break; }
+        while (chol_peek(&flags[r]) == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if ((++spins & 255u) == 0) {
+            if (chol_peek(info) & 2) { aborted = true; break; }
             if ((long long)wall_clock64() - t0 > 300000000LL) { atomicOr(info, 2); aborted = true; break; }   // 3 s at 100 MHz
           }
         }
@@ -814,6 +876,187 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
   }
 }
 
+// ---- persistent factorisation (round 4) -----------------------------------------------------------------------------------------
+// The launch-per-step form above leaves the chain of diagonal blocks exposed wherever the trailing matrix is too small to hide it
+// (the last ~8,000 rows of an order-18,000 system, ~8 of its 44 ms) and its small kernels queue behind 110 us update tiles for a
+// free CU.  Here ONE pair of kernels runs the whole factorisation: k_chol_chain (one workgroup, the potrf2 body: 640 threads, 157 KB
+// of LDS) walks the diagonal blocks, k_chol_workers (255 workgroups of the update kernel's shape; its 104 KB of LDS make every one
+// the only tenant of its CU, so the two kernels are co-resident by arithmetic: 255 + 1 CUs) pull TASKS from a static list with one
+// atomic counter.  Tasks, on the absolute tile grid (row tiles of 256, column tiles = the 128-wide panels):
+//   S(k, i)     strip i (64 rows) of the panel solve of panel k                            (k_chol_panel's workgroup)
+//   u(k, R, J)  tile (R, J) -= X(R, k) X(J, k)^T, rank 128, J in the rest of k's outer panel (k_chol_update_lds's workgroup)
+//   U(o, R, J)  tile (R, J) -= X(R, o) X(J, o)^T, rank W x 128, J beyond outer panel o
+// Dependencies are words in device memory (zeroed by a memset in front of the pair): pdone[k] (chain: L_kk, Linv_k published),
+// sdone[k][R] (strips of row tile R solved for panel k; complete at ns[k][R]), ver[R][J] (updates applied to tile (R, J): every
+// update carries its sequence number, waits for ver == seq and leaves ver = seq + 1 -- read-modify-write order and "tile final"
+// in one word).  The list is in an order in which every task's prerequisites come earlier (or are the chain's), so a workgroup
+// that spins on a word waits for work another RESIDENT workgroup already holds: no deadlock whatever the dispatch order; the
+// next outer panel's chain-dependent tasks sit between batches of the previous outer panel's far updates (look-ahead without
+// streams or events).  Hand-offs follow the guide's recipe R1: payload stored write-through (sc1), every storing wave drains,
+// one lane publishes the word; consumers poll relaxed from one lane, ONE agent-scope acquire, plain loads.  Every spin is bounded
+// (bit 1 of info + an abort word that stops all other spins).
+struct CholTask { int type, a, b, c; };   // 0: S(panel a, strip b)   1: u(panel a, row tile b, column tile c)   2: U(outer panel a, row tile b, column tile c)
+struct CholPlan {
+  int n = 0, np = 0, W = 0, n_outer = 0, nR = 0;
+  std::vector<CholTask> tasks;
+  std::vector<int> ns;   // [np][nR]
+};
+inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
+  const long rows = (long)n + 1;
+  pl.n = n; pl.W = W; pl.np = (n + kNB - 1) / kNB; pl.n_outer = (pl.np + W - 1) / W; pl.nR = (int)((rows + 255) / 256);
+  const int np = pl.np, nR = pl.nR;
+  pl.ns.assign((size_t)np * nR, 0);
+  pl.tasks.clear();
+  auto live = [&](int R, int J) { return 256L * R + 255 >= 128L * J && 256L * R < rows; };   // the tile meets the lower triangle (or the b row)
+  auto strips = [&](int k) { const long k0 = 128L * k, nb = std::min<long>(kNB, n - k0), below = rows - (k0 + nb); return (int)(below > 0 ? (below + 63) / 64 : 0); };
+  for (int k = 0; k < np; ++k) {
+    const long k0 = 128L * k, nb = std::min<long>(kNB, n - k0);
+    for (int i = 0; i < strips(k); ++i) pl.ns[(size_t)k * nR + (size_t)((k0 + nb + 64L * i) / 256)]++;
+  }
+  std::vector<CholTask> prevA, prevB;   // the previous outer panel's rank-(W x 128) updates: this outer panel's columns / everything beyond
+  for (int o = 0; o < pl.n_outer; ++o) {
+    const int kb = o * W, ke = std::min(np, kb + W);
+    pl.tasks.insert(pl.tasks.end(), prevA.begin(), prevA.end());
+    size_t bpos = 0;
+    auto fill = [&]() { const size_t e = std::min(prevB.size(), bpos + (size_t)filler); pl.tasks.insert(pl.tasks.end(), prevB.begin() + bpos, prevB.begin() + e); bpos = e; };
+    for (int k = kb; k < ke; ++k) {
+      fill();                                              // (work for the others while the chain factors block k)
+      for (int i = 0; i < strips(k); ++i) pl.tasks.push_back(CholTask{0, k, i, 0});
+      bool any = false;
+      for (int J = k + 1; J < ke; ++J)
+        for (int R = J / 2; R < nR; ++R)
+          if (live(R, J)) { if (!any) { fill(); any = true; } pl.tasks.push_back(CholTask{1, k, R, J}); }
+    }
+    pl.tasks.insert(pl.tasks.end(), prevB.begin() + bpos, prevB.end());
+    prevA.clear(); prevB.clear();
+    const int ne = std::min(np, ke + W);
+    for (int J = ke; J < np; ++J)
+      for (int R = J / 2; R < nR; ++R)
+        if (live(R, J)) (J < ne ? prevA : prevB).push_back(CholTask{2, o, R, J});
+  }
+}
+// sync words: [0] task counter, [1] abort, [4 ..) pdone[np], sdone[np][nR], ver[nR][np]
+inline size_t chol_sync_words(int np, int nR) { return 4 + (size_t)np + 2 * (size_t)np * nR; }
+__device__ long long g_chol_timeout_ticks = 300000000LL;   // 3 s at 100 MHz (ESL_CHOL_TIMEOUT_MS overrides it: debugging)
+// Spin until *word >= want (ONE lane; bounded).  Every poll is a chol_peek -- a device-scope atomic -- so the pollers are RATE
+// LIMITED: 255 workgroups polling back to back saturate the atomic units (~90 atomics per us on one word) and every other atomic
+// of the launch -- the chain's own polls, the task counter, the publishes -- queues behind them: measured, the first 30 panels of an
+// order-8,192 system then take 300 ms instead of 4.  SLEEP = argument of s_sleep (64 cycles each): workers wait ~2.7 us between
+// polls (at most ~95 polls per us from all of them together), the chain -- one poller -- ~0.1 us.
+template <int SLEEP>
+__device__ __forceinline__ bool chol_wait_ge(int* word, int want, int* abortw, int* info) {
+  // fast path: a plain agent-scope load.  The words only ever grow, so a stale copy can under-report but never over-report; most
+  // waits of tasks deep in the list were satisfied long ago and this XCD has either never fetched the line or fetched it late enough
+  if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+  if (chol_peek(word) >= want) return true;
+  const long long t0 = (long long)wall_clock64();
+  for (unsigned spins = 1;; ++spins) {
+    __builtin_amdgcn_s_sleep(SLEEP);
+    if (chol_peek(word) >= want) return true;
+    if ((spins & 15u) == 0) {
+      // (abort: a plain agent-scope load is enough -- a poller that keeps seeing a stale 0 runs into its own timeout)
+      if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      if ((long long)wall_clock64() - t0 > g_chol_timeout_ticks) {
+        atomicOr(info, 2);
+        __hip_atomic_store(abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+constexpr size_t kP2Lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
+static_assert(kP2Lds >= kCholLdsBig, "the persistent kernel's LDS is sized by the diagonal-block role");
+constexpr int kPwThreads = 512, kPwGrid = 256;
+constexpr size_t kPwLds = kP2Lds + 16;
+// ONE kernel, two roles (round 4, second form): workgroup 0 is the chain, workgroups 1..255 the workers.  (The first form ran the two
+// roles as two kernels on two streams: correct and as fast -- but whether two queues of one process run side by side or in turns
+// is the scheduler's business: creating or destroying any stream while the pair ran made it time-slice them, each role then only
+// moved during its own quantum, and an order-18,000 factorisation went from 42 ms to its 3 s spin limit.)  The 157 KB of LDS the
+// diagonal-block role needs make every workgroup the only tenant of its CU -- which the 104 KB of the update role did anyway.
+static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __restrict__ M, long lda, int n, int np, int W, int nR,
+                                                                   double* __restrict__ Linv_ws, const CholTask* __restrict__ tasks,
+                                                                   int n_tasks, const int* __restrict__ ns, int* sync, int* info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  int* slot = reinterpret_cast<int*>(sm + kP2Lds / sizeof(double));   // (behind the roles' LDS: no static __shared__, guide G17)
+  int* pdone = sync + 4;
+  int* sdone = pdone + np;
+  int* ver = sdone + (size_t)np * nR;
+  const int t = threadIdx.x;
+  const long rows = (long)n + 1;
+  if (blockIdx.x == 0) {   // ---- the chain: diagonal blocks in order
+    for (int k = 0; k < np; ++k) {
+      const int k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+      if (t == 0) {
+        const bool ok = chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], k / W + k % W, sync + 1, info);   // every update of the diagonal block's tile is in
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        slot[0] = ok ? 1 : 0;
+      }
+      __syncthreads();
+      if (!slot[0]) return;
+      chol_potrf2_body<true, kPwThreads>(sm, M, lda, k0, nb, Linv_ws + (size_t)k * kNB * kNB, info);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+      __syncthreads();
+      if (t == 0) __hip_atomic_store(&pdone[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then ONE lane publishes
+    }
+    return;
+  }
+  for (;;) {               // ---- a worker: the next task of the list
+    // (nothing but the kernel arguments is live across a task body: the task is re-read from the list afterwards -- with the
+    //  descriptor, the publish address and the diagnostics kept in registers the update tile's 212 spilled 60 B per lane)
+    if (t == 0) slot[0] = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (slot[0] >= n_tasks) return;
+    if (t == 0) {
+      const CholTask tk = tasks[slot[0]];
+      bool ok = true;
+      if (tk.type == 0) {
+        const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+        const int R = (int)(((long)k0 + nb + 64L * tk.b) / 256);
+        ok = chol_wait_ge<100>(&pdone[k], 1, sync + 1, info) && chol_wait_ge<100>(&ver[(size_t)R * np + k], k / W + k % W, sync + 1, info);
+      } else {
+        const int R = tk.b, J = tk.c;
+        const int ke = (tk.type == 1) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
+        // the LAST panel's strips of a row tile are solved only after every earlier panel of the same outer panel has solved its own
+        // there and updated them (S waits for its tile to be final): one pair of words stands for all W panels
+        ok = chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + R], ns[(size_t)(ke - 1) * nR + R], sync + 1, info) &&
+             chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + J / 2], ns[(size_t)(ke - 1) * nR + J / 2], sync + 1, info);
+        const int seq = (tk.type == 1) ? J / W + tk.a % W : tk.a;
+        ok = ok && chol_wait_ge<100>(&ver[(size_t)R * np + J], seq, sync + 1, info);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      slot[1] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!slot[1]) return;
+    {
+      const CholTask tk = tasks[slot[0]];
+      if (tk.type == 0) {
+        const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+        chol_panel_body<true>(M, lda, rows, k0, nb, Linv_ws + (size_t)k * kNB * kNB, (long)tk.b);
+      } else {
+        const int kb = (tk.type == 1) ? tk.a : tk.a * W, ke = (tk.type == 1) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
+        const long c0 = (long)kb * kNB;
+        const int K = (int)(((long)ke * kNB < n ? (long)ke * kNB : (long)n) - c0);
+        chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * tk.c, false);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+    __syncthreads();
+    if (t == 0) {                                         // ... then ONE lane publishes
+      const CholTask tk = tasks[slot[0]];
+      if (tk.type == 0) {
+        const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+        __hip_atomic_fetch_add(&sdone[(size_t)k * nR + (size_t)(((long)k0 + nb + 64L * tk.b) / 256)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __hip_atomic_store(&ver[(size_t)tk.b * np + tk.c], ((tk.type == 1) ? tk.c / W + tk.a % W : tk.a) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();                                      // (slot[0] is free for the next task)
+  }
+}
+
+inline hipError_t chol_sync_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }   // (polled words: read through chol_peek only)
+
 // Per-context state of the host driver: the look-ahead stream and its events live on the CONTEXT's device and are used by one
 // context only (two contexts sharing them could wait on each other's records), and hipFuncSetAttribute is per device.
 struct CholRuntime {
@@ -824,9 +1067,18 @@ struct CholRuntime {
   std::vector<hipEvent_t> ev_packed, ev_recv, ev_unpacked;  // per outer panel: message staged / received / copied out of its staging buffer
   bool attr_set = false;
   int* bs_flags = nullptr; int bs_flags_cap = 0;            // one "x_p published" word per 128-panel of k_chol_backsub
+  // persistent factorisation: the task list / strip counts of the last (n, W) on the device, the sync words, begin / done events
+  CholPlan plan;
+  CholTask* d_tasks = nullptr; int* d_ns = nullptr; int* d_sync = nullptr;
+  size_t d_tasks_cap = 0, d_ns_cap = 0, d_sync_cap = 0;
+  int sw_persistent = -1;                                   // ESL_CHOL_PERSISTENT = 1 / 0 forces it on / off (default: by size)
   int sw_backsub = -1;                                      // ESL_CHOL_BACKSUB_LAUNCHES=1 keeps the launch-per-panel form (A/B)
   void release() {
     if (bs_flags) { (void)hipFree(bs_flags); bs_flags = nullptr; bs_flags_cap = 0; }
+    if (d_tasks) { (void)hipFree(d_tasks); d_tasks = nullptr; d_tasks_cap = 0; }
+    if (d_ns) { (void)hipFree(d_ns); d_ns = nullptr; d_ns_cap = 0; }
+    if (d_sync) { (void)hipFree(d_sync); d_sync = nullptr; d_sync_cap = 0; }
+    plan = CholPlan();
     for (hipEvent_t e : ev_panel) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_trail) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_packed) (void)hipEventDestroy(e);
@@ -849,8 +1101,47 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBsLds);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwLds);
+  if (e != hipSuccess) return e;
   rt.attr_set = true;
   return hipSuccess;
+}
+
+// the persistent kernel on the caller's stream (one launch; the sync words are cleared in front of it)
+inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Linv_ws, int* info, hipStream_t st, CholRuntime& rt) {
+  const char* wenv = std::getenv("ESL_CHOL_W");   // (debugging: outer-panel width of the persistent form)
+  const int W = wenv ? std::max(1, std::atoi(wenv)) : chol_outer_panels(n);
+  if (rt.plan.n != n || rt.plan.W != W) {
+    chol_plan_build(n, W, /*filler*/ 128, rt.plan);
+    auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
+      if (*cap >= need) return hipSuccess;
+      if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+      hipError_t e = hipMalloc(p, need); if (e == hipSuccess) *cap = need;
+      return e;
+    };
+    hipError_t e = grow((void**)&rt.d_tasks, &rt.d_tasks_cap, std::max<size_t>(rt.plan.tasks.size(), 1) * sizeof(CholTask)); if (e != hipSuccess) return e;
+    e = grow((void**)&rt.d_ns, &rt.d_ns_cap, std::max<size_t>(rt.plan.ns.size(), 1) * sizeof(int)); if (e != hipSuccess) return e;
+    {
+      const size_t need = chol_sync_words(rt.plan.np, rt.plan.nR) * sizeof(int);
+      if (rt.d_sync_cap < need) {
+        if (rt.d_sync) { (void)hipFree(rt.d_sync); rt.d_sync = nullptr; rt.d_sync_cap = 0; }
+        e = chol_sync_alloc((void**)&rt.d_sync, need); if (e != hipSuccess) return e;
+        rt.d_sync_cap = need;
+      }
+    }
+    // (synchronous copies: once per system size)
+    if (!rt.plan.tasks.empty()) { e = hipMemcpy(rt.d_tasks, rt.plan.tasks.data(), rt.plan.tasks.size() * sizeof(CholTask), hipMemcpyHostToDevice); if (e != hipSuccess) return e; }
+    e = hipMemcpy(rt.d_ns, rt.plan.ns.data(), rt.plan.ns.size() * sizeof(int), hipMemcpyHostToDevice); if (e != hipSuccess) return e;
+  }
+  const CholPlan& pl = rt.plan;
+  if (const char* tm = std::getenv("ESL_CHOL_TIMEOUT_MS")) {
+    const long long ticks = 100000LL * std::max(1, std::atoi(tm));
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_chol_timeout_ticks), &ticks, sizeof(ticks)); if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipMemsetAsync(rt.d_sync, 0, chol_sync_words(pl.np, pl.nR) * sizeof(int), st); if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_chol_persist, dim3(kPwGrid), dim3(kPwThreads), kPwLds, st, M, lda, n, pl.np, pl.W, pl.nR, Linv_ws, (const CholTask*)rt.d_tasks,
+                     (int)pl.tasks.size(), (const int*)rt.d_ns, rt.d_sync, info);
+  return hipGetLastError();
 }
 
 // Host driver.  M: (n+1) x n col-major (lda), Linv_ws: ceil(n/NB) * NB*NB doubles, z_ws: NB doubles,
@@ -1009,6 +1300,12 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
         launch_update(st, c_begin, c_end - c_begin, b2, e2);
       }
     }
+  } else if (([&]() { if (rt.sw_persistent < 0) { const char* sw = std::getenv("ESL_CHOL_PERSISTENT"); rt.sw_persistent = sw ? (sw[0] == '1' ? 1 : 0) : 2; }
+                      // by size: measured on MI355X (profiles/r4_cholesky_microbench.txt) the one-launch form wins where the trailing updates
+                      // are long enough to cover its per-task hand-offs and short enough for the exposed chain to matter: n = 12,000 18.0 vs
+                      // 18.2 ms, 18,000 42.6 vs 43.8; 8,192 9.8 vs 9.1 and 32,768 213 vs 214 (a draw)
+                      return rt.sw_persistent == 1 || (rt.sw_persistent == 2 && n >= 10000 && n < 30000); })()) {
+    hipError_t e = chol_factor_persistent(M, lda, n, Linv_ws, info, st, rt); if (e != hipSuccess) return e;
   } else {
   bool trail_pending = false;   // ev_trail[o - 1] has been recorded and not yet waited for
   for (int o = 0; o < n_outer; ++o) {
@@ -1049,7 +1346,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     if (rt.bs_flags_cap < np) {
       if (rt.bs_flags) { (void)hipFree(rt.bs_flags); rt.bs_flags = nullptr; rt.bs_flags_cap = 0; }
       const int cap = std::max(np, 512);
-      hipError_t e = hipMalloc((void**)&rt.bs_flags, (size_t)cap * sizeof(int)); if (e != hipSuccess) return e;
+      hipError_t e = chol_sync_alloc((void**)&rt.bs_flags, (size_t)cap * sizeof(int)); if (e != hipSuccess) return e;
       rt.bs_flags_cap = cap;
     }
     hipError_t e = hipMemsetAsync(rt.bs_flags, 0, (size_t)np * sizeof(int), st); if (e != hipSuccess) return e;

@@ -814,6 +814,10 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
   ST_TRY(hipEventRecord(e0, c->stream));
   ST_TRY(chol_factor_solve(M, lda, n, Linv, z, x, info, c->stream, chol_rt(c)));
   ST_TRY(hipEventRecord(e1, c->stream));
+  if (std::getenv("ESL_CHOL_DEBUG")) {   // a stream created and destroyed while the factorisation runs: the disturbance that made the
+    hipStream_t w2 = nullptr;             // scheduler time-slice the first (two-kernel) persistent form
+    if (hipStreamCreateWithFlags(&w2, hipStreamNonBlocking) == hipSuccess) (void)hipStreamDestroy(w2);
+  }
   hipLaunchKernelGGL(k_selftest_resid, dim3((unsigned)n), dim3(256), 0, c->stream, x, (long)n, out2);
   double h2[2] = {0, 0};
   int hinfo = 0;
@@ -857,5 +861,24 @@ extern "C" int esl_lm_solver_stats(esl_ctx* c, double* st) {
 extern "C" int esl_lm_solver_used(esl_ctx* c, int32_t* solver_out) {
   if (!c || !solver_out) return ESL_ERR_INVALID;
   *solver_out = c->lm_solver_used;
+  return ESL_OK;
+}
+
+// test / debug: the task list of the persistent dense factorisation (esl_chol.hpp) for an order-n system with outer panels of W
+// 128-panels -- a pure host function (tests/test_chol_plan.py replays it on the CPU: order, dependency words, result)
+extern "C" int esl_debug_chol_plan(int32_t n, int32_t W, int32_t filler, int32_t* tasks_out /* 4 per task */, int64_t cap_tasks,
+                                   int32_t* ns_out /* np x nR */, int64_t cap_ns, int32_t meta_out[5] /* np, n_outer, nR, n_tasks, W */) {
+  if (n < 1 || W < 1 || !meta_out) return ESL_ERR_INVALID;
+  esl::CholPlan pl;
+  esl::chol_plan_build(n, W, filler, pl);
+  meta_out[0] = pl.np; meta_out[1] = pl.n_outer; meta_out[2] = pl.nR; meta_out[3] = (int32_t)pl.tasks.size(); meta_out[4] = pl.W;
+  if (tasks_out) {
+    if ((int64_t)pl.tasks.size() > cap_tasks) return ESL_ERR_INVALID;
+    for (size_t i = 0; i < pl.tasks.size(); ++i) { tasks_out[4 * i] = pl.tasks[i].type; tasks_out[4 * i + 1] = pl.tasks[i].a; tasks_out[4 * i + 2] = pl.tasks[i].b; tasks_out[4 * i + 3] = pl.tasks[i].c; }
+  }
+  if (ns_out) {
+    if ((int64_t)pl.ns.size() > cap_ns) return ESL_ERR_INVALID;
+    for (size_t i = 0; i < pl.ns.size(); ++i) ns_out[i] = pl.ns[i];
+  }
   return ESL_OK;
 }

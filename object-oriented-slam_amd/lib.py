@@ -22,7 +22,7 @@ EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
     "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
-    "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_solver_stats", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_set_replicated", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky",
+    "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_solver_stats", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_set_replicated", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky", "esl_debug_chol_plan",
     "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane", "esl_extract_planes",
 ]
 
@@ -392,6 +392,19 @@ def default_fit_params(**kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def chol_plan(n, W, filler=128):
+    """The persistent dense factorisation's static task list for an order-n system (esl_debug_chol_plan; host only):
+    dict(np, n_outer, nR, W, tasks (n_tasks, 4) int32 {type, a, b, c}, ns (np, nR) int32)."""
+    meta = (C.c_int32 * 5)()
+    ip = C.POINTER(C.c_int32)
+    _check(load().esl_debug_chol_plan(C.c_int32(n), C.c_int32(W), C.c_int32(filler), ip(), C.c_int64(0), ip(), C.c_int64(0), meta), "esl_debug_chol_plan")
+    np_, n_outer, nR, n_tasks, W_ = [int(v) for v in meta]
+    tasks = np.zeros((max(n_tasks, 1), 4), dtype=np.int32); ns = np.zeros((np_, nR), dtype=np.int32)
+    _check(load().esl_debug_chol_plan(C.c_int32(n), C.c_int32(W), C.c_int32(filler), tasks.ctypes.data_as(ip), C.c_int64(n_tasks),
+                                      ns.ctypes.data_as(ip), C.c_int64(ns.size), meta), "esl_debug_chol_plan")
+    return dict(np=np_, n_outer=n_outer, nR=nR, W=W_, tasks=tasks[:n_tasks], ns=ns)
 
 
 def partition_objects(graph, n_parts):

@@ -1,0 +1,112 @@
+"""The persistent dense factorisation (csrc/esl_chol.hpp, round 4) on the CPU: its STATIC TASK LIST is replayed by a sequential
+executor that owns the same dependency words as the device code (pdone / sdone / ver) and numpy versions of the three task bodies
+and the chain's potrf.  What this pins without a GPU:
+  * the list is a schedule: taken strictly in list order by ONE worker (the chain advancing whenever its tile is final) no task
+    ever finds a prerequisite missing -- so on the device a workgroup that spins always waits for work a resident workgroup
+    already holds (no deadlock for any number of workgroups, any dispatch order);
+  * every read-modify-write of a tile happens at its sequence number, every strip is solved once, every word ends at its expected
+    value;
+  * executing the list IS a Cholesky factorisation: L and the forward-substituted right-hand side row equal numpy's.
+The device kernels reuse the bodies of the launch-per-step kernels (k_chol_potrf2 / k_chol_panel / k_chol_update_lds) that the GPU
+suite already holds to 1e-15 residuals; the GPU tests run the pair itself (tests/test_gpu_slam.py)."""
+import numpy as np
+import pytest
+
+
+def replay(pkg, n, W, filler, seed=0):
+    pl = pkg.lib.chol_plan(n, W, filler)
+    np_, nR, tasks, ns = pl["np"], pl["nR"], pl["tasks"], pl["ns"]
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n))
+    A = G @ G.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    rows = n + 1
+    M = np.zeros((rows, n))
+    M[:n] = np.tril(A); M[n] = b
+    M0 = M.copy()
+    pdone = np.zeros(np_, int); sdone = np.zeros((np_, nR), int); ver = np.zeros((nR, np_), int)
+    Linv = [None] * np_
+    chain_k = [0]
+    final = lambda J: J // W + J % W
+    nb_of = lambda k: min(128, n - 128 * k)
+
+    def advance_chain():
+        while chain_k[0] < np_ and ver[chain_k[0] // 2, chain_k[0]] >= final(chain_k[0]):
+            k = chain_k[0]; k0, nb = 128 * k, nb_of(k)
+            assert ver[k // 2, k] == final(k)
+            D = np.tril(M[k0:k0 + nb, k0:k0 + nb]); D = D + np.tril(D, -1).T
+            L = np.linalg.cholesky(D)
+            M[k0:k0 + nb, k0:k0 + nb] = np.triu(M[k0:k0 + nb, k0:k0 + nb], 1) + L
+            Linv[k] = np.linalg.inv(L)
+            pdone[k] = 1
+            chain_k[0] += 1
+
+    counts = {0: 0, 1: 0, 2: 0}
+    for ty, a, bb, c in tasks:
+        advance_chain()
+        counts[int(ty)] += 1
+        if ty == 0:
+            k, i = a, bb; k0, nb = 128 * k, nb_of(k)
+            r0 = k0 + nb + 64 * i; r1 = min(r0 + 64, rows); R = r0 // 256
+            assert r0 < rows
+            assert pdone[k] == 1, ("S before its diagonal block", k, i)
+            assert ver[R, k] == final(k), ("S on a tile that is not final", k, i, ver[R, k], final(k))
+            M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
+            sdone[k, R] += 1
+        else:
+            R, J = bb, c
+            ks = [a] if ty == 1 else list(range(a * W, min(np_, a * W + W)))
+            seq = (J // W + a % W) if ty == 1 else a
+            # (the device code polls the LAST panel's words only: S waits for its tile to be final, so the last panel's strips of a
+            #  row tile are solved after every earlier panel of the outer panel has solved its own there -- asserted here for all)
+            assert ns[ks[-1], R] > 0 and ns[ks[-1], J // 2] > 0
+            for k in ks:
+                assert sdone[k, R] == ns[k, R], ("update before its row operand", ty, a, R, J, k)
+                assert sdone[k, J // 2] == ns[k, J // 2], ("update before its column operand", ty, a, R, J, k)
+                if ty == 1:
+                    assert k // W == J // W and J > k
+                else:
+                    assert J >= min(np_, a * W + W)
+            assert ver[R, J] == seq, ("update out of sequence", ty, a, R, J, ver[R, J], seq)
+            c0, c1 = 128 * ks[0], min(128 * (ks[-1] + 1), n)
+            i0, i1 = 256 * R, min(256 * R + 256, rows); j0, j1 = 128 * J, min(128 * J + 128, n)
+            P_i, P_j = M[i0:i1, c0:c1], M[j0:j1, c0:c1]
+            upd = P_i @ P_j.T
+            rr, cc = np.meshgrid(np.arange(i0, i1), np.arange(j0, j1), indexing="ij")
+            mask = rr >= cc                        # the kernel writes the lower triangle only (row n = the right-hand side's row)
+            blk = M[i0:i1, j0:j1]
+            blk[mask] -= upd[mask]
+            ver[R, J] = seq + 1
+    advance_chain()
+    assert chain_k[0] == np_, "the chain never got its last blocks"
+    # every word at its final value
+    assert (sdone == ns).all()
+    for J in range(np_):
+        for R in range(nR):
+            live = 256 * R + 255 >= 128 * J and 256 * R < rows
+            assert ver[R, J] == (final(J) if live else 0), (R, J)
+    Lref = np.linalg.cholesky(A)
+    np.testing.assert_allclose(np.tril(M[:n]), Lref, rtol=0, atol=1e-9 * np.abs(Lref).max())
+    np.testing.assert_allclose(M[n], np.linalg.solve(Lref, b), rtol=0, atol=1e-9 * np.abs(b).max())   # y = L^-1 b rides along as row n
+    return pl, counts, M0
+
+
+@pytest.mark.parametrize("n,W,filler", [(1, 2, 128), (7, 2, 128), (128, 2, 128), (130, 2, 4), (450, 2, 128), (777, 2, 3), (1000, 4, 2), (1153, 4, 128),
+                                         (2994, 2, 128), (2500, 4, 16)])
+def test_task_list_is_a_schedule_and_a_cholesky(pkg, n, W, filler):
+    pl, counts, _ = replay(pkg, n, W, filler)
+    np_ = pl["np"]
+    assert counts[0] == int(pl["ns"].sum())
+    print("n %d W %d: %d panels, %d tasks (%d strips, %d rank-128 tiles, %d rank-%d tiles)" % (n, W, np_, len(pl["tasks"]), counts[0], counts[1], counts[2], 128 * W))
+
+
+def test_look_ahead_order_of_the_list(pkg):
+    """the next outer panel's chain-dependent tasks must not queue behind ALL far updates of the previous one (that would be the
+    launch-per-step order without any look-ahead): the first strip of panel W comes before the last far update of outer panel 0"""
+    pl = pkg.lib.chol_plan(18000, 4, 128)
+    t = pl["tasks"]
+    first_s = int(np.nonzero((t[:, 0] == 0) & (t[:, 1] == 4))[0][0])
+    far0 = np.nonzero((t[:, 0] == 2) & (t[:, 1] == 0))[0]
+    look0 = far0[t[far0, 3] < 8]
+    assert look0.max() < first_s < far0.max()
+    assert len(t) > 50000 and pl["np"] == 141 and pl["nR"] == 71

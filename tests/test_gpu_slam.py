@@ -182,6 +182,23 @@ def test_dense_cholesky_selftest_residual(ctx, n):
     assert ms >= 0
 
 
+@pytest.mark.parametrize("n", [1, 7, 130, 777, 1153, 3000, 8192, 9001, 18000])
+def test_persistent_dense_cholesky_selftest_residual(pkg, monkeypatch, n):
+    """the persistent form of the dense factorisation (k_chol_chain + k_chol_workers: one launch pair, tasks and dependency words
+    instead of ~1,000 launches and stream events; the CPU replay of its task list is tests/test_chol_plan.py) forced on at every
+    size, against the same generated SPD systems as the launch-per-step form: residual at round-off, and the same x twice"""
+    monkeypatch.setenv("ESL_CHOL_PERSISTENT", "1")
+    cx = pkg.Context(0)
+    try:
+        ms, res = cx.selftest_cholesky(n)
+        ms2, res2 = cx.selftest_cholesky(n)
+    finally:
+        cx.close()
+        monkeypatch.delenv("ESL_CHOL_PERSISTENT", raising=False)
+    print("persistent Cholesky n = %d: %.3f ms (second call %.3f ms), residual %.1e" % (n, ms, ms2, res))
+    assert res < 1e-13 and res2 == res
+
+
 def test_slam_runs_are_bitwise_reproducible(pkg, ctx):
     """SLAM mode has no order-dependent reduction left (round 1's Schur complement scattered into S with fp64 atomics): the
     same graph twice gives the same bits, trace and states."""
