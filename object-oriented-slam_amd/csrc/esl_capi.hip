@@ -252,25 +252,9 @@ static void free_graph(esl_ctx* c) {
   c->n_chunks = 0;
   forget(&c->cams); forget(&c->cams_trial); forget(&c->objs); forget(&c->objs_trial);
   forget(&c->Hoo); forget(&c->bo); forget(&c->xo); forget(&c->obj_part);
-  // SLAM-mode buffers and snapshots are separate allocations (esl_slam.hip, esl_states_snapshot)
-  dev_free(&g.ue_start); dev_free(&g.ue_id); dev_free(&g.ue_slot);
-  dev_free(&g.cu_start); dev_free(&g.cu_obj); dev_free(&g.cu_id);
-  dev_free(&c->Linv_ws); dev_free(&c->z_ws);
-  dev_free(&c->Hcc); dev_free(&c->bc); dev_free(&c->xc); dev_free(&c->Wbb); dev_free(&c->We3);
-  dev_free(&c->Abb); dev_free(&c->Ae3); dev_free(&c->Aod); dev_free(&c->Dinv); dev_free(&c->Yb); dev_free(&c->Wt); dev_free(&c->Tb); dev_free(&c->Ye3);
-  dev_free(&c->S); dev_free(&c->cam_part); dev_free(&c->od_part);
-  dev_free(&c->cf_oe_start); dev_free(&c->cf_oe_u); dev_free(&c->cf_oe_slot); dev_free(&c->cf_od_start); dev_free(&c->cf_od_edge); dev_free(&c->cf_oe_cst);
-  dev_free(&c->cf_Linv); dev_free(&c->cf_M); dev_free(&c->cf_N); dev_free(&c->cf_V); dev_free(&c->cf_vy); dev_free(&c->cf_z);
-  dev_free(&c->cf_Xt); dev_free(&c->cf_T); dev_free(&c->cf_Linv_ws); dev_free(&c->cf_part); dev_free(&c->cf_B); dev_free(&c->cf_Lfac); dev_free(&c->cf_G);
-  dev_free(&c->cf_Zt); dev_free(&c->cf_Hs); dev_free(&c->cf_Bs); dev_free(&c->cf_LfacS); dev_free(&c->cf_GS); dev_free(&c->cf_LiS);
-  dev_free(&c->cf_MS); dev_free(&c->cf_NS); dev_free(&c->cf_R);
-  dev_free(&c->cf_seg_start); dev_free(&c->cf_seg_obj); dev_free(&c->cf_seg_first); dev_free(&c->cf_cmap); dev_free(&c->cf_xld); dev_free(&c->cf_fwork);
-  dev_free(&c->cf_mask); dev_free(&c->cf_xoff); dev_free(&c->cf_Xc); dev_free(&c->cf_Xs);
+  // SLAM-mode tables and buffers are interior pointers of the context's grow-only blobs (esl_slam.hip): forgotten, not freed
+  slam_forget(c);
   dev_free(&c->chol_pack); dev_free(&c->chol_pack2); c->chol_pack_len = 0;
-  dev_free(&c->cf_boff); dev_free(&c->cf_roff); dev_free(&c->cf_twork); dev_free(&c->cf_P); dev_free(&c->cf_Prhs);
-  c->cf_sp_built = c->cf_sparse = false;
-  c->cf_chain_ok = false;
-  c->cf_ready = false; c->cf_unavailable = false;
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->S_n = 0;
   c->graph_loaded = false;
@@ -282,6 +266,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (!c) return ESL_OK;
   (void)hipSetDevice(c->device);
   free_graph(c);
+  slam_release(c);
   if (c->arena_graph) (void)hipFree(c->arena_graph);
   if (c->arena_work) (void)hipFree(c->arena_work);
   if (c->stage_host) (void)hipHostFree(c->stage_host);

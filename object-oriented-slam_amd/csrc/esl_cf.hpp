@@ -1001,4 +1001,57 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
   }
 }
 
+
+// ---- the camera-first form's index tables, generated on the device (round 4) ---------------------------------------------------
+// The host ships only what it takes a sort to know (esl_slam.hip cf_ensure_impl): the per-ellipsoid lists in (slot, u) order and
+// the (segment, ellipsoid) incidences with their rank inside the segment.  The dense tables -- N x (chunks + 1) entry ranges,
+// segments x (N + 1) column map, the tile lists -- were 15 MB built by one host core at BASELINE configs[3]; here they are a few
+// microseconds of scatter.
+// oe_cst[o][chk] = first entry of ellipsoid o's list whose slot is >= chk * kCfFwdCh
+static __global__ __launch_bounds__(256) void k_cf_make_cst(int N, int n_chunks, const int* __restrict__ oe_start, const int* __restrict__ oe_slot,
+                                                            int* __restrict__ cst) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * (n_chunks + 1)) return;
+  const int o = (int)(t / (n_chunks + 1)), chk = (int)(t - (long)o * (n_chunks + 1));
+  int lo = oe_start[o], hi = oe_start[o + 1];
+  const int want = chk * kCfFwdCh;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (oe_slot[mid] < want) lo = mid + 1; else hi = mid; }
+  cst[t] = lo;
+}
+// incidence q = (segment p, ellipsoid o, first interior camera f, position `at` in the concatenated per-segment column lists):
+// cmap / seg_obj / seg_first entries and the ellipsoid's segment bitmap (cmap preset to -1, mask to 0)
+static __global__ __launch_bounds__(256) void k_cf_make_cmap(int n_inc, const int* __restrict__ inc /* [4][n_inc]: p, o, f, at */, int N1, int nw,
+                                                             const int* __restrict__ seg_start, int* __restrict__ cmap, unsigned long long* __restrict__ mask,
+                                                             int* __restrict__ seg_obj, int* __restrict__ seg_first) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n_inc) return;
+  const int p = inc[q], o = inc[n_inc + q], f = inc[2 * n_inc + q], at = inc[3 * n_inc + q];
+  cmap[(long)p * N1 + o] = (f << 24) | (at - seg_start[p]);
+  seg_obj[at] = o; seg_first[at] = f;
+  atomicOr(&mask[(long)o * nw + p / 64], 1ull << (p & 63));
+}
+// per segment: the right-hand side's column (index = the segment's column count, "ellipsoid" N) and the work lists of the
+// per-segment kernels -- (p, q) per 64 columns of the slab, (p, ti, tj) per tile of the product on and below the diagonal
+static __global__ __launch_bounds__(64) void k_cf_make_work(int nseg, int N, int nw, const int* __restrict__ seg_start, const int* __restrict__ fw_off,
+                                                            const long long* __restrict__ tw_off, int* __restrict__ cmap, unsigned long long* __restrict__ mask,
+                                                            int* __restrict__ fwork, int* __restrict__ twork) {
+  const int p = blockIdx.x;
+  if (p >= nseg) return;
+  const int cnt = seg_start[p + 1] - seg_start[p];
+  if (threadIdx.x == 0) {
+    cmap[(long)p * (N + 1) + N] = cnt;
+    atomicOr(&mask[(long)N * nw + p / 64], 1ull << (p & 63));
+  }
+  const int nq = fw_off[p + 1] - fw_off[p];
+  for (int q = threadIdx.x; q < nq; q += 64) { fwork[2 * (fw_off[p] + q)] = p; fwork[2 * (fw_off[p] + q) + 1] = q; }
+  const int nt = (9 * cnt + kCfSyT - 1) / kCfSyT;
+  const long long base = tw_off[p];
+  for (int t = threadIdx.x; t < nt * (nt + 1) / 2; t += 64) {
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    twork[3 * (base + t)] = p; twork[3 * (base + t) + 1] = ti; twork[3 * (base + t) + 2] = tj;
+  }
+}
 }  // namespace esl

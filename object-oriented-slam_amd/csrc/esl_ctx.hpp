@@ -75,6 +75,8 @@ struct LmState {
 
 }  // namespace esl
 
+// device blob + its pinned staging twin + the event of the last staging -> device copy
+struct BlobArena { char* dev = nullptr; size_t cap = 0; char* host = nullptr; size_t host_cap = 0; hipEvent_t ev = nullptr; };
 struct esl_ctx;
 namespace esl {
 // RAII event bracket around a group of launches of one kernel class
@@ -168,6 +170,10 @@ struct esl_ctx {
   char* arena_graph = nullptr; size_t arena_graph_cap = 0;
   char* arena_work = nullptr;  size_t arena_work_cap = 0;
   char* stage_host = nullptr;  size_t stage_host_cap = 0;   // pinned staging blob
+  // grow-only blobs of SLAM mode (esl_slam.hip BlobStage): what slam_alloc builds at upload / what the first trial's solver needs
+  BlobArena arena_slam, arena_solve;
+  const int *h_cu_start = nullptr, *h_cu_obj = nullptr, *h_cu_id = nullptr;   // the per-camera lists in arena_slam's staging blob
+  std::vector<int> h_ue_start, h_ue_id, h_ue_slot;   // host copy of the unified per-ellipsoid edge lists (the camera-first tables are built from it on first use)
   char* fit_slab = nullptr; size_t fit_slab_cap = 0;        // esl_fit_frame's device slab (esl_fit.hip)
   char* fit_in = nullptr;  size_t fit_in_cap = 0;           // pinned staging of its inputs / outputs
   char* fit_out = nullptr; size_t fit_out_cap = 0;

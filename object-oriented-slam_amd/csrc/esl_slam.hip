@@ -4,9 +4,11 @@
 #include "esl_slam.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "esl_cf.hpp"
 #include "esl_chol.hpp"
@@ -15,207 +17,200 @@
 namespace esl {
 
 template <class T>
-static int up(T** dst, const T* src, size_t n, hipStream_t st) {
-  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
-  ESL_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
-  if (n) ESL_HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, st));
-  return ESL_OK;
-}
-template <class T>
 static int al(T** dst, size_t n) {
   if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
   ESL_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
   return ESL_OK;
 }
 
+// ---- grow-only blobs of SLAM mode (round 4) -------------------------------------------------------------------------------
+// Rounds 2-3 gave every table and work buffer of SLAM mode its own hipFree + hipMalloc + pageable copy at every upload (~40 of
+// them) and freed the solver's multi-GB buffers with the graph: 21 ms per esl_graph_upload at BASELINE configs[3], paid by every
+// esl_optimize call of the drop-in adapter.  Now two BlobArenas (esl_ctx.hpp): arena_slam holds what slam_alloc makes at upload,
+// arena_solve what the first trial step's solver needs (the camera-first tables + slabs + T, or S).  A BlobStage plans a layout
+// (256-byte aligned items, uploads first), grows the arena and its pinned staging blob when needed, lets the caller build the
+// uploaded tables IN the staging blob, and ships them with one copy.  Pointers handed out are interior pointers: never hipFree()d,
+// only forgotten (slam_forget) -- the arenas live until the context is destroyed (slam_release).
+namespace {
+struct BlobStage {
+  struct Item { void** dst; size_t bytes, off; bool upload; };
+  std::vector<Item> items;
+  size_t total = 0, up_end = 0;
+  BlobArena* a = nullptr;
+  template <class T> int up(T** dst, size_t n) { return add((void**)dst, n * sizeof(T), true); }      // -> item index
+  template <class T> int work(T** dst, size_t n) { return add((void**)dst, n * sizeof(T), false); }
+  int add(void** dst, size_t bytes, bool upload) {
+    const size_t off = (total + 255) / 256 * 256;
+    items.push_back({dst, bytes, off, upload});
+    total = off + std::max<size_t>(bytes, 8);
+    if (upload) up_end = total;
+    return (int)items.size() - 1;
+  }
+  // grows the arena / the staging blob; afterwards host<T>(i) is where item i's table is to be built
+  int reserve(BlobArena& arena) {
+    a = &arena;
+    if (a->ev) ESL_HIP_TRY(hipEventSynchronize(a->ev));   // the previous blob's copy still reads the staging memory
+    else ESL_HIP_TRY(hipEventCreateWithFlags(&a->ev, hipEventDisableTiming));
+    if (up_end > a->host_cap) {
+      if (a->host) { (void)hipHostFree(a->host); a->host = nullptr; a->host_cap = 0; }
+      const size_t want = up_end + up_end / 2 + 4096;
+      ESL_HIP_TRY(hipHostMalloc((void**)&a->host, want, hipHostMallocDefault));
+      a->host_cap = want;
+    }
+    if (total > a->cap) {
+      if (a->dev) { (void)hipFree(a->dev); a->dev = nullptr; a->cap = 0; }
+      const size_t want = total + total / 8 + 4096;
+      ESL_HIP_TRY(hipMalloc((void**)&a->dev, want));
+      a->cap = want;
+    }
+    for (const Item& it : items) *it.dst = a->dev + it.off;
+    return ESL_OK;
+  }
+  template <class T> T* host(int i) const { return (T*)(a->host + items[(size_t)i].off); }
+  int ship(hipStream_t st) {
+    if (up_end) ESL_HIP_TRY(hipMemcpyAsync(a->dev, a->host, up_end, hipMemcpyHostToDevice, st));
+    ESL_HIP_TRY(hipEventRecord(a->ev, st));
+    return ESL_OK;
+  }
+};
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+static void cf_forget(esl_ctx* c);
+// the graph goes away: every interior pointer is forgotten, the arenas stay (esl_capi.hip free_graph)
+void slam_forget(esl_ctx* c) {
+  DevGraph& g = c->g;
+  g.ue_start = g.ue_id = g.ue_slot = g.cu_start = g.cu_obj = g.cu_id = nullptr;
+  c->Hcc = c->bc = c->xc = c->Wbb = c->Abb = c->Aod = c->Dinv = c->Yb = c->Wt = c->Tb = c->cam_part = c->od_part = c->z_ws = nullptr;
+  c->cf_od_start = c->cf_od_edge = nullptr;
+  c->S = c->Linv_ws = nullptr;
+  cf_forget(c);
+  c->cf_chain_ok = false; c->cf_unavailable = false;
+  c->h_ue_start.clear(); c->h_ue_id.clear(); c->h_ue_slot.clear();
+  c->h_cu_start = c->h_cu_obj = c->h_cu_id = nullptr;
+}
+static void blob_release(BlobArena& a) {
+  if (a.dev) (void)hipFree(a.dev);
+  if (a.host) (void)hipHostFree(a.host);
+  if (a.ev) (void)hipEventDestroy(a.ev);
+  a = BlobArena{};
+}
+void slam_release(esl_ctx* c) { slam_forget(c); blob_release(c->arena_slam); blob_release(c->arena_solve); }
+
+// SLAM-mode lists of a freshly uploaded graph + its per-graph work buffers.  All lists come out of counting sorts (no comparison
+// sort: the per-ellipsoid order "ascending u" falls out of walking the edge arrays in order, "ascending (slot, u)" out of walking
+// the per-camera lists in slot order).
 int slam_alloc(esl_ctx* c) {
   DevGraph& g = c->g;
   const int N = g.n_objs, F = g.n_cams, nf = g.n_free_cams;
-  int rc;
-  // unified per-ellipsoid list of edges whose camera is free
-  std::vector<int> start((size_t)N + 1, 0), id, slot;
+  const bool timing = std::getenv("ESL_UPLOAD_HOST_TIMING") != nullptr;
+  const double t0 = timing ? now_us() : 0;
+  // unified per-ellipsoid list of edges whose camera is free (u = bounding-box edge i, or n_bbox + 3-D edge i), ascending u
+  std::vector<int>& start = c->h_ue_start;
+  std::vector<int>& id = c->h_ue_id;
+  std::vector<int>& slot = c->h_ue_slot;
+  start.assign((size_t)N + 1, 0);
+  for (int i = 0; i < g.n_bbox; ++i) if (c->h_cam_slot[c->h_bb_cam[i]] >= 0) ++start[(size_t)c->h_bb_obj[i] + 1];
+  for (int i = 0; i < g.n_e3d; ++i) if (c->h_cam_slot[c->h_e3_cam[i]] >= 0) ++start[(size_t)c->h_e3_obj[i] + 1];
+  for (int o = 0; o < N; ++o) start[(size_t)o + 1] += start[o];
+  const size_t nue = (size_t)start[N];
+  id.resize(nue); slot.resize(nue);
   {
-    std::vector<std::vector<std::pair<int, int>>> per((size_t)N);
+    std::vector<int> cur(start.begin(), start.end() - 1);
     for (int i = 0; i < g.n_bbox; ++i) {
       const int s = c->h_cam_slot[c->h_bb_cam[i]];
-      if (s >= 0) per[c->h_bb_obj[i]].push_back({i, s});
+      if (s >= 0) { const int at = cur[c->h_bb_obj[i]]++; id[at] = i; slot[at] = s; }
     }
     for (int i = 0; i < g.n_e3d; ++i) {
       const int s = c->h_cam_slot[c->h_e3_cam[i]];
-      if (s >= 0) per[c->h_e3_obj[i]].push_back({g.n_bbox + i, s});
-    }
-    for (int o = 0; o < N; ++o) {
-      start[(size_t)o + 1] = start[o] + (int)per[o].size();
-      for (auto& pr : per[o]) { id.push_back(pr.first); slot.push_back(pr.second); }
+      if (s >= 0) { const int at = cur[c->h_e3_obj[i]]++; id[at] = g.n_bbox + i; slot[at] = s; }
     }
   }
-  g.n_ue = (int)id.size();
-  // the same edges per free camera, sorted by (ellipsoid, u): two of these lists are intersected per block of S
+  g.n_ue = (int)nue;
+  // odometry edges of every pair of neighbouring slots (the camera chain of esl_cf.hpp): the camera-first form applies when ALL
+  // odometry edges between free cameras join neighbours.  (Its other tables are built by the first trial step that picks it.)
+  std::vector<int> ods((size_t)std::max(nf, 1) + 1, 0), ode;
+  bool chain = true;
   {
-    std::vector<int> cstart((size_t)nf + 1, 0), cobj(id.size()), cid(id.size());
-    for (size_t k = 0; k < id.size(); ++k) ++cstart[(size_t)slot[k] + 1];
-    for (int sidx = 0; sidx < nf; ++sidx) cstart[(size_t)sidx + 1] += cstart[sidx];
-    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
-    // walking the ellipsoids in order and, inside one, its edges in ascending u keeps every camera's list sorted
-    for (int o = 0; o < N; ++o) {
-      std::vector<std::pair<int, int>> es;   // (u, slot)
-      for (int k = start[o]; k < start[(size_t)o + 1]; ++k) es.push_back({id[k], slot[k]});
-      std::sort(es.begin(), es.end());
-      for (auto& e : es) { const int at = fill[e.second]++; cobj[at] = o; cid[at] = e.first; }
-    }
-    g.cu_max = 0;
-    for (int sidx = 0; sidx < nf; ++sidx) g.cu_max = std::max(g.cu_max, cstart[(size_t)sidx + 1] - cstart[sidx]);
-    if ((rc = up(&g.cu_start, cstart.data(), cstart.size(), c->stream))) return rc;
-    if ((rc = up(&g.cu_obj, cobj.data(), cobj.size(), c->stream))) return rc;
-    if ((rc = up(&g.cu_id, cid.data(), cid.size(), c->stream))) return rc;
-  }
-  // camera-first elimination (esl_cf.hpp): every ellipsoid's free-camera edges sorted by (slot, u), and for every pair of
-  // neighbouring slots the odometry edges that join them; it applies when ALL odometry edges between free cameras do
-  {
-    std::vector<int> ou(id.size()), os(id.size());
-    for (int o = 0; o < N; ++o) {
-      std::vector<std::pair<int, int>> es;   // (slot, u)
-      for (int k = start[o]; k < start[(size_t)o + 1]; ++k) es.push_back({slot[k], id[k]});
-      std::sort(es.begin(), es.end());
-      for (size_t k = 0; k < es.size(); ++k) { os[(size_t)start[o] + k] = es[k].first; ou[(size_t)start[o] + k] = es[k].second; }
-    }
-    // entry range of every (ellipsoid, chunk of kCfFwdCh slots) in those lists: the forward substitution's gather phase
-    const int nch = (nf + kCfFwdCh - 1) / kCfFwdCh;
-    std::vector<int> cst((size_t)std::max(N, 1) * (nch + 1), 0);
-    for (int o = 0; o < N; ++o) {
-      int k = start[o];
-      for (int chk = 0; chk <= nch; ++chk) {
-        while (k < start[(size_t)o + 1] && os[k] < chk * kCfFwdCh) ++k;
-        cst[(size_t)o * (nch + 1) + chk] = k;
-      }
-    }
-    c->cf_n_list = (int)id.size(); c->cf_n_chunks = nch;
-    if ((rc = up(&c->cf_oe_cst, cst.data(), cst.size(), c->stream))) return rc;
-    std::vector<int> ods((size_t)std::max(nf, 1) + 1, 0), ode;
-    bool chain = true;
-    std::vector<std::vector<int>> per_pair((size_t)std::max(nf, 1));
+    std::vector<std::pair<int, int>> pe;   // (lower slot, 2 e + orientation)
     for (int e = 0; e < g.n_odom; ++e) {
       const int si = c->h_cam_slot[c->h_od_i[e]], sj = c->h_cam_slot[c->h_od_j[e]];
       if (si < 0 || sj < 0) continue;                       // a fixed end: the edge only adds to the free end's diagonal block
-      if (si == sj + 1) per_pair[sj].push_back(e * 2);      // rows = first vertex = the higher slot: B as stored
-      else if (sj == si + 1) per_pair[si].push_back(e * 2 + 1);
+      if (si == sj + 1) pe.push_back({sj, e * 2});          // rows = first vertex = the higher slot: B as stored
+      else if (sj == si + 1) pe.push_back({si, e * 2 + 1});
       else chain = false;                                   // (si == sj: a self edge; |si - sj| > 1: fill-in outside the band)
     }
-    for (int k = 0; k < nf; ++k) { ods[(size_t)k + 1] = ods[k] + (int)per_pair[k].size(); ode.insert(ode.end(), per_pair[k].begin(), per_pair[k].end()); }
-    c->cf_chain_ok = chain && nf > 0 && N > 0;
-    if ((rc = up(&c->cf_oe_start, start.data(), start.size(), c->stream))) return rc;
-    if ((rc = up(&c->cf_oe_u, ou.data(), ou.size(), c->stream))) return rc;
-    if ((rc = up(&c->cf_oe_slot, os.data(), os.size(), c->stream))) return rc;
-    if ((rc = up(&c->cf_od_start, ods.data(), ods.size(), c->stream))) return rc;
-    if ((rc = up(&c->cf_od_edge, ode.data(), ode.size(), c->stream))) return rc;
-    // X = L^-1 W is SPARSE over a short run of cameras (esl_cf.hpp): per segment of kCfFwdCh slots (the last one the separator) the
-    // ellipsoids seen by its interior cameras, where each one's column starts, and per ellipsoid the bitmap of its segments
-    c->cf_sp_built = false;
-    // (the column map is nseg x (N + 1) ints: not built beyond 1 GB of it -- such a graph runs the dense-X form or the reduced camera system)
-    if (chain && nf >= 256 && N > 0 && (size_t)((nf + kCfFwdCh - 1) / kCfFwdCh) * (size_t)(N + 1) <= ((size_t)1 << 28)) {
-      const int nseg = (nf + kCfFwdCh - 1) / kCfFwdCh, nw = (nseg + 63) / 64, N1 = N + 1;
-      std::vector<int> cmap((size_t)nseg * N1, -1), seg_start((size_t)nseg + 1, 0), seg_obj, xld((size_t)nseg), fwork;
-      std::vector<unsigned long long> mask((size_t)N1 * nw, 0ull);
-      std::vector<long long> xoff((size_t)nseg + 1, 0), boff((size_t)nseg + 1, 0), roff((size_t)nseg + 1, 0);
-      std::vector<int> twork;
-      for (int o = 0; o < N; ++o)
-        for (int k = start[o]; k < start[(size_t)o + 1]; ++k) {
-          const int sl = os[k], p = sl / kCfFwdCh, pos = sl - p * kCfFwdCh;
-          if (pos == kCfFwdCh - 1) continue;                       // the separator's own edges
-          int& e = cmap[(size_t)p * N1 + o];
-          if (e < 0) e = pos << 24;                                // (lists sorted by slot: the first hit is the first camera)
-          mask[(size_t)o * nw + p / 64] |= 1ull << (p & 63);
-        }
-      // compact order inside a segment: by FIRST camera, then by ellipsoid -- the slab is then upper-trapezoidal (column c is zero
-      // above row 6 first(c)), and a tile of the segment's product starts at the first camera of its first column
-      double fl = 0;
-      std::vector<int> seg_first;
-      std::vector<std::pair<int, int>> ord;
-      for (int p = 0; p < nseg; ++p) {
-        ord.clear();
-        for (int o = 0; o < N; ++o) {
-          const int e = cmap[(size_t)p * N1 + o];
-          if (e >= 0) ord.push_back({e >> 24, o});
-        }
-        std::sort(ord.begin(), ord.end());
-        const int cnt = (int)ord.size();
-        for (int k = 0; k < cnt; ++k) {
-          cmap[(size_t)p * N1 + ord[k].second] = (ord[k].first << 24) | k;
-          seg_obj.push_back(ord[k].second); seg_first.push_back(ord[k].first);
-          fl += 81.0 * (k + 1) * (6 * (kCfFwdCh - 1 - ord[k].first));   // block row k of the product: k + 1 blocks, rows from its first camera on
-        }
-        cmap[(size_t)p * N1 + N] = cnt;                            // the right-hand side: the column after the last ellipsoid's
-        mask[(size_t)N * nw + p / 64] |= 1ull << (p & 63);
-        seg_start[(size_t)p + 1] = seg_start[p] + cnt;
-        const int m = 9 * cnt + 1;
-        xld[p] = (m + 15) / 16 * 16 + 16;                          // + 16: the T kernel reads 16 columns from any column start
-        xoff[(size_t)p + 1] = xoff[p] + (long long)kCfSegRows * xld[p];
-        for (int q = 0; q < (m + 63) / 64; ++q) { fwork.push_back(p); fwork.push_back(q); }
-        boff[(size_t)p + 1] = boff[p] + (long long)cnt * (cnt + 1) / 2;
-        roff[(size_t)p + 1] = roff[p] + 9LL * cnt;
-        for (int ti = 0; ti < (9 * cnt + kCfSyT - 1) / kCfSyT; ++ti)   // tiles of the product on and below the diagonal (ellipsoid columns only)
-          for (int tj = 0; tj <= ti; ++tj) { twork.push_back(p); twork.push_back(ti); twork.push_back(tj); }
-      }
-      if ((rc = up(&c->cf_seg_first, seg_first.data(), seg_first.size(), c->stream))) return rc;
-      c->cf_sp_nseg = nseg; c->cf_sp_nw = nw; c->cf_n_fwork = (int)(fwork.size() / 2); c->cf_sp_flops = fl; c->cf_xc_len = (size_t)xoff[nseg] + 2 * kCfSyT;   // (+: the product kernel's last tile reads past the last slab's columns)
-      if ((rc = up(&c->cf_cmap, cmap.data(), cmap.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_mask, mask.data(), mask.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_seg_start, seg_start.data(), seg_start.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_seg_obj, seg_obj.data(), seg_obj.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_xld, xld.data(), xld.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_xoff, xoff.data(), xoff.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_fwork, fwork.data(), fwork.size(), c->stream))) return rc;
-      c->cf_n_twork = (int)(twork.size() / 3); c->cf_p_blocks = (size_t)boff[nseg]; c->cf_prhs_len = (size_t)roff[nseg];
-      if ((rc = up(&c->cf_boff, boff.data(), boff.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_roff, roff.data(), roff.size(), c->stream))) return rc;
-      if ((rc = up(&c->cf_twork, twork.data(), twork.size(), c->stream))) return rc;
-      ESL_HIP_TRY(hipStreamSynchronize(c->stream));
-      c->cf_sp_built = true;
-    }
-    ESL_HIP_TRY(hipStreamSynchronize(c->stream));           // the host vectors go out of scope
+    for (auto& p : pe) ++ods[(size_t)p.first + 1];
+    for (int k = 0; k < nf; ++k) ods[(size_t)k + 1] += ods[k];
+    ode.resize(pe.size());
+    std::vector<int> cur(ods.begin(), ods.end() - 1);
+    for (auto& p : pe) ode[(size_t)cur[p.first]++] = p.second;   // (edges of one pair stay in ascending e)
   }
-  if ((rc = up(&g.ue_start, start.data(), start.size(), c->stream))) return rc;
-  if ((rc = up(&g.ue_id, id.data(), id.size(), c->stream))) return rc;
-  if ((rc = up(&g.ue_slot, slot.data(), slot.size(), c->stream))) return rc;
-  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  c->cf_chain_ok = chain && nf > 0 && N > 0;
+  const double t1 = timing ? now_us() : 0;
+  // layout: uploads first, then the work buffers
   const size_t EU = (size_t)g.n_bbox + g.n_e3d;
-  if ((rc = al(&c->Hcc, (size_t)nf * 36))) return rc;
-  if ((rc = al(&c->bc, (size_t)nf * 6))) return rc;
-  if ((rc = al(&c->Wbb, EU * 54))) return rc;   // unified W  [54][EU]
-  if ((rc = al(&c->Abb, EU * 27))) return rc;   // unified A  [EU][27] (per-edge records)
-  if ((rc = al(&c->Yb, EU * 54))) return rc;    // unified Y  [EU][54]
-  if ((rc = al(&c->Wt, EU * 54))) return rc;    // W once more as per-edge records [EU][9][6]: what k_slam_schur_pull gathers
-  if ((rc = al(&c->Tb, EU * 6))) return rc;     // Y_e b_o    [6][EU]
-  if ((rc = al(&c->Aod, (size_t)g.n_odom * 90))) return rc;
-  if ((rc = al(&c->Dinv, (size_t)N * 81))) return rc;
-  if ((rc = al(&c->cam_part, (size_t)F * 4))) return rc;
-  if ((rc = al(&c->od_part, (size_t)g.n_odom))) return rc;
   const int64_t n = 6 * (int64_t)nf;
   c->S_n = n;
   c->S_lda = ((n + 1 + 15) / 16) * 16;
-  // the reduced camera system S (28.8 GB at C4) and the buffers of the camera-first form are allocated by the first trial step
-  // that needs them (slam_ensure_S / cf_ensure): a run uses one form or the other
-  if (c->S) { (void)hipFree(c->S); c->S = nullptr; }
-  if (c->Linv_ws) { (void)hipFree(c->Linv_ws); c->Linv_ws = nullptr; }
-  if ((rc = al(&c->xc, (size_t)n))) return rc;
-  if ((rc = al(&c->z_ws, (size_t)kNB))) return rc;
+  BlobStage st;
+  const int i_ust = st.up(&g.ue_start, start.size()), i_uid = st.up(&g.ue_id, nue), i_usl = st.up(&g.ue_slot, nue);
+  const int i_cst = st.up(&g.cu_start, (size_t)nf + 1), i_cob = st.up(&g.cu_obj, nue), i_cid = st.up(&g.cu_id, nue);
+  const int i_ods = st.up(&c->cf_od_start, ods.size()), i_ode = st.up(&c->cf_od_edge, ode.size());
+  st.work(&c->Hcc, (size_t)nf * 36); st.work(&c->bc, (size_t)nf * 6);
+  st.work(&c->Wbb, EU * 54);    // unified W  [54][EU]
+  st.work(&c->Abb, EU * 27);    // unified A  [EU][27] (per-edge records)
+  st.work(&c->Yb, EU * 54);     // unified Y  [EU][54]
+  st.work(&c->Wt, EU * 54);     // W once more as per-edge records [EU][9][6]: what k_slam_schur_pull gathers
+  st.work(&c->Tb, EU * 6);      // Y_e b_o    [6][EU]
+  st.work(&c->Aod, (size_t)g.n_odom * 90); st.work(&c->Dinv, (size_t)N * 81);
+  st.work(&c->cam_part, (size_t)F * 4); st.work(&c->od_part, (size_t)g.n_odom);
+  st.work(&c->xc, (size_t)n); st.work(&c->z_ws, (size_t)kNB);
+  if (int rc = st.reserve(c->arena_slam)) return rc;
+  std::memcpy(st.host<int>(i_ust), start.data(), start.size() * sizeof(int));
+  if (nue) { std::memcpy(st.host<int>(i_uid), id.data(), nue * sizeof(int)); std::memcpy(st.host<int>(i_usl), slot.data(), nue * sizeof(int)); }
+  std::memcpy(st.host<int>(i_ods), ods.data(), ods.size() * sizeof(int));
+  if (!ode.empty()) std::memcpy(st.host<int>(i_ode), ode.data(), ode.size() * sizeof(int));
+  // the same edges per free camera, sorted by (ellipsoid, u): two of these lists are intersected per block of S.  Walking the
+  // unified list in order (ellipsoids ascending, u ascending inside one) keeps every camera's list sorted.
+  {
+    int* cstart = st.host<int>(i_cst); int* cobj = st.host<int>(i_cob); int* cid = st.host<int>(i_cid);
+    c->h_cu_start = cstart; c->h_cu_obj = cobj; c->h_cu_id = cid;   // (staging memory: valid until the next upload; cf_ensure_impl reads them)
+    std::fill(cstart, cstart + nf + 1, 0);
+    for (size_t k = 0; k < nue; ++k) ++cstart[(size_t)slot[k] + 1];
+    g.cu_max = 0;
+    for (int s = 0; s < nf; ++s) { g.cu_max = std::max(g.cu_max, cstart[(size_t)s + 1]); cstart[(size_t)s + 1] += cstart[s]; }
+    std::vector<int> cur(cstart, cstart + nf);
+    for (int o = 0; o < N; ++o)
+      for (int k = start[o]; k < start[(size_t)o + 1]; ++k) { const int at = cur[slot[k]]++; cobj[at] = o; cid[at] = id[k]; }
+  }
+  if (int rc = st.ship(c->stream)) return rc;
   // W / A of edges that are never written (fixed camera) must not hold NaN garbage where they are summed
   ESL_HIP_TRY(hipMemsetAsync(c->Abb, 0, std::max<size_t>(EU, 1) * 27 * sizeof(double), c->stream));
   ESL_HIP_TRY(hipMemsetAsync(c->Wbb, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
-  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (timing) {
+    const double t2 = now_us();
+    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+    fprintf(stderr, "[slam_alloc host, us] lists %.0f  layout + per-camera lists + enqueue %.0f  wait %.0f  (blob %.1f MB uploaded, %.1f MB in all)\n",
+            t1 - t0, t2 - t1, now_us() - t2, st.up_end / 1e6, st.total / 1e6);
+  }
   return ESL_OK;
 }
 
 static CholRuntime& chol_rt(esl_ctx* c);
 static __global__ void k_info_to_double(const int* __restrict__ info, double* __restrict__ d) { d[0] = info[0] ? 1.0 : 0.0; }
 static __global__ void k_double_to_info(const double* __restrict__ d, int* __restrict__ info) { if (d[0] > 0.5) info[0] |= 1; }
+// the reduced camera system S (28.8 GB at C4) lives in the solver arena, like the camera-first form's buffers: a graph uses one
+// form or the other, and the arena is kept from graph to graph
 static int slam_ensure_S(esl_ctx* c) {
   if (c->S) return ESL_OK;
-  int rc;
+  cf_forget(c);                // (the two forms share the arena)
   const size_t n = (size_t)c->S_n, np = (n + kNB - 1) / kNB;
-  if ((rc = al(&c->S, (size_t)c->S_lda * n))) return rc;
-  if ((rc = al(&c->Linv_ws, np * kNB * kNB))) return rc;
-  return ESL_OK;
+  BlobStage st;
+  st.work(&c->S, (size_t)c->S_lda * n); st.work(&c->Linv_ws, np * kNB * kNB);
+  const int rc = st.reserve(c->arena_solve);
+  if (rc) { c->S = c->Linv_ws = nullptr; return rc; }
+  return st.ship(c->stream);
 }
 
 // ---- camera-first elimination: host side (kernels and the maths: esl_cf.hpp) ---------------------------------------------
@@ -260,89 +255,219 @@ static int slam_pick_solver(const esl_ctx* c) {
 }
 template <class T>
 static void fr(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
-// everything cf_ensure allocates (the tables slam_alloc builds at upload stay)
-static void cf_free_work(esl_ctx* c) {
-  fr(&c->cf_Linv); fr(&c->cf_M); fr(&c->cf_N); fr(&c->cf_V); fr(&c->cf_B); fr(&c->cf_Lfac); fr(&c->cf_G); fr(&c->cf_vy); fr(&c->cf_z);
-  fr(&c->cf_T); fr(&c->cf_Linv_ws); fr(&c->cf_part);
-  fr(&c->cf_Zt); fr(&c->cf_Hs); fr(&c->cf_Bs); fr(&c->cf_LfacS); fr(&c->cf_GS); fr(&c->cf_LiS); fr(&c->cf_MS); fr(&c->cf_NS); fr(&c->cf_R);
-  fr(&c->cf_Xc); fr(&c->cf_Xs); fr(&c->cf_P); fr(&c->cf_Prhs); fr(&c->cf_Xt);
-  c->cf_ready = false;
+// everything cf_ensure hands out (interior pointers of the solver arena: forgotten, not freed)
+static void cf_forget(esl_ctx* c) {
+  c->cf_oe_start = c->cf_oe_u = c->cf_oe_slot = c->cf_oe_cst = nullptr;
+  c->cf_seg_start = c->cf_seg_obj = c->cf_seg_first = c->cf_cmap = c->cf_xld = c->cf_fwork = c->cf_twork = nullptr;
+  c->cf_mask = nullptr; c->cf_xoff = c->cf_boff = c->cf_roff = nullptr;
+  c->cf_Linv = c->cf_M = c->cf_N = c->cf_V = c->cf_B = c->cf_Lfac = c->cf_G = c->cf_vy = c->cf_z = nullptr;
+  c->cf_T = c->cf_Linv_ws = c->cf_part = nullptr;
+  c->cf_Zt = c->cf_Hs = c->cf_Bs = c->cf_LfacS = c->cf_GS = c->cf_LiS = c->cf_MS = c->cf_NS = c->cf_R = nullptr;
+  c->cf_Xc = c->cf_Xs = c->cf_P = c->cf_Prhs = c->cf_Xt = nullptr;
+  c->cf_ready = false; c->cf_sp_built = c->cf_sparse = false;
 }
 static int cf_ensure_impl(esl_ctx* c);
-// The buffers of the camera-first form exist and are initialised <=> cf_ready.  A failed allocation half-way (cf_Xt alone is 8.6 GB
-// at BASELINE configs[3] with dense X) frees the partial set again: the next trial step starts from scratch instead of launching
-// on null pointers.
+// The tables and buffers of the camera-first form exist and are initialised <=> cf_ready.  A failed allocation (dense X alone is
+// 8.6 GB at BASELINE configs[3]) forgets the set again: the next trial step starts from scratch instead of launching on null
+// pointers.
 static int cf_ensure(esl_ctx* c) {
   if (c->cf_ready) return ESL_OK;
   const int rc = cf_ensure_impl(c);
-  if (rc) { cf_free_work(c); (void)hipGetLastError(); return rc; }
+  if (rc) { cf_forget(c); (void)hipGetLastError(); return rc; }
   c->cf_ready = true;
   return ESL_OK;
 }
+// Built by the FIRST trial step that picks the camera-first form -- not at upload (a graph whose trials run the reduced
+// camera system, or that is sharded over ranks, never pays for them):
+//   - every ellipsoid's free-camera edges sorted by (slot, u), and the entry range of every (ellipsoid, chunk of kCfFwdCh slots) in
+//     those lists: the forward substitution's gather phase;
+//   - when X = L^-1 W is kept SPARSE over runs of cameras (esl_cf.hpp): per segment of kCfFwdCh slots (the last one the separator)
+//     the ellipsoids seen by its interior cameras, where each one's column starts, per ellipsoid the bitmap of its segments, the
+//     work lists of the per-segment kernels;
+//   - the factor of the camera block, V, X (slabs or dense), T and its solver workspace.
+// No comparison sort on the host, and the dense index tables (entry ranges, column map, tile lists) are generated on the device.
 static int cf_ensure_impl(esl_ctx* c) {
   const DevGraph& g = c->g;
-  const size_t nf = (size_t)g.n_free_cams, EU = (size_t)g.n_bbox + g.n_e3d, n_o = (size_t)9 * g.n_objs;
+  const int N = g.n_objs, nfi = g.n_free_cams;
+  const size_t nf = (size_t)nfi, EU = (size_t)g.n_bbox + g.n_e3d, n_o = (size_t)9 * N;
+  const bool timing = std::getenv("ESL_UPLOAD_HOST_TIMING") != nullptr;
+  const double t0 = timing ? now_us() : 0;
+  c->S = c->Linv_ws = nullptr;   // (the two forms share the arena)
   c->cf_ldx = (int64_t)((n_o + 1 + 15) / 16 * 16);
   c->cf_kpad = (int64_t)((6 * nf + kKC - 1) / kKC * kKC);
   c->cf_ldt = c->cf_ldx;
-  // X sparse or dense (esl_cf.hpp, "sparse interior rows"): flops of the dense rank-6 nf update against the separators' dense rows
-  // plus the per-segment products at a quarter of the MFMA rate; ESL_CF_SPARSE=1 / 0 forces it (A/B and the parity tests)
-  c->cf_sparse = false;
-  if (c->cf_sp_built && !std::getenv("ESL_CF_NO_ND")) {
+  const std::vector<int>& start = c->h_ue_start;
+  const size_t nue = c->h_ue_id.size();
+  const int nch = (nfi + kCfFwdCh - 1) / kCfFwdCh;
+  c->cf_n_list = (int)nue; c->cf_n_chunks = nch;
+  if ((size_t)std::max(N, 1) * (size_t)(nch + 1) > ((size_t)1 << 28)) {
+    set_error("camera-first elimination: the (ellipsoid, camera chunk) range table of this graph exceeds 1 GB");
+    return ESL_ERR_ALLOC;
+  }
+  // (slot, u) order per ellipsoid = the per-camera lists of slam_alloc (ellipsoids, then u, ascending inside a slot) walked in slot
+  // order and dealt to the ellipsoids.  The same walk meets, for the sparse form, every (segment, ellipsoid) pair first at the
+  // ellipsoid's FIRST interior camera of the segment, slot by slot: the incidences come out sorted by (segment, first camera,
+  // ellipsoid) -- the compact column order of a segment's slab (upper-trapezoidal: column c is zero above row 6 first(c); a tile of
+  // the segment's product starts at the first camera of its first column) -- with no sort at all.
+  const bool want_sp = c->cf_chain_ok && nfi >= 256 && N > 0 && (size_t)nch * (size_t)(N + 1) <= ((size_t)1 << 28) && !std::getenv("ESL_CF_NO_ND");
+  const int nseg = nch, nw = (nseg + 63) / 64, N1 = N + 1;
+  std::vector<int> os(nue), ou(nue);
+  std::vector<int> inc_p, inc_o, inc_first;
+  std::vector<int> seg_start, xld, fw_off;
+  std::vector<long long> xoff, boff, roff, tw_off;
+  size_t n_fwork = 0, n_twork = 0;
+  double fl = 0;
+  {
+    std::vector<int> cur(start.begin(), start.end() - 1), last_seg(want_sp ? (size_t)N : 0, -1);
+    const int* cstart = c->h_cu_start; const int* cobj = c->h_cu_obj; const int* cid = c->h_cu_id;
+    if (want_sp) { inc_p.reserve(nue / 4 + 16); inc_o.reserve(nue / 4 + 16); inc_first.reserve(nue / 4 + 16); }
+    for (int sl = 0; sl < nfi; ++sl) {
+      const int p = sl / kCfFwdCh, pos = sl - p * kCfFwdCh;
+      const bool interior = want_sp && pos != kCfFwdCh - 1;   // (the last slot of a segment is its separator)
+      for (int q = cstart[sl]; q < cstart[sl + 1]; ++q) {
+        const int o = cobj[q], at = cur[o]++;
+        os[at] = sl; ou[at] = cid[q];
+        if (interior && last_seg[o] != p) { last_seg[o] = p; inc_p.push_back(p); inc_o.push_back(o); inc_first.push_back(pos); }
+      }
+    }
+  }
+  const size_t n_inc = inc_p.size();
+  if (want_sp) {
+    seg_start.assign((size_t)nseg + 1, 0); xld.assign((size_t)nseg, 0); fw_off.assign((size_t)nseg + 1, 0);
+    xoff.assign((size_t)nseg + 1, 0); boff.assign((size_t)nseg + 1, 0); roff.assign((size_t)nseg + 1, 0); tw_off.assign((size_t)nseg + 1, 0);
+    for (size_t q = 0; q < n_inc; ++q) ++seg_start[(size_t)inc_p[q] + 1];
+    for (int p = 0; p < nseg; ++p) seg_start[(size_t)p + 1] += seg_start[p];
+    for (size_t q = 0; q < n_inc; ++q)    // block row k of the product: k + 1 blocks, rows from its first camera on
+      fl += 81.0 * (double)(q - (size_t)seg_start[inc_p[q]] + 1) * (6.0 * (kCfFwdCh - 1 - inc_first[q]));
+    for (int p = 0; p < nseg; ++p) {
+      const int cnt = seg_start[(size_t)p + 1] - seg_start[p];
+      const int m = 9 * cnt + 1;
+      xld[p] = (m + 15) / 16 * 16 + 16;                          // + 16: the T kernel reads 16 columns from any column start
+      xoff[(size_t)p + 1] = xoff[p] + (long long)kCfSegRows * xld[p];
+      fw_off[(size_t)p + 1] = fw_off[p] + (m + 63) / 64;
+      boff[(size_t)p + 1] = boff[p] + (long long)cnt * (cnt + 1) / 2;
+      roff[(size_t)p + 1] = roff[p] + 9LL * cnt;
+      const long long nt = (9 * cnt + kCfSyT - 1) / kCfSyT;
+      tw_off[(size_t)p + 1] = tw_off[p] + nt * (nt + 1) / 2;     // tiles of the product on and below the diagonal (ellipsoid columns only)
+    }
+    n_fwork = (size_t)fw_off[nseg]; n_twork = (size_t)tw_off[nseg];
+    c->cf_sp_nseg = nseg; c->cf_sp_nw = nw; c->cf_n_fwork = (int)n_fwork; c->cf_sp_flops = fl;
+    c->cf_xc_len = (size_t)xoff[nseg] + 2 * kCfSyT;   // (+: the product kernel's last tile reads past the last slab's columns)
+    c->cf_n_twork = (int)n_twork; c->cf_p_blocks = (size_t)boff[nseg]; c->cf_prhs_len = (size_t)roff[nseg];
+    c->cf_sp_built = true;
+    // X sparse or dense (esl_cf.hpp, "sparse interior rows"): flops of the dense rank-6 nf update against the separators' dense
+    // rows plus the per-segment products at a quarter of the MFMA rate; ESL_CF_SPARSE=1 / 0 forces it (A/B and the parity tests)
     const double dense = (double)n_o * (double)n_o * 6.0 * (double)nf;
     const double sparse = (double)n_o * (double)n_o * 6.0 * (double)(nf / kCfFwdCh) + 24.0 * c->cf_sp_flops;   // (cf_sp_flops: FMAs of the products' lower triangles)
     const char* sw = std::getenv("ESL_CF_SPARSE");
     c->cf_sparse = sw ? sw[0] != '0' : (n_o >= 2048 && sparse < 0.5 * dense);
     // the per-segment products are stored when they fit beside everything else (C4: 14 GB); else (or ESL_CF_SPARSE=2) the blocks
-    // of T come straight from the slabs (k_cf_T_sparse)
-    // decided from the graph's size against the device's TOTAL memory, not from what happens to be free at the first trial: the two
-    // forms add in different orders, so the bits of T must not depend on what else occupies the GPU; every rank of a
-    // replicated run takes the same decision by construction.  esl_lm_solver_stats reports the form.
+    // of T come straight from the slabs (k_cf_T_sparse).  Decided from the graph's size against the device's TOTAL memory, not from
+    // what happens to be free at the first trial: the two forms add in different orders, so the bits of T must not depend on what
+    // else occupies the GPU; every rank of a replicated run takes the same decision by construction.
+    // esl_lm_solver_stats reports the form.
     size_t free_b = 0, total_b = 0;
     ESL_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double n_sep = (double)(nf / kCfFwdCh);
     const double need = 8.0 * (81.0 * (double)c->cf_p_blocks + (double)c->cf_xc_len + 2.0 * (double)c->cf_ldt * (double)n_o +
                                2.0 * 6.0 * n_sep * (double)c->cf_ldx /* Xs, R */ + 54.0 * (double)EU /* V */);
     c->cf_sp_form = (sw && sw[0] == '2') || need > 0.4 * (double)total_b ? 2 : 1;
+    if (!c->cf_sparse) c->cf_sp_built = false;   // (none of the sparse-form tables are shipped)
   }
-  int rc;
-  if ((rc = al(&c->cf_Linv, nf * 36)) || (rc = al(&c->cf_M, nf * 36)) || (rc = al(&c->cf_N, nf * 36)) || (rc = al(&c->cf_V, EU * 54)) ||
-      (rc = al(&c->cf_B, nf * 36)) || (rc = al(&c->cf_Lfac, nf * 21)) || (rc = al(&c->cf_G, nf * 36)) ||
-      (rc = al(&c->cf_vy, nf * 6)) || (rc = al(&c->cf_z, nf * 6)) ||
-      (rc = al(&c->cf_T, (size_t)c->cf_ldt * n_o)) || (rc = al(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB)))
-    return rc;
-  if (n_o <= 1024 && (rc = al(&c->cf_part, (size_t)kCholMaxSplit * (size_t)c->cf_ldt * n_o))) return rc;   // split-K workspace of small systems
+  const bool sp = c->cf_sparse;
   // nested dissection of the camera chain from 128 free cameras on: stride = 16 x round(sqrt(nf) / 16) in [16, 128] (a multiple
   // of the forward substitution's chunk, so that segments start on chunk boundaries), kCfFwdCh when X is kept sparse;
   // ESL_CF_NO_ND=1 keeps the plain chain (A/B)
   c->cf_stride = 0; c->cf_n_sep = 0; c->cf_n_seg = 1;
-  if (nf >= 128 && !std::getenv("ESL_CF_NO_ND")) {
-    int st = 16 * (int)std::max(1.0, std::floor(std::sqrt((double)nf) / 16.0 + 0.5));
-    st = std::min(st, kCfMaxStride);
-    if (c->cf_sparse) st = kCfFwdCh;
-    c->cf_stride = st; c->cf_n_sep = (int)(nf / st); c->cf_n_seg = (int)((nf + st - 1) / st);
-    const size_t ns = (size_t)std::max(c->cf_n_sep, 1);
-    if ((rc = al(&c->cf_Zt, nf * 36)) || (rc = al(&c->cf_Hs, ns * 36)) || (rc = al(&c->cf_Bs, ns * 36)) || (rc = al(&c->cf_LfacS, ns * 21)) ||
-        (rc = al(&c->cf_GS, ns * 36)) || (rc = al(&c->cf_LiS, ns * 36)) || (rc = al(&c->cf_MS, ns * 36)) || (rc = al(&c->cf_NS, ns * 36)) ||
-        (rc = al(&c->cf_R, ns * 6 * (size_t)c->cf_ldx)))
-      return rc;
-    ESL_HIP_TRY(hipMemsetAsync(c->cf_Zt, 0, nf * 36 * sizeof(double), c->stream));
+  const bool nd = nf >= 128 && !std::getenv("ESL_CF_NO_ND");
+  if (nd) {
+    int sd = 16 * (int)std::max(1.0, std::floor(std::sqrt((double)nf) / 16.0 + 0.5));
+    sd = std::min(sd, kCfMaxStride);
+    if (sp) sd = kCfFwdCh;
+    c->cf_stride = sd; c->cf_n_sep = (int)(nf / sd); c->cf_n_seg = (int)((nf + sd - 1) / sd);
   }
-  if (c->cf_sparse) {
+  const double t1 = timing ? now_us() : 0;
+  // ---- layout: what the host ships first, then the device-generated tables (esl_cf.hpp k_cf_make_*), then the buffers ----
+  BlobStage st;
+  const int i_st = st.up(&c->cf_oe_start, start.size()), i_ou = st.up(&c->cf_oe_u, nue), i_os = st.up(&c->cf_oe_slot, nue);
+  int* d_inc = nullptr; int* d_fw_off = nullptr; long long* d_tw_off = nullptr;
+  int i_inc = -1, i_ss = -1, i_xld = -1, i_xoff = -1, i_boff = -1, i_roff = -1, i_fwo = -1, i_two = -1;
+  if (sp) {
+    i_inc = st.up(&d_inc, 4 * n_inc); i_ss = st.up(&c->cf_seg_start, (size_t)nseg + 1); i_xld = st.up(&c->cf_xld, (size_t)nseg);
+    i_xoff = st.up(&c->cf_xoff, (size_t)nseg + 1); i_boff = st.up(&c->cf_boff, (size_t)nseg + 1); i_roff = st.up(&c->cf_roff, (size_t)nseg + 1);
+    i_fwo = st.up(&d_fw_off, (size_t)nseg + 1); i_two = st.up(&d_tw_off, (size_t)nseg + 1);
+  }
+  st.work(&c->cf_oe_cst, (size_t)std::max(N, 1) * (nch + 1));
+  if (sp) {
+    st.work(&c->cf_cmap, (size_t)nseg * N1); st.work(&c->cf_mask, (size_t)N1 * nw); st.work(&c->cf_seg_obj, n_inc); st.work(&c->cf_seg_first, n_inc);
+    st.work(&c->cf_fwork, 2 * n_fwork); st.work(&c->cf_twork, 3 * n_twork);
+  }
+  st.work(&c->cf_Linv, nf * 36); st.work(&c->cf_M, nf * 36); st.work(&c->cf_N, nf * 36); st.work(&c->cf_V, EU * 54);
+  st.work(&c->cf_B, nf * 36); st.work(&c->cf_Lfac, nf * 21); st.work(&c->cf_G, nf * 36); st.work(&c->cf_vy, nf * 6); st.work(&c->cf_z, nf * 6);
+  st.work(&c->cf_T, (size_t)c->cf_ldt * n_o); st.work(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB);
+  if (n_o <= 1024) st.work(&c->cf_part, (size_t)kCholMaxSplit * (size_t)c->cf_ldt * n_o);   // split-K workspace of small systems
+  if (nd) {
+    const size_t ns = (size_t)std::max(c->cf_n_sep, 1);
+    st.work(&c->cf_Zt, nf * 36); st.work(&c->cf_Hs, ns * 36); st.work(&c->cf_Bs, ns * 36); st.work(&c->cf_LfacS, ns * 21);
+    st.work(&c->cf_GS, ns * 36); st.work(&c->cf_LiS, ns * 36); st.work(&c->cf_MS, ns * 36); st.work(&c->cf_NS, ns * 36);
+    st.work(&c->cf_R, ns * 6 * (size_t)c->cf_ldx);
+  }
+  if (sp) {
+    c->cf_kpad_s = (int64_t)((6 * (size_t)c->cf_n_sep + kKC - 1) / kKC * kKC);
+    st.work(&c->cf_Xc, c->cf_xc_len); st.work(&c->cf_Xs, (size_t)c->cf_ldx * (size_t)c->cf_kpad_s);
+    if (c->cf_sp_form == 1) { st.work(&c->cf_P, c->cf_p_blocks * 81); st.work(&c->cf_Prhs, c->cf_prhs_len); }
+  } else {
+    st.work(&c->cf_Xt, (size_t)c->cf_ldx * (size_t)c->cf_kpad);
+  }
+  if (int rc = st.reserve(c->arena_solve)) return rc;
+  // ---- fill the staging blob, ship it, generate the dense tables ----
+  std::memcpy(st.host<int>(i_st), start.data(), start.size() * sizeof(int));
+  if (nue) { std::memcpy(st.host<int>(i_ou), ou.data(), nue * sizeof(int)); std::memcpy(st.host<int>(i_os), os.data(), nue * sizeof(int)); }
+  if (sp) {
+    int* inc = st.host<int>(i_inc);
+    if (n_inc) {
+      std::memcpy(inc, inc_p.data(), n_inc * sizeof(int)); std::memcpy(inc + n_inc, inc_o.data(), n_inc * sizeof(int));
+      std::memcpy(inc + 2 * n_inc, inc_first.data(), n_inc * sizeof(int));
+      for (size_t q = 0; q < n_inc; ++q) inc[3 * n_inc + q] = (int)q;   // (already in column order)
+    }
+    std::memcpy(st.host<int>(i_ss), seg_start.data(), seg_start.size() * sizeof(int));
+    std::memcpy(st.host<int>(i_xld), xld.data(), xld.size() * sizeof(int));
+    std::memcpy(st.host<int>(i_fwo), fw_off.data(), fw_off.size() * sizeof(int));
+    std::memcpy(st.host<long long>(i_xoff), xoff.data(), xoff.size() * sizeof(long long));
+    std::memcpy(st.host<long long>(i_boff), boff.data(), boff.size() * sizeof(long long));
+    std::memcpy(st.host<long long>(i_roff), roff.data(), roff.size() * sizeof(long long));
+    std::memcpy(st.host<long long>(i_two), tw_off.data(), tw_off.size() * sizeof(long long));
+  }
+  if (int rc = st.ship(c->stream)) return rc;
+  if (N > 0) {
+    const long nt = (long)N * (nch + 1);
+    hipLaunchKernelGGL(k_cf_make_cst, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, N, nch, c->cf_oe_start, c->cf_oe_slot, c->cf_oe_cst);
+  }
+  if (sp) {
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_cmap, 0xFF, (size_t)nseg * N1 * sizeof(int), c->stream));
+    ESL_HIP_TRY(hipMemsetAsync(c->cf_mask, 0, (size_t)N1 * nw * sizeof(unsigned long long), c->stream));
+    if (n_inc)
+      hipLaunchKernelGGL(k_cf_make_cmap, dim3((unsigned)((n_inc + 255) / 256)), dim3(256), 0, c->stream, (int)n_inc, d_inc, N1, nw, c->cf_seg_start, c->cf_cmap,
+                         c->cf_mask, c->cf_seg_obj, c->cf_seg_first);
+    hipLaunchKernelGGL(k_cf_make_work, dim3((unsigned)nseg), dim3(64), 0, c->stream, nseg, N, nw, c->cf_seg_start, d_fw_off, d_tw_off, c->cf_cmap, c->cf_mask,
+                       c->cf_fwork, c->cf_twork);
+  }
+  // ---- what must be zero ----
+  if (nd) ESL_HIP_TRY(hipMemsetAsync(c->cf_Zt, 0, nf * 36 * sizeof(double), c->stream));
+  if (sp) {
     // slabs: pad columns and rows 90 .. 95 stay zero; Xs: rows 6 n_sep .. kpad_s (the K padding of the rank-K update) stay zero;
     // T: the blocks above the diagonal are never written
-    c->cf_kpad_s = (int64_t)((6 * (size_t)c->cf_n_sep + kKC - 1) / kKC * kKC);
-    if ((rc = al(&c->cf_Xc, c->cf_xc_len)) || (rc = al(&c->cf_Xs, (size_t)c->cf_ldx * (size_t)c->cf_kpad_s))) return rc;
     ESL_HIP_TRY(hipMemsetAsync(c->cf_Xc, 0, std::max<size_t>(c->cf_xc_len, 1) * sizeof(double), c->stream));
-    if (c->cf_sp_form == 1 && ((rc = al(&c->cf_P, c->cf_p_blocks * 81)) || (rc = al(&c->cf_Prhs, c->cf_prhs_len)))) return rc;
     ESL_HIP_TRY(hipMemsetAsync(c->cf_Xs, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad_s * sizeof(double), c->stream));
     ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)c->cf_ldt * n_o * sizeof(double), c->stream));
   } else {
     // rows 6 nf .. kpad of X (the K padding of the rank-K update) and the columns of never-written edges stay zero
-    if ((rc = al(&c->cf_Xt, (size_t)c->cf_ldx * (size_t)c->cf_kpad))) return rc;
     ESL_HIP_TRY(hipMemsetAsync(c->cf_Xt, 0, (size_t)c->cf_ldx * (size_t)c->cf_kpad * sizeof(double), c->stream));
   }
   ESL_HIP_TRY(hipMemsetAsync(c->cf_V, 0, std::max<size_t>(EU, 1) * 54 * sizeof(double), c->stream));
+  if (timing)
+    fprintf(stderr, "[cf_ensure host, us] sorts + structure %.0f  layout + tables + enqueue %.0f  (blob %.1f MB uploaded, %.1f MB in all; sparse %d form %d)\n",
+            t1 - t0, now_us() - t1, st.up_end / 1e6, st.total / 1e6, (int)sp, c->cf_sp_form);
   return ESL_OK;
 }
 // One LM trial with the cameras eliminated first: x_c, x_o, trial states, chi2 of the trial (same outputs as the other form)
@@ -838,7 +963,8 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
   }
   *ms_out = ms;
   *rel_residual_out = h2[1] > 0 ? std::sqrt(h2[0] / h2[1]) : 0.0;
-  if (hinfo) { set_error("self test: non-positive pivot"); rc = ESL_ERR_STATE; }
+  if (hinfo & 2) { set_error("self test: a device-side hand-off of the dense solver timed out"); rc = ESL_ERR_HIP; }
+  else if (hinfo) { set_error("self test: non-positive pivot"); rc = ESL_ERR_STATE; }
   cleanup();
   return rc;
 }

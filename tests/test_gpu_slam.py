@@ -187,7 +187,8 @@ def test_persistent_dense_cholesky_selftest_residual(pkg, monkeypatch, n):
     """the persistent form of the dense factorisation (k_chol_persist: ONE launch, workgroup 0 walks the diagonal blocks, the others
     pull tasks off a static list, dependency words instead of ~1,000 launches and stream events; the CPU replay of its task list is
     tests/test_chol_plan.py) forced on at every size, against the same generated SPD systems as the launch-per-step form: residual
-    at round-off, and the same x twice"""
+    at round-off, and the same x twice (the residual's own sum is an atomic reduction: its last bits vary, a different x would move
+    it by a sizeable fraction of itself)"""
     monkeypatch.setenv("ESL_CHOL_PERSISTENT", "1")
     monkeypatch.setenv("ESL_CHOL_DEBUG", "1")     # the self test creates and destroys a stream while the kernel runs (what broke the two-kernel form)
     cx = pkg.Context(0)
@@ -199,7 +200,7 @@ def test_persistent_dense_cholesky_selftest_residual(pkg, monkeypatch, n):
         monkeypatch.delenv("ESL_CHOL_PERSISTENT", raising=False)
         monkeypatch.delenv("ESL_CHOL_DEBUG", raising=False)
     print("persistent Cholesky n = %d: %.3f ms (second call %.3f ms), residual %.1e" % (n, ms, ms2, res))
-    assert res < 1e-13 and res2 == res
+    assert res < 1e-13 and abs(res2 - res) <= 1e-9 * res
 
 
 def test_slam_runs_are_bitwise_reproducible(pkg, ctx):
