@@ -79,13 +79,26 @@ __device__ __forceinline__ void stage_sync() {
 // symmetry-grid points of the box (object frame, float) staged in LDS for the brute-force 1-NN of the symmetry cost
 constexpr int kSymLds = 1024;
 // One raw LDS buffer, carved per stage (the stages are separated by barriers):
-//   clustering (M <= kClLds points):  cell keys u32[kClCells] | cell heads i32[kClCells] | next i32[kClLds] | parent i32[kClLds]
-//                       afterwards:   min centre distance u64[kClLds] | min voxel key u64[kClLds] | size i32[kClLds] | parent
-//   symmetry:                         candidate points float4[kSymLds]
+//   clustering (M <= kClLds points):  cell keys u32[kClCells] | cell starts i32[kClCells + 1] | cell-sorted points float4[kClLds] | parent i32[kClLds]
+//                       afterwards:   min centre distance u64[kClLds] | min voxel key u64[kClLds] | size i32[kClLds] | parent = root of every point
+//   (the symmetry kernel's candidate points float4[kSymLds] have their own array, g_sym_cand)
 constexpr int kClLds = 2048, kClCells = 4096;
 constexpr unsigned int kEmpty32 = 0xFFFFFFFFu;
-__shared__ __attribute__((aligned(16))) unsigned char g_fit_lds[(kClCells * 2 + kClLds * 2) * 4];
-static_assert(sizeof(float) * 4 * kSymLds <= sizeof(g_fit_lds), "symmetry candidates (float4) must fit the shared buffer");
+constexpr int kLdsKey = 0;                                   // cell keys u32[kClCells]            | later: min centre distance u64[kClLds]
+constexpr int kLdsCst = kClCells * 4;                        // cell starts i32[kClCells + 1]      | later: min voxel key u64[kClLds]
+constexpr int kLdsPts = kLdsCst + kClCells * 4 + 256;        // cell-sorted points float4[kClLds]  | later: cluster size i32[kClLds]
+constexpr int kLdsPar = kLdsPts + kClLds * 16;               // union-find parent i32[kClLds] (root of every point at the end)
+__shared__ __attribute__((aligned(16))) unsigned char g_fit_lds[kLdsPar + kClLds * 4];
+// the symmetry kernel's 1-NN candidates (its own array: k_fit_sym must not inherit the clustering tables' 72 KB)
+__shared__ float4 g_sym_cand[1024];
+// the box's points (world frame) for the LDS clustering path and what follows it in k_fit_pre: x[kClLds] | y[kClLds] | z[kClLds].
+// Round 3 read them from global memory inside the neighbour-list walks -- one dependent L2 round trip per candidate pair.
+// (gfx950 gives a workgroup up to 160 KB; k_fit_pre now takes 75 KB and runs one 1,024-thread workgroup per CU as before.)
+__shared__ float g_fit_xyz[3 * kClLds];
+// per-thread strips of neighbour indices found by the LDS clustering path (k_fit_pre)
+constexpr int kNbCap = 16;
+__shared__ unsigned short g_fit_nb[kFitThreads * kNbCap];
+static_assert(kSymLds <= 1024, "symmetry candidates (float4) must fit g_sym_cand");
 #define ESL_FIT_MARK(k) do { if (a.clk && tid == 0) a.clk[16 * b + (k)] = (long long)wall_clock64(); } while (0)
 
 // block-wide sum, result to every thread (wave shuffle + LDS)
@@ -163,6 +176,23 @@ __device__ __forceinline__ int uf_find(int* parent, int i) {
     const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == i) return i;
     const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp == p) return p;
+    __hip_atomic_store(&parent[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    i = gp;
+  }
+}
+
+// The same walk on CACHED loads (workgroup-scope relaxed atomics = plain loads the compiler may not fold): an agent-scope load
+// goes past this XCD's L2 to the fabric for every hop (~1 - 2 us, and a find is a chain of them); a cached copy of the forest may be
+// stale, but a stale parent is an OLDER ancestor of the same node (roots only ever gain parents, halving only re-points at
+// ancestors), so the walk still ends at an ancestor: "same ancestor" proves the two points are joined, and a stale "root" is
+// caught by the linking CAS, whose return value is the truth (cl_union continues from it).  Only the union stage may use this --
+// the statistics stage of the next kernel needs the real roots.
+__device__ __forceinline__ int uf_find_cached(int* parent, int i) {
+  for (;;) {
+    const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (p == i) return i;
+    const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (gp == p) return p;
     __hip_atomic_store(&parent[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     i = gp;
@@ -309,7 +339,7 @@ __device__ double sym_error_wave(const SymCtx& c, const PlaneT& pl, bool dual) {
           // candidates broadcast from LDS as float4 (one ds_read_b128 each), four independent running minima: the plain
           // loop (three scalar LDS reads and a compare-and-branch per candidate) cost ~0.25 us PER CANDIDATE and was the
           // whole symmetry stage (22 us per evaluation round at 46 points)
-          const float4* cand = (const float4*)g_fit_lds;
+          const float4* cand = g_sym_cand;
           double b0 = 1e300, b1 = 1e300, b2 = 1e300, b3 = 1e300;
           int j = 0;
           for (; j + 4 <= c.n; j += 4) {
@@ -349,45 +379,92 @@ __device__ double sym_error_wave(const SymCtx& c, const PlaneT& pl, bool dual) {
   return -aver;
 }
 
-// Eigen-style pivoted LDLT for n <= 3 (what g2o's LinearSolverDense runs on the 2x2 / 3x3 system)
-__device__ bool ldlt_small(double* A, int n, const double* b, double* x) {
-  int tr[3];
+// Eigen-style pivoted LDLT for n <= 3 (what g2o's LinearSolverDense runs on the 2x2 / 3x3 system).  N is a template parameter and
+// every loop is unrolled with the pivot position resolved by compile-time cases: all indices are static, the matrix lives in
+// registers.  (Round 3's runtime-n form indexed its arrays dynamically -> 184 bytes of scratch per lane in k_fit_sym, a dozen
+// dependent scratch round trips in front of every trial evaluation of the symmetry LM.)  Same operations in the same order.
+template <int N>
+__device__ __forceinline__ bool ldlt_small(double* A, const double* b, double* x) {
+  int tr[N];
   int sign = 0;
-  for (int k = 0; k < n; ++k) {
+  bool stop = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (stop) break;
     int big = k;
-    double bv = fabs(A[k * n + k]);
-    for (int i = k + 1; i < n; ++i) { const double v = fabs(A[i * n + i]); if (v > bv) { bv = v; big = i; } }
+    double bv = fabs(A[k * N + k]);
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) { const double v = fabs(A[i * N + i]); if (v > bv) { bv = v; big = i; } }
     tr[k] = big;
-    if (k != big) {
-      const int s = n - big - 1;
-      for (int j = 0; j < k; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[big * n + j]; A[big * n + j] = t; }
-      for (int i = 0; i < s; ++i) { const double t = A[(big + 1 + i) * n + k]; A[(big + 1 + i) * n + k] = A[(big + 1 + i) * n + big]; A[(big + 1 + i) * n + big] = t; }
-      for (int i = k + 1; i < big; ++i) { const double t = A[i * n + k]; A[i * n + k] = A[big * n + i]; A[big * n + i] = t; }
-      const double t = A[k * n + k]; A[k * n + k] = A[big * n + big]; A[big * n + big] = t;
-    }
-    const int rs = n - k - 1;
+#pragma unroll
+    for (int c = k + 1; c < N; ++c)
+      if (big == c) {   // symmetric swap of rows / columns k and c of the lower triangle
+#pragma unroll
+        for (int j = 0; j < k; ++j) { const double t = A[k * N + j]; A[k * N + j] = A[c * N + j]; A[c * N + j] = t; }
+#pragma unroll
+        for (int i = c + 1; i < N; ++i) { const double t = A[i * N + k]; A[i * N + k] = A[i * N + c]; A[i * N + c] = t; }
+#pragma unroll
+        for (int i = k + 1; i < c; ++i) { const double t = A[i * N + k]; A[i * N + k] = A[c * N + i]; A[c * N + i] = t; }
+        const double t = A[k * N + k]; A[k * N + k] = A[c * N + c]; A[c * N + c] = t;
+      }
     if (k > 0) {
-      double temp[3], s = 0;
-      for (int j = 0; j < k; ++j) { temp[j] = A[j * n + j] * A[k * n + j]; s += A[k * n + j] * temp[j]; }
-      A[k * n + k] -= s;
-      for (int i = 0; i < rs; ++i) { double t = 0; for (int j = 0; j < k; ++j) t += A[(k + 1 + i) * n + j] * temp[j]; A[(k + 1 + i) * n + k] -= t; }
+      double temp[N], sacc = 0;
+#pragma unroll
+      for (int j = 0; j < k; ++j) { temp[j] = A[j * N + j] * A[k * N + j]; sacc += A[k * N + j] * temp[j]; }
+      A[k * N + k] -= sacc;
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) {
+        double t = 0;
+#pragma unroll
+        for (int j = 0; j < k; ++j) t += A[i * N + j] * temp[j];
+        A[i * N + k] -= t;
+      }
     }
-    const double akk = A[k * n + k];
+    const double akk = A[k * N + k];
     const bool valid = fabs(akk) > 0;
-    if (k == 0 && !valid) { sign = 0; for (int j = 0; j < n; ++j) tr[j] = j; break; }
-    if (rs > 0 && valid) for (int i = 0; i < rs; ++i) A[(k + 1 + i) * n + k] /= akk;
-    if (sign == 1) { if (akk < 0) sign = 2; }
-    else if (sign == -1) { if (akk > 0) sign = 2; }
-    else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+    if (k == 0 && !valid) {
+      sign = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) tr[j] = j;
+      stop = true;
+    } else {
+      if (valid) {
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) A[i * N + k] /= akk;
+      }
+      if (sign == 1) { if (akk < 0) sign = 2; }
+      else if (sign == -1) { if (akk > 0) sign = 2; }
+      else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+    }
   }
   const bool positive = (sign == 1 || sign == 0);
   if (positive) {
-    for (int i = 0; i < n; ++i) x[i] = b[i];
-    for (int i = 0; i < n; ++i) if (tr[i] != i) { const double t = x[i]; x[i] = x[tr[i]]; x[tr[i]] = t; }
-    for (int i = 0; i < n; ++i) { double s = x[i]; for (int j = 0; j < i; ++j) s -= A[i * n + j] * x[j]; x[i] = s; }
-    for (int i = 0; i < n; ++i) { const double d = A[i * n + i]; x[i] = (fabs(d) > 2.2250738585072014e-308) ? x[i] / d : 0.0; }
-    for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int j = i + 1; j < n; ++j) s -= A[j * n + i] * x[j]; x[i] = s; }
-    for (int i = n - 1; i >= 0; --i) if (tr[i] != i) { const double t = x[i]; x[i] = x[tr[i]]; x[tr[i]] = t; }
+    auto swap_x = [&](int i) {   // x[i] <-> x[tr[i]], tr[i] >= i
+#pragma unroll
+      for (int c = 0; c < N; ++c) if (c > i && tr[i] == c) { const double t = x[i]; x[i] = x[c]; x[c] = t; }
+    };
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = b[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) swap_x(i);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double sacc = x[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) sacc -= A[i * N + j] * x[j];
+      x[i] = sacc;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { const double d = A[i * N + i]; x[i] = (fabs(d) > 2.2250738585072014e-308) ? x[i] / d : 0.0; }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+      double sacc = x[i];
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) sacc -= A[j * N + i] * x[j];
+      x[i] = sacc;
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) swap_x(i);
   }
   return positive;
 }
@@ -440,9 +517,12 @@ __device__ void cl_insert(const FitArgs& a, long base, long pbase, int M, double
 // 300 us serial path per thread at 8.5k points; split this way the longest chain is one cell's list
 __device__ void cl_union(const FitArgs& a, long base, long pbase, int M, double tol, long t0, long stride) {
   const double tol2 = tol * tol;
-  for (long w = t0; w < 27L * M; w += stride) {
-    const int i = (int)(w / 27), cidx = (int)(w % 27);
+  // every pair of neighbouring cells is visited from ONE side: the point's own cell (with j > i) and the 13 cells after it in
+  // (z, y, x) order -- the same pairs as all 27 cells with j > i
+  for (long w = t0; w < 14L * M; w += stride) {
+    const int i = (int)(w / 14), cidx = (int)(w % 14) + 13;   // 13 = the own cell in the 3 x 3 x 3 numbering
     const int dx = cidx % 3 - 1, dy = (cidx / 3) % 3 - 1, dz = cidx / 9 - 1;
+    const bool own = cidx == 13;
     const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
     const unsigned long long key = cell_key(xi, yi, zi, tol, dx, dy, dz);
     unsigned long long slot = hash64(key) & (unsigned long long)(a.H - 1);
@@ -455,7 +535,7 @@ __device__ void cl_union(const FitArgs& a, long base, long pbase, int M, double 
     }
     int ri = i;   // last known root of i
     for (int j = head; j >= 0; j = a.nxt[pbase + j]) {
-      if (j <= i) continue;
+      if (own && j <= i) continue;
       const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
       if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
         // cheap pre-check with cached loads: equal parents (even stale ones) mean the two were joined already --
@@ -463,10 +543,17 @@ __device__ void cl_union(const FitArgs& a, long base, long pbase, int M, double 
         if (a.parent[pbase + ri] == a.parent[pbase + j]) continue;
         int ra = ri, rb = j;
         for (;;) {
-          ra = uf_find(a.parent + pbase, ra); rb = uf_find(a.parent + pbase, rb);
+          ra = uf_find_cached(a.parent + pbase, ra); rb = uf_find_cached(a.parent + pbase, rb);
           if (ra == rb) break;
           if (ra < rb) { const int t = ra; ra = rb; rb = t; }
-          if (atomicCAS(&a.parent[pbase + ra], ra, rb) == ra) { ra = rb; break; }
+          const int seen = atomicCAS(&a.parent[pbase + ra], ra, rb);
+          if (seen == ra) { ra = rb; break; }
+          // lost the race -- or uf_find walked a STALE copy of the forest: its loads are served by this XCD's L2, which another
+          // XCD's hook does not update (the eight L2s are not coherent with each other; measured in round 4 on the Cholesky's
+          // flag words: such a line can stay stale for as long as nothing evicts it).  The atomic's return value is the truth:
+          // continue from ra's real parent instead of re-reading the stale line and failing the same CAS again -- the
+          // 150 - 400 us "contention" of this kernel at 8.5k points was this loop
+          ra = seen;
         }
         ri = ra;
       }
@@ -667,6 +754,9 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   __syncthreads();
   const int M = S.M;
   if (M < 1) { if (tid == 0) { a.out_status[b] = 4; a.out_dbg[16 * b] = S.n0; a.out_dbg[16 * b + 1] = S.n1; } return; }
+  float* lx = g_fit_xyz; float* ly = g_fit_xyz + kClLds; float* lz = g_fit_xyz + 2 * kClLds;
+  bool pts_in_lds = false;   // the LDS clustering path ran: points in lx / ly / lz, root of point i in lroot[i]
+  int* lroot = (int*)(g_fit_lds + kLdsPar);
   ESL_FIT_MARK(2);
   if (a.wide && a.out_status[b] != 0) return;   // the grid-wide centre stage already gave up on this box
   if (!a.wide) {
@@ -700,8 +790,9 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   {
     int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
     for (int i = tid; i < M; i += kFitThreads) {
-      const int cc[3] = {(int)(long long)floor((double)a.pwx[pbase + i] / tol), (int)(long long)floor((double)a.pwy[pbase + i] / tol),
-                         (int)(long long)floor((double)a.pwz[pbase + i] / tol)};
+      const float px = a.pwx[pbase + i], py = a.pwy[pbase + i], pz = a.pwz[pbase + i];
+      if (M <= kClLds) { lx[i] = px; ly[i] = py; lz[i] = pz; }
+      const int cc[3] = {(int)(long long)floor((double)px / tol), (int)(long long)floor((double)py / tol), (int)(long long)floor((double)pz / tol)};
 #pragma unroll
       for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], cc[k]); hi[k] = max(hi[k], cc[k]); }
     }
@@ -716,12 +807,20 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   const bool lds_path = M <= kClLds && (long)S.cmax[0] - S.cmin[0] < 1020 && (long)S.cmax[1] - S.cmin[1] < 1020 &&
                         (long)S.cmax[2] - S.cmin[2] < 1020;
   if (lds_path) {
-    unsigned int* ckey = (unsigned int*)g_fit_lds;
-    int* chead = (int*)(g_fit_lds + kClCells * 4);
-    int* lnxt = (int*)(g_fit_lds + kClCells * 8);
-    int* lpar = (int*)(g_fit_lds + kClCells * 8 + kClLds * 4);
+    // Cells as CONTIGUOUS runs of a cell-sorted copy of the points (round 4; round 3 chained a cell's points through a linked
+    // list and read their coordinates from global memory): count per cell while inserting (the atomic's return value is the
+    // point's rank in its cell), exclusive scan of the counts over the table, scatter (x, y, z, index) as one float4 per point --
+    // a cell is then [cst[slot], cst[slot + 1]) and a candidate is one 16-byte LDS read.  The order inside a cell depends on the
+    // atomics' order; the components and their roots (= smallest index: larger roots are always hooked under smaller ones) do
+    // not.  Measured at BASELINE's 20-box frame (stage = tables + search + linking, mean per box): 46.6 us -> 51 us with this
+    // alone (the list walk was NOT the cost) -> 37 us with search and linking in separate loops (below) -> half-space search.
+    unsigned int* ckey = (unsigned int*)(g_fit_lds + kLdsKey);
+    int* cst = (int*)(g_fit_lds + kLdsCst);
+    float4* spts = (float4*)(g_fit_lds + kLdsPts);
+    int* lpar = (int*)(g_fit_lds + kLdsPar);
+    int* wsum = (int*)S.red;                                                  // 16 wave totals of the scan
     const int mx = S.cmin[0] - 1, my = S.cmin[1] - 1, mz = S.cmin[2] - 1;   // neighbour offsets stay >= 0
-    for (int sidx = tid; sidx < kClCells; sidx += kFitThreads) { ckey[sidx] = kEmpty32; chead[sidx] = -1; }
+    for (int sidx = tid; sidx <= kClCells; sidx += kFitThreads) { if (sidx < kClCells) ckey[sidx] = kEmpty32; cst[sidx] = 0; }
     for (int i = tid; i < M; i += kFitThreads) lpar[i] = i;
     __syncthreads();
     auto key_of = [&](float x, float y, float z, int dx, int dy, int dz) -> unsigned int {
@@ -729,51 +828,112 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
                 cz_ = (int)(long long)floor((double)z / tol) + dz - mz;
       return ((unsigned int)cz_ << 20) | ((unsigned int)cy_ << 10) | (unsigned int)cx_;
     };
-    for (int i = tid; i < M; i += kFitThreads) {
-      const unsigned int key = key_of(a.pwx[pbase + i], a.pwy[pbase + i], a.pwz[pbase + i], 0, 0, 0);
-      unsigned int slot = (unsigned int)hash64(key) & (kClCells - 1);
-      for (;;) {
-        const unsigned int prev = atomicCAS(&ckey[slot], kEmpty32, key);
-        if (prev == kEmpty32 || prev == key) break;
-        slot = (slot + 1) & (kClCells - 1);
+    static_assert(kClLds <= 2 * kFitThreads && kClCells == 4 * kFitThreads, "two points and four table slots per thread");
+    int my_slot[2] = {0, 0}, my_rank[2] = {0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + t * kFitThreads;
+      if (i < M) {
+        const unsigned int key = key_of(lx[i], ly[i], lz[i], 0, 0, 0);
+        unsigned int slot = (unsigned int)hash64(key) & (kClCells - 1);
+        for (;;) {
+          const unsigned int prev = atomicCAS(&ckey[slot], kEmpty32, key);
+          if (prev == kEmpty32 || prev == key) break;
+          slot = (slot + 1) & (kClCells - 1);
+        }
+        my_slot[t] = (int)slot; my_rank[t] = atomicAdd(&cst[slot], 1);
       }
-      lnxt[i] = atomicExch(&chead[slot], i);
     }
     __syncthreads();
-    for (int i = tid; i < M; i += kFitThreads) {
-      const float xi = a.pwx[pbase + i], yi = a.pwy[pbase + i], zi = a.pwz[pbase + i];
-      for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-          for (int dx = -1; dx <= 1; ++dx) {
+    {  // exclusive scan of the per-slot counts, in place; cst[kClCells] = M
+      const int v0 = cst[4 * tid], v1 = cst[4 * tid + 1], v2 = cst[4 * tid + 2], v3 = cst[4 * tid + 3];
+      const int mine = v0 + v1 + v2 + v3;
+      int incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += up; }
+      if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+      __syncthreads();
+      int base_w = 0;
+      for (int w = 0; w < (tid >> 6); ++w) base_w += wsum[w];
+      const int ex = base_w + incl - mine;
+      cst[4 * tid] = ex; cst[4 * tid + 1] = ex + v0; cst[4 * tid + 2] = ex + v0 + v1; cst[4 * tid + 3] = ex + v0 + v1 + v2;
+      if (tid == kFitThreads - 1) cst[kClCells] = ex + mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + t * kFitThreads;
+      if (i < M) spts[cst[my_slot[t]] + my_rank[t]] = make_float4(lx[i], ly[i], lz[i], __int_as_float(i));
+    }
+    __syncthreads();
+    // Neighbour search and linking are SEPARATE loops.  Fused (round 3), the 64 lanes of a wave met their few true neighbours at
+    // different candidates, so nearly every one of a point's ~200 candidate steps carried some lane's union (two finds + a CAS:
+    // ~1,300 cycles of dependent LDS round trips) for the whole wave -- measured 80 us for a 1,628-voxel box.  Now a lane only
+    // RECORDS the neighbours it finds (16-bit indices in a private LDS strip) and links them afterwards in a loop whose trip
+    // count is the largest neighbour count of the wave (~10), not the candidate count.
+    unsigned short* nb = (unsigned short*)g_fit_nb + tid * kNbCap;
+    const float tol2_hi = (float)(tol2 * (1.0 + 1e-5)), tol2_lo = (float)(tol2 * (1.0 - 1e-5));
+    auto link_all = [&](int i, int cnt) {
+      for (int k = 0; k < cnt; ++k) {
+        int ra = i, rb = nb[k];
+        for (;;) {
+          ra = uf_find_lds(lpar, ra); rb = uf_find_lds(lpar, rb);
+          if (ra == rb) break;
+          if (ra < rb) { const int tt = ra; ra = rb; rb = tt; }
+          if (atomicCAS(&lpar[ra], ra, rb) == ra) break;
+        }
+      }
+    };
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + t * kFitThreads;
+      if (i >= M) continue;
+      const float xi = lx[i], yi = ly[i], zi = lz[i];
+      int cnt = 0;
+      // every pair of neighbouring cells is visited from ONE side (the 13 cells "after" the point's own in (z, y, x) order) and the
+      // own cell with j > i: the same set of pairs as all 27 cells with j > i, half the probes and half the candidates
+      for (int dz = 0; dz <= 1; ++dz)
+        for (int dy = (dz == 0 ? 0 : -1); dy <= 1; ++dy)
+          for (int dx = ((dz == 0 && dy == 0) ? 0 : -1); dx <= 1; ++dx) {
+            const bool own = dz == 0 && dy == 0 && dx == 0;
             const unsigned int key = key_of(xi, yi, zi, dx, dy, dz);
             unsigned int slot = (unsigned int)hash64(key) & (kClCells - 1);
-            int head = -1;
+            int e0 = 0, e1 = 0;
             for (;;) {
               const unsigned int k = ckey[slot];
-              if (k == key) { head = chead[slot]; break; }
+              if (k == key) { e0 = cst[slot]; e1 = cst[slot + 1]; break; }
               if (k == kEmpty32) break;
               slot = (slot + 1) & (kClCells - 1);
             }
-            for (int j = head; j >= 0; j = lnxt[j]) {
-              if (j <= i) continue;
-              const double ddx = (double)xi - a.pwx[pbase + j], ddy = (double)yi - a.pwy[pbase + j], ddz = (double)zi - a.pwz[pbase + j];
-              if (ddx * ddx + ddy * ddy + ddz * ddz <= tol2) {
-                int ra = i, rb = j;
-                for (;;) {
-                  ra = uf_find_lds(lpar, ra); rb = uf_find_lds(lpar, rb);
-                  if (ra == rb) break;
-                  if (ra < rb) { const int t = ra; ra = rb; rb = t; }
-                  if (atomicCAS(&lpar[ra], ra, rb) == ra) break;
-                }
+            for (int e = e0; e < e1; ++e) {
+              // the candidate scan is ISSUE-bound on the box's one CU (1,628 points x ~216 candidates): a single-precision screen
+              // (relative error < 1e-6) settles all but the candidates within 1e-5 of the radius; those take the reference's
+              // double-precision test, so every decision is the reference's
+              const float4 q = spts[e];
+              const float fx = xi - q.x, fy = yi - q.y, fz = zi - q.z;
+              const float d2f = fx * fx + fy * fy + fz * fz;
+              if (d2f > tol2_hi) continue;
+              const int j = __float_as_int(q.w);
+              if (own && j <= i) continue;
+              bool in = d2f < tol2_lo;
+              if (!in) {
+                const double ddx = (double)xi - q.x, ddy = (double)yi - q.y, ddz = (double)zi - q.z;
+                in = ddx * ddx + ddy * ddy + ddz * ddz <= tol2;
+              }
+              if (in) {
+                if (cnt == kNbCap) { link_all(i, cnt); cnt = 0; }   // (a strip holds kNbCap neighbours: rare)
+                nb[cnt++] = (unsigned short)j;
               }
             }
           }
+      link_all(i, cnt);
     }
     __syncthreads();
-    // per-root statistics (the cell tables are dead now: their space holds the three statistics arrays)
-    unsigned long long* lmind = (unsigned long long*)g_fit_lds;
-    unsigned long long* lmink = (unsigned long long*)(g_fit_lds + kClCells * 4);
-    int* lsize = (int*)(g_fit_lds + kClCells * 8);
+    ESL_FIT_MARK(9);
+    // per-root statistics (the cell tables and the sorted copy are dead now: their space holds the three statistics arrays)
+    unsigned long long* lmind = (unsigned long long*)(g_fit_lds + kLdsKey);
+    unsigned long long* lmink = (unsigned long long*)(g_fit_lds + kLdsCst);
+    int* lsize = (int*)(g_fit_lds + kLdsPts);
     for (int i = tid; i < M; i += kFitThreads) { lmind[i] = kEmpty; lmink[i] = kEmpty; lsize[i] = 0; }
     __syncthreads();
     for (int i = tid; i < M; i += kFitThreads) {
@@ -781,13 +941,15 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
       a.nxt[pbase + i] = r;  // root of every point
       atomicAdd(&lsize[r], 1);
       atomicMin(&lmink[r], a.pkey[pbase + i]);
-      const double dx = S.center[0] - a.pwx[pbase + i], dy = S.center[1] - a.pwy[pbase + i], dz = S.center[2] - a.pwz[pbase + i];
+      const double dx = S.center[0] - lx[i], dy = S.center[1] - ly[i], dz = S.center[2] - lz[i];
       const double d = sqrt(dx * dx + dy * dy + dz * dz);
       atomicMin(&lmind[r], (unsigned long long)__double_as_longlong(d));
+      lroot[i] = r;   // (= the forest's parent array: pointing i at its root is a valid compression while others still search)
     }
+    pts_in_lds = true;
     __syncthreads();
+    // (k_fit_post reads the sizes; the choice below reads the LDS copies: no global round trip, no stage_sync)
     for (int i = tid; i < M; i += kFitThreads) { a.csize[pbase + i] = lsize[i]; a.cminkey[pbase + i] = lmink[i]; a.cmind[pbase + i] = lmind[i]; }
-    stage_sync();
   } else {
     cl_init(a, base, pbase, M, tid, kFitThreads);
     stage_sync();
@@ -800,28 +962,31 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   }
   }   // !a.wide
   // choose the cluster: the only one, else the largest (ties: smaller voxel key) within center_dis of the centre
+  const unsigned long long* s_mind = (const unsigned long long*)(g_fit_lds + kLdsKey);
+  const unsigned long long* s_mink = (const unsigned long long*)(g_fit_lds + kLdsCst);
+  const int* s_size = (const int*)(g_fit_lds + kLdsPts);
+  auto size_of = [&](int r) { return pts_in_lds ? s_size[r] : __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto mind_of = [&](int r) {
+    return __longlong_as_double((long long)(pts_in_lds ? s_mind[r] : __hip_atomic_load(&a.cmind[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+  };
+  auto mink_of = [&](int r) { return pts_in_lds ? s_mink[r] : __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   for (int r = tid; r < M; r += kFitThreads) {
-    const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int sz = size_of(r);
     if (sz >= a.fr->p.min_cluster_size) {
       atomicAdd(&S.ncl, 1);
       atomicMax(&S.only, r);
-      const double md = __longlong_as_double((long long)__hip_atomic_load(&a.cmind[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (md < a.fr->p.center_dis) atomicMax(&S.maxsize, sz);
+      if (mind_of(r) < a.fr->p.center_dis) atomicMax(&S.maxsize, sz);
     }
   }
   __syncthreads();
   for (int r = tid; r < M; r += kFitThreads) {
-    const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sz >= a.fr->p.min_cluster_size && sz == S.maxsize) {
-      const double md = __longlong_as_double((long long)__hip_atomic_load(&a.cmind[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (md < a.fr->p.center_dis) atomicMin(&S.minkey, __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
+    const int sz = size_of(r);
+    if (sz >= a.fr->p.min_cluster_size && sz == S.maxsize && mind_of(r) < a.fr->p.center_dis) atomicMin(&S.minkey, mink_of(r));
   }
   __syncthreads();
   for (int r = tid; r < M; r += kFitThreads) {
-    const int sz = __hip_atomic_load(&a.csize[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sz >= a.fr->p.min_cluster_size && sz == S.maxsize && S.maxsize > 0 &&
-        __hip_atomic_load(&a.cminkey[pbase + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S.minkey) S.chosen = r;
+    const int sz = size_of(r);
+    if (sz >= a.fr->p.min_cluster_size && sz == S.maxsize && S.maxsize > 0 && mink_of(r) == S.minkey) S.chosen = r;
   }
   __syncthreads();
   if (tid == 0 && S.ncl == 1) S.chosen = S.only;
@@ -831,19 +996,22 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
     if (tid == 0) { a.out_status[b] = 2; a.out_dbg[16 * b] = S.n0; a.out_dbg[16 * b + 1] = S.n1; a.out_dbg[16 * b + 2] = M; a.out_dbg[16 * b + 3] = S.ncl; }
     return;
   }
-  const int nc = a.csize[pbase + chosen];
+  const int nc = size_of(chosen);
   ESL_FIT_MARK(4);
   // 7. PCA of the chosen cluster (two passes like PCL: centroid, then normalised covariance)
   {
     double sx = 0, sy = 0, sz = 0;
-    for (int i = tid; i < M; i += kFitThreads)
-      if (a.nxt[pbase + i] == chosen) { sx += a.pwx[pbase + i]; sy += a.pwy[pbase + i]; sz += a.pwz[pbase + i]; }
+    for (int i = tid; i < M; i += kFitThreads) {
+      if (pts_in_lds) { if (lroot[i] == chosen) { sx += lx[i]; sy += ly[i]; sz += lz[i]; } }
+      else if (a.nxt[pbase + i] == chosen) { sx += a.pwx[pbase + i]; sy += a.pwy[pbase + i]; sz += a.pwz[pbase + i]; }
+    }
     { double v3[3] = {sx, sy, sz}; block_sum_n<3>(v3, S.red); sx = v3[0]; sy = v3[1]; sz = v3[2]; }
     const double cen[3] = {sx / nc, sy / nc, sz / nc};
     double cv[6] = {0, 0, 0, 0, 0, 0};
     for (int i = tid; i < M; i += kFitThreads)
-      if (a.nxt[pbase + i] == chosen) {
-        const double d0 = a.pwx[pbase + i] - cen[0], d1 = a.pwy[pbase + i] - cen[1], d2 = a.pwz[pbase + i] - cen[2];
+      if ((pts_in_lds ? lroot[i] : a.nxt[pbase + i]) == chosen) {
+        const float px = pts_in_lds ? lx[i] : a.pwx[pbase + i], py = pts_in_lds ? ly[i] : a.pwy[pbase + i], pz = pts_in_lds ? lz[i] : a.pwz[pbase + i];
+        const double d0 = px - cen[0], d1 = py - cen[1], d2 = pz - cen[2];
         cv[0] += d0 * d0; cv[1] += d0 * d1; cv[2] += d0 * d2; cv[3] += d1 * d1; cv[4] += d1 * d2; cv[5] += d2 * d2;
       }
     __syncthreads();   // S.red is reused
@@ -923,8 +1091,8 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
   {
     const float inv = 1.0f / (float)a.fr->p.symmetry_grid;
     for (int i = tid; i < M; i += kFitThreads)
-      if (a.nxt[pbase + i] == chosen) {
-        const float px = a.pwx[pbase + i], py = a.pwy[pbase + i], pz = a.pwz[pbase + i];
+      if ((pts_in_lds ? lroot[i] : a.nxt[pbase + i]) == chosen) {
+        const float px = pts_in_lds ? lx[i] : a.pwx[pbase + i], py = pts_in_lds ? ly[i] : a.pwy[pbase + i], pz = pts_in_lds ? lz[i] : a.pwz[pbase + i];
         vox_insert(ag, base, vox_key(px, py, pz, inv), px, py, pz);
       }
   }
@@ -1002,7 +1170,7 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
   __syncthreads();
   const int n = sc.n;
   if (n <= kSymLds)
-    for (int i = tid; i < n; i += kSymThreads) ((float4*)g_fit_lds)[i] = make_float4(sc.pof[3 * i], sc.pof[3 * i + 1], sc.pof[3 * i + 2], 0.f);
+    for (int i = tid; i < n; i += kSymThreads) g_sym_cand[i] = make_float4(sc.pof[3 * i], sc.pof[3 * i + 1], sc.pof[3 * i + 2], 0.f);
   __syncthreads();
   const bool dual = st->stype == 2;
   const int dim = dual ? 3 : 2, iters = a.fr->p.symmetry_lm_iters;
@@ -1013,7 +1181,11 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
     const double dis = -0.2 + 0.2 * i, ang = -(M_PI / 180.0 * 5) + (M_PI / 180.0 * 5) * m;
     pl.p[0] = sin(ang); pl.p[1] = -cos(ang); pl.p[2] = 0; pl.p[3] = -dis; pl.dual = 0;
   }
-  // every thread carries the LM state; the evaluations come from ev[] -> identical decisions in all threads
+  // every thread carries the LM state; the evaluations come from ev[] -> identical decisions in all threads.
+  // (Measured and dropped in round 4: the NEXT iteration's linearisation issued inside the trial round, around the first trial's
+  // plane, on waves 1 .. 2 dim -- it saves a round whenever the first trial is accepted, but leaves only 8 - 2 dim trials in the
+  // first batch, and these problems reject often enough that the slowest hypothesis of a box went from 10 to 13 rounds:
+  // 77 -> 100 us per frame at BASELINE's 20-box frame.)
   double lambda = 0, ni = 2;
   int nbad = 0;
   if (wv == 0) { const double e = sym_error_wave(sc, pl, dual); if ((tid & 63) == 0) ev[0] = e; }
@@ -1042,13 +1214,21 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
     e_last = e0;
     double cur = e0 * e0;
     const double ini = cur;
-    double J[3] = {0, 0, 0}, H[9], bvec[3];
-    for (int d = 0; d < dim; ++d) J[d] = (1.0 / (2 * delta)) * (ev[1 + 2 * d] - ev[2 + 2 * d]);
+    // (all arrays statically indexed -> registers: a runtime `dim` in the subscripts put them in scratch memory)
+    double J[3] = {0, 0, 0}, H3[9], bvec[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) if (d < dim) J[d] = (1.0 / (2 * delta)) * (ev[1 + 2 * d] - ev[2 + 2 * d]);
     __syncthreads();
-    for (int r = 0; r < dim; ++r) { bvec[r] = J[r] * (-(1.0 * e0)); for (int k = 0; k < dim; ++k) H[r * dim + k] = J[r] * 1.0 * J[k]; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      bvec[r] = J[r] * (-(1.0 * e0));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) H3[r * 3 + k] = J[r] * 1.0 * J[k];   // row / column 2 are zero when the hypothesis has two parameters
+    }
     if (it == 0) {
       double md = 0;
-      for (int r = 0; r < dim; ++r) md = fmax(md, fabs(H[r * dim + r]));
+#pragma unroll
+      for (int r = 0; r < 3; ++r) if (r < dim) md = fmax(md, fabs(H3[r * 3 + r]));
       lambda = 1e-5 * md; ni = 2; nbad = 0;
     }
     double rho = 0;
@@ -1061,10 +1241,18 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
       {
         double lam_k = lambda, ni_k = ni;
         for (int k = 0; k < wv; ++k) { lam_k *= ni_k; ni_k *= 2; }
-        double Mx[9], x[3] = {0, 0, 0};
-        for (int r = 0; r < dim * dim; ++r) Mx[r] = H[r];
-        for (int r = 0; r < dim; ++r) Mx[r * dim + r] += lam_k;
-        const bool ok = ldlt_small(Mx, dim, bvec, x);
+        double x[3] = {0, 0, 0};
+        bool ok;
+        if (dual) {
+          double Mx[9];
+#pragma unroll
+          for (int r = 0; r < 9; ++r) Mx[r] = H3[r];
+          Mx[0] += lam_k; Mx[4] += lam_k; Mx[8] += lam_k;
+          ok = ldlt_small<3>(Mx, bvec, x);
+        } else {
+          double Mx[4] = {H3[0] + lam_k, H3[1], H3[3], H3[4] + lam_k};
+          ok = ldlt_small<2>(Mx, bvec, x);
+        }
         PlaneT pt = pl;
         plane_update(pt, x, dual);
         const double e = sym_error_wave(sc, pt, dual);
@@ -1081,7 +1269,8 @@ static __global__ __launch_bounds__(kSymThreads) void k_fit_sym(FitArgs a) {
         e_last = et;
         const double tmp = (s_ok[k] > 0.5) ? et * et : 1.7976931348623157e308;
         double scale = 0;
-        for (int r = 0; r < dim; ++r) scale += s_x[k][r] * (lambda * s_x[k][r] + bvec[r]);   // lambda == wave k's lam_k here
+#pragma unroll
+        for (int r = 0; r < 3; ++r) if (r < dim) scale += s_x[k][r] * (lambda * s_x[k][r] + bvec[r]);   // lambda == wave k's lam_k here
         rho = (cur - tmp) / (scale + 1e-3);
         if (rho > 0 && isfinite(tmp)) {
           double alpha = 1. - pow((2 * rho - 1), 3);
@@ -1397,7 +1586,7 @@ static int fit_frame_impl(esl_ctx* c, const uint16_t* depth, int32_t width, int3
         const long tiles_pts = std::min<long>(64, std::max<long>(1, cap / 1024));
         hipLaunchKernelGGL(k_fit_cl_init, dim3((unsigned)tiles_hash, n_boxes), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_fit_cl_insert, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_fit_cl_union, dim3((unsigned)std::min<long>(1024, tiles_pts * 27), n_boxes), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_fit_cl_union, dim3((unsigned)std::min<long>(1024, tiles_pts * 14), n_boxes), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_fit_cl_stats, dim3((unsigned)tiles_pts, n_boxes), dim3(256), 0, st, a);
       }
       hipLaunchKernelGGL(k_fit_pre, dim3(n_boxes), dim3(kFitThreads), 0, st, a);
@@ -1458,6 +1647,14 @@ static int fit_frame_impl(esl_ctx* c, const uint16_t* depth, int32_t width, int3
         }
       fprintf(stderr, "[esl_fit timing, us per box]");
       for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f", names[k], cnt[k] ? sum[k] / cnt[k] : 0.0);
+      {  // inside the cluster stage (LDS path): centre mark -> neighbour search + linking done
+        double s9 = 0, m9 = 0; int c9 = 0;
+        for (size_t bx = 0; bx < B; ++bx) {
+          const long long t0 = clk[16 * bx + 3], t1 = clk[16 * bx + 9];
+          if (t0 > 0 && t1 >= t0) { const double d = (double)(t1 - t0) * 0.01; s9 += d; m9 = std::max(m9, d); c9++; }
+        }
+        if (c9) fprintf(stderr, " (cluster: tables + search + linking %.1f, max %.1f)", s9 / c9, m9);
+      }
       size_t slow = 0; double slow_t = 0;
       for (size_t bx = 0; bx < B; ++bx) {
         long long last = clk[16 * bx];
