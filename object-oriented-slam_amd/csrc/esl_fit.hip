@@ -775,7 +775,7 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
         }
       }
     }
-    sx = block_sum(sx, S.red); sy = block_sum(sy, S.red); sz = block_sum(sz, S.red); cn = block_sum(cn, S.red);
+    { double v4[4] = {sx, sy, sz, cn}; block_sum_n<4>(v4, S.red); sx = v4[0]; sy = v4[1]; sz = v4[2]; cn = v4[3]; }   // (one barrier pair, same per-value summation order as four block_sum calls)
     if (cn < 2) { if (tid == 0) a.out_status[b] = 1; return; }
     if (tid == 0) { const double c[3] = {sx / cn, sy / cn, sz / cn}; xform(Rwc, Twc.t, c, S.center); }
   }
@@ -1086,25 +1086,12 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
     while (Hs < 2L * nc) Hs <<= 1;
     ag.H = Hs < a.H ? Hs : a.H;
   }
-  for (long s = tid; s < ag.H; s += kFitThreads) { a.hk[base + s] = kEmpty; a.hsx[base + s] = 0; a.hsy[base + s] = 0; a.hsz[base + s] = 0; a.hcnt[base + s] = 0; }
-  stage_sync();
-  {
-    const float inv = 1.0f / (float)a.fr->p.symmetry_grid;
-    for (int i = tid; i < M; i += kFitThreads)
-      if ((pts_in_lds ? lroot[i] : a.nxt[pbase + i]) == chosen) {
-        const float px = pts_in_lds ? lx[i] : a.pwx[pbase + i], py = pts_in_lds ? ly[i] : a.pwy[pbase + i], pz = pts_in_lds ? lz[i] : a.pwz[pbase + i];
-        vox_insert(ag, base, vox_key(px, py, pz, inv), px, py, pz);
-      }
-  }
-  stage_sync();
   double* po = a.po + 12 * pbase;   // up to 4 * cap points
   float* pof = a.pof + 3 * pbase;
-  for (long s = tid; s < ag.H; s += kFitThreads) {
-    const unsigned int cnt = __hip_atomic_load(&a.hcnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!cnt) continue;
+  // a grid cell -> the point the symmetry stage sees: centroid (fixed-point sums, exact) rounded to float, into the object frame
+  auto emit = [&](unsigned int cnt, long long sxv, long long syv, long long szv) {
     const double c = (double)cnt;
-    const double p[3] = {(double)(float)((double)a.hsx[base + s] / c / ESL_FIX), (double)(float)((double)a.hsy[base + s] / c / ESL_FIX),
-                         (double)(float)((double)a.hsz[base + s] / c / ESL_FIX)};
+    const double p[3] = {(double)(float)((double)sxv / c / ESL_FIX), (double)(float)((double)syv / c / ESL_FIX), (double)(float)((double)szv / c / ESL_FIX)};
     const int i = atomicAdd(&S.ns0, 1);
     double q[3];
     q[0] = S.Row[0] * p[0] + S.Row[1] * p[1] + S.Row[2] * p[2] + S.Tow[0];
@@ -1112,8 +1099,56 @@ static __global__ __launch_bounds__(kFitThreads) void k_fit_pre(FitArgs a) {
     q[2] = S.Row[6] * p[0] + S.Row[7] * p[1] + S.Row[8] * p[2] + S.Tow[2];
     po[3 * i] = q[0]; po[3 * i + 1] = q[1]; po[3 * i + 2] = q[2];
     pof[3 * i] = (float)q[0]; pof[3 * i + 1] = (float)q[1]; pof[3 * i + 2] = (float)q[2];
+  };
+  const float inv_grid = 1.0f / (float)a.fr->p.symmetry_grid;
+  if (pts_in_lds && ag.H <= 2048) {
+    // the grid's hash in LDS (round 4): the clustering tables are dead, the points and their roots are still there.  Same keys, same
+    // slots, same exact sums as the global-memory table below -- three global-atomic round trips and two stage_syncs shorter.
+    const int Hg = (int)ag.H;
+    unsigned long long* gk = (unsigned long long*)g_fit_lds;
+    unsigned long long* gsx = gk + Hg; unsigned long long* gsy = gk + 2 * Hg; unsigned long long* gsz = gk + 3 * Hg;   // 32 Hg <= 65,536 < kLdsPar
+    unsigned int* gcnt = (unsigned int*)g_fit_nb;
+    static_assert(32 * 2048 <= kLdsPar && 4 * 2048 <= (int)sizeof(g_fit_nb), "symmetry grid table must fit under the roots");
+    for (int sidx = tid; sidx < Hg; sidx += kFitThreads) { gk[sidx] = kEmpty; gsx[sidx] = 0; gsy[sidx] = 0; gsz[sidx] = 0; gcnt[sidx] = 0; }
+    __syncthreads();
+    for (int i = tid; i < M; i += kFitThreads)
+      if (lroot[i] == chosen) {
+        const float px = lx[i], py = ly[i], pz = lz[i];
+        const unsigned long long key = vox_key(px, py, pz, inv_grid);
+        unsigned int slot = (unsigned int)(hash64(key) & (unsigned long long)(Hg - 1));
+        for (;;) {
+          const unsigned long long prev = atomicCAS(&gk[slot], kEmpty, key);
+          if (prev == kEmpty || prev == key) break;
+          slot = (slot + 1) & (unsigned int)(Hg - 1);
+        }
+        atomicAdd(&gsx[slot], (unsigned long long)llrint((double)px * ESL_FIX));
+        atomicAdd(&gsy[slot], (unsigned long long)llrint((double)py * ESL_FIX));
+        atomicAdd(&gsz[slot], (unsigned long long)llrint((double)pz * ESL_FIX));
+        atomicAdd(&gcnt[slot], 1u);
+      }
+    __syncthreads();
+    for (int sidx = tid; sidx < Hg; sidx += kFitThreads) {
+      const unsigned int cnt = gcnt[sidx];
+      if (cnt) emit(cnt, (long long)gsx[sidx], (long long)gsy[sidx], (long long)gsz[sidx]);
+    }
+    __syncthreads();
+  } else {
+  for (long s = tid; s < ag.H; s += kFitThreads) { a.hk[base + s] = kEmpty; a.hsx[base + s] = 0; a.hsy[base + s] = 0; a.hsz[base + s] = 0; a.hcnt[base + s] = 0; }
+  stage_sync();
+  {
+    for (int i = tid; i < M; i += kFitThreads)
+      if ((pts_in_lds ? lroot[i] : a.nxt[pbase + i]) == chosen) {
+        const float px = pts_in_lds ? lx[i] : a.pwx[pbase + i], py = pts_in_lds ? ly[i] : a.pwy[pbase + i], pz = pts_in_lds ? lz[i] : a.pwz[pbase + i];
+        vox_insert(ag, base, vox_key(px, py, pz, inv_grid), px, py, pz);
+      }
   }
   stage_sync();
+  for (long s = tid; s < ag.H; s += kFitThreads) {
+    const unsigned int cnt = __hip_atomic_load(&a.hcnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt) emit(cnt, a.hsx[base + s], a.hsy[base + s], a.hsz[base + s]);
+  }
+  stage_sync();
+  }
   const int ns0 = S.ns0;
   ESL_FIT_MARK(6);
   // 9. symmetry: 9 hypotheses, one wavefront each
