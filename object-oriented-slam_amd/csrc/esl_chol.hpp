@@ -895,12 +895,23 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
 // streams or events).  Hand-offs follow the guide's recipe R1: payload stored write-through (sc1), every storing wave drains,
 // one lane publishes the word; consumers poll relaxed from one lane, ONE agent-scope acquire, plain loads.  Every spin is bounded
 // (bit 1 of info + an abort word that stops all other spins).
-struct CholTask { int type, a, b, c; };   // 0: S(panel a, strip b)   1: u(panel a, row tile b, column tile c)   2: U(outer panel a, row tile b, column tile c)
+// 0: S(panel a, strip b)   1: u(panel a, row tile b, column tile c)   2: U(outer panel a, row tile b, column tile c)
+// 3: a QUARTER of u(panel a, row tile b, column tile c & 0xffff): rows 256 b + 128 h, columns 128 J + 64 g with h = bit 16, g = bit 17
+//    of c, bits 18.. = the number of quarters this tile's update is made of (those that meet the lower triangle and the matrix).
+//    The DIAGONAL tile of the next panels takes its rank-128 updates in quarters: it sits between the solve of panel k and the
+//    diagonal block of panel k + 1, i.e. on the critical path of the chain, where one workgroup needs 42 us for the whole tile and
+//    four need ~12 us for a quarter each (round 4: 62 panels x 30 us of the last 8,000 columns of an order-18,000 system).
+struct CholTask { int type, a, b, c; };
 struct CholPlan {
   int n = 0, np = 0, W = 0, n_outer = 0, nR = 0;
   std::vector<CholTask> tasks;
   std::vector<int> ns;   // [np][nR]
 };
+// quarter (h, g) of tile (R, J): rows 256 R + 128 h .. + 128, columns 128 J + 64 g .. + 64
+inline bool chol_quarter_live(int R, int J, int h, int g, long rows, int n) {
+  const long i0 = 256L * R + 128L * h, j0 = 128L * J + 64L * g;
+  return i0 < rows && j0 < n && i0 + 127 >= j0;
+}
 inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
   const long rows = (long)n + 1;
   pl.n = n; pl.W = W; pl.np = (n + kNB - 1) / kNB; pl.n_outer = (pl.np + W - 1) / W; pl.nR = (int)((rows + 255) / 256);
@@ -925,7 +936,14 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
       bool any = false;
       for (int J = k + 1; J < ke; ++J)
         for (int R = J / 2; R < nR; ++R)
-          if (live(R, J)) { if (!any) { fill(); any = true; } pl.tasks.push_back(CholTask{1, k, R, J}); }
+          if (live(R, J)) {
+            if (!any) { fill(); any = true; }
+            if (R != J / 2) { pl.tasks.push_back(CholTask{1, k, R, J}); continue; }
+            int cnt = 0;
+            for (int q = 0; q < 4; ++q) cnt += chol_quarter_live(R, J, q & 1, q >> 1, rows, n) ? 1 : 0;
+            for (int q = 0; q < 4; ++q)
+              if (chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) pl.tasks.push_back(CholTask{3, k, R, J | ((q & 1) << 16) | ((q >> 1) << 17) | (cnt << 18)});
+          }
     }
     pl.tasks.insert(pl.tasks.end(), prevB.begin() + bpos, prevB.end());
     prevA.clear(); prevB.clear();
@@ -935,8 +953,8 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
         if (live(R, J)) (J < ne ? prevA : prevB).push_back(CholTask{2, o, R, J});
   }
 }
-// sync words: [0] task counter, [1] abort, [4 ..) pdone[np], sdone[np][nR], ver[nR][np]
-inline size_t chol_sync_words(int np, int nR) { return 4 + (size_t)np + 2 * (size_t)np * nR; }
+// sync words: [0] task counter, [1] abort, [4 ..) pdone[np], sdone[np][nR], ver[nR][np], quarters done [nR][np]
+inline size_t chol_sync_words(int np, int nR) { return 4 + (size_t)np + 3 * (size_t)np * nR; }
 __device__ long long g_chol_timeout_ticks = 300000000LL;   // 3 s at 100 MHz (ESL_CHOL_TIMEOUT_MS overrides it: debugging)
 // Spin until *word >= want (ONE lane; bounded).  Every poll is a chol_peek -- a device-scope atomic -- so the pollers are RATE
 // LIMITED: 255 workgroups polling back to back saturate the atomic units (~90 atomics per us on one word) and every other atomic
@@ -967,7 +985,12 @@ __device__ __forceinline__ bool chol_wait_ge(int* word, int want, int* abortw, i
 constexpr size_t kP2Lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
 static_assert(kP2Lds >= kCholLdsBig, "the persistent kernel's LDS is sized by the diagonal-block role");
 constexpr int kPwThreads = 512, kPwGrid = 256;
-constexpr size_t kPwLds = kP2Lds + 16;
+// diagnostics of the persistent kernel (ESL_CHOL_TIMING=1 in the self test): per workgroup {ticks waiting on dependency words, ticks
+// inside task bodies, tasks, first tick, last tick} of the last launch, wall_clock64 ticks (100 MHz)
+__device__ int g_chol_stats_on;
+__device__ long long g_chol_stats[kPwGrid * 5];
+__device__ long long g_chol_chain_log[2 * 1024];   // per diagonal block: tick its tile was final, tick its factor was published
+constexpr size_t kPwLds = kP2Lds + 64;   // + the task slot words and the diagnostics accumulators
 // ONE kernel, two roles (round 4, second form): workgroup 0 is the chain, workgroups 1..255 the workers.  (The first form ran the two
 // roles as two kernels on two streams: correct and as fast -- but whether two queues of one process run side by side or in turns
 // is the scheduler's business: creating or destroying any stream while the pair ran made it time-slice them, each role then only
@@ -978,26 +1001,36 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
                                                                    int n_tasks, const int* __restrict__ ns, int* sync, int* info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   int* slot = reinterpret_cast<int*>(sm + kP2Lds / sizeof(double));   // (behind the roles' LDS: no static __shared__, guide G17)
+  long long* lstat = reinterpret_cast<long long*>(slot + 4);           // diagnostics accumulate in LDS, not in registers (see below)
+  const bool stats = g_chol_stats_on != 0;
+  if (stats && threadIdx.x == 0) { lstat[0] = lstat[1] = lstat[2] = 0; lstat[3] = (long long)wall_clock64(); }
   int* pdone = sync + 4;
   int* sdone = pdone + np;
   int* ver = sdone + (size_t)np * nR;
+  int* qdone = ver + (size_t)np * nR;
   const int t = threadIdx.x;
   const long rows = (long)n + 1;
   if (blockIdx.x == 0) {   // ---- the chain: diagonal blocks in order
     for (int k = 0; k < np; ++k) {
       const int k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
       if (t == 0) {
+        const long long tw = stats ? (long long)wall_clock64() : 0;
         const bool ok = chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], k / W + k % W, sync + 1, info);   // every update of the diagonal block's tile is in
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         slot[0] = ok ? 1 : 0;
+        if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; lstat[4] = now; if (k < 1024) g_chol_chain_log[2 * k] = now; }
       }
       __syncthreads();
       if (!slot[0]) return;
       chol_potrf2_body<true, kPwThreads>(sm, M, lda, k0, nb, Linv_ws + (size_t)k * kNB * kNB, info);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
       __syncthreads();
-      if (t == 0) __hip_atomic_store(&pdone[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then ONE lane publishes
+      if (t == 0) {
+        __hip_atomic_store(&pdone[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then ONE lane publishes
+        if (stats) { const long long now = (long long)wall_clock64(); lstat[1] += now - lstat[4]; lstat[2] += 1; if (k < 1024) g_chol_chain_log[2 * k + 1] = now; }
+      }
     }
+    if (stats && t == 0) { for (int q = 0; q < 4; ++q) g_chol_stats[q] = lstat[q]; g_chol_stats[4] = (long long)wall_clock64(); }
     return;
   }
   for (;;) {               // ---- a worker: the next task of the list
@@ -1005,26 +1038,31 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
     //  descriptor, the publish address and the diagnostics kept in registers the update tile's 212 spilled 60 B per lane)
     if (t == 0) slot[0] = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (slot[0] >= n_tasks) return;
+    if (slot[0] >= n_tasks) {
+      if (stats && t == 0) { for (int q = 0; q < 4; ++q) g_chol_stats[5 * blockIdx.x + q] = lstat[q]; g_chol_stats[5 * blockIdx.x + 4] = (long long)wall_clock64(); }
+      return;
+    }
     if (t == 0) {
       const CholTask tk = tasks[slot[0]];
       bool ok = true;
+      const long long tw = stats ? (long long)wall_clock64() : 0;
       if (tk.type == 0) {
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
         const int R = (int)(((long)k0 + nb + 64L * tk.b) / 256);
         ok = chol_wait_ge<100>(&pdone[k], 1, sync + 1, info) && chol_wait_ge<100>(&ver[(size_t)R * np + k], k / W + k % W, sync + 1, info);
       } else {
-        const int R = tk.b, J = tk.c;
-        const int ke = (tk.type == 1) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
+        const int R = tk.b, J = tk.c & 0xffff;
+        const int ke = (tk.type != 2) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
         // the LAST panel's strips of a row tile are solved only after every earlier panel of the same outer panel has solved its own
         // there and updated them (S waits for its tile to be final): one pair of words stands for all W panels
         ok = chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + R], ns[(size_t)(ke - 1) * nR + R], sync + 1, info) &&
              chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + J / 2], ns[(size_t)(ke - 1) * nR + J / 2], sync + 1, info);
-        const int seq = (tk.type == 1) ? J / W + tk.a % W : tk.a;
+        const int seq = (tk.type != 2) ? J / W + tk.a % W : tk.a;
         ok = ok && chol_wait_ge<100>(&ver[(size_t)R * np + J], seq, sync + 1, info);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       slot[1] = ok ? 1 : 0;
+      if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; lstat[4] = now; }
     }
     __syncthreads();
     if (!slot[1]) return;
@@ -1034,10 +1072,14 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
         chol_panel_body<true>(M, lda, rows, k0, nb, Linv_ws + (size_t)k * kNB * kNB, (long)tk.b);
       } else {
-        const int kb = (tk.type == 1) ? tk.a : tk.a * W, ke = (tk.type == 1) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
+        const int kb = (tk.type != 2) ? tk.a : tk.a * W, ke = (tk.type != 2) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
         const long c0 = (long)kb * kNB;
         const int K = (int)(((long)ke * kNB < n ? (long)ke * kNB : (long)n) - c0);
-        chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * tk.c, false);
+        if (tk.type == 3)
+          chol_update_tile<128, 64, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b + 128L * ((tk.c >> 16) & 1),
+                                                128L * (tk.c & 0xffff) + 64L * ((tk.c >> 17) & 1), false);
+        else
+          chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * tk.c, false);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
@@ -1047,9 +1089,17 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       if (tk.type == 0) {
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
         __hip_atomic_fetch_add(&sdone[(size_t)k * nR + (size_t)(((long)k0 + nb + 64L * tk.b) / 256)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (tk.type == 3) {
+        // quarters of ONE update run side by side; the one that completes the set moves the tile's sequence number on.  (The counter
+        // only grows: panel a is the (a % W + 1)-th rank-128 update of this tile, which belongs to a's own outer panel.)
+        const int J = tk.c & 0xffff, cnt = tk.c >> 18;
+        const int old = __hip_atomic_fetch_add(&qdone[(size_t)tk.b * np + J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == cnt * (tk.a % W + 1))
+          __hip_atomic_store(&ver[(size_t)tk.b * np + J], J / W + tk.a % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         __hip_atomic_store(&ver[(size_t)tk.b * np + tk.c], ((tk.type == 1) ? tk.c / W + tk.a % W : tk.a) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (stats) { lstat[1] += (long long)wall_clock64() - lstat[4]; lstat[2] += 1; }
     }
     __syncthreads();                                      // (slot[0] is free for the next task)
   }
@@ -1072,6 +1122,7 @@ struct CholRuntime {
   CholTask* d_tasks = nullptr; int* d_ns = nullptr; int* d_sync = nullptr;
   size_t d_tasks_cap = 0, d_ns_cap = 0, d_sync_cap = 0;
   int sw_persistent = -1;                                   // ESL_CHOL_PERSISTENT = 1 / 0 forces it on / off (default: by size)
+  int stats_on = 0;                                         // g_chol_stats_on as last written (ESL_CHOL_TIMING)
   int sw_backsub = -1;                                      // ESL_CHOL_BACKSUB_LAUNCHES=1 keeps the launch-per-panel form (A/B)
   void release() {
     if (bs_flags) { (void)hipFree(bs_flags); bs_flags = nullptr; bs_flags_cap = 0; }
@@ -1137,6 +1188,10 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
   if (const char* tm = std::getenv("ESL_CHOL_TIMEOUT_MS")) {
     const long long ticks = 100000LL * std::max(1, std::atoi(tm));
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_chol_timeout_ticks), &ticks, sizeof(ticks)); if (e != hipSuccess) return e;
+  }
+  {
+    const int on = std::getenv("ESL_CHOL_TIMING") ? 1 : 0;
+    if (on != rt.stats_on) { hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_chol_stats_on), &on, sizeof(on)); if (e != hipSuccess) return e; rt.stats_on = on; }
   }
   hipError_t e = hipMemsetAsync(rt.d_sync, 0, chol_sync_words(pl.np, pl.nR) * sizeof(int), st); if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_chol_persist, dim3(kPwGrid), dim3(kPwThreads), kPwLds, st, M, lda, n, pl.np, pl.W, pl.nR, Linv_ws, (const CholTask*)rt.d_tasks,

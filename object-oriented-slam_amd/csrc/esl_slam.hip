@@ -953,6 +953,43 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
   ST_TRY(hipEventElapsedTime(&ms, e0, e1));
 #undef ST_TRY
   if (std::getenv("ESL_CHOL_TIMING")) {
+    std::vector<long long> ps((size_t)kPwGrid * 5, 0);
+    if (hipMemcpyFromSymbol(ps.data(), HIP_SYMBOL(g_chol_stats), ps.size() * sizeof(long long)) == hipSuccess && ps[2] > 0) {
+      // persistent kernel, last launch: workgroup 0 = the chain of diagonal blocks, the others pull tasks off the list
+      long long t_first = ps[3], t_last = ps[4];
+      double w_wait = 0, w_body = 0, w_tasks = 0, w_span = 0, w_wait_max = 0, w_end_min = 1e300, w_end_max = 0; int nw = 0;
+      for (int b = 1; b < kPwGrid; ++b) {
+        const long long* q = &ps[(size_t)b * 5];
+        if (q[4] == 0) continue;
+        t_first = std::min(t_first, q[3]); t_last = std::max(t_last, q[4]);
+      }
+      for (int b = 1; b < kPwGrid; ++b) {
+        const long long* q = &ps[(size_t)b * 5];
+        if (q[4] == 0) continue;
+        ++nw; w_wait += (double)q[0]; w_body += (double)q[1]; w_tasks += (double)q[2]; w_span += (double)(q[4] - q[3]);
+        w_wait_max = std::max(w_wait_max, (double)q[0]);
+        w_end_min = std::min(w_end_min, (double)(q[4] - t_first)); w_end_max = std::max(w_end_max, (double)(q[4] - t_first));
+      }
+      fprintf(stderr, "[k_chol_persist, last launch] span %.2f ms | chain: %lld blocks, waiting %.2f ms, factoring %.2f ms | %d workers: mean waiting %.2f ms (max %.2f), "
+                      "in task bodies %.2f ms, %.0f tasks each, alive %.2f ms, first / last exit at %.2f / %.2f ms\n",
+              (double)(t_last - t_first) * 1e-5, ps[2], (double)ps[0] * 1e-5, (double)ps[1] * 1e-5, nw, nw ? w_wait / nw * 1e-5 : 0.0, w_wait_max * 1e-5,
+              nw ? w_body / nw * 1e-5 : 0.0, nw ? w_tasks / nw : 0.0, nw ? w_span / nw * 1e-5 : 0.0, w_end_min * 1e-5, w_end_max * 1e-5);
+    }
+    {
+      std::vector<long long> cl(2048, 0);
+      const int npl = std::min(1024, (n + kNB - 1) / kNB);
+      if (ps[2] > 0 && hipMemcpyFromSymbol(cl.data(), HIP_SYMBOL(g_chol_chain_log), cl.size() * sizeof(long long)) == hipSuccess && npl > 8) {
+        // the chain's timeline, averaged over eighths of the panels: factor time and the gap between one factor published and the next tile final
+        fprintf(stderr, "[k_chol_persist chain, us per panel by eighth of the matrix: potrf / gap to the next block]");
+        for (int e = 0; e < 8; ++e) {
+          const int k0 = e * npl / 8, k1 = std::min(npl - 1, (e + 1) * npl / 8);
+          double f = 0, g = 0; int c = 0;
+          for (int k = k0; k < k1; ++k) { f += (double)(cl[2 * k + 1] - cl[2 * k]); g += (double)(cl[2 * k + 2] - cl[2 * k + 1]); ++c; }
+          if (c) fprintf(stderr, " %.0f/%.0f", f / c * 0.01, g / c * 0.01);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
     long long clk[16];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_potrf_clk), sizeof(clk)) == hipSuccess) {
       static const char* names[9] = {"load", "rank-4 steps", "-", "-", "-", "store L", "-", "inverse", "store Linv"};

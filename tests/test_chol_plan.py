@@ -41,10 +41,36 @@ def replay(pkg, n, W, filler, seed=0):
             pdone[k] = 1
             chain_k[0] += 1
 
-    counts = {0: 0, 1: 0, 2: 0}
+    counts = {0: 0, 1: 0, 2: 0, 3: 0}
+    qdone = np.zeros((nR, np_), int)
     for ty, a, bb, c in tasks:
         advance_chain()
         counts[int(ty)] += 1
+        if ty == 3:
+            # a quarter of the rank-128 update of the NEXT panels' diagonal tile: the quarters of one update may run side by side (all
+            # of them see the tile at the update's sequence number), the last one moves the number on
+            R, J, h, g, cnt = bb, c & 0xFFFF, (c >> 16) & 1, (c >> 17) & 1, c >> 18
+            k = a
+            assert R == J // 2 and k // W == J // W and J > k and 1 <= cnt <= 4
+            seq = J // W + a % W
+            assert sdone[k, R] == ns[k, R] and sdone[k, J // 2] == ns[k, J // 2], ("quarter before its operands", a, R, J)
+            assert ver[R, J] == seq, ("quarter out of sequence", a, R, J, ver[R, J], seq)
+            i0 = 256 * R + 128 * h; j0 = 128 * J + 64 * g
+            assert i0 < rows and j0 < n and i0 + 127 >= j0
+            i1, j1 = min(i0 + 128, rows), min(j0 + 64, n)
+            c0, c1 = 128 * k, 128 * k + 128
+            upd = M[i0:i1, c0:c1] @ M[j0:j1, c0:c1].T
+            rr, cc = np.meshgrid(np.arange(i0, i1), np.arange(j0, j1), indexing="ij")
+            mask = rr >= cc
+            blk = M[i0:i1, j0:j1]
+            blk[mask] -= upd[mask]
+            qdone[R, J] += 1
+            # the live quarters of the tile cover its whole lower-triangle part, and cnt is their number
+            live_q = [(hh, gg) for hh in (0, 1) for gg in (0, 1) if 256 * R + 128 * hh < rows and 128 * J + 64 * gg < n and 256 * R + 128 * hh + 127 >= 128 * J + 64 * gg]
+            assert cnt == len(live_q) and (h, g) in live_q
+            if qdone[R, J] == cnt * (a % W + 1):
+                ver[R, J] = seq + 1
+            continue
         if ty == 0:
             k, i = a, bb; k0, nb = 128 * k, nb_of(k)
             r0 = k0 + nb + 64 * i; r1 = min(r0 + 64, rows); R = r0 // 256
@@ -97,7 +123,8 @@ def test_task_list_is_a_schedule_and_a_cholesky(pkg, n, W, filler):
     pl, counts, _ = replay(pkg, n, W, filler)
     np_ = pl["np"]
     assert counts[0] == int(pl["ns"].sum())
-    print("n %d W %d: %d panels, %d tasks (%d strips, %d rank-128 tiles, %d rank-%d tiles)" % (n, W, np_, len(pl["tasks"]), counts[0], counts[1], counts[2], 128 * W))
+    print("n %d W %d: %d panels, %d tasks (%d strips, %d rank-128 tiles + %d quarters of diagonal tiles, %d rank-%d tiles)"
+          % (n, W, np_, len(pl["tasks"]), counts[0], counts[1], counts[3], counts[2], 128 * W))
 
 
 def test_look_ahead_order_of_the_list(pkg):
