@@ -907,6 +907,15 @@ struct CholPlan {
   std::vector<CholTask> tasks;
   std::vector<int> ns;   // [np][nR]
 };
+// Updates a tile (R, J) of the lower triangle receives before panel J is factored, in this order: nU rank-(W x 128) updates U(o), one
+// per EARLIER outer panel, then rank-128 updates from the panels in front of J.  Ordinarily those are the J % W panels of J's own
+// outer panel.  The DIAGONAL tile of an outer panel's FIRST column panel (J % W == 0, R == J / 2) is special: it takes the
+// previous outer panel's contribution as W rank-128 updates (in quarters), one per panel as that panel is solved, instead of
+// inside U(o - 1) -- otherwise the chain's step across an outer-panel boundary waits for a whole rank-512 tile update (~150 us)
+// that cannot start before the LAST panel of the outer panel is solved.
+__host__ __device__ __forceinline__ bool chol_tile_special(int R, int J, int W) { return J >= W && J % W == 0 && R == J / 2; }
+__host__ __device__ __forceinline__ int chol_tile_nU(int R, int J, int W) { return J / W - (chol_tile_special(R, J, W) ? 1 : 0); }
+__host__ __device__ __forceinline__ int chol_tile_final(int R, int J, int W) { return chol_tile_nU(R, J, W) + (chol_tile_special(R, J, W) ? W : J % W); }
 // quarter (h, g) of tile (R, J): rows 256 R + 128 h .. + 128, columns 128 J + 64 g .. + 64
 inline bool chol_quarter_live(int R, int J, int h, int g, long rows, int n) {
   const long i0 = 256L * R + 128L * h, j0 = 128L * J + 64L * g;
@@ -934,15 +943,21 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
       fill();                                              // (work for the others while the chain factors block k)
       for (int i = 0; i < strips(k); ++i) pl.tasks.push_back(CholTask{0, k, i, 0});
       bool any = false;
+      auto quarters = [&](int R, int J) {
+        int cnt = 0;
+        for (int q = 0; q < 4; ++q) cnt += chol_quarter_live(R, J, q & 1, q >> 1, rows, n) ? 1 : 0;
+        for (int q = 0; q < 4; ++q)
+          if (chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) pl.tasks.push_back(CholTask{3, k, R, J | ((q & 1) << 16) | ((q >> 1) << 17) | (cnt << 18)});
+      };
+      // the next outer panel's first diagonal tile takes this panel's rank-128 contribution now (chol_tile_special); of all of the
+      // panel's updates it is the one the chain will wait for soonest when k is the outer panel's last, so it goes first
+      if (ke < np && live(ke / 2, ke)) { fill(); any = true; quarters(ke / 2, ke); }
       for (int J = k + 1; J < ke; ++J)
         for (int R = J / 2; R < nR; ++R)
           if (live(R, J)) {
             if (!any) { fill(); any = true; }
             if (R != J / 2) { pl.tasks.push_back(CholTask{1, k, R, J}); continue; }
-            int cnt = 0;
-            for (int q = 0; q < 4; ++q) cnt += chol_quarter_live(R, J, q & 1, q >> 1, rows, n) ? 1 : 0;
-            for (int q = 0; q < 4; ++q)
-              if (chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) pl.tasks.push_back(CholTask{3, k, R, J | ((q & 1) << 16) | ((q >> 1) << 17) | (cnt << 18)});
+            quarters(R, J);
           }
     }
     pl.tasks.insert(pl.tasks.end(), prevB.begin() + bpos, prevB.end());
@@ -950,7 +965,7 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
     const int ne = std::min(np, ke + W);
     for (int J = ke; J < np; ++J)
       for (int R = J / 2; R < nR; ++R)
-        if (live(R, J)) (J < ne ? prevA : prevB).push_back(CholTask{2, o, R, J});
+        if (live(R, J) && !(J == ke && R == ke / 2)) (J < ne ? prevA : prevB).push_back(CholTask{2, o, R, J});   // (the special tile: see chol_tile_special)
   }
 }
 // sync words: [0] task counter, [1] abort, [4 ..) pdone[np], sdone[np][nR], ver[nR][np], quarters done [nR][np]
@@ -1015,7 +1030,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       const int k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
       if (t == 0) {
         const long long tw = stats ? (long long)wall_clock64() : 0;
-        const bool ok = chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], k / W + k % W, sync + 1, info);   // every update of the diagonal block's tile is in
+        const bool ok = chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], chol_tile_final(k / 2, k, W), sync + 1, info);   // every update of the diagonal block's tile is in
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         slot[0] = ok ? 1 : 0;
         if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; lstat[4] = now; if (k < 1024) g_chol_chain_log[2 * k] = now; }
@@ -1049,7 +1064,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       if (tk.type == 0) {
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
         const int R = (int)(((long)k0 + nb + 64L * tk.b) / 256);
-        ok = chol_wait_ge<100>(&pdone[k], 1, sync + 1, info) && chol_wait_ge<100>(&ver[(size_t)R * np + k], k / W + k % W, sync + 1, info);
+        ok = chol_wait_ge<100>(&pdone[k], 1, sync + 1, info) && chol_wait_ge<100>(&ver[(size_t)R * np + k], chol_tile_final(R, k, W), sync + 1, info);
       } else {
         const int R = tk.b, J = tk.c & 0xffff;
         const int ke = (tk.type != 2) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
@@ -1057,7 +1072,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         // there and updated them (S waits for its tile to be final): one pair of words stands for all W panels
         ok = chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + R], ns[(size_t)(ke - 1) * nR + R], sync + 1, info) &&
              chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + J / 2], ns[(size_t)(ke - 1) * nR + J / 2], sync + 1, info);
-        const int seq = (tk.type != 2) ? J / W + tk.a % W : tk.a;
+        const int seq = (tk.type != 2) ? chol_tile_nU(R, J, W) + tk.a % W : tk.a;
         ok = ok && chol_wait_ge<100>(&ver[(size_t)R * np + J], seq, sync + 1, info);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1095,7 +1110,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         const int J = tk.c & 0xffff, cnt = tk.c >> 18;
         const int old = __hip_atomic_fetch_add(&qdone[(size_t)tk.b * np + J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1 == cnt * (tk.a % W + 1))
-          __hip_atomic_store(&ver[(size_t)tk.b * np + J], J / W + tk.a % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&ver[(size_t)tk.b * np + J], chol_tile_nU(tk.b, J, W) + tk.a % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         __hip_atomic_store(&ver[(size_t)tk.b * np + tk.c], ((tk.type == 1) ? tk.c / W + tk.a % W : tk.a) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

@@ -27,13 +27,17 @@ def replay(pkg, n, W, filler, seed=0):
     pdone = np.zeros(np_, int); sdone = np.zeros((np_, nR), int); ver = np.zeros((nR, np_), int)
     Linv = [None] * np_
     chain_k = [0]
-    final = lambda J: J // W + J % W
+    # what a tile receives before its panel is factored (csrc/esl_chol.hpp chol_tile_special / _nU / _final): the diagonal tile of an
+    # outer panel's first column panel takes the previous outer panel's contribution as W rank-128 updates instead of one rank-(128 W)
+    special = lambda R, J: J >= W and J % W == 0 and R == J // 2
+    n_big = lambda R, J: J // W - (1 if special(R, J) else 0)
+    final = lambda R, J: n_big(R, J) + (W if special(R, J) else J % W)
     nb_of = lambda k: min(128, n - 128 * k)
 
     def advance_chain():
-        while chain_k[0] < np_ and ver[chain_k[0] // 2, chain_k[0]] >= final(chain_k[0]):
+        while chain_k[0] < np_ and ver[chain_k[0] // 2, chain_k[0]] >= final(chain_k[0] // 2, chain_k[0]):
             k = chain_k[0]; k0, nb = 128 * k, nb_of(k)
-            assert ver[k // 2, k] == final(k)
+            assert ver[k // 2, k] == final(k // 2, k)
             D = np.tril(M[k0:k0 + nb, k0:k0 + nb]); D = D + np.tril(D, -1).T
             L = np.linalg.cholesky(D)
             M[k0:k0 + nb, k0:k0 + nb] = np.triu(M[k0:k0 + nb, k0:k0 + nb], 1) + L
@@ -51,8 +55,9 @@ def replay(pkg, n, W, filler, seed=0):
             # of them see the tile at the update's sequence number), the last one moves the number on
             R, J, h, g, cnt = bb, c & 0xFFFF, (c >> 16) & 1, (c >> 17) & 1, c >> 18
             k = a
-            assert R == J // 2 and k // W == J // W and J > k and 1 <= cnt <= 4
-            seq = J // W + a % W
+            assert R == J // 2 and J > k and 1 <= cnt <= 4
+            assert (k // W == J // W) or (special(R, J) and k // W == J // W - 1)
+            seq = n_big(R, J) + a % W
             assert sdone[k, R] == ns[k, R] and sdone[k, J // 2] == ns[k, J // 2], ("quarter before its operands", a, R, J)
             assert ver[R, J] == seq, ("quarter out of sequence", a, R, J, ver[R, J], seq)
             i0 = 256 * R + 128 * h; j0 = 128 * J + 64 * g
@@ -76,7 +81,7 @@ def replay(pkg, n, W, filler, seed=0):
             r0 = k0 + nb + 64 * i; r1 = min(r0 + 64, rows); R = r0 // 256
             assert r0 < rows
             assert pdone[k] == 1, ("S before its diagonal block", k, i)
-            assert ver[R, k] == final(k), ("S on a tile that is not final", k, i, ver[R, k], final(k))
+            assert ver[R, k] == final(R, k), ("S on a tile that is not final", k, i, ver[R, k], final(R, k))
             M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
             sdone[k, R] += 1
         else:
@@ -90,9 +95,9 @@ def replay(pkg, n, W, filler, seed=0):
                 assert sdone[k, R] == ns[k, R], ("update before its row operand", ty, a, R, J, k)
                 assert sdone[k, J // 2] == ns[k, J // 2], ("update before its column operand", ty, a, R, J, k)
                 if ty == 1:
-                    assert k // W == J // W and J > k
+                    assert k // W == J // W and J > k and R != J // 2      # (diagonal tiles take their rank-128 updates in quarters)
                 else:
-                    assert J >= min(np_, a * W + W)
+                    assert J >= min(np_, a * W + W) and not (special(R, J) and J // W == a + 1)
             assert ver[R, J] == seq, ("update out of sequence", ty, a, R, J, ver[R, J], seq)
             c0, c1 = 128 * ks[0], min(128 * (ks[-1] + 1), n)
             i0, i1 = 256 * R, min(256 * R + 256, rows); j0, j1 = 128 * J, min(128 * J + 128, n)
@@ -110,7 +115,7 @@ def replay(pkg, n, W, filler, seed=0):
     for J in range(np_):
         for R in range(nR):
             live = 256 * R + 255 >= 128 * J and 256 * R < rows
-            assert ver[R, J] == (final(J) if live else 0), (R, J)
+            assert ver[R, J] == (final(R, J) if live else 0), (R, J)
     Lref = np.linalg.cholesky(A)
     np.testing.assert_allclose(np.tril(M[:n]), Lref, rtol=0, atol=1e-9 * np.abs(Lref).max())
     np.testing.assert_allclose(M[n], np.linalg.solve(Lref, b), rtol=0, atol=1e-9 * np.abs(b).max())   # y = L^-1 b rides along as row n
