@@ -879,22 +879,40 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
 // ---- persistent factorisation (round 4) -----------------------------------------------------------------------------------------
 // The launch-per-step form above leaves the chain of diagonal blocks exposed wherever the trailing matrix is too small to hide it
 // (the last ~8,000 rows of an order-18,000 system, ~8 of its 44 ms) and its small kernels queue behind 110 us update tiles for a
-// free CU.  Here ONE pair of kernels runs the whole factorisation: k_chol_chain (one workgroup, the potrf2 body: 640 threads, 157 KB
-// of LDS) walks the diagonal blocks, k_chol_workers (255 workgroups of the update kernel's shape; its 104 KB of LDS make every one
-// the only tenant of its CU, so the two kernels are co-resident by arithmetic: 255 + 1 CUs) pull TASKS from a static list with one
-// atomic counter.  Tasks, on the absolute tile grid (row tiles of 256, column tiles = the 128-wide panels):
-//   S(k, i)     strip i (64 rows) of the panel solve of panel k                            (k_chol_panel's workgroup)
-//   u(k, R, J)  tile (R, J) -= X(R, k) X(J, k)^T, rank 128, J in the rest of k's outer panel (k_chol_update_lds's workgroup)
+// free CU.  Here ONE kernel, k_chol_persist, runs the whole factorisation: 256 workgroups of 512 threads, every one the only
+// tenant of its CU (157 KB of LDS).  Workgroup 0 is the CHAIN: it walks the diagonal blocks (the potrf2 body).  The other 255 pull
+// TASKS from a static list with one atomic counter.  Tasks, on the absolute tile grid (row tiles of 256, column tiles = the
+// 128-wide panels):
+//   S(k, i)     strip i (64 rows) of the panel solve of panel k                            (k_chol_panel's body)
+//   u(k, R, J)  tile (R, J) -= X(R, k) X(J, k)^T, rank 128, J in the rest of k's outer panel (k_chol_update_lds's body); the
+//               DIAGONAL tile of a panel takes these in quarters (task type 3, below)
 //   U(o, R, J)  tile (R, J) -= X(R, o) X(J, o)^T, rank W x 128, J beyond outer panel o
-// Dependencies are words in device memory (zeroed by a memset in front of the pair): pdone[k] (chain: L_kk, Linv_k published),
+// Dependencies are words in device memory (zeroed by a memset in front of the launch): pdone[k] (chain: L_kk, Linv_k published),
 // sdone[k][R] (strips of row tile R solved for panel k; complete at ns[k][R]), ver[R][J] (updates applied to tile (R, J): every
 // update carries its sequence number, waits for ver == seq and leaves ver = seq + 1 -- read-modify-write order and "tile final"
 // in one word).  The list is in an order in which every task's prerequisites come earlier (or are the chain's), so a workgroup
 // that spins on a word waits for work another RESIDENT workgroup already holds: no deadlock whatever the dispatch order; the
 // next outer panel's chain-dependent tasks sit between batches of the previous outer panel's far updates (look-ahead without
-// streams or events).  Hand-offs follow the guide's recipe R1: payload stored write-through (sc1), every storing wave drains,
-// one lane publishes the word; consumers poll relaxed from one lane, ONE agent-scope acquire, plain loads.  Every spin is bounded
-// (bit 1 of info + an abort word that stops all other spins).
+// streams or events).  tests/test_chol_plan.py replays the list on the CPU.  Hand-offs follow the guide's recipe R1: payload
+// stored write-through (sc1), every storing wave drains, one lane publishes the word; the consumer polls from one lane, ONE
+// agent-scope acquire, plain loads.  Every spin is bounded (bit 1 of info + an abort word that stops all other spins).
+// What the first versions taught (all measured on MI355X, round 4):
+//   * TWO kernels (chain / workers) on two streams are co-resident only until something else touches the queues: a stream created
+//     or destroyed anywhere in the process while they run gets them TIME-SLICED against each other, and a spinning consumer whose
+//     producer is switched out turns a 40 ms factorisation into seconds.  One kernel cannot be split that way.
+//   * a polled word must be read with a WRITING atomic (chol_peek: an atomic add of zero).  Agent-scope loads, fetch_or(0) (the
+//     compiler folds it into a load) and failing compare-and-swaps are all served from the polling XCD's L2, which another XCD's
+//     write-through store does not update: once every workgroup of an XCD waits, nothing evicts the line and the stale value is
+//     read forever.  Pollers back to back saturate the atomic units (255 of them slowed the whole kernel 100x): workers sleep
+//     ~2.7 us between polls, the chain ~0.1 us; a plain agent-scope load goes first (the words only grow: stale can under-report).
+//   * where the time goes at n = 18,000 (ESL_CHOL_TIMING=1 prints it): workers spend 35.5 of 40 ms inside task bodies (the
+//     rank-512 tiles run at ~73 % of a CU's MFMA peak) and 3.5 ms waiting; the chain is idle 31 ms -- and sets the pace over the
+//     last three eighths of the panels, where a step costs potrf 62 us + 40 us (strips under the diagonal block -> the quarters of
+//     the next diagonal tile -> the next block) against 3 - 70 us of trailing work.  Two schedule changes got it there from
+//     62 + 68 us: the diagonal tile's rank-128 updates in four quarters (42 us for one workgroup), and the first diagonal tile of
+//     the NEXT outer panel fed rank-128 updates panel by panel instead of waiting for its rank-512 tile (chol_tile_special).
+//     What is left needs the chain to stop waiting for other workgroups at all (solve the next block's rows and update the next
+//     diagonal block inside the chain's own kernel body): not done.
 // 0: S(panel a, strip b)   1: u(panel a, row tile b, column tile c)   2: U(outer panel a, row tile b, column tile c)
 // 3: a QUARTER of u(panel a, row tile b, column tile c & 0xffff): rows 256 b + 128 h, columns 128 J + 64 g with h = bit 16, g = bit 17
 //    of c, bits 18.. = the number of quarters this tile's update is made of (those that meet the lower triangle and the matrix).
@@ -1371,10 +1389,11 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
       }
     }
   } else if (([&]() { if (rt.sw_persistent < 0) { const char* sw = std::getenv("ESL_CHOL_PERSISTENT"); rt.sw_persistent = sw ? (sw[0] == '1' ? 1 : 0) : 2; }
-                      // by size: measured on MI355X (profiles/r4_cholesky_microbench.txt) the one-launch form wins where the trailing updates
-                      // are long enough to cover its per-task hand-offs and short enough for the exposed chain to matter: n = 12,000 18.0 vs
-                      // 18.2 ms, 18,000 42.6 vs 43.8; 8,192 9.8 vs 9.1 and 32,768 213 vs 214 (a draw)
-                      return rt.sw_persistent == 1 || (rt.sw_persistent == 2 && n >= 10000 && n < 30000); })()) {
+                      // by size, measured on MI355X (profiles/r4_cholesky_microbench.txt), one launch vs launch per step: n = 2,994 2.43 vs
+                      // 2.24 ms, 4,096 3.23 vs 3.24, 6,000 4.88 vs 5.75, 8,192 7.94 vs 8.95, 12,000 15.9 vs 17.9, 18,000 40.3 vs 43.9,
+                      // 24,000 88.0 vs 91.8, 32,768 214.4 vs 214.5 (a draw: the launch path is kept there, it is the form that has run the
+                      // order-59,994 reduced camera system since round 1)
+                      return rt.sw_persistent == 1 || (rt.sw_persistent == 2 && n >= 4096 && n < 30000); })()) {
     hipError_t e = chol_factor_persistent(M, lda, n, Linv_ws, info, st, rt); if (e != hipSuccess) return e;
   } else {
   bool trail_pending = false;   // ev_trail[o - 1] has been recorded and not yet waited for
