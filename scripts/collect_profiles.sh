@@ -1,7 +1,7 @@
 # after `gpurun -- bash scripts/gpu_round_bench.sh <tag>`: copy the judged summaries from gpurun_out/<tag>/ (scratch) into profiles/
 # (tracked) under the round's name:   bash scripts/collect_profiles.sh <tag> [round-name, default r3]
-TAG=${1:-r3}
-RN=${2:-r3}
+TAG=${1:-r4}
+RN=${2:-r4}
 R=gpurun_out/$TAG
 cp $R/bench_default.json profiles/${RN}_bench_default.json
 cp $R/bench_default_kernel_stats.md profiles/${RN}_bench_default_kernel_stats.md
@@ -11,5 +11,6 @@ cp $R/pmc_traffic_device_lm.json profiles/${RN}_pmc_traffic_device_lm.json
 cp $R/c3_slam_camera_first_kernel_stats.md profiles/${RN}_c3_slam_camera_first_kernel_stats.md
 cp $R/mapping_c4_kernel_stats.md profiles/${RN}_mapping_c4_kernel_stats.md
 cp $R/cholesky_microbench.txt profiles/${RN}_cholesky_microbench.txt
+for n in slam_upload_probe fit_stage_timing fit_kernel_times; do [ -s $R/$n.txt ] && cp $R/$n.txt profiles/${RN}_$n.txt; done
 grep -v "^$" $R/gputest.log | grep -v "^\.\+$" | tail -60 > profiles/${RN}_gputest_tail.txt
 ls -la profiles

@@ -3,7 +3,7 @@
 #   the -m gpu test-suite, the default bench line (C4 SLAM timed + all records, with CPU baselines) and rocprofv3 kernel stats of
 #   the SAME command, PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes) of one C4 SLAM optimize and of the mapping-mode LM,
 #   C3 SLAM kernel stats, mapping kernel stats, fit kernel times, Cholesky micro-benchmark, other configs
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=gpurun_out/$TAG
 mkdir -p $R
 export TMPDIR=/tmp
@@ -30,7 +30,12 @@ rm -rf $R/pmc_map_FETCH_SIZE $R/pmc_map_WRITE_SIZE
 python profiles/summarize_rocpd.py $(ls -t $R/prof_c3/*/*_results.db | head -1) > $R/c3_slam_camera_first_kernel_stats.md; rm -rf $R/prof_c3
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$R/prof_map -- python $ROOT/scripts/prof_map.py C4 20 > $ROOT/$R/prof_map.log 2>&1)
 python profiles/summarize_rocpd.py $(ls -t $R/prof_map/*/*_results.db | head -1) > $R/mapping_c4_kernel_stats.md; rm -rf $R/prof_map
-timeout 300 python scripts/chol_bench.py 450 2994 8192 18000 32768 > $R/cholesky_microbench.txt 2>&1
+{ echo "== default selection (one launch from n = 4,096 to 30,000, launch per step elsewhere)"; timeout 300 python scripts/chol_bench.py 450 2994 4096 6000 8192 12000 18000 24000 32768
+  echo "== ESL_CHOL_PERSISTENT=0 (launch per step everywhere)"; ESL_CHOL_PERSISTENT=0 timeout 300 python scripts/chol_bench.py 2994 4096 6000 8192 12000 18000 24000
+  echo "== ESL_CHOL_TIMING=1, n = 18000: where the persistent kernel's time goes"; ESL_CHOL_TIMING=1 timeout 120 python scripts/chol_bench.py 18000 2>&1 | grep -v "k_chol_potrf2, last"; } > $R/cholesky_microbench.txt 2>&1
+ESL_UPLOAD_HOST_TIMING=1 timeout 300 python scripts/upload_slam_probe.py C4 2>&1 | tail -12 > $R/slam_upload_probe.txt
+timeout 200 python scripts/fit_timing.py > $R/fit_stage_timing.txt 2>&1
+timeout 300 bash scripts/gpu_prof_fit.sh $TAG > $R/fit_kernel_times.txt 2>&1; rm -rf gpurun_out/prof_fit_$TAG
 run() { name=$1; shift; timeout 900 python bench.py --no-cpu-baseline --no-extras "$@" > $R/$name.json 2> $R/$name.err; }
 run c3_slam_camera_first --config C3 --solver ellipsoid --steps 5 --warmup 2
 run c3_slam_reduced_camera --config C3 --solver camera --steps 5 --warmup 2
