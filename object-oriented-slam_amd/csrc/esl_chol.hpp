@@ -911,17 +911,22 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
 //     the next diagonal tile -> the next block) against 3 - 70 us of trailing work.  Two schedule changes got it there from
 //     62 + 68 us: the diagonal tile's rank-128 updates in four quarters (42 us for one workgroup), and the first diagonal tile of
 //     the NEXT outer panel fed rank-128 updates panel by panel instead of waiting for its rank-512 tile (chol_tile_special).
-//     What is left needs the chain to stop waiting for other workgroups at all (solve the next block's rows and update the next
-//     diagonal block inside the chain's own kernel body): not done.
+//   * the chain then stopped waiting for other workgroups between two blocks: it solves the 128 rows under its block against the
+//     inverse that is still in its LDS and applies the rank-128 update to the next diagonal block itself (chol_chain_solve_rows /
+//     chol_chain_update_next; strips 0, 1 and the diagonal half of the quarters leave the task list; ESL_CHOL_FUSE=0 is the
+//     form before).  Its own 25 us (14 + 10 + drain) replace 40 us of hand-offs: the step is 66 + 36 us, n = 18,000 40.5 -> 40.0 ms.
+//     The chain's own arithmetic is now what the last eighths of the panels cost; the next lever is the 66 us of potrf2.
 // 0: S(panel a, strip b)   1: u(panel a, row tile b, column tile c)   2: U(outer panel a, row tile b, column tile c)
 // 3: a QUARTER of u(panel a, row tile b, column tile c & 0xffff): rows 256 b + 128 h, columns 128 J + 64 g with h = bit 16, g = bit 17
-//    of c, bits 18.. = the number of quarters this tile's update is made of (those that meet the lower triangle and the matrix).
+//    of c, bits 18-20 = the number of quarters of THIS update that are tasks, bits 21-23 = the number a whole update of the tile has
+//    (those that meet the lower triangle and the matrix; fewer are tasks when the chain takes the diagonal block itself).
 //    The DIAGONAL tile of the next panels takes its rank-128 updates in quarters: it sits between the solve of panel k and the
 //    diagonal block of panel k + 1, i.e. on the critical path of the chain, where one workgroup needs 42 us for the whole tile and
 //    four need ~12 us for a quarter each (round 4: 62 panels x 30 us of the last 8,000 columns of an order-18,000 system).
 struct CholTask { int type, a, b, c; };
 struct CholPlan {
   int n = 0, np = 0, W = 0, n_outer = 0, nR = 0;
+  int fuse = 0;          // the chain solves the two strips under its diagonal block and updates the next diagonal block itself (below)
   std::vector<CholTask> tasks;
   std::vector<int> ns;   // [np][nR]
 };
@@ -935,12 +940,13 @@ __host__ __device__ __forceinline__ bool chol_tile_special(int R, int J, int W) 
 __host__ __device__ __forceinline__ int chol_tile_nU(int R, int J, int W) { return J / W - (chol_tile_special(R, J, W) ? 1 : 0); }
 __host__ __device__ __forceinline__ int chol_tile_final(int R, int J, int W) { return chol_tile_nU(R, J, W) + (chol_tile_special(R, J, W) ? W : J % W); }
 // quarter (h, g) of tile (R, J): rows 256 R + 128 h .. + 128, columns 128 J + 64 g .. + 64
-inline bool chol_quarter_live(int R, int J, int h, int g, long rows, int n) {
+__host__ __device__ inline bool chol_quarter_live(int R, int J, int h, int g, long rows, int n) {
   const long i0 = 256L * R + 128L * h, j0 = 128L * J + 64L * g;
   return i0 < rows && j0 < n && i0 + 127 >= j0;
 }
-inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
+inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = false) {
   const long rows = (long)n + 1;
+  pl.fuse = fuse ? 1 : 0;
   pl.n = n; pl.W = W; pl.np = (n + kNB - 1) / kNB; pl.n_outer = (pl.np + W - 1) / W; pl.nR = (int)((rows + 255) / 256);
   const int np = pl.np, nR = pl.nR;
   pl.ns.assign((size_t)np * nR, 0);
@@ -959,13 +965,18 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl) {
     auto fill = [&]() { const size_t e = std::min(prevB.size(), bpos + (size_t)filler); pl.tasks.insert(pl.tasks.end(), prevB.begin() + bpos, prevB.begin() + e); bpos = e; };
     for (int k = kb; k < ke; ++k) {
       fill();                                              // (work for the others while the chain factors block k)
-      for (int i = 0; i < strips(k); ++i) pl.tasks.push_back(CholTask{0, k, i, 0});
+      for (int i = fuse ? 2 : 0; i < strips(k); ++i) pl.tasks.push_back(CholTask{0, k, i, 0});   // (fused: strips 0, 1 are the chain's)
       bool any = false;
       auto quarters = [&](int R, int J) {
-        int cnt = 0;
-        for (int q = 0; q < 4; ++q) cnt += chol_quarter_live(R, J, q & 1, q >> 1, rows, n) ? 1 : 0;
+        // (q & 1 = h: which 128 rows, q >> 1 = g: which 64 columns.)  Fused chain: panel J - 1's update of the diagonal BLOCK of
+        // tile (J / 2, J) -- the half h = J & 1 -- is the chain's; the workers keep the other half, if it is below the diagonal
+        const bool chains = fuse && k == J - 1;
+        int full = 0, mine = 0;
         for (int q = 0; q < 4; ++q)
-          if (chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) pl.tasks.push_back(CholTask{3, k, R, J | ((q & 1) << 16) | ((q >> 1) << 17) | (cnt << 18)});
+          if (chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) { ++full; if (!(chains && (q & 1) == (J & 1))) ++mine; }
+        for (int q = 0; q < 4; ++q)
+          if (chol_quarter_live(R, J, q & 1, q >> 1, rows, n) && !(chains && (q & 1) == (J & 1)))
+            pl.tasks.push_back(CholTask{3, k, R, J | ((q & 1) << 16) | ((q >> 1) << 17) | (mine << 18) | (full << 21)});
       };
       // the next outer panel's first diagonal tile takes this panel's rank-128 contribution now (chol_tile_special); of all of the
       // panel's updates it is the one the chain will wait for soonest when k is the outer panel's last, so it goes first
@@ -1015,6 +1026,114 @@ __device__ __forceinline__ bool chol_wait_ge(int* word, int want, int* abortw, i
     }
   }
 }
+
+// ---- the chain's own step to the next diagonal block (round 4, "fused chain") -------------------------------------------------
+// After chol_potrf2_body the LDS array L holds Linv_k.  The next diagonal block waits for two things that other workgroups used to
+// deliver: the solve of the 128 rows under block k (strips 0, 1 of panel k) and the rank-128 update of block k + 1 with them --
+// 40 us of task bodies, drains and polls per panel against ~8 us of arithmetic.  Here the chain does both itself:
+//   stage B   X = A[r0 .. r0 + 128, panel k] Linv_k^T   (rows < `rows`: the right-hand side's row rides along), Linv from LDS, A from
+//             global memory; X goes to global memory (it IS L's rows) and, once every wave has finished with Linv, into the LDS array
+//   stage C   A[r0 + i, c1 + j] -= sum_c X(i, c) X(j, c),  i >= j: the lower triangle of the next diagonal block (and the
+//             right-hand side's row when it lies in these rows), X from LDS
+// Both products are formed transposed (lane & 15 = the matrix ROW), so every global access is 128 contiguous bytes per 16 lanes.
+// 512 threads = 8 waves.  The caller provides the waits (stage B: the tile of these rows final for panel k; stage C: every earlier
+// update of the next diagonal tile applied) and the publish afterwards.
+template <bool WT>
+__device__ __forceinline__ void chol_chain_solve_rows(double* __restrict__ sm, double* __restrict__ M, long lda, long rows, int k0) {
+  double* L = sm;
+#define LL(i, j) L[(i) + (j) * kLdsPad]
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, kq = lane >> 4;
+  const long r0 = (long)k0 + kNB;
+  const long row = r0 + 16 * wave + r;
+  const bool rv = row < rows;
+  const double* ap = M + (rv ? row : rows - 1) + (long)(k0 + kq) * lda;
+  double a[32];
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) a[s2] = ap[(long)(4 * s2) * lda];
+  double4_t acc[8];
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) acc[jb] = double4_t{0, 0, 0, 0};
+#pragma unroll
+  for (int s2 = 0; s2 < 32; ++s2) {
+    const double av = rv ? a[s2] : 0.0;
+    const int k = 4 * s2 + kq;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+      if (4 * s2 < 16 * jb + 16) {   // Linv(c, k) = 0 for k > c (compile-time after unrolling)
+        const int c = 16 * jb + r;
+        const double lv = (k <= c) ? LL(c, k) : 0.0;
+        acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, av, acc[jb], 0, 0, 0);   // D[c = 4 g + kq][row = r]
+      }
+  }
+  // X -> global memory: lane r = row, 16 lanes store 128 contiguous bytes of a column
+  if (rv) {
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) chol_store<WT>(&M[row + (long)(k0 + 16 * jb + 4 * g + kq) * lda], acc[jb][g]);
+  }
+  __syncthreads();   // every wave has read Linv: the array now holds X (rows past the matrix as zeros)
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) LL(16 * wave + r, 16 * jb + 4 * g + kq) = rv ? acc[jb][g] : 0.0;
+  __syncthreads();
+#undef LL
+}
+// tiles (ib >= jb) of the next diagonal block owned by wave w: w, w + 8, ... of the 36, at most 5
+__device__ __forceinline__ void chol_chain_tile(int tl, int& ib, int& jb) {
+  ib = 0; int off = 0;
+  while (off + ib + 1 <= tl) { off += ib + 1; ++ib; }
+  jb = tl - off;
+}
+// the current values of the wave's entries of the next diagonal block, requested BEFORE the solve of the rows (every earlier update
+// of that tile has been waited for by then): fetched one tile at a time in front of its own products, each was ~2 us of exposed
+// latency, five in a row
+struct CholChainC { double v[5][4]; };
+__device__ __forceinline__ void chol_chain_prefetch_next(const double* __restrict__ M, long lda, long rows, int n, int k0, CholChainC& c) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+  const long c1 = (long)k0 + kNB;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int tl = wave + 8 * q;
+    int ib, jb;
+    chol_chain_tile(tl < 36 ? tl : 35, ib, jb);
+    const long row = c1 + 16 * ib + r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long col = c1 + 16 * jb + 4 * g + kq;
+      c.v[q][g] = M[(row < rows ? row : rows - 1) + (col < n ? col : (long)n - 1) * lda];
+    }
+  }
+}
+template <bool WT>
+__device__ __forceinline__ void chol_chain_update_next(double* __restrict__ sm, double* __restrict__ M, long lda, long rows, int n, int k0,
+                                                       const CholChainC& c) {
+  double* L = sm;
+#define LL(i, j) L[(i) + (j) * kLdsPad]
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, kq = lane >> 4;
+  const long c1 = (long)k0 + kNB;   // first row AND first column of the next diagonal block
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int tl = wave + 8 * q;
+    if (tl >= 36) break;
+    int ib, jb;
+    chol_chain_tile(tl, ib, jb);
+    double4_t acc = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int kk = 0; kk < kNB; kk += 4) {
+      const double xj = LL(16 * jb + r, kk + kq), xi = LL(16 * ib + r, kk + kq);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xj, xi, acc, 0, 0, 0);   // D[j = 4 g + kq][i = r]
+    }
+    const long row = c1 + 16 * ib + r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long col = c1 + 16 * jb + 4 * g + kq;
+      if (row < rows && col < n && row >= col) chol_store<WT>(&M[row + col * lda], c.v[q][g] - acc[g]);
+    }
+  }
+#undef LL
+}
 constexpr size_t kP2Lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
 static_assert(kP2Lds >= kCholLdsBig, "the persistent kernel's LDS is sized by the diagonal-block role");
 constexpr int kPwThreads = 512, kPwGrid = 256;
@@ -1022,7 +1141,8 @@ constexpr int kPwThreads = 512, kPwGrid = 256;
 // inside task bodies, tasks, first tick, last tick} of the last launch, wall_clock64 ticks (100 MHz)
 __device__ int g_chol_stats_on;
 __device__ long long g_chol_stats[kPwGrid * 5];
-__device__ long long g_chol_chain_log[2 * 1024];   // per diagonal block: tick its tile was final, tick its factor was published
+__device__ long long g_chol_chain_log[2 * 1024];
+__device__ long long g_chol_fuse_ticks[4];   // fused chain stage, totals of the last launch: waits, row solve, next-block update, drain + publish   // per diagonal block: tick its tile was final, tick its factor was published
 constexpr size_t kPwLds = kP2Lds + 64;   // + the task slot words and the diagnostics accumulators
 // ONE kernel, two roles (round 4, second form): workgroup 0 is the chain, workgroups 1..255 the workers.  (The first form ran the two
 // roles as two kernels on two streams: correct and as fast -- but whether two queues of one process run side by side or in turns
@@ -1031,12 +1151,12 @@ constexpr size_t kPwLds = kP2Lds + 64;   // + the task slot words and the diagno
 // diagonal-block role needs make every workgroup the only tenant of its CU -- which the 104 KB of the update role did anyway.
 static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __restrict__ M, long lda, int n, int np, int W, int nR,
                                                                    double* __restrict__ Linv_ws, const CholTask* __restrict__ tasks,
-                                                                   int n_tasks, const int* __restrict__ ns, int* sync, int* info) {
+                                                                   int n_tasks, const int* __restrict__ ns, int* sync, int* info, int fuse) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   int* slot = reinterpret_cast<int*>(sm + kP2Lds / sizeof(double));   // (behind the roles' LDS: no static __shared__, guide G17)
   long long* lstat = reinterpret_cast<long long*>(slot + 4);           // diagnostics accumulate in LDS, not in registers (see below)
   const bool stats = g_chol_stats_on != 0;
-  if (stats && threadIdx.x == 0) { lstat[0] = lstat[1] = lstat[2] = 0; lstat[3] = (long long)wall_clock64(); }
+  if (stats && threadIdx.x == 0) { lstat[0] = lstat[1] = lstat[2] = 0; lstat[3] = (long long)wall_clock64(); if (blockIdx.x == 0) { g_chol_fuse_ticks[0] = g_chol_fuse_ticks[1] = g_chol_fuse_ticks[2] = g_chol_fuse_ticks[3] = 0; } }
   int* pdone = sync + 4;
   int* sdone = pdone + np;
   int* ver = sdone + (size_t)np * nR;
@@ -1044,11 +1164,12 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
   const int t = threadIdx.x;
   const long rows = (long)n + 1;
   if (blockIdx.x == 0) {   // ---- the chain: diagonal blocks in order
+    bool have_next = false;   // fused: block k already carries every update (the previous step applied the last one itself)
     for (int k = 0; k < np; ++k) {
       const int k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
       if (t == 0) {
         const long long tw = stats ? (long long)wall_clock64() : 0;
-        const bool ok = chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], chol_tile_final(k / 2, k, W), sync + 1, info);   // every update of the diagonal block's tile is in
+        const bool ok = have_next || chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], chol_tile_final(k / 2, k, W), sync + 1, info);   // every update of the diagonal block's tile is in
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         slot[0] = ok ? 1 : 0;
         if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; lstat[4] = now; if (k < 1024) g_chol_chain_log[2 * k] = now; }
@@ -1061,6 +1182,49 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       if (t == 0) {
         __hip_atomic_store(&pdone[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then ONE lane publishes
         if (stats) { const long long now = (long long)wall_clock64(); lstat[1] += now - lstat[4]; lstat[2] += 1; if (k < 1024) g_chol_chain_log[2 * k + 1] = now; }
+      }
+      have_next = false;
+      const long below = rows - ((long)k0 + nb);
+      if (fuse && below > 0) {
+        // the rows under the block (strips 0, 1 of panel k: a full panel -- only the last one is short, and it has just the
+        // right-hand side's row under it, which the same code handles) and the next diagonal block: chol_chain_solve_rows / _update_next
+        const int R1 = (int)(((long)k0 + nb) / 256);
+        const int nstr = below > 64 ? 2 : 1;
+        const bool next = k + 1 < np;
+        if (t == 0) {
+          const long long tw = stats ? (long long)wall_clock64() : 0;
+          bool ok = chol_wait_ge<2>(&ver[(size_t)R1 * np + k], chol_tile_final(R1, k, W), sync + 1, info);
+          if (ok && next) ok = chol_wait_ge<2>(&ver[(size_t)((k + 1) / 2) * np + k + 1], chol_tile_nU((k + 1) / 2, k + 1, W) + k % W, sync + 1, info);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          slot[0] = ok ? 1 : 0;
+          if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; g_chol_fuse_ticks[0] += now - tw; lstat[4] = now; }
+        }
+        __syncthreads();
+        if (!slot[0]) return;
+        CholChainC cnext;
+        if (next) chol_chain_prefetch_next(M, lda, rows, n, k0, cnext);
+        if (nb == kNB) chol_chain_solve_rows<true>(sm, M, lda, rows, k0);
+        else {   // the short last panel: one row (the right-hand side's) against a partial inverse -- the strip body
+          chol_panel_body<true>(M, lda, rows, k0, nb, Linv_ws + (size_t)k * kNB * kNB, 0L);
+        }
+        if (stats && t == 0) { const long long now = (long long)wall_clock64(); g_chol_fuse_ticks[1] += now - lstat[4]; lstat[4] = now; }
+        if (next) chol_chain_update_next<true>(sm, M, lda, rows, n, k0, cnext);
+        if (stats && t == 0) { const long long now = (long long)wall_clock64(); g_chol_fuse_ticks[2] += now - lstat[4]; lstat[4] = now; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+          if (stats) { const long long now = (long long)wall_clock64(); g_chol_fuse_ticks[3] += now - lstat[4]; }
+          __hip_atomic_fetch_add(&sdone[(size_t)k * nR + R1], nstr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (next) {
+            // panel k's update of tile ((k + 1) / 2, k + 1): the workers' quarters (the half that is not the diagonal block) move the
+            // sequence number on when they are done; when there are none (k + 1 odd: the other half lies above the diagonal) the chain does
+            const int J = k + 1, R = J / 2;
+            int mine = 0;
+            for (int q = 0; q < 4; ++q) if ((q & 1) != (J & 1) && chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) ++mine;
+            if (mine == 0) __hip_atomic_store(&ver[(size_t)R * np + J], chol_tile_nU(R, J, W) + k % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        have_next = next;
       }
     }
     if (stats && t == 0) { for (int q = 0; q < 4; ++q) g_chol_stats[q] = lstat[q]; g_chol_stats[4] = (long long)wall_clock64(); }
@@ -1125,9 +1289,9 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       } else if (tk.type == 3) {
         // quarters of ONE update run side by side; the one that completes the set moves the tile's sequence number on.  (The counter
         // only grows: panel a is the (a % W + 1)-th rank-128 update of this tile, which belongs to a's own outer panel.)
-        const int J = tk.c & 0xffff, cnt = tk.c >> 18;
+        const int J = tk.c & 0xffff, mine = (tk.c >> 18) & 7, full = (tk.c >> 21) & 7;
         const int old = __hip_atomic_fetch_add(&qdone[(size_t)tk.b * np + J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == cnt * (tk.a % W + 1))
+        if (old + 1 == full * (tk.a % W) + mine)
           __hip_atomic_store(&ver[(size_t)tk.b * np + J], chol_tile_nU(tk.b, J, W) + tk.a % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         __hip_atomic_store(&ver[(size_t)tk.b * np + tk.c], ((tk.type == 1) ? tk.c / W + tk.a % W : tk.a) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1191,12 +1355,15 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
   return hipSuccess;
 }
 
+inline bool chol_fuse_default() { const char* e = std::getenv("ESL_CHOL_FUSE"); return !(e && e[0] == '0'); }
 // the persistent kernel on the caller's stream (one launch; the sync words are cleared in front of it)
 inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Linv_ws, int* info, hipStream_t st, CholRuntime& rt) {
   const char* wenv = std::getenv("ESL_CHOL_W");   // (debugging: outer-panel width of the persistent form)
   const int W = wenv ? std::max(1, std::atoi(wenv)) : chol_outer_panels(n);
-  if (rt.plan.n != n || rt.plan.W != W) {
-    chol_plan_build(n, W, /*filler*/ 128, rt.plan);
+  // ESL_CHOL_FUSE=0: strips under the diagonal block and the next block's update as worker tasks (the first form of round 4; A/B)
+  const bool fuse = chol_fuse_default();
+  if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0)) {
+    chol_plan_build(n, W, /*filler*/ 128, rt.plan, fuse);
     auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
       if (*cap >= need) return hipSuccess;
       if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
@@ -1228,7 +1395,7 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
   }
   hipError_t e = hipMemsetAsync(rt.d_sync, 0, chol_sync_words(pl.np, pl.nR) * sizeof(int), st); if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_chol_persist, dim3(kPwGrid), dim3(kPwThreads), kPwLds, st, M, lda, n, pl.np, pl.W, pl.nR, Linv_ws, (const CholTask*)rt.d_tasks,
-                     (int)pl.tasks.size(), (const int*)rt.d_ns, rt.d_sync, info);
+                     (int)pl.tasks.size(), (const int*)rt.d_ns, rt.d_sync, info, pl.fuse);
   return hipGetLastError();
 }
 

@@ -980,6 +980,10 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
       const int npl = std::min(1024, (n + kNB - 1) / kNB);
       if (ps[2] > 0 && hipMemcpyFromSymbol(cl.data(), HIP_SYMBOL(g_chol_chain_log), cl.size() * sizeof(long long)) == hipSuccess && npl > 8) {
         // the chain's timeline, averaged over eighths of the panels: factor time and the gap between one factor published and the next tile final
+        long long ft[4] = {0, 0, 0, 0};
+        if (hipMemcpyFromSymbol(ft, HIP_SYMBOL(g_chol_fuse_ticks), sizeof(ft)) == hipSuccess && (ft[1] | ft[2]))
+          fprintf(stderr, "[k_chol_persist chain, fused stage, us per panel] waits %.1f  rows under the block %.1f  next block's update %.1f  drain %.1f\n",
+                  (double)ft[0] * 0.01 / npl, (double)ft[1] * 0.01 / npl, (double)ft[2] * 0.01 / npl, (double)ft[3] * 0.01 / npl);
         fprintf(stderr, "[k_chol_persist chain, us per panel by eighth of the matrix: potrf / gap to the next block]");
         for (int e = 0; e < 8; ++e) {
           const int k0 = e * npl / 8, k1 = std::min(npl - 1, (e + 1) * npl / 8);
@@ -1033,7 +1037,7 @@ extern "C" int esl_debug_chol_plan(int32_t n, int32_t W, int32_t filler, int32_t
                                    int32_t* ns_out /* np x nR */, int64_t cap_ns, int32_t meta_out[5] /* np, n_outer, nR, n_tasks, W */) {
   if (n < 1 || W < 1 || !meta_out) return ESL_ERR_INVALID;
   esl::CholPlan pl;
-  esl::chol_plan_build(n, W, filler, pl);
+  esl::chol_plan_build(n, W, filler, pl, esl::chol_fuse_default());
   meta_out[0] = pl.np; meta_out[1] = pl.n_outer; meta_out[2] = pl.nR; meta_out[3] = (int32_t)pl.tasks.size(); meta_out[4] = pl.W;
   if (tasks_out) {
     if ((int64_t)pl.tasks.size() > cap_tasks) return ESL_ERR_INVALID;

@@ -13,7 +13,9 @@ import numpy as np
 import pytest
 
 
-def replay(pkg, n, W, filler, seed=0):
+def replay(pkg, n, W, filler, seed=0, fuse=True):
+    # fuse: the chain itself solves the (<= 128) rows under its diagonal block -- strips 0, 1 of the panel -- and applies the panel's
+    # update to the NEXT diagonal block (ESL_CHOL_FUSE, on by default; the caller sets the environment before building the plan)
     pl = pkg.lib.chol_plan(n, W, filler)
     np_, nR, tasks, ns = pl["np"], pl["nR"], pl["tasks"], pl["ns"]
     rng = np.random.default_rng(seed)
@@ -34,15 +36,55 @@ def replay(pkg, n, W, filler, seed=0):
     final = lambda R, J: n_big(R, J) + (W if special(R, J) else J % W)
     nb_of = lambda k: min(128, n - 128 * k)
 
+    chain_stage = [0]      # 0: block chain_k is next to be factored; 1 (fused): factored, its rows below and the next block's update pending
+    have_next = [False]    # fused: the block to be factored already carries every update (the chain applied the last one)
+    quarter_live = lambda R, J, h, g: 256 * R + 128 * h < rows and 128 * J + 64 * g < n and 256 * R + 128 * h + 127 >= 128 * J + 64 * g
+
     def advance_chain():
-        while chain_k[0] < np_ and ver[chain_k[0] // 2, chain_k[0]] >= final(chain_k[0] // 2, chain_k[0]):
+        while chain_k[0] < np_:
             k = chain_k[0]; k0, nb = 128 * k, nb_of(k)
-            assert ver[k // 2, k] == final(k // 2, k)
-            D = np.tril(M[k0:k0 + nb, k0:k0 + nb]); D = D + np.tril(D, -1).T
-            L = np.linalg.cholesky(D)
-            M[k0:k0 + nb, k0:k0 + nb] = np.triu(M[k0:k0 + nb, k0:k0 + nb], 1) + L
-            Linv[k] = np.linalg.inv(L)
-            pdone[k] = 1
+            if chain_stage[0] == 0:
+                if not (have_next[0] or ver[k // 2, k] >= final(k // 2, k)):
+                    return
+                if not have_next[0]:
+                    assert ver[k // 2, k] == final(k // 2, k)
+                D = np.tril(M[k0:k0 + nb, k0:k0 + nb]); D = D + np.tril(D, -1).T
+                L = np.linalg.cholesky(D)
+                M[k0:k0 + nb, k0:k0 + nb] = np.triu(M[k0:k0 + nb, k0:k0 + nb], 1) + L
+                Linv[k] = np.linalg.inv(L)
+                pdone[k] = 1
+                have_next[0] = False
+                if fuse and rows - (k0 + nb) > 0:
+                    chain_stage[0] = 1
+                else:
+                    chain_k[0] += 1
+                continue
+            # fused stage: rows r0 .. r0 + 128 of panel k, then block k + 1 -= X X^T
+            r0 = k0 + nb; r1 = min(r0 + 128, rows); R1 = r0 // 256; nxt = k + 1 < np_
+            below = rows - r0; nstr = 2 if below > 64 else 1
+            if ver[R1, k] < final(R1, k):
+                return
+            if nxt and ver[(k + 1) // 2, k + 1] < n_big((k + 1) // 2, k + 1) + k % W:
+                return
+            assert ver[R1, k] == final(R1, k)
+            if nxt:
+                assert nb == 128 and ver[(k + 1) // 2, k + 1] == n_big((k + 1) // 2, k + 1) + k % W, "the next diagonal tile is not at the chain's sequence number"
+            M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
+            sdone[k, R1] += nstr
+            if nxt:
+                c1 = r0; i1 = min(c1 + 128, rows); j1 = min(c1 + 128, n)
+                X = M[c1:i1, k0:k0 + nb]
+                upd = X @ X[:j1 - c1].T
+                rr, cc = np.meshgrid(np.arange(c1, i1), np.arange(c1, j1), indexing="ij")
+                mask = rr >= cc
+                blk = M[c1:i1, c1:j1]
+                blk[mask] -= upd[mask]
+                J = k + 1; R = J // 2
+                mine = sum(1 for hh in (0, 1) for gg in (0, 1) if hh != (J & 1) and quarter_live(R, J, hh, gg))
+                if mine == 0:
+                    ver[R, J] = n_big(R, J) + k % W + 1
+            have_next[0] = nxt
+            chain_stage[0] = 0
             chain_k[0] += 1
 
     counts = {0: 0, 1: 0, 2: 0, 3: 0}
@@ -53,9 +95,10 @@ def replay(pkg, n, W, filler, seed=0):
         if ty == 3:
             # a quarter of the rank-128 update of the NEXT panels' diagonal tile: the quarters of one update may run side by side (all
             # of them see the tile at the update's sequence number), the last one moves the number on
-            R, J, h, g, cnt = bb, c & 0xFFFF, (c >> 16) & 1, (c >> 17) & 1, c >> 18
+            R, J, h, g, cnt, full = bb, c & 0xFFFF, (c >> 16) & 1, (c >> 17) & 1, (c >> 18) & 7, (c >> 21) & 7
             k = a
-            assert R == J // 2 and J > k and 1 <= cnt <= 4
+            chains = fuse and k == J - 1      # the chain applies this update to the diagonal block (the half h == J & 1) itself
+            assert R == J // 2 and J > k and 1 <= cnt <= full <= 4
             assert (k // W == J // W) or (special(R, J) and k // W == J // W - 1)
             seq = n_big(R, J) + a % W
             assert sdone[k, R] == ns[k, R] and sdone[k, J // 2] == ns[k, J // 2], ("quarter before its operands", a, R, J)
@@ -71,15 +114,16 @@ def replay(pkg, n, W, filler, seed=0):
             blk[mask] -= upd[mask]
             qdone[R, J] += 1
             # the live quarters of the tile cover its whole lower-triangle part, and cnt is their number
-            live_q = [(hh, gg) for hh in (0, 1) for gg in (0, 1) if 256 * R + 128 * hh < rows and 128 * J + 64 * gg < n and 256 * R + 128 * hh + 127 >= 128 * J + 64 * gg]
-            assert cnt == len(live_q) and (h, g) in live_q
-            if qdone[R, J] == cnt * (a % W + 1):
+            live_q = [(hh, gg) for hh in (0, 1) for gg in (0, 1) if quarter_live(R, J, hh, gg)]
+            task_q = [(hh, gg) for hh, gg in live_q if not (chains and hh == (J & 1))]
+            assert full == len(live_q) and cnt == len(task_q) and (h, g) in task_q
+            if qdone[R, J] == full * (a % W) + cnt:
                 ver[R, J] = seq + 1
             continue
         if ty == 0:
             k, i = a, bb; k0, nb = 128 * k, nb_of(k)
             r0 = k0 + nb + 64 * i; r1 = min(r0 + 64, rows); R = r0 // 256
-            assert r0 < rows
+            assert r0 < rows and (i >= 2 or not fuse), "strips 0, 1 are the fused chain's"
             assert pdone[k] == 1, ("S before its diagonal block", k, i)
             assert ver[R, k] == final(R, k), ("S on a tile that is not final", k, i, ver[R, k], final(R, k))
             M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
@@ -127,9 +171,17 @@ def replay(pkg, n, W, filler, seed=0):
 def test_task_list_is_a_schedule_and_a_cholesky(pkg, n, W, filler):
     pl, counts, _ = replay(pkg, n, W, filler)
     np_ = pl["np"]
-    assert counts[0] == int(pl["ns"].sum())
+    assert counts[0] == int(pl["ns"].sum()) - sum(min(2, -(-(n + 1 - (128 * k + min(128, n - 128 * k))) // 64)) for k in range(np_))   # (the fused chain's strips are not tasks)
     print("n %d W %d: %d panels, %d tasks (%d strips, %d rank-128 tiles + %d quarters of diagonal tiles, %d rank-%d tiles)"
           % (n, W, np_, len(pl["tasks"]), counts[0], counts[1], counts[3], counts[2], 128 * W))
+
+
+@pytest.mark.parametrize("n,W,filler", [(130, 2, 4), (777, 2, 3), (1153, 4, 128), (2500, 4, 16)])
+def test_task_list_without_the_fused_chain(pkg, monkeypatch, n, W, filler):
+    """ESL_CHOL_FUSE=0: every strip and every quarter is a worker task (the first form of the round, kept for A/B)"""
+    monkeypatch.setenv("ESL_CHOL_FUSE", "0")
+    pl, counts, _ = replay(pkg, n, W, filler, fuse=False)
+    assert counts[0] == int(pl["ns"].sum())
 
 
 def test_look_ahead_order_of_the_list(pkg):
