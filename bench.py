@@ -239,7 +239,7 @@ def slam_roofline(prof, n_c, n_o, solver, trials, stats=None):
         traffic = None
         if n_c == 59994 and n_o == 18000:   # HBM bytes per launch from the committed PMC passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE), not this run
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_c4_slam.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_c4_slam.json")))
                 if bool(pmc.get("x_sparse")) == sparse:
                     traffic = pmc["rank_k_update_launch"]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
@@ -252,7 +252,7 @@ def slam_roofline(prof, n_c, n_o, solver, trials, stats=None):
                    tile, k_rows, n_o, "; X kept sparse: these are the separators' rows, the interior rows go through the per-segment products"
                    if sparse else ""),
                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": traffic,
-               "traffic_source": "profiles/r3_pmc_traffic_c4_slam.json (committed PMC passes of this workload)" if traffic else None,
+               "traffic_source": "profiles/r4_pmc_traffic_c4_slam.json (committed PMC passes of this workload)" if traffic else None,
                "algorithmic_flops_per_launch": fl["rank_k_update"], "avg_launch_ms": avg, "launches": rk["count"], "measured_ceiling": ceiling,
                "linear_solve_ms_per_trial": solve_ms, "cholesky_order_9N_ms_per_trial": ch_avg,
                "cholesky_order_9N_tflops": (fl["cholesky"] / (ch_avg * 1e-3) / 1e12) if ch_avg > 0 else 0.0,
@@ -455,12 +455,12 @@ def mapping_bench(pkg, ctx, config="C4", jacobian="analytic", steps=20, warmup=1
     traffic = None
     try:   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file) -- same workload only
         if config == "C4" and jacobian == "analytic":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_device_lm.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_device_lm.json")))["kernels"]
             traffic = [v for k, v in pmc.items() if "k_chunk_linearize_both<1, 0" in k or "k_chunk_linearize_both<1, false" in k][0]["traffic_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         traffic = None
     roof = {"kernel": "k_chunk_linearize_both (bbox + 3-D chunks, one launch)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r3_pmc_traffic_device_lm.json (committed PMC passes, not this run)",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r4_pmc_traffic_device_lm.json (committed PMC passes, not this run)",
             "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": avg_ms, "launches": lin["count"],
             "sampling": "HIP events around ONE linearisation launch (the second trial's) of every FOURTH optimize() of the timed region: an event pair "
                         "splits two back-to-back dispatches and costs that trial ~20 us"}
