@@ -970,7 +970,7 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
       auto quarters = [&](int R, int J) {
         // (q & 1 = h: which 128 rows, q >> 1 = g: which 64 columns.)  Fused chain: panel J - 1's update of the diagonal BLOCK of
         // tile (J / 2, J) -- the half h = J & 1 -- is the chain's; the workers keep the other half, if it is below the diagonal
-        const bool chains = fuse && k == J - 1;
+        const bool chains = fuse && k == J - 1 && R == J / 2;
         int full = 0, mine = 0;
         for (int q = 0; q < 4; ++q)
           if (chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) { ++full; if (!(chains && (q & 1) == (J & 1))) ++mine; }
@@ -985,7 +985,10 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
         for (int R = J / 2; R < nR; ++R)
           if (live(R, J)) {
             if (!any) { fill(); any = true; }
-            if (R != J / 2) { pl.tasks.push_back(CholTask{1, k, R, J}); continue; }
+            // quarters for the diagonal tile AND, when panel J's block is the lower half of its tile (J odd), for the tile under it:
+            // its upper half holds the rows under block J, which the fused chain solves next -- as one task it is 42 us in the
+            // chain's way on every other step
+            if (R != J / 2 && R != (J + 1) / 2) { pl.tasks.push_back(CholTask{1, k, R, J}); continue; }
             quarters(R, J);
           }
     }

@@ -97,8 +97,8 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
             # of them see the tile at the update's sequence number), the last one moves the number on
             R, J, h, g, cnt, full = bb, c & 0xFFFF, (c >> 16) & 1, (c >> 17) & 1, (c >> 18) & 7, (c >> 21) & 7
             k = a
-            chains = fuse and k == J - 1      # the chain applies this update to the diagonal block (the half h == J & 1) itself
-            assert R == J // 2 and J > k and 1 <= cnt <= full <= 4
+            chains = fuse and k == J - 1 and R == J // 2     # the chain applies this update to the diagonal block (the half h == J & 1) itself
+            assert R in (J // 2, (J + 1) // 2) and J > k and 1 <= cnt <= full <= 4
             assert (k // W == J // W) or (special(R, J) and k // W == J // W - 1)
             seq = n_big(R, J) + a % W
             assert sdone[k, R] == ns[k, R] and sdone[k, J // 2] == ns[k, J // 2], ("quarter before its operands", a, R, J)
@@ -139,7 +139,7 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
                 assert sdone[k, R] == ns[k, R], ("update before its row operand", ty, a, R, J, k)
                 assert sdone[k, J // 2] == ns[k, J // 2], ("update before its column operand", ty, a, R, J, k)
                 if ty == 1:
-                    assert k // W == J // W and J > k and R != J // 2      # (diagonal tiles take their rank-128 updates in quarters)
+                    assert k // W == J // W and J > k and R not in (J // 2, (J + 1) // 2)   # (the diagonal tile and the one under an odd panel's block take their rank-128 updates in quarters)
                 else:
                     assert J >= min(np_, a * W + W) and not (special(R, J) and J // W == a + 1)
             assert ver[R, J] == seq, ("update out of sequence", ty, a, R, J, ver[R, J], seq)
