@@ -302,6 +302,15 @@ static __global__ __launch_bounds__(kP2Threads) void k_chol_potrf2(double* __res
   chol_potrf2_body<false, kP2Threads>(sm, M, lda, k0, nb, Linv, info);
 }
 
+// (diagnostic, ESL_CHOL_POTRF512=1: the 512-thread shape and the write-through stores of the persistent kernel's chain as a kernel
+//  of their own -- separates what the shape costs from what sharing a kernel with the 212-register update tile costs)
+template <bool WT>
+static __global__ __launch_bounds__(512) void k_chol_potrf2_512(double* __restrict__ M, long lda, int k0, int nb,
+                                                                double* __restrict__ Linv, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  chol_potrf2_body<WT, 512>(sm, M, lda, k0, nb, Linv, info);
+}
+
 // ---- MFMA micro-kernel: acc(64x64 per wave) += X[i0.., 0..K) * Y[j0.., 0..K)^T ------------------------------
 // X, Y column-major (element (r,k) at X[r + k*ld]); rows beyond the limits read as zero.
 // acc[mi][nj] is the 16x16 tile (mi,nj) in the f64 MFMA C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
@@ -1323,6 +1332,7 @@ struct CholRuntime {
   size_t d_tasks_cap = 0, d_ns_cap = 0, d_sync_cap = 0;
   int sw_persistent = -1;                                   // ESL_CHOL_PERSISTENT = 1 / 0 forces it on / off (default: by size)
   int stats_on = 0;                                         // g_chol_stats_on as last written (ESL_CHOL_TIMING)
+  int sw_potrf512 = -1;                                     // ESL_CHOL_POTRF512=1: diagnostic kernel shape in the launch path
   int sw_backsub = -1;                                      // ESL_CHOL_BACKSUB_LAUNCHES=1 keeps the launch-per-panel form (A/B)
   void release() {
     if (bs_flags) { (void)hipFree(bs_flags); bs_flags = nullptr; bs_flags_cap = 0; }
@@ -1347,6 +1357,10 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
   if (rt.attr_set) return hipSuccess;
   const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)k_chol_potrf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_chol_potrf2_512<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_chol_potrf2_512<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBig);
   if (e != hipSuccess) return e;
@@ -1573,7 +1587,10 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
     for (int p = p0; p < p1; ++p) {
       const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
       double* Linv = Linv_ws + (size_t)p * kNB * kNB;
-      hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
+      if (rt.sw_potrf512 < 0) { const char* e5 = std::getenv("ESL_CHOL_POTRF512"); rt.sw_potrf512 = e5 ? std::atoi(e5) : 0; }
+      if (rt.sw_potrf512 == 1) hipLaunchKernelGGL(k_chol_potrf2_512<true>, dim3(1), dim3(512), lds, st, M, lda, k0, nb, Linv, info);
+      else if (rt.sw_potrf512 == 2) hipLaunchKernelGGL(k_chol_potrf2_512<false>, dim3(1), dim3(512), lds, st, M, lda, k0, nb, Linv, info);
+      else hipLaunchKernelGGL(k_chol_potrf2, dim3(1), dim3(kP2Threads), lds, st, M, lda, k0, nb, Linv, info);
       const long below = rows - (k0 + nb);
       if (below > 0) hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)((below + 63) / 64)), dim3(512), 0, st, M, lda, rows, k0, nb, Linv);
       // bring the rest of the outer panel's columns up to date (rank-nb update restricted to those columns)
