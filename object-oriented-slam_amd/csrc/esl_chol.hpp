@@ -94,6 +94,20 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
       const int i = 4 * bi + r, j = 4 * bj + c;
       a[r][c] = (own && i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);   // identity padding
     }
+  // NT = 512: the second block of threads 0..15 is fetched NOW, with everything else (fetched at the hand-over inside step 0 it was a
+  // global round trip on the critical path of the whole workgroup: 4 - 6 us of the chain's every step)
+  double a2[4][4];
+  int bi2 = 0, bj2 = 0;
+  if constexpr (NT == 512) {
+    if (t < 16) block_of(512 + t, bi2, bj2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * bi2 + r, j = 4 * bj2 + c;
+        a2[r][c] = (t < 16 && i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);
+      }
+  }
   // Rank-4 steps: block column J = the four columns of the 4 x 4 blocks (., J).  Per step, two barriers instead of four:
   //   (a) the owner of the diagonal block (J, J) factors it in registers (four dependent rsqrt chains) and publishes its
   //       inverse (10 numbers)                                                                       -> barrier A
@@ -150,6 +164,7 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
   __syncthreads();                                      // barrier A of step 0
   POTRF_MARK(1);
   for (int J = 0; J < kNB / 4; ++J) {
+    if (t == 0 && (J == 1 || J == 8 || J == 16 || J == 24)) g_potrf_clk[10 + (J + 7) / 8 - (J == 1 ? 1 : 0)] = (long long)wall_clock64();   // (diagnostic: 10 = J 1, 11 = J 8, 12 = J 16, 13 = J 24)
     if (own && bj == J && bi > J) {                     // (b) X = A L_JJ^-T: X(r,c) = sum_{k <= c} A(r,k) Linv(c,k)
       double li[10];
 #pragma unroll
@@ -180,14 +195,11 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
               LL(i, j) = (bi == 0) ? xd[r][c] : a[r][c];
             }
           }
-        block_of(512 + t, bi, bj);
+        bi = bi2; bj = bj2;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 4 * bi + r, j = 4 * bj + c;
-            a[r][c] = (i < nb && j < nb && i >= j) ? M[(long)(k0 + i) + (long)(k0 + j) * lda] : ((i == j) ? 1.0 : 0.0);
-          }
+          for (int r = 0; r < 4; ++r) a[r][c] = a2[r][c];
       }
     }
     if (own && bj > J) {                                // (c) rank-4 update

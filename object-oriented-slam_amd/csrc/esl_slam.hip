@@ -997,6 +997,8 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
     long long clk[16];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_potrf_clk), sizeof(clk)) == hipSuccess) {
       static const char* names[9] = {"load", "rank-4 steps", "-", "-", "-", "store L", "-", "inverse", "store Linv"};
+      fprintf(stderr, "[k_chol_potrf2, last launch, us into the rank-4 loop at step 1 / 8 / 16 / 24: %.1f %.1f %.1f %.1f]\n", (double)(clk[10] - clk[1]) * 0.01,
+              (double)(clk[11] - clk[1]) * 0.01, (double)(clk[12] - clk[1]) * 0.01, (double)(clk[13] - clk[1]) * 0.01);
       fprintf(stderr, "[k_chol_potrf2, last launch, us]");
       for (int k = 0; k < 9; ++k) fprintf(stderr, " %s=%.1f", names[k], (double)(clk[k + 1] - clk[k]) * 0.01);
       fprintf(stderr, "\n");
