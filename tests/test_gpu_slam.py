@@ -182,7 +182,7 @@ def test_dense_cholesky_selftest_residual(ctx, n):
     assert ms >= 0
 
 
-@pytest.mark.parametrize("n", [1, 7, 130, 777, 1153, 3000, 8192, 9001, 18000])
+@pytest.mark.parametrize("n", [1, 7, 129, 130, 257, 777, 1153, 3000, 4097, 5000, 8192, 9001, 18000])
 def test_persistent_dense_cholesky_selftest_residual(pkg, monkeypatch, n):
     """the persistent form of the dense factorisation (k_chol_persist: ONE launch, workgroup 0 walks the diagonal blocks, the others
     pull tasks off a static list, dependency words instead of ~1,000 launches and stream events; the CPU replay of its task list is
@@ -201,6 +201,20 @@ def test_persistent_dense_cholesky_selftest_residual(pkg, monkeypatch, n):
         monkeypatch.delenv("ESL_CHOL_DEBUG", raising=False)
     print("persistent Cholesky n = %d: %.3f ms (second call %.3f ms), residual %.1e" % (n, ms, ms2, res))
     assert res < 1e-13 and abs(res2 - res) <= 1e-9 * res
+
+
+@pytest.mark.parametrize("n", [130, 1153, 4097, 9001])
+def test_persistent_cholesky_without_the_fused_chain(pkg, monkeypatch, n):
+    """ESL_CHOL_FUSE=0: the strips under the diagonal block and the next block's update as worker tasks (the first form of round 4,
+    kept as the A/B switch of the fused chain)"""
+    monkeypatch.setenv("ESL_CHOL_PERSISTENT", "1")
+    monkeypatch.setenv("ESL_CHOL_FUSE", "0")
+    cx = pkg.Context(0)
+    try:
+        ms, res = cx.selftest_cholesky(n)
+    finally:
+        cx.close()
+    assert res < 1e-13
 
 
 def test_slam_runs_are_bitwise_reproducible(pkg, ctx):
