@@ -472,6 +472,8 @@ static __global__ __launch_bounds__(512) void k_chol_panel(double* __restrict__ 
 // chain of one wave is then 4 MFMAs per k-step instead of 16 and a trailing matrix of 1,500 rows still spreads over ~140
 // workgroups; with the big tile it occupied 20 CUs for 86 us whatever its size.
 constexpr int kKC = 16;
+__device__ int g_chol_stats_on;     // ESL_CHOL_TIMING (esl_selftest_cholesky): diagnostics of the solver's kernels on
+__device__ long long g_upd_clk[4];  // k_chol_update_lds, one tile of the last launch: shader clock ticks, 100 MHz ticks, K, tile rows
 // One tile of C -= P P^T: rows [i0, i0 + BM) x columns [j0, j0 + BN) of M (lower triangle only), P = (rows x K) column-major with
 // leading dimension ldp; `assign`: C = -P P^T (split-K slices).  WT: C leaves with write-through stores (persistent factorisation).
 template <int BM, int BN, int WM, int WN, bool WT>
@@ -658,7 +660,13 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
     M = part + (size_t)blockIdx.y * (size_t)lda * (size_t)ncols;
     if (K <= 0) return;
   }
+  // (diagnostic, ESL_CHOL_TIMING: shader clock ticks against 100 MHz wall-clock ticks over one tile of the last launch -- is the
+  //  K loop's distance from the MFMA peak a matter of the clock the part sustains under this load?)
+  const bool clk_on = BM == 256 && K >= 512 && gridDim.x >= 2048 && g_chol_stats_on != 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;   // (a tile in the middle of a launch that fills the chip)
+  long long c0 = 0, w0 = 0;
+  if (clk_on) { c0 = (long long)clock64(); w0 = (long long)wall_clock64(); }
   chol_update_tile<BM, BN, WM, WN, false>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, part != nullptr);
+  if (clk_on) { g_upd_clk[0] = (long long)clock64() - c0; g_upd_clk[1] = (long long)wall_clock64() - w0; g_upd_clk[2] = K; g_upd_clk[3] = BM; }
 }
 
 // ---- backward substitution L^T x = y, panel by panel from the last ------------------------------------------
@@ -1163,7 +1171,6 @@ static_assert(kP2Lds >= kCholLdsBig, "the persistent kernel's LDS is sized by th
 constexpr int kPwThreads = 512, kPwGrid = 256;
 // diagnostics of the persistent kernel (ESL_CHOL_TIMING=1 in the self test): per workgroup {ticks waiting on dependency words, ticks
 // inside task bodies, tasks, first tick, last tick} of the last launch, wall_clock64 ticks (100 MHz)
-__device__ int g_chol_stats_on;
 __device__ long long g_chol_stats[kPwGrid * 5];
 __device__ long long g_chol_chain_log[2 * 1024];
 __device__ long long g_chol_fuse_ticks[4];   // fused chain stage, totals of the last launch: waits, row solve, next-block update, drain + publish   // per diagonal block: tick its tile was final, tick its factor was published
@@ -1380,6 +1387,12 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPwLds);
   if (e != hipSuccess) return e;
+  {
+    const int on = std::getenv("ESL_CHOL_TIMING") ? 1 : 0;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_chol_stats_on), &on, sizeof(on));
+    if (e != hipSuccess) return e;
+    rt.stats_on = on;
+  }
   rt.attr_set = true;
   return hipSuccess;
 }

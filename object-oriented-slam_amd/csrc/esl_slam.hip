@@ -994,6 +994,12 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
         fprintf(stderr, "\n");
       }
     }
+    {
+      long long uc[4] = {0, 0, 0, 0};
+      if (hipMemcpyFromSymbol(uc, HIP_SYMBOL(g_upd_clk), sizeof(uc)) == hipSuccess && uc[1] > 0)
+        fprintf(stderr, "[k_chol_update_lds, one %lld-row tile of the last launch, K = %lld] %.1f us at a shader clock of %.0f MHz -> MFMA peak at that clock %.1f TFLOP/s\n",
+                uc[3], uc[2], (double)uc[1] * 0.01, (double)uc[0] / (double)uc[1] * 100.0, 78.6 * ((double)uc[0] / (double)uc[1] * 100.0) / 2400.0);
+    }
     long long clk[16];
     if (hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_potrf_clk), sizeof(clk)) == hipSuccess) {
       static const char* names[9] = {"load", "rank-4 steps", "-", "-", "-", "store L", "-", "inverse", "store Linv"};
