@@ -1029,7 +1029,7 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
         if (live(R, J) && !(J == ke && R == ke / 2)) (J < ne ? prevA : prevB).push_back(CholTask{2, o, R, J});   // (the special tile: see chol_tile_special)
   }
 }
-// sync words: [0] task counter, [1] abort, [4 ..) pdone[np], sdone[np][nR], ver[nR][np], quarters done [nR][np]
+// sync words: [0] task counter, [1] abort, [2] arrival tickets (0 = the chain), [4 ..) pdone[np], sdone[np][nR], ver[nR][np], quarters done [nR][np]
 inline size_t chol_sync_words(int np, int nR) { return 4 + (size_t)np + 3 * (size_t)np * nR; }
 __device__ long long g_chol_timeout_ticks = 300000000LL;   // 3 s at 100 MHz (ESL_CHOL_TIMEOUT_MS overrides it: debugging)
 // Spin until *word >= want (ONE lane; bounded).  Every poll is a chol_peek -- a device-scope atomic -- so the pollers are RATE
@@ -1194,7 +1194,12 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
   int* qdone = ver + (size_t)np * nR;
   const int t = threadIdx.x;
   const long rows = (long)n + 1;
-  if (blockIdx.x == 0) {   // ---- the chain: diagonal blocks in order
+  // the chain is whichever workgroup gets here FIRST (a ticket in sync[2]), not blockIdx 0: the workers' waits end only if the chain
+  // is resident, and nothing guarantees that the dispatcher starts with block 0 (guide G16: no dispatch-order assumption)
+  if (t == 0) slot[2] = __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const bool is_chain = slot[2] == 0;
+  if (is_chain) {   // ---- the chain: diagonal blocks in order
     bool have_next = false;   // fused: block k already carries every update (the previous step applied the last one itself)
     for (int k = 0; k < np; ++k) {
       const int k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
@@ -1267,7 +1272,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
     if (t == 0) slot[0] = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (slot[0] >= n_tasks) {
-      if (stats && t == 0) { for (int q = 0; q < 4; ++q) g_chol_stats[5 * blockIdx.x + q] = lstat[q]; g_chol_stats[5 * blockIdx.x + 4] = (long long)wall_clock64(); }
+      if (stats && t == 0) { const int me = slot[2] < kPwGrid ? slot[2] : kPwGrid - 1; for (int q = 0; q < 4; ++q) g_chol_stats[5 * me + q] = lstat[q]; g_chol_stats[5 * me + 4] = (long long)wall_clock64(); }
       return;
     }
     if (t == 0) {
