@@ -1288,10 +1288,17 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         const int ke = (tk.type != 2) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
         // the LAST panel's strips of a row tile are solved only after every earlier panel of the same outer panel has solved its own
         // there and updated them (S waits for its tile to be final): one pair of words stands for all W panels
-        ok = chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + R], ns[(size_t)(ke - 1) * nR + R], sync + 1, info) &&
-             chol_wait_ge<100>(&sdone[(size_t)(ke - 1) * nR + J / 2], ns[(size_t)(ke - 1) * nR + J / 2], sync + 1, info);
+        // the three words are fetched TOGETHER first (agent-scope loads go to the fabric, ~1.5 us each one after the other; most
+        // tasks find all three satisfied) and only the unsatisfied ones enter the polling wait
+        int* w0 = &sdone[(size_t)(ke - 1) * nR + R];
+        int* w1 = &sdone[(size_t)(ke - 1) * nR + J / 2];
+        int* w2 = &ver[(size_t)R * np + J];
+        const int want0 = ns[(size_t)(ke - 1) * nR + R], want1 = ns[(size_t)(ke - 1) * nR + J / 2];
         const int seq = (tk.type != 2) ? chol_tile_nU(R, J, W) + tk.a % W : tk.a;
-        ok = ok && chol_wait_ge<100>(&ver[(size_t)R * np + J], seq, sync + 1, info);
+        const int v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (v0 >= want0 || chol_wait_ge<100>(w0, want0, sync + 1, info)) && (v1 >= want1 || chol_wait_ge<100>(w1, want1, sync + 1, info)) &&
+             (v2 >= seq || chol_wait_ge<100>(w2, seq, sync + 1, info));
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       slot[1] = ok ? 1 : 0;
