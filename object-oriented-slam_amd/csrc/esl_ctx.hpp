@@ -118,15 +118,12 @@ struct esl_ctx {
   double* bc = nullptr;       // n_free_cams x 6
   double* xc = nullptr;       // n_free_cams x 6 (solution of the reduced system)
   double* Wbb = nullptr;      // n_bbox x 54  (H_co blocks, 6x9 row-major)
-  double* We3 = nullptr;      // n_e3d x 54
   double* Abb = nullptr;      // n_bbox x 27 (per-edge camera contributions: 21 packed + 6)
-  double* Ae3 = nullptr;      // n_e3d x 27
   double* Aod = nullptr;      // n_odom x (2*27 + 36): per-edge Hii, bi, Hjj, bj packed, Hij full
   double* Dinv = nullptr;     // n_objs x 81
   double* Yb = nullptr;       // [EU][54] : W D^-1, one record per edge
   double* Wt = nullptr;       // [EU][9][6] : W as per-edge records (k_slam_schur_pull)
   double* Tb = nullptr;       // [6][EU] : Y_e b_o per edge (its share of b_s), summed per camera by the Schur kernel
-  double* Ye3 = nullptr;      // n_e3d x 54
   double* S = nullptr;        // n x (n+1) column-major reduced system [S | b_s], n = 6 n_free_cams
   int64_t S_n = 0;
   double* cam_part = nullptr; // n_cams x 4
