@@ -263,6 +263,7 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
       LL(mg * 2 * b + b + i, mg * 2 * b + j) = T[e];
     }
     __syncthreads();
+    if (t == 0) g_potrf_clk[b == 4 ? 14 : 15] = (long long)wall_clock64();   // (diagnostic: end of the b = 4 / b = 8 level)
   }
 #pragma unroll 1
   for (int b = 16; b <= 64; b *= 2) {
