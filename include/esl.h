@@ -39,9 +39,11 @@
 extern "C" {
 #endif
 
-#define ESL_ABI_VERSION 3   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append
+#define ESL_ABI_VERSION 4   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append
                              * 3: esl_linear_solver gains ESL_SOLVER_REDUCED_CAMERA / ESL_SOLVER_REDUCED_ELLIPSOID, esl_lm_solver_used,
-                             *    esl_lm_solver_stats, esl_comm_set_replicated, ESL_PROF_KINDS 9 */
+                             *    esl_lm_solver_stats, esl_comm_set_replicated, ESL_PROF_KINDS 9
+                             * 4: ESL_PROF_KINDS 10 (class 9: the dense factorisation alone), esl_ctx_trim, esl_comm_set_replicated refuses a
+                             *    mode change under a resident graph, esl_graph_append accepts SLAM-mode graphs (free cameras + odometry) */
 #define ESL_MAX_TRACE 32
 
 typedef enum {
@@ -175,6 +177,11 @@ int esl_device_count(void);
 int esl_ctx_create(int device_id, esl_ctx** out);
 int esl_ctx_destroy(esl_ctx* ctx);
 int esl_ctx_synchronize(esl_ctx* ctx);
+/* The context keeps its device buffers in grow-only blobs from graph to graph (no hipMalloc per esl_optimize: Optimizer.cpp:127,166,250
+ * rebuilds its whole graph every frame).  esl_ctx_trim releases the SLAM-mode SOLVER blobs (camera-first set / reduced camera
+ * system: tens of GB at 10k cameras) -- and the SLAM list blob when the resident graph has no free cameras; whatever a later
+ * trial step needs is built again.  Uploading a graph WITHOUT free cameras over a SLAM-mode one trims by itself. */
+int esl_ctx_trim(esl_ctx* ctx);
 void esl_lm_params_default(esl_lm_params* p);
 
 /* ---- one-shot optimiser (host buffers in, host buffers out) ------------------------------------*/
@@ -217,12 +224,14 @@ int esl_graph_sizes(esl_ctx* ctx, int32_t* n_cams, int32_t* n_objs, int32_t* n_b
  *             the camera block + X + the rank-K update), 3 dense Cholesky + solves, 4 reductions / misc, 5 single-frame fit,
  *             6 RCCL all-reduce of the reduced system (sharded SLAM), 7 the MFMA rank-K update T -= X^T X of the camera-first
  *             form alone (nested inside class 2), 8 the block products of the sparse interior rows of X (k_cf_T_sparse, nested
- *             inside class 2; with class 8 present class 7 is the dense update with the separators' rows only).
+ *             inside class 2; with class 8 present class 7 is the dense update with the separators' rows only), 9 the dense
+ *             FACTORISATION of the reduced system alone (nested inside class 3: one k_chol_persist launch from 4,096 unknowns on,
+ *             the launch-per-step chain otherwise; class 3 minus class 9 = back-substitutions).
  * esl_profile_enable(ctx, 0) off; 1 = bracket only kernel class 0, and inside esl_optimize_resident's device-driven
  * mapping run only ONE linearisation launch per run (cheap enough to stay on inside a timed region: an event record
  * is a barrier packet between two otherwise back-to-back dispatches); 2 = bracket every launch of every class.
  * esl_profile_get drains the events: count[k] launches, total_ms[k] summed durations. */
-#define ESL_PROF_KINDS 9
+#define ESL_PROF_KINDS 10
 int esl_profile_enable(esl_ctx* ctx, int enable);
 int esl_profile_get(esl_ctx* ctx, int64_t count[ESL_PROF_KINDS], double total_ms[ESL_PROF_KINDS]);
 
@@ -405,8 +414,11 @@ int esl_init_plane_error(esl_ctx* ctx, const double* poses_Twc /* n x 7 */, cons
 int esl_selftest_cholesky(esl_ctx* ctx, int32_t n, double* ms_out, double* rel_residual_out);
 /* test / debug: the static task list of the persistent dense factorisation for an order-n system (outer panels of W 128-panels,
  * `filler` far-update tasks between the chain-dependent groups): 4 int32 per task {type, a, b, c} -- 0: S(panel a, strip b),
- * 1: u(panel a, row tile b, column tile c), 2: U(outer panel a, row tile b, column tile c) --, ns[np][nR] = strips of row tile R that
- * panel k solves, meta = {np, n_outer, nR, n_tasks, W}.  Pure host code (no device needed); call with null buffers for the sizes. */
+ * 1: u(panel a, row tile b, column tile c), 2: U(outer panel a, row tile b, column tile c), 3: one 128 x 64 QUARTER of a rank-128 update
+ * u (c = column tile | quarter << 16: the diagonal tiles' updates run as quarters) --, ns[np][nR] = strips of row tile R that
+ * panel k solves, meta = {np, n_outer, nR, n_tasks, W}.  Host code only (no device needed), but the list depends on the environment:
+ * ESL_CHOL_FUSE=0 puts strips 0, 1 of every panel and the diagonal halves of the quarter tasks back on the list (the chain does
+ * them itself by default).  Call with null buffers for the sizes. */
 int esl_debug_chol_plan(int32_t n, int32_t W, int32_t filler, int32_t* tasks_out, int64_t cap_tasks, int32_t* ns_out, int64_t cap_ns, int32_t meta_out[5]);
 
 #ifdef __cplusplus

@@ -260,6 +260,7 @@ static void free_graph(esl_ctx* c) {
   c->graph_loaded = false;
   c->states_loaded = false;
   c->lm.begun = false;
+  c->repl_checked = false;
 }
 
 int esl_ctx_destroy(esl_ctx* c) {
@@ -286,6 +287,17 @@ int esl_ctx_destroy(esl_ctx* c) {
   slam_release_runtime(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  return ESL_OK;
+}
+
+// Release the grow-only SOLVER blobs of SLAM mode (the camera-first set: 19.8 GB at BASELINE configs[3]; the reduced camera system:
+// 28.8 GB) -- and, when the resident graph has no free cameras, the SLAM list blob too.  The next trial step that needs one
+// builds it again (index tables included).  Device pointers obtained from esl_lm_reduced_system die here.
+int esl_ctx_trim(esl_ctx* c) {
+  if (!c) return ESL_ERR_INVALID;
+  ESL_HIP_TRY(hipSetDevice(c->device));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  slam_trim(c, c->graph_loaded && c->g.n_free_cams > 0);
   return ESL_OK;
 }
 
@@ -514,6 +526,11 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   if ((rc = up.commit())) return rc;
   if ((rc = wk.commit(c))) return rc;
   ESL_HIP_TRY(hipMemsetAsync(c->obj_part, 0, std::max<size_t>(N, 1) * 4 * sizeof(double), st));
+  if (d.n_free_cams == 0 && c->arena_solve.cap + c->arena_S.cap + c->arena_slam.cap > ((size_t)256 << 20)) {
+    // a mapping-mode graph follows a SLAM-mode one: the solver blobs of the old graph (tens of GB at BASELINE configs[3]) would stay
+    // pinned for the life of the context
+    slam_trim(c, false);
+  }
   if (d.n_free_cams > 0) {
     if ((rc = slam_alloc(c))) return rc;
   }
@@ -1266,6 +1283,7 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
   }
   if (p->bbox_residual != ESL_BBOX_REPROJECTION && p->bbox_residual != ESL_BBOX_TANGENCY) { set_error("esl_lm_params::bbox_residual: unknown mode"); return ESL_ERR_INVALID; }
   std::memset(out, 0, sizeof(*out));
+  if (c->graph_loaded) { const int rcr = comm_check_replicated(c); if (rcr) return rcr; }
   if (c->graph_loaded && c->g.n_free_cams == 0) {   // mapping mode: the LM runs on the device, nothing waits on the host
     int rc0 = lm_begin_enqueue(c, p, true);
     if (rc0) return rc0;

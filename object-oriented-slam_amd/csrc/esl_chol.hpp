@@ -712,8 +712,10 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
 // drains its stores, one lane stores the flag; the consumer polls the flag relaxed from ONE lane and reads x_r with sc1 loads
 // (L1 bypassed: no acquire fence on the chain).  Flags are zeroed by a memset in front of every launch.  Every spin is bounded:
 // on a timeout bit 1 of info is set and every waiter gives up (the host reports an error instead of hanging the device).
-// Workgroup b only ever waits for panels owned by workgroups that were dispatched before it or for its own earlier panels;
-// with G <= 256 workgroups of one per CU (128 KB of LDS each) all of them are resident anyway.
+// Workgroup b only ever waits for panels owned by workgroups with a LOWER index or for its own earlier panels, and b is an ARRIVAL
+// TICKET (flags[np], round 5), not blockIdx: whoever holds a lower ticket has started, i.e. is resident -- no assumption
+// about dispatch order or about all G workgroups fitting the device at once (a CU-partitioned or shared device runs the late
+// arrivals when the early ones are done, and they then find every flag they need already set).  G = min(np, CUs of the device).
 // Read a word other workgroups of the SAME launch write: a device-scope atomic ADD OF ZERO, written as inline assembly.
 // Measured on MI355X (round 4): an agent-scope (sc1) LOAD in a poll loop -- and every atomic the compiler or the L2 can treat as a
 // read: fetch_or 0 is folded into a load, a compare-and-swap that fails writes nothing -- can keep returning the value the line had
@@ -757,7 +759,10 @@ static __global__ __launch_bounds__(kBsThreads) void k_chol_backsub(const double
   bool aborted = false;            // (thread 0 only; no static __shared__ here: it would shift the 16-byte alignment of sm, guide G17)
   const int c0 = 16 * wave;                                                   // this wave's 16 columns of the panel
   const int vcol = c0 + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);   // bs_reduce16: whose total this lane ends up with
-  for (int p = np - 1 - (int)blockIdx.x; p >= 0; p -= (int)gridDim.x) {
+  if (t == 0) reinterpret_cast<int*>(zs)[0] = atomicAdd(&flags[np], 1);       // arrival ticket (the word behind the np panel flags)
+  __syncthreads();
+  const int ticket = reinterpret_cast<const int*>(zs)[0];                     // (zs is first written behind the loop's leading barrier)
+  for (int p = np - 1 - ticket; p >= 0; p -= (int)gridDim.x) {
     const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
     __syncthreads();                                                           // the previous panel's readers of Li / zs are done
     {
@@ -1366,6 +1371,11 @@ struct CholRuntime {
   int stats_on = 0;                                         // g_chol_stats_on as last written (ESL_CHOL_TIMING)
   int sw_potrf512 = -1;                                     // ESL_CHOL_POTRF512=1: diagnostic kernel shape in the launch path
   int sw_backsub = -1;                                      // ESL_CHOL_BACKSUB_LAUNCHES=1 keeps the launch-per-panel form (A/B)
+  int n_cu = 0;                                             // hipDeviceProp_t::multiProcessorCount of the context's device (grids of the one-launch forms)
+  int fallbacks = 0;                                        // trials redone launch-per-step after a device-side hand-off timed out (esl_slam.hip)
+  // optional event bracket around the FACTORISATION alone (not the back-substitution): mark(user, 1) before, mark(user, 0) after
+  void (*prof_mark)(void* user, int begin) = nullptr;
+  void* prof_user = nullptr;
   void release() {
     if (bs_flags) { (void)hipFree(bs_flags); bs_flags = nullptr; bs_flags_cap = 0; }
     if (d_tasks) { (void)hipFree(d_tasks); d_tasks = nullptr; d_tasks_cap = 0; }
@@ -1406,6 +1416,15 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
     if (e != hipSuccess) return e;
     rt.stats_on = on;
   }
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    rt.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kPwGrid;
+  }
   rt.attr_set = true;
   return hipSuccess;
 }
@@ -1418,6 +1437,7 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
   // ESL_CHOL_FUSE=0: strips under the diagonal block and the next block's update as worker tasks (the first form of round 4; A/B)
   const bool fuse = chol_fuse_default();
   if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0)) {
+    { hipError_t e0 = hipStreamSynchronize(st); if (e0 != hipSuccess) return e0; }   // the old list / sync words may still be in use
     chol_plan_build(n, W, /*filler*/ 128, rt.plan, fuse);
     auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
       if (*cap >= need) return hipSuccess;
@@ -1435,9 +1455,14 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
         rt.d_sync_cap = need;
       }
     }
-    // (synchronous copies: once per system size)
-    if (!rt.plan.tasks.empty()) { e = hipMemcpy(rt.d_tasks, rt.plan.tasks.data(), rt.plan.tasks.size() * sizeof(CholTask), hipMemcpyHostToDevice); if (e != hipSuccess) return e; }
-    e = hipMemcpy(rt.d_ns, rt.plan.ns.data(), rt.plan.ns.size() * sizeof(int), hipMemcpyHostToDevice); if (e != hipSuccess) return e;
+    // once per system size.  The stream is NON-BLOCKING (no implicit ordering with the null stream's copies): wait for whatever still
+    // reads the old list, then ship the new one ON the stream, in front of the launch that reads it.  The source is
+    // rt.plan (lives as long as the runtime); a pageable source is staged by the runtime before hipMemcpyAsync returns.
+    // (The buffers above were re-allocated after the same wait would have been due: nothing of this context runs during a plan
+    // change -- the previous factorisation's caller has read its info word, i.e. synchronised -- but the wait makes it a fact.)
+    e = hipStreamSynchronize(st); if (e != hipSuccess) return e;
+    if (!rt.plan.tasks.empty()) { e = hipMemcpyAsync(rt.d_tasks, rt.plan.tasks.data(), rt.plan.tasks.size() * sizeof(CholTask), hipMemcpyHostToDevice, st); if (e != hipSuccess) return e; }
+    e = hipMemcpyAsync(rt.d_ns, rt.plan.ns.data(), rt.plan.ns.size() * sizeof(int), hipMemcpyHostToDevice, st); if (e != hipSuccess) return e;
   }
   const CholPlan& pl = rt.plan;
   if (const char* tm = std::getenv("ESL_CHOL_TIMEOUT_MS")) {
@@ -1449,7 +1474,9 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
     if (on != rt.stats_on) { hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_chol_stats_on), &on, sizeof(on)); if (e != hipSuccess) return e; rt.stats_on = on; }
   }
   hipError_t e = hipMemsetAsync(rt.d_sync, 0, chol_sync_words(pl.np, pl.nR) * sizeof(int), st); if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_chol_persist, dim3(kPwGrid), dim3(kPwThreads), kPwLds, st, M, lda, n, pl.np, pl.W, pl.nR, Linv_ws, (const CholTask*)rt.d_tasks,
+  // one workgroup per CU of THIS device (the kernel is correct for any grid >= 2: the first arrival is the chain, the others pull tasks)
+  const int grid = std::max(2, std::min(rt.n_cu > 0 ? rt.n_cu : kPwGrid, kPwGrid));
+  hipLaunchKernelGGL(k_chol_persist, dim3((unsigned)grid), dim3(kPwThreads), kPwLds, st, M, lda, n, pl.np, pl.W, pl.nR, Linv_ws, (const CholTask*)rt.d_tasks,
                      (int)pl.tasks.size(), (const int*)rt.d_ns, rt.d_sync, info, pl.fuse);
   return hipGetLastError();
 }
@@ -1463,6 +1490,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
   int np = (n + kNB - 1) / kNB;
   { hipError_t e = chol_set_attributes(rt); if (e != hipSuccess) return e; }
+  if (rt.prof_mark) rt.prof_mark(rt.prof_user, 1);
   auto launch_update = [&](hipStream_t stream, int kcol0, int K, long base, long col_limit) {
     chol_launch_update(M, lda, rows, stream, kcol0, K, base, col_limit);
   };
@@ -1654,17 +1682,19 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   }
   if (trail_pending) { hipError_t e = hipStreamWaitEvent(st, ev_trail[n_outer - 2], 0); if (e != hipSuccess) return e; }
   }
+  if (rt.prof_mark) rt.prof_mark(rt.prof_user, 0);
   if (rt.sw_backsub < 0) { const char* sw = std::getenv("ESL_CHOL_BACKSUB_LAUNCHES"); rt.sw_backsub = (sw && sw[0] == '1') ? 1 : 0; }
   // the one-launch form reads the factor as 16-byte pairs: even leading dimension, 16-byte aligned base
   if (rt.sw_backsub == 0 && (lda & 1) == 0 && ((uintptr_t)M & 15) == 0 && ((uintptr_t)Linv_ws & 15) == 0) {
-    if (rt.bs_flags_cap < np) {
+    if (rt.bs_flags_cap < np + 1) {   // np panel flags + the arrival-ticket word
       if (rt.bs_flags) { (void)hipFree(rt.bs_flags); rt.bs_flags = nullptr; rt.bs_flags_cap = 0; }
-      const int cap = std::max(np, 512);
+      const int cap = std::max(np + 1, 512);
       hipError_t e = chol_sync_alloc((void**)&rt.bs_flags, (size_t)cap * sizeof(int)); if (e != hipSuccess) return e;
       rt.bs_flags_cap = cap;
     }
-    hipError_t e = hipMemsetAsync(rt.bs_flags, 0, (size_t)np * sizeof(int), st); if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_chol_backsub, dim3((unsigned)std::min(np, kBsMaxGrid)), dim3(kBsThreads), kBsLds, st, M, lda, n, np, Linv_ws, x, rt.bs_flags, info);
+    hipError_t e = hipMemsetAsync(rt.bs_flags, 0, (size_t)(np + 1) * sizeof(int), st); if (e != hipSuccess) return e;
+    const int bs_grid = std::min(np, std::min(rt.n_cu > 0 ? rt.n_cu : kBsMaxGrid, kBsMaxGrid));
+    hipLaunchKernelGGL(k_chol_backsub, dim3((unsigned)bs_grid), dim3(kBsThreads), kBsLds, st, M, lda, n, np, Linv_ws, x, rt.bs_flags, info);
     return hipGetLastError();
   }
   for (int p = np - 1; p >= 0; --p) {

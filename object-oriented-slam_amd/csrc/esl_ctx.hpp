@@ -95,6 +95,8 @@ int comm_gather_scalars_device(esl_ctx* c);
 int comm_allreduce_sum(esl_ctx* c, double* dev_buf, size_t count, hipStream_t st = nullptr);
 int comm_reduce_sum_root(esl_ctx* c, double* dev_buf, size_t count, int root);   // sum over the ranks, delivered to root
 int comm_bcast(esl_ctx* c, double* dev_buf, size_t count, int root, hipStream_t st = nullptr);
+// replicated-graph communicator: compare this graph's structure fingerprint across the ranks (once per upload); ESL_ERR_STATE on a mismatch
+int comm_check_replicated(esl_ctx* c);
 // {sum, max, sum, min} of 4 device scalars over ranks -> host
 int comm_reduce4(esl_ctx* c, const double* dev_src4, double out[4]);
 }  // namespace esl
@@ -168,7 +170,10 @@ struct esl_ctx {
   char* arena_work = nullptr;  size_t arena_work_cap = 0;
   char* stage_host = nullptr;  size_t stage_host_cap = 0;   // pinned staging blob
   // grow-only blobs of SLAM mode (esl_slam.hip BlobStage): what slam_alloc builds at upload / what the first trial's solver needs
-  BlobArena arena_slam, arena_solve;
+  // arena_solve: the camera-first form's tables, slabs and T; arena_S: the reduced camera system S + its solver workspace.  Separate
+  // blobs since round 5: a graph normally runs ONE form, but esl_lm_reduced_system / esl_lm_reduced_residual build S
+  // beside a camera-first run, and with one shared blob that re-laid out (and memset) the camera-first set under the caller's feet.
+  BlobArena arena_slam, arena_solve, arena_S;
   const int *h_cu_start = nullptr, *h_cu_obj = nullptr, *h_cu_id = nullptr;   // the per-camera lists in arena_slam's staging blob
   std::vector<int> h_ue_start, h_ue_id, h_ue_slot;   // host copy of the unified per-ellipsoid edge lists (the camera-first tables are built from it on first use)
   char* fit_slab = nullptr; size_t fit_slab_cap = 0;        // esl_fit_frame's device slab (esl_fit.hip)
@@ -237,6 +242,8 @@ struct esl_ctx {
   // per-context runtime of the dense solver (esl_chol.hpp CholRuntime: look-ahead stream + events on THIS device, one-time
   // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context
   void* chol_rt = nullptr;
+  void* chol_prof_scope = nullptr;   // the open ProfScope (class 9) around a dense factorisation (esl_slam.hip chol_prof_mark)
+  bool repl_checked = false;         // replicated-graph communicator: this graph's fingerprint has been compared across the ranks
   double *chol_pack = nullptr, *chol_pack2 = nullptr;   // staging buffers of the distributed factorisation's panel messages (esl_chol.hpp CholDist)
   size_t chol_pack_len = 0;
   bool schur_attr_set = false;

@@ -546,6 +546,15 @@ ESL_HD void res_e3d(const SE3& Tcw, const Ell& est, const Ell& meas, const YawTa
 ESL_HD void res_e3d_from_E0(const SE3& E0, const double est_s[3], const double meas_s[3], const YawTable& yt, double r[9],
                             E3dHyp* best_out) {
   const Mat3 R0 = q_to_R(E0.r);
+  // (round 5) the half-turn exclusion below must leave something to take: when E_0 itself is a half turn about a
+  // HORIZONTAL axis (the estimate upside-down relative to the measurement) every Rz_k^T E_0 is one too -- then all four stay
+  // eligible and the first minimum as written wins, which is what the reference and the checker compute there
+  bool all_half = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double tr = (yt.cy[k] * R0.m[0] + yt.sy[k] * R0.m[3]) + (yt.cy[k] * R0.m[4] - yt.sy[k] * R0.m[1]) + R0.m[8];
+    all_half = all_half && !(0.5 * (tr - 1.0) > -1.0 + 1e-12);
+  }
   double best = 0, b_cy = 1, b_sy = 0;
   LogAux b_a;
   b_a.d = 1; b_a.theta = 0; b_a.st = 0; b_a.f = 0.5; b_a.c = 1. / 12.; b_a.small = true;
@@ -569,7 +578,7 @@ ESL_HD void res_e3d_from_E0(const SE3& E0, const double est_s[3], const double m
     // to the measurement's yaw exactly and keeps a tilt residual eps, and Rz(pi) R_tilt(eps) is a half turn for ANY eps.  Its true
     // norm is pi (never the minimum over the four yaws); measured on the streaming sequence, frame 11: this code took it at 7e-13
     // where the checker's (and the numpy restatement's) arithmetic lands on the other side and keeps the true minimum 1.88e-2.
-    const double nn = (h.a.d > -1.0 + 1e-12) ? sqrt(n2) : 1.7976931348623157e308;
+    const double nn = (all_half || h.a.d > -1.0 + 1e-12) ? sqrt(n2) : 1.7976931348623157e308;
     const bool take = (k == 0) || (nn < best);
     best = take ? nn : best;
 #pragma unroll

@@ -26,8 +26,9 @@ static int al(T** dst, size_t n) {
 // ---- grow-only blobs of SLAM mode (round 4) -------------------------------------------------------------------------------
 // Rounds 2-3 gave every table and work buffer of SLAM mode its own hipFree + hipMalloc + pageable copy at every upload (~40 of
 // them) and freed the solver's multi-GB buffers with the graph: 21 ms per esl_graph_upload at BASELINE configs[3], paid by every
-// esl_optimize call of the drop-in adapter.  Now two BlobArenas (esl_ctx.hpp): arena_slam holds what slam_alloc makes at upload,
-// arena_solve what the first trial step's solver needs (the camera-first tables + slabs + T, or S).  A BlobStage plans a layout
+// esl_optimize call of the drop-in adapter.  Now BlobArenas (esl_ctx.hpp): arena_slam holds what slam_alloc makes at upload,
+// arena_solve what the first camera-first trial step needs (tables + slabs + T), arena_S the reduced camera system (round 5: a blob
+// of its own, so that esl_lm_reduced_system beside a camera-first run no longer re-lays out that form).  A BlobStage plans a layout
 // (256-byte aligned items, uploads first), grows the arena and its pinned staging blob when needed, lets the caller build the
 // uploaded tables IN the staging blob, and ships them with one copy.  Pointers handed out are interior pointers: never hipFree()d,
 // only forgotten (slam_forget) -- the arenas live until the context is destroyed (slam_release).
@@ -59,7 +60,9 @@ struct BlobStage {
     }
     if (total > a->cap) {
       if (a->dev) { (void)hipFree(a->dev); a->dev = nullptr; a->cap = 0; }
-      const size_t want = total + total / 8 + 4096;
+      // growth slack only where it is cheap: 12.5 % of the 28.8 GB reduced camera system of BASELINE configs[3] is 3.6 GB that can turn
+      // a fit into an out-of-memory; blobs of that size are sized by ONE graph shape, not by a growing sequence of them
+      const size_t want = total + (total < ((size_t)1 << 30) ? total / 8 : 0) + 4096;
       ESL_HIP_TRY(hipMalloc((void**)&a->dev, want));
       a->cap = want;
     }
@@ -95,7 +98,16 @@ static void blob_release(BlobArena& a) {
   if (a.ev) (void)hipEventDestroy(a.ev);
   a = BlobArena{};
 }
-void slam_release(esl_ctx* c) { slam_forget(c); blob_release(c->arena_slam); blob_release(c->arena_solve); }
+void slam_release(esl_ctx* c) { slam_forget(c); blob_release(c->arena_slam); blob_release(c->arena_solve); blob_release(c->arena_S); }
+// esl_ctx_trim: drop the solver blobs (tens of GB at BASELINE configs[3]); the next trial step that needs one builds it again.
+// keep_lists: the resident graph has free cameras, so arena_slam (its lists, W, Y ...) is still in use.
+void slam_trim(esl_ctx* c, bool keep_lists) {
+  cf_forget(c);
+  c->S = c->Linv_ws = nullptr;
+  c->cf_unavailable = false;
+  blob_release(c->arena_solve); blob_release(c->arena_S);
+  if (!keep_lists) { slam_forget(c); blob_release(c->arena_slam); }
+}
 
 // SLAM-mode lists of a freshly uploaded graph + its per-graph work buffers.  All lists come out of counting sorts (no comparison
 // sort: the per-ellipsoid order "ascending u" falls out of walking the edge arrays in order, "ascending (slot, u)" out of walking
@@ -200,15 +212,15 @@ int slam_alloc(esl_ctx* c) {
 static CholRuntime& chol_rt(esl_ctx* c);
 static __global__ void k_info_to_double(const int* __restrict__ info, double* __restrict__ d) { d[0] = info[0] ? 1.0 : 0.0; }
 static __global__ void k_double_to_info(const double* __restrict__ d, int* __restrict__ info) { if (d[0] > 0.5) info[0] |= 1; }
-// the reduced camera system S (28.8 GB at C4) lives in the solver arena, like the camera-first form's buffers: a graph uses one
-// form or the other, and the arena is kept from graph to graph
+// the reduced camera system S (28.8 GB at C4) lives in a grow-only blob of its own, kept from graph to graph (esl_ctx_trim drops
+// it); the pointer esl_lm_reduced_system hands out stays valid until the next graph upload, trim or context destroy -- its
+// CONTENT only until the next trial step that factors S in place
 static int slam_ensure_S(esl_ctx* c) {
   if (c->S) return ESL_OK;
-  cf_forget(c);                // (the two forms share the arena)
   const size_t n = (size_t)c->S_n, np = (n + kNB - 1) / kNB;
   BlobStage st;
   st.work(&c->S, (size_t)c->S_lda * n); st.work(&c->Linv_ws, np * kNB * kNB);
-  const int rc = st.reserve(c->arena_solve);
+  const int rc = st.reserve(c->arena_S);
   if (rc) { c->S = c->Linv_ws = nullptr; return rc; }
   return st.ship(c->stream);
 }
@@ -292,7 +304,6 @@ static int cf_ensure_impl(esl_ctx* c) {
   const size_t nf = (size_t)nfi, EU = (size_t)g.n_bbox + g.n_e3d, n_o = (size_t)9 * N;
   const bool timing = std::getenv("ESL_UPLOAD_HOST_TIMING") != nullptr;
   const double t0 = timing ? now_us() : 0;
-  c->S = c->Linv_ws = nullptr;   // (the two forms share the arena)
   c->cf_ldx = (int64_t)((n_o + 1 + 15) / 16 * 16);
   c->cf_kpad = (int64_t)((6 * nf + kKC - 1) / kKC * kKC);
   c->cf_ldt = c->cf_ldx;
@@ -612,8 +623,18 @@ static bool slam_dist_chol(esl_ctx* c) {
   if (c->sw_chol_dist >= 0) return c->sw_chol_dist == 1;   // ESL_CHOL_DIST as read when the communicator was created
   return c->S_n >= 8192;
 }
+// event bracket around the dense FACTORISATION alone (class 9, nested in class 3): k_chol_persist, or the launch-per-step chain
+static void chol_prof_mark(void* user, int begin) {
+  esl_ctx* c = (esl_ctx*)user;
+  if (begin) { if (!c->chol_prof_scope) c->chol_prof_scope = new ProfScope(c, 9); }
+  else if (c->chol_prof_scope) { delete (ProfScope*)c->chol_prof_scope; c->chol_prof_scope = nullptr; }
+}
 static CholRuntime& chol_rt(esl_ctx* c) {
-  if (!c->chol_rt) c->chol_rt = new CholRuntime();
+  if (!c->chol_rt) {
+    CholRuntime* rt = new CholRuntime();
+    rt->prof_mark = chol_prof_mark; rt->prof_user = c;
+    c->chol_rt = rt;
+  }
   return *(CholRuntime*)c->chol_rt;
 }
 void slam_release_runtime(esl_ctx* c) {
@@ -797,7 +818,20 @@ int slam_try_step(esl_ctx* c, double lambda) {
   int info = 0;
   ESL_HIP_TRY(hipMemcpyAsync(&info, c->chol_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
-  if (info & 2) { set_error("dense solver: a device-side hand-off timed out (k_chol_backsub / persistent panel kernel)"); return ESL_ERR_HIP; }
+  if (info & 2) {
+    // A spin of the one-launch forms ran into its wall-clock bound (3 s): the kernel was preempted or time-sliced for that long
+    // (two processes on one GPU, a debugger, a profiler) or a producer never became resident.  The factorisation itself is not
+    // wrong, so the trial is redone ONCE with the launch-per-step factorisation and back-substitution, which have no device-side
+    // waits, and the context keeps that form from then on.  Not in a multi-rank run: the other ranks would not redo
+    // their collectives.
+    CholRuntime& rt = chol_rt(c);
+    const bool can_retry = !(c->comm && c->comm_ranks > 1) && !(rt.sw_persistent == 0 && rt.sw_backsub == 1);
+    if (!can_retry) { set_error("dense solver: a device-side hand-off timed out (k_chol_backsub / persistent panel kernel)"); return ESL_ERR_HIP; }
+    rt.sw_persistent = 0; rt.sw_backsub = 1; rt.fallbacks += 1;
+    fprintf(stderr, "[libesl_hip] a device-side hand-off of the dense solver timed out; this context now uses the launch-per-step form\n");
+    ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
+    return slam_try_step(c, lambda);
+  }
   if (info) {
     const double zero = 0.0;
     ESL_HIP_TRY(hipMemcpyAsync(c->dev_part + 3, &zero, sizeof(double), hipMemcpyHostToDevice, c->stream));

@@ -6,6 +6,7 @@ namespace esl {
 int slam_alloc(esl_ctx* c);
 void slam_forget(esl_ctx* c);    // the graph goes away: interior pointers of the SLAM blobs are dropped, the blobs stay (free_graph)
 void slam_release(esl_ctx* c);   // + the blobs themselves (esl_ctx_destroy)
+void slam_trim(esl_ctx* c, bool keep_lists);   // esl_ctx_trim: the solver blobs (and, without free cameras, the list blob) are released
 int slam_linearize(esl_ctx* c);
 // full_sum (sharded runs): true = every rank ends up with the SUM of the shards' partial systems (all-reduce: callers that read
 // S itself -- esl_lm_reduced_system, the residual diagnostic); false = the form the factorisation that follows wants (per-panel

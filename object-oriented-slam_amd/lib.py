@@ -20,7 +20,7 @@ _lib = None
 
 EXPORTS = [
     "esl_abi_version", "esl_last_error", "esl_device_count", "esl_ctx_create", "esl_ctx_destroy",
-    "esl_ctx_synchronize", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
+    "esl_ctx_synchronize", "esl_ctx_trim", "esl_lm_params_default", "esl_optimize", "esl_graph_upload", "esl_graph_append", "esl_graph_sizes", "esl_states_upload",
     "esl_states_download", "esl_optimize_resident", "esl_states_snapshot", "esl_states_restore", "esl_profile_enable", "esl_profile_get", "esl_lm_begin", "esl_lm_linearize", "esl_lm_reduced_system", "esl_lm_reduced_residual",
     "esl_lm_try_step", "esl_lm_commit", "esl_lm_solver_used", "esl_lm_solver_stats", "esl_lm_download", "esl_comm_unique_id", "esl_comm_init", "esl_comm_init_host", "esl_comm_set_replicated", "esl_comm_destroy", "esl_partition_objects", "esl_fit_params_default", "esl_fit_frame", "esl_fit_frame_debug", "esl_fit_frame_ex", "esl_selftest_cholesky", "esl_debug_chol_plan",
     "esl_init_quadric", "esl_init_from_qstar", "esl_init_plane_error", "esl_plane_params_default", "esl_extract_ground_plane", "esl_extract_planes",
@@ -219,10 +219,11 @@ class Context:
         _check(load().esl_profile_enable(self._h, C.c_int(lv)), "esl_profile_enable")
 
     def profile_get(self):
-        cnt = (C.c_int64 * 9)()
-        ms = (C.c_double * 9)()
+        cnt = (C.c_int64 * 10)()   # ESL_PROF_KINDS
+        ms = (C.c_double * 10)()
         _check(load().esl_profile_get(self._h, cnt, ms), "esl_profile_get")
-        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "shard_allreduce", "rank_k_update", "sparse_block_products"]
+        names = ["linearize", "lm_trial", "schur_build", "cholesky_solve", "reduce", "k5", "shard_allreduce", "rank_k_update", "sparse_block_products",
+                 "dense_factorisation"]
         return {n: dict(count=int(cnt[i]), total_ms=float(ms[i])) for i, n in enumerate(names) if cnt[i]}
 
     def init_quadric(self, poses_Twc, bboxes, K, rows=480, cols=640, faithful=1):
@@ -365,6 +366,10 @@ class Context:
 
     def synchronize(self):
         _check(load().esl_ctx_synchronize(self._h), "esl_ctx_synchronize")
+
+    def trim(self):
+        """Release the grow-only solver blobs of SLAM mode (esl_ctx_trim); they are rebuilt on demand."""
+        _check(load().esl_ctx_trim(self._h), "esl_ctx_trim")
 
 
 class _Sizes:

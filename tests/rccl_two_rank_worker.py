@@ -15,7 +15,6 @@ g, c, o, _ = pkg.synth.make_graph(120 if slam else 30, 10 if slam else 8, 1500 i
 part = pkg.lib.partition_objects(g, 2)
 idx = np.arange(g.n_objs) if repl else np.nonzero(part == rank)[0]
 ctx = pkg.Context(rank)                       # one GPU per rank
-ctx.upload_graph(g.subset_objects(idx)); ctx.upload_states(c, o[idx])
 if rank == 0:
     uid = bytes(pkg.lib.comm_unique_id())
     with open(id_file + ".tmp", "wb") as f:
@@ -30,7 +29,8 @@ else:
     uid = open(id_file, "rb").read()
 ctx.comm_init(2, rank, uid)
 if repl:
-    ctx.comm_set_replicated(True)
+    ctx.comm_set_replicated(True)     # the mode first, then the graph (ABI 4)
+ctx.upload_graph(g.subset_objects(idx)); ctx.upload_states(c, o[idx])
 rep = ctx.optimize_resident(pkg.default_lm_params(jacobian_mode=1))
 cc, oo = ctx.download_states()
 ctx.comm_destroy(); ctx.close()

@@ -26,7 +26,7 @@ def test_header_symbols_exported(pkg):
 
 def test_abi_version_and_struct_sizes(pkg):
     L = pkg.lib.load()
-    assert L.esl_abi_version() == 3
+    assert L.esl_abi_version() == 4
     p = pkg.abi.EslLmParams()
     L.esl_lm_params_default(ctypes.byref(p))
     assert (p.max_iters, p.max_trials, p.tau, p.numeric_delta, p.drop_nan_bbox) == (10, 10, 1e-5, 1e-9, 1)

@@ -16,10 +16,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--steps", "1", "--warmup", "0", "--config", "C3", "--no-cpu-baseline", "--no-extras"]
+COMMON_DEFAULT = ["--steps", "1", "--warmup", "0", "--config", "C3", "--no-cpu-baseline", "--no-extras"]
 
 
-def run_bench(extra_args, n_ranks, env_extra, port):
+def run_bench(extra_args, n_ranks, env_extra, port, common=None):
+    COMMON = common if common is not None else COMMON_DEFAULT
     env = dict(os.environ)
     env.update(env_extra)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
@@ -60,3 +61,21 @@ def test_two_processes_on_one_gpu_take_the_single_gpu_run(single, mode, env, tol
     assert multi["chi2"]["initial"] == pytest.approx(ref["chi2"]["initial"], rel=1e-12)
     if mode == "slam" and "ESL_BENCH_SHARDED_SLAM" not in env:
         assert "replicated graph" in multi["config"]["parallelism"]
+
+
+def test_two_rank_default_line_carries_both_slam_designs(single):
+    """`bench.py --gpus N` as the driver launches it (no --no-extras) reports the timed replicated-graph run AND, as the record
+    `slam_ellipsoid_partition`, the design BASELINE.json's north_star names: ellipsoids partitioned over the ranks, camera blocks
+    all-reduced, the partial reduced camera systems summed to the panels' owners.  Both must take the
+    single-GPU LM run."""
+    port = 29600 + (os.getpid() % 300) + 71
+    multi = run_bench(["--mode", "slam"], 2, {"ESL_CHOL_DIST": "1"}, port, common=["--steps", "1", "--warmup", "0", "--config", "C3", "--no-cpu-baseline"])
+    ref = single["slam"]
+    assert "replicated graph" in multi["config"]["parallelism"]
+    sec = multi["slam_ellipsoid_partition"]
+    assert "ellipsoid-sharded x2" in sec["config"]["parallelism"] and sec["n_gpus"] == 2 and sec["value"] > 0
+    assert "reduced camera system" in sec["config"]["linear_solver"]
+    for rec, tol in ((multi, 1e-9), (sec, 1e-7)):
+        assert rec["chi2"]["trials"] == ref["chi2"]["trials"]
+        np.testing.assert_allclose(rec["chi2"]["trace"], ref["chi2"]["trace"], rtol=tol)
+    print("both designs in one line: replicated %.1f it/s, ellipsoid partition %.1f it/s (host transport: not timings)" % (multi["value"], sec["value"]))

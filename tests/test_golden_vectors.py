@@ -45,6 +45,22 @@ def test_oracle_reproduces_golden_lm_runs(po, pkg, seed, mode):
     np.testing.assert_allclose(co, G[tag + "_cams"], atol=1e-10)
 
 
+def test_oracle_reproduces_first_iteration_of_the_mid_size_slam_fixture(po, pkg):
+    """tests/golden/mid_slam_run.npz (the camera-first checker's whole optimize(10) on 2,000 cameras / 300 ellipsoids, two minutes on
+    one core) is what tests/test_gpu_slam.py holds the GPU's BASELINE-configs[3] form to; here the checker re-runs its FIRST iteration
+    (~25 s) and must land on the stored trace: the fixture is this restatement's output, not a stale file."""
+    import importlib.util
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_golden_mid_slam", os.path.join(gdir, "gen_golden_mid_slam.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    G = np.load(os.path.join(gdir, "mid_slam_run.npz"))
+    g, c, o, _ = pkg.synth.make_graph(**gen.ARGS)
+    _, _, rep = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=float(G["numeric_delta"]), max_iters=1), solver=po.ORACLE_CAMFIRST)
+    assert rep["trace_trials"] == [int(G["trace_trials"][0])]
+    assert rep["chi2_initial"] == pytest.approx(float(G["chi2_initial"]), rel=1e-12)
+    assert rep["trace_chi2"][0] == pytest.approx(float(G["trace_chi2"][0]), rel=1e-11)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("mode,jac", [("map", 0), ("map", 1), ("slam", 0), ("slam", 1)])

@@ -276,9 +276,9 @@ def run_replicated(pkg, g, cams, objs, params, n_ranks=2):
     ctxs, reps, errs, used = [], [None] * n_ranks, [None] * n_ranks, [0] * n_ranks
     for r in range(n_ranks):
         c = pkg.Context(0)
-        c.upload_graph(g); c.upload_states(cams, objs)
         c.comm_init_host(n_ranks, r, ar.make(r))
-        c.comm_set_replicated(True)
+        c.comm_set_replicated(True)                      # the mode first, then the graph (ABI 4: no mode change under a resident graph)
+        c.upload_graph(g); c.upload_states(cams, objs)
         ctxs.append(c)
 
     def work(r):
@@ -324,7 +324,8 @@ def test_slam_replicated_graph_divides_the_dense_solve(pkg, ctx, monkeypatch, n_
     n_tr = sum(ref["trace_trials"])
     # per trial: one message per outer panel (its rows from the diagonal down + the diagonal blocks' inverses) and the 8-byte pivot flag
     n_outer = 2 if used_ref == 2 else 3
-    assert ar.calls[0] == n_tr * (n_outer + 1), (ar.calls[0], n_tr)
+    # (+ 1: the once-per-graph check that every rank holds the same graph, esl_comm.hip comm_check_replicated)
+    assert ar.calls[0] == n_tr * (n_outer + 1) + 1, (ar.calls[0], n_tr)
     for r in range(n_ranks):
         assert reps[r]["trace_trials"] == ref["trace_trials"] and reps[r]["stop_reason"] == ref["stop_reason"]
         np.testing.assert_allclose(reps[r]["trace_chi2"], ref["trace_chi2"], rtol=1e-9)
@@ -356,7 +357,7 @@ def test_distributed_factorisation_overlapped_messages_same_bits(pkg, ctx, monke
         reps, states, used, ar = run_replicated(pkg, g, c, o, p, n_ranks)
         assert used == [2] * n_ranks
         n_outer = (9 * 150 + 255) // 256
-        assert ar.calls[0] == sum(ref["trace_trials"]) * (n_outer + 1)
+        assert ar.calls[0] == sum(ref["trace_trials"]) * (n_outer + 1) + 1
         for r in range(1, n_ranks):
             np.testing.assert_array_equal(states[r][0], states[0][0]); np.testing.assert_array_equal(states[r][1], states[0][1])
         runs[ov] = (reps[0], states[0])
@@ -367,3 +368,45 @@ def test_distributed_factorisation_overlapped_messages_same_bits(pkg, ctx, monke
     assert runs["1"][0]["trace_trials"] == ref["trace_trials"]
     np.testing.assert_allclose(runs["1"][1][0], rc, atol=1e-8)
     np.testing.assert_allclose(runs["1"][1][1], ro, atol=1e-8)
+
+
+def test_replicated_mode_is_a_checked_contract(pkg, ctx):
+    """esl_comm_set_replicated (ABI 4): (i) the mode cannot flip under a resident graph -- ESL_ERR_STATE instead of silently summing
+    whole graphs / treating shards as complete (this was a comment); (ii) "the same whole graph on every rank" is compared
+    across the ranks by the first optimisation: two contexts in replicated mode, one of them holding only a shard, must BOTH refuse."""
+    g, c, o, _ = pkg.synth.make_graph(40, 10, 400, seed=5, slam=True)
+    ar = ThreadAllreduce(2)
+    cx = pkg.Context(0)
+    try:
+        cx.comm_init_host(2, 0, ar.make(0))
+        cx.upload_graph(g); cx.upload_states(c, o)
+        with pytest.raises(pkg.EslError, match="resident graph"):
+            cx.comm_set_replicated(True)
+    finally:
+        cx.comm_destroy(); cx.close()
+    ctxs = []
+    for r in range(2):
+        cx = pkg.Context(0)
+        cx.comm_init_host(2, r, ar.make(r))
+        cx.comm_set_replicated(True)          # the sanctioned order: mode, then graph; rank 1 cheats with a shard
+        ctxs.append(cx)
+    try:
+        idx = np.arange(g.n_objs // 2)
+        ctxs[0].upload_graph(g); ctxs[0].upload_states(c, o)
+        ctxs[1].upload_graph(g.subset_objects(idx)); ctxs[1].upload_states(c, o[idx])
+        errs = [None, None]
+
+        def work(r):
+            try:
+                ctxs[r].optimize_resident(pkg.default_lm_params(jacobian_mode=1))
+            except Exception as e:   # noqa: BLE001
+                errs[r] = e
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        [t.start() for t in th]
+        [t.join(60) for t in th]
+        assert not any(t.is_alive() for t in th), "the contract check hung"
+        for e in errs:
+            assert isinstance(e, pkg.EslError) and "DIFFERENT graphs" in str(e), errs
+    finally:
+        for cx in ctxs:
+            cx.comm_destroy(); cx.close()

@@ -469,3 +469,49 @@ def test_sparse_camera_first_trial_matches_cpu_camera_first_checker(pkg, po, mon
     finally:
         cx.close()
         monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
+
+
+def test_mid_size_slam_full_run_matches_cpu_camera_first_checker(pkg, monkeypatch):
+    """A WHOLE optimize(10) in SLAM mode on the form BASELINE configs[3] runs (chain dissected into 16-slot segments, X kept sparse,
+    stored per-segment products, separators' rows on the MFMA update, dense factorisation of the 2,700 ellipsoid unknowns) against the
+    CPU checker's camera-first restatement (plain chain, dense Y, pivoted LDLT: none of that machinery) -- 11,994 camera + 2,700
+    ellipsoid unknowns, the graph bench.py times as `mid_2k_cams_300_ellipsoids` (the gap between "C3 whole run"
+    and "C4 one trial / residual only").  The checker's run is a committed fixture (two minutes on one core:
+    tests/golden/gen_golden_mid_slam.py; tests/test_golden_vectors.py re-runs its first iteration on the CPU).  Like for like: numeric
+    Jacobians at delta = 1e-6 on both sides -> same trial counts, same chi2 trace, same states.  Then the product default (analytic
+    Jacobians) and the reference's delta = 1e-9 against that run at north_star's 1e-4."""
+    import os
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden_mid_slam", os.path.join(sys_path, "gen_golden_mid_slam.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    G = np.load(os.path.join(sys_path, "mid_slam_run.npz"))
+    g, c, o, _ = pkg.synth.make_graph(**gen.ARGS)
+    assert list(G["n_edges"]) == [len(g.bbox_cam), len(g.e3d_cam), len(g.odom_i)]
+    co, oo = G["cams"], G["objs"]
+    ro = dict(trace_chi2=list(G["trace_chi2"]), trace_trials=list(G["trace_trials"]), iterations=int(G["iterations"]), stop_reason=int(G["stop_reason"]),
+              chi2_final=float(G["chi2_final"]), chi2_initial=float(G["chi2_initial"]))
+    assert ro["iterations"] >= 3 and ro["chi2_final"] < ro["chi2_initial"]
+    monkeypatch.setenv("ESL_CF_SPARSE", "1")
+    cx = pkg.Context(0)
+    try:
+        cg, og, rg = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, linear_solver=2))
+        st = cx.lm_solver_stats()
+        assert cx.lm_solver_used() == 2 and st["x_form"] == 1 and st["stride"] == 16 and st["separators"] == 1999 // 16
+        tr = float(np.abs(np.array(rg["trace_chi2"]) / np.array(ro["trace_chi2"]) - 1).max()) if rg["trace_trials"] == ro["trace_trials"] else float("nan")
+        print("2,000 cams / 300 ellipsoids, full SLAM run, sparse camera-first (numeric 1e-6) vs CPU camera-first checker: %d iterations, trials %s / %s, "
+              "chi2 trace rel %.2e, final chi2 rel %.2e, cameras %.2e, ellipsoids %.2e" % (
+                  rg["iterations"], rg["trace_trials"], ro["trace_trials"], tr, abs(rg["chi2_final"] / ro["chi2_final"] - 1), cam_err(cg, co), obj_rel(og, oo)))
+        assert rg["trace_trials"] == ro["trace_trials"] and rg["stop_reason"] == ro["stop_reason"] and rg["chi2_initial"] == pytest.approx(ro["chi2_initial"], rel=1e-9)
+        np.testing.assert_allclose(rg["trace_chi2"], ro["trace_chi2"], rtol=1e-7)
+        assert cam_err(cg, co) < 1e-5 and obj_rel(og, oo) < 1e-5
+        # the product default and the reference's own step size: north_star's tolerance
+        for jac, delta, tag in ((1, 1e-6, "analytic"), (0, 1e-9, "numeric 1e-9 (g2o's)")):
+            ca, oa, ra = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=delta, linear_solver=2))
+            print("   %s Jacobians vs that checker run: %d iterations, final chi2 rel %.2e, cameras %.2e, ellipsoids %.2e" % (
+                tag, ra["iterations"], abs(ra["chi2_final"] / ro["chi2_final"] - 1), cam_err(ca, co), obj_rel(oa, oo)))
+            assert ra["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-4)
+            assert cam_err(ca, co) < 1e-4 and obj_rel(oa, oo) < 1e-4
+    finally:
+        cx.close()
+        monkeypatch.delenv("ESL_CF_SPARSE", raising=False)

@@ -121,7 +121,7 @@ def half_turn_corrections(po, gf, cams, objs):
             a = q * np.pi / 2
             Rz = np.eye(4); Rz[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
             E = npo.T_inv(Tmw @ Rz) @ To
-            if 0.5 * (np.trace(E[:3, :3]) - 1) < -1 + 1e-9:
+            if 0.5 * (np.trace(E[:3, :3]) - 1) < -1 + 1e-12:   # the product's threshold (esl_math.hpp res_e3d_from_E0)
                 degenerate = True
                 continue
             sk = sm[[1, 0, 2]] if q in (-1, 1) else sm
