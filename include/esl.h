@@ -207,13 +207,23 @@ int esl_states_restore(esl_ctx* ctx);
  * esl_graph_upload of the concatenated graph (edges of an ellipsoid keep their arrival order).  Edges are stored sorted by
  * ellipsoid with slack behind every ellipsoid's slice: an append writes the new edges into free slots (one staged copy + two
  * small launches, independent of the size of the graph) and re-lays the arrays out, with doubled slack, only when a slice or an
- * array is full.  Mapping-mode graphs only (all cameras fixed, no odometry edges: the shipped setting). */
+ * array is full.
+ * SLAM mode (ABI 4; the reference's bSLAM_mode branch, Optimizer.cpp:126-158): a delta may bring FREE cameras (new_cam_fixed) and
+ * odometry edges; the edge records and the states still go into the resident arrays in place, the camera-side index tables
+ * (camera slots, per-camera edge lists, the odometry arrays: a few bytes per edge) are rebuilt from the host's mirror of the layout
+ * and shipped as one blob, and the solver's lists follow on the next trial step -- no re-upload, no re-sort of the graph.  One GPU
+ * (no communicator). */
 typedef struct {
   int32_t n_new_cams; const double* new_cams;   /* n_new_cams x 7 (Tcw) */
   int32_t n_new_objs; const double* new_objs;   /* n_new_objs x 10 */
   int32_t n_bbox; const int32_t* bbox_cam; const int32_t* bbox_obj; const double* bbox_meas; const double* bbox_weight;
   int32_t n_e3d; const int32_t* e3d_cam; const int32_t* e3d_obj; const double* e3d_meas; const double* e3d_weight;
   int32_t n_grav; const int32_t* grav_obj;      /* gravity priors on (new or old) ellipsoids */
+  /* ABI 4 -- SLAM mode, all optional (a zero-initialised tail = the mapping-mode delta of ABI 2/3): */
+  const uint8_t* new_cam_fixed;                 /* n_new_cams flags; null: the new cameras are fixed */
+  int32_t n_odom; const int32_t* odom_i; const int32_t* odom_j;   /* odometry edges (previous frame, current frame), extended numbering */
+  const double* odom_meas;                      /* n_odom x 7: Z = Tcw_j * Tcw_i^-1 */
+  const double* odom_info;                      /* n_odom x 6 diagonal information, or null = ones */
 } esl_graph_delta;
 int esl_graph_append(esl_ctx* ctx, const esl_graph_delta* d);
 /* sizes of the resident graph (after uploads / appends) */

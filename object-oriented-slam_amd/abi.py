@@ -39,6 +39,8 @@ class EslGraphDelta(C.Structure):
         ("n_bbox", C.c_int32), ("bbox_cam", c_int32_p), ("bbox_obj", c_int32_p), ("bbox_meas", c_double_p), ("bbox_weight", c_double_p),
         ("n_e3d", C.c_int32), ("e3d_cam", c_int32_p), ("e3d_obj", c_int32_p), ("e3d_meas", c_double_p), ("e3d_weight", c_double_p),
         ("n_grav", C.c_int32), ("grav_obj", c_int32_p),
+        ("new_cam_fixed", C.POINTER(C.c_uint8)), ("n_odom", C.c_int32), ("odom_i", c_int32_p), ("odom_j", c_int32_p),
+        ("odom_meas", c_double_p), ("odom_info", c_double_p),
     ]
 
 

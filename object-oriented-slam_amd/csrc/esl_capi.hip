@@ -272,6 +272,7 @@ int esl_ctx_destroy(esl_ctx* c) {
   if (c->arena_work) (void)hipFree(c->arena_work);
   if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->append_dev) (void)hipFree(c->append_dev);
+  if (c->slam_tab_dev) (void)hipFree(c->slam_tab_dev);
   fit_release(c);
   plane_release(c);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -558,6 +559,15 @@ struct HostImage {
   std::vector<int> bb_begin, bb_cnt, bb_cap, e3_begin, e3_cnt, e3_cap, gr_cnt;
   std::vector<int> bb_cam, bb_obj, e3_cam, e3_obj;
   std::vector<double> bb_meas, bb_w, e3_meas, e3_w;
+  // SLAM mode (round 5): which cameras are fixed (empty = all of them) and the odometry edges
+  std::vector<unsigned char> cam_fixed;
+  std::vector<int> od_i, od_j;
+  std::vector<double> od_meas, od_info;
+  bool slam() const {
+    if (!od_i.empty()) return true;
+    for (unsigned char f : cam_fixed) if (!f) return true;
+    return false;
+  }
 };
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -602,6 +612,12 @@ static int image_from_device(esl_ctx* c, HostImage& im) {
       (rc = dl(im.e3_cam.data(), g.e3_cam, (size_t)g.n_e3d * 4)) || (rc = dl(im.e3_obj.data(), g.e3_obj, (size_t)g.n_e3d * 4)) ||
       (rc = dl(im.e3_meas.data(), g.e3_meas, (size_t)g.n_e3d * 80)) || (rc = dl(im.e3_w.data(), g.e3_w, (size_t)g.n_e3d * 8)))
     return rc;
+  im.cam_fixed.assign((size_t)g.n_cams, 1);
+  im.od_i.resize((size_t)g.n_odom); im.od_j.resize((size_t)g.n_odom); im.od_meas.resize((size_t)g.n_odom * 7); im.od_info.resize((size_t)g.n_odom * 6);
+  if ((rc = dl(im.cam_fixed.data(), g.cam_fixed, (size_t)g.n_cams)) || (rc = dl(im.od_i.data(), g.od_i, (size_t)g.n_odom * 4)) ||
+      (rc = dl(im.od_j.data(), g.od_j, (size_t)g.n_odom * 4)) || (rc = dl(im.od_meas.data(), g.od_meas, (size_t)g.n_odom * 56)) ||
+      (rc = dl(im.od_info.data(), g.od_info, (size_t)g.n_odom * 48)))
+    return rc;
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   im.bb_begin.assign(bs.begin(), bs.end() - 1); im.e3_begin.assign(es.begin(), es.end() - 1);
   im.bb_cnt.resize(N); im.e3_cnt.resize(N);
@@ -618,6 +634,7 @@ static void image_relayout(const HostImage& old, HostImage& im, const std::vecto
   im.appendable = true;
   im.relayouts = old.relayouts + 1;
   im.n_cams = n_cams; im.n_objs = n_objs; im.n_grav = old.n_grav;
+  im.cam_fixed = old.cam_fixed; im.od_i = old.od_i; im.od_j = old.od_j; im.od_meas = old.od_meas; im.od_info = old.od_info;
   im.cap_cams = n_cams * 2 + 64; im.cap_objs = n_objs * 2 + 16;
   im.bb_begin.resize(n_objs); im.bb_cnt.assign(n_objs, 0); im.bb_cap.resize(n_objs);
   im.e3_begin.resize(n_objs); im.e3_cnt.assign(n_objs, 0); im.e3_cap.resize(n_objs);
@@ -647,6 +664,82 @@ static void image_relayout(const HostImage& old, HostImage& im, const std::vecto
     }
     im.e3_cnt[o] = old.e3_cnt[o];
   }
+}
+
+// SLAM mode of the appendable layout: everything that is indexed by CAMERA -- fixed flags, free-camera slots, the per-camera lists
+// of bbox / 3-D / odometry edges (positions in the ellipsoid-sorted arrays, ascending: the order esl_graph_upload produces, so the
+// camera blocks are summed in the same order) -- and the odometry arrays are rebuilt from the host image and shipped as ONE blob
+// into a grow-only buffer of their own (a few bytes per edge: 2 MB at BASELINE configs[3], nothing at streaming sizes); then the
+// solver-side lists of esl_slam.hip (slam_alloc) are rebuilt from the same mirror.  The edge records and the states stay where
+// they are.
+static int slam_tables_refresh(esl_ctx* c, const HostImage& im) {
+  DevGraph& d = c->g;
+  const int F = im.n_cams, N = im.n_objs, no = (int)im.od_i.size();
+  std::vector<unsigned char> fixed((size_t)F, 1);
+  for (int i = 0; i < F && i < (int)im.cam_fixed.size(); ++i) fixed[i] = im.cam_fixed[i] ? 1 : 0;
+  // a free camera only enters the system if it has an active edge (sparse_optimizer.cpp:236-257)
+  std::vector<unsigned char> touched((size_t)F, 0);
+  std::vector<int> nbc((size_t)F + 1, 0), nec((size_t)F + 1, 0);
+  size_t nb = 0, ne = 0;
+  for (int o = 0; o < N; ++o) {
+    for (int k = 0; k < im.bb_cnt[o]; ++k) { const int cm = im.bb_cam[(size_t)im.bb_begin[o] + k]; touched[cm] = 1; ++nbc[(size_t)cm + 1]; ++nb; }
+    for (int k = 0; k < im.e3_cnt[o]; ++k) { const int cm = im.e3_cam[(size_t)im.e3_begin[o] + k]; touched[cm] = 1; ++nec[(size_t)cm + 1]; ++ne; }
+  }
+  for (int e = 0; e < no; ++e)
+    if (!(fixed[im.od_i[e]] && fixed[im.od_j[e]])) { touched[im.od_i[e]] = 1; touched[im.od_j[e]] = 1; }
+  std::vector<int> slot((size_t)F, -1);
+  int nf = 0;
+  for (int i = 0; i < F; ++i) if (!fixed[i] && touched[i]) slot[i] = nf++;
+  for (int i = 0; i < F; ++i) { nbc[(size_t)i + 1] += nbc[i]; nec[(size_t)i + 1] += nec[i]; }
+  std::vector<int> cbe(std::max<size_t>(nb, 1)), cee(std::max<size_t>(ne, 1));
+  {
+    std::vector<int> pb(nbc.begin(), nbc.end() - 1), pe(nec.begin(), nec.end() - 1);
+    for (int o = 0; o < N; ++o) {   // ascending position = ellipsoids ascending, arrival order inside one
+      for (int k = 0; k < im.bb_cnt[o]; ++k) { const int at = im.bb_begin[o] + k; cbe[(size_t)pb[im.bb_cam[at]]++] = at; }
+      for (int k = 0; k < im.e3_cnt[o]; ++k) { const int at = im.e3_begin[o] + k; cee[(size_t)pe[im.e3_cam[at]]++] = at; }
+    }
+  }
+  std::vector<int> key((size_t)no * 2), cos, coe;
+  for (int e = 0; e < no; ++e) { key[(size_t)2 * e] = im.od_i[e]; key[(size_t)2 * e + 1] = im.od_j[e]; }
+  csr_by_key(key.data(), no * 2, F, cos, coe);
+  // one staged blob
+  struct Put { void** dst; const void* src; size_t bytes, off; };
+  std::vector<Put> puts;
+  size_t total = 0;
+  auto put = [&](void* dstp, const void* src, size_t bytes) {
+    const size_t off = align_up(total, 256);
+    puts.push_back({(void**)dstp, src, bytes, off});
+    total = off + std::max<size_t>(bytes, 8);
+  };
+  put(&d.cam_fixed, fixed.data(), (size_t)F); put(&d.cam_slot, slot.data(), (size_t)F * 4);
+  put(&d.cbb_start, nbc.data(), nbc.size() * 4); put(&d.cbb_edge, cbe.data(), nb * 4);
+  put(&d.ce3_start, nec.data(), nec.size() * 4); put(&d.ce3_edge, cee.data(), ne * 4);
+  put(&d.cod_start, cos.data(), cos.size() * 4); put(&d.cod_edge, coe.data(), coe.size() * 4);
+  put(&d.od_i, im.od_i.data(), (size_t)no * 4); put(&d.od_j, im.od_j.data(), (size_t)no * 4);
+  put(&d.od_meas, im.od_meas.data(), (size_t)no * 56); put(&d.od_info, im.od_info.data(), (size_t)no * 48);
+  UploadStage st(c);   // (the context's pinned staging block; the caller has synchronised the stream: it is free)
+  if (!st.reserve(total)) return st.err;
+  for (const Put& p : puts) if (p.bytes) std::memcpy(c->stage_host + p.off, p.src, p.bytes);
+  int rc = arena_reserve(&c->slam_tab_dev, &c->slam_tab_cap, total);
+  if (rc) return rc;
+  ESL_HIP_TRY(hipMemcpyAsync(c->slam_tab_dev, c->stage_host, total, hipMemcpyHostToDevice, c->stream));
+  for (const Put& p : puts) *p.dst = c->slam_tab_dev + p.off;
+  d.n_free_cams = nf; d.n_odom = no;
+  // the mirrors slam_alloc reads: position-indexed, free slots carry obj = -1
+  c->h_cam_slot = slot;
+  c->h_od_i = im.od_i; c->h_od_j = im.od_j;
+  c->h_bb_cam.assign(im.bb_cam.begin(), im.bb_cam.begin() + (long)im.used_bb); c->h_bb_obj.assign(im.bb_obj.begin(), im.bb_obj.begin() + (long)im.used_bb);
+  c->h_e3_cam.assign(im.e3_cam.begin(), im.e3_cam.begin() + (long)im.used_e3); c->h_e3_obj.assign(im.e3_obj.begin(), im.e3_obj.begin() + (long)im.used_e3);
+  if (!im.appendable) {   // the compact layout of esl_graph_upload has no free slots, and its image does not mark any
+    for (int o = 0; o < N; ++o) {
+      for (int k = im.bb_cnt[o]; k < im.bb_cap[o]; ++k) c->h_bb_obj[(size_t)im.bb_begin[o] + k] = -1;
+      for (int k = im.e3_cnt[o]; k < im.e3_cap[o]; ++k) c->h_e3_obj[(size_t)im.e3_begin[o] + k] = -1;
+    }
+  }
+  slam_forget(c);
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // the staging block is free again (slam_alloc stages through its own blob)
+  if (nf > 0 && (rc = slam_alloc(c))) return rc;
+  return ESL_OK;
 }
 
 // the whole image to the device (capacities included) + the states; replaces what esl_graph_upload laid out
@@ -722,6 +815,7 @@ static int image_upload(esl_ctx* c, const HostImage& im, const double* cams, con
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   c->n_grav_edges = im.n_grav;
   c->graph_loaded = true; c->states_loaded = true; c->cams_match_snap = false; c->lm.begun = false;
+  if (im.slam()) return slam_tables_refresh(c, im);
   return ESL_OK;
 }
 
@@ -741,7 +835,8 @@ int esl_graph_sizes(esl_ctx* c, int32_t* n_cams, int32_t* n_objs, int32_t* n_bbo
 int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
   if (!c || !dl) return ESL_ERR_INVALID;
   if (!c->graph_loaded || !c->states_loaded) { set_error("esl_graph_append: upload a graph and its states first"); return ESL_ERR_STATE; }
-  if (c->g.n_free_cams > 0 || c->g.n_odom > 0 || c->comm) { set_error("esl_graph_append: mapping-mode graphs on one GPU only (all cameras fixed, no odometry)"); return ESL_ERR_STATE; }
+  if (c->comm) { set_error("esl_graph_append: one GPU only (no communicator)"); return ESL_ERR_STATE; }
+  if (dl->n_odom < 0 || (dl->n_odom && (!dl->odom_i || !dl->odom_j || !dl->odom_meas))) { set_error("esl_graph_delta: null odometry array or negative size"); return ESL_ERR_INVALID; }
   if (dl->n_new_cams < 0 || dl->n_new_objs < 0 || dl->n_bbox < 0 || dl->n_e3d < 0 || dl->n_grav < 0 || (dl->n_new_cams && !dl->new_cams) ||
       (dl->n_new_objs && !dl->new_objs) || (dl->n_bbox && (!dl->bbox_cam || !dl->bbox_obj || !dl->bbox_meas || !dl->bbox_weight)) ||
       (dl->n_e3d && (!dl->e3d_cam || !dl->e3d_obj || !dl->e3d_meas || !dl->e3d_weight)) || (dl->n_grav && !dl->grav_obj)) {
@@ -763,6 +858,17 @@ int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
     if (dl->e3d_cam[i] < 0 || dl->e3d_cam[i] >= F || dl->e3d_obj[i] < 0 || dl->e3d_obj[i] >= N) { set_error("esl_graph_delta: 3-D edge index out of range"); return ESL_ERR_INVALID; }
   for (int i = 0; i < dl->n_grav; ++i)
     if (dl->grav_obj[i] < 0 || dl->grav_obj[i] >= N) { set_error("esl_graph_delta: gravity edge index out of range"); return ESL_ERR_INVALID; }
+  for (int i = 0; i < dl->n_odom; ++i)
+    if (dl->odom_i[i] < 0 || dl->odom_i[i] >= F || dl->odom_j[i] < 0 || dl->odom_j[i] >= F) { set_error("esl_graph_delta: odometry edge index out of range"); return ESL_ERR_INVALID; }
+  auto add_cameras_and_odometry = [&](HostImage& I) {   // the delta's camera flags and odometry edges into an image whose n_cams is already F
+    I.cam_fixed.resize((size_t)F, 1);
+    for (int i = 0; i < dl->n_new_cams; ++i) I.cam_fixed[(size_t)(F - dl->n_new_cams + i)] = dl->new_cam_fixed ? (dl->new_cam_fixed[i] ? 1 : 0) : 1;
+    for (int i = 0; i < dl->n_odom; ++i) {
+      I.od_i.push_back(dl->odom_i[i]); I.od_j.push_back(dl->odom_j[i]);
+      for (int q = 0; q < 7; ++q) I.od_meas.push_back(dl->odom_meas[(size_t)i * 7 + q]);
+      for (int q = 0; q < 6; ++q) I.od_info.push_back(dl->odom_info ? dl->odom_info[(size_t)i * 6 + q] : 1.0);
+    }
+  };
   std::vector<int> add_bb((size_t)N, 0), add_e3((size_t)N, 0), add_gr((size_t)N, 0);
   for (int i = 0; i < dl->n_bbox; ++i) add_bb[dl->bbox_obj[i]]++;
   for (int i = 0; i < dl->n_e3d; ++i) add_e3[dl->e3d_obj[i]]++;
@@ -817,6 +923,7 @@ int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
     HostImage* ni = new HostImage();
     image_relayout(im, *ni, add_bb, add_e3, F, N);
     place(*ni, false);
+    add_cameras_and_odometry(*ni);
     c->append_img = nullptr;   // free_graph (inside image_upload) must not drop the image under construction
     rc = image_upload(c, *ni, cams.data(), objs.data(), gd.K, gd.grav_n, gd.grav_w, gd.yt, gd.check_vis, gd.img_rows, gd.img_cols);
     delete &im;
@@ -835,6 +942,7 @@ int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
   const int F0 = im.n_cams, N0 = im.n_objs;
   im.n_cams = F; im.n_objs = N;
   place(im, true);
+  add_cameras_and_odometry(im);
   std::vector<int> co, cty, cb, ce, cos, ib, ie, bbs((size_t)N + 1, 0), e3s((size_t)N + 1, 0);
   image_chunks(im, co, cty, cb, ce, cos, ib, ie);
   for (int o = 0; o < N; ++o) { bbs[o] = im.bb_begin[o]; e3s[o] = im.e3_begin[o]; }
@@ -876,6 +984,7 @@ int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->cams_match_snap = false;
   c->lm.begun = false;
+  if (im.slam()) return slam_tables_refresh(c, im);   // the camera-indexed tables + the solver's lists (SLAM mode)
   return ESL_OK;
 }
 

@@ -165,6 +165,7 @@ struct esl_ctx {
   double* dev_scal = nullptr;    // {chi2_lin, max_diag}
   void* append_img = nullptr;    // host image of the appendable layout (esl_graph_append, esl_capi.hip)
   char* append_dev = nullptr; size_t append_dev_cap = 0;   // device scratch of an append's staged blob
+  char* slam_tab_dev = nullptr; size_t slam_tab_cap = 0;   // SLAM-mode append: the camera-side tables + odometry arrays, rebuilt per append (esl_capi.hip)
   // grow-only arenas behind esl_graph_upload (esl_capi.hip)
   char* arena_graph = nullptr; size_t arena_graph_cap = 0;
   char* arena_work = nullptr;  size_t arena_work_cap = 0;

@@ -122,18 +122,21 @@ int slam_alloc(esl_ctx* c) {
   std::vector<int>& id = c->h_ue_id;
   std::vector<int>& slot = c->h_ue_slot;
   start.assign((size_t)N + 1, 0);
-  for (int i = 0; i < g.n_bbox; ++i) if (c->h_cam_slot[c->h_bb_cam[i]] >= 0) ++start[(size_t)c->h_bb_obj[i] + 1];
-  for (int i = 0; i < g.n_e3d; ++i) if (c->h_cam_slot[c->h_e3_cam[i]] >= 0) ++start[(size_t)c->h_e3_obj[i] + 1];
+  // (appendable layout, esl_graph_append in SLAM mode: the arrays have slack behind every ellipsoid's slice -- free slots carry obj = -1)
+  for (int i = 0; i < g.n_bbox; ++i) if (c->h_bb_obj[i] >= 0 && c->h_cam_slot[c->h_bb_cam[i]] >= 0) ++start[(size_t)c->h_bb_obj[i] + 1];
+  for (int i = 0; i < g.n_e3d; ++i) if (c->h_e3_obj[i] >= 0 && c->h_cam_slot[c->h_e3_cam[i]] >= 0) ++start[(size_t)c->h_e3_obj[i] + 1];
   for (int o = 0; o < N; ++o) start[(size_t)o + 1] += start[o];
   const size_t nue = (size_t)start[N];
   id.resize(nue); slot.resize(nue);
   {
     std::vector<int> cur(start.begin(), start.end() - 1);
     for (int i = 0; i < g.n_bbox; ++i) {
+      if (c->h_bb_obj[i] < 0) continue;
       const int s = c->h_cam_slot[c->h_bb_cam[i]];
       if (s >= 0) { const int at = cur[c->h_bb_obj[i]]++; id[at] = i; slot[at] = s; }
     }
     for (int i = 0; i < g.n_e3d; ++i) {
+      if (c->h_e3_obj[i] < 0) continue;
       const int s = c->h_cam_slot[c->h_e3_cam[i]];
       if (s >= 0) { const int at = cur[c->h_e3_obj[i]]++; id[at] = g.n_bbox + i; slot[at] = s; }
     }

@@ -104,9 +104,10 @@ class Context:
         g = graph.c_struct()
         _check(load().esl_graph_upload(self._h, C.byref(g)), "esl_graph_upload")
 
-    def append_graph(self, new_cams=(), new_objs=(), bbox=None, e3d=None, grav_obj=()):
+    def append_graph(self, new_cams=(), new_objs=(), bbox=None, e3d=None, grav_obj=(), new_cam_fixed=None, odom=None):
         """esl_graph_append: bbox = (cam, obj, meas (n,4), weight), e3d = (cam, obj, meas (n,10), weight); indices in the extended
-        numbering (new cameras / ellipsoids follow the existing ones)."""
+        numbering (new cameras / ellipsoids follow the existing ones).  SLAM mode: new_cam_fixed = flags of the new cameras (None:
+        fixed), odom = (i, j, meas (n,7)[, info (n,6)])."""
         keep = []
 
         def arr(a, dt, tail=None):
@@ -131,6 +132,15 @@ class Context:
         go = arr(grav_obj, np.int32)
         if go.size:
             d.n_grav = len(go); d.grav_obj = go.ctypes.data_as(ip)
+        if new_cam_fixed is not None and d.n_new_cams:
+            fx = arr(new_cam_fixed, np.uint8)
+            assert fx.size == d.n_new_cams
+            d.new_cam_fixed = fx.ctypes.data_as(C.POINTER(C.c_uint8))
+        if odom is not None and len(odom[0]):
+            oi, oj, om = arr(odom[0], np.int32), arr(odom[1], np.int32), arr(odom[2], np.float64, (7,))
+            d.n_odom = len(oi); d.odom_i = oi.ctypes.data_as(ip); d.odom_j = oj.ctypes.data_as(ip); d.odom_meas = om.ctypes.data_as(_dp)
+            if len(odom) > 3 and odom[3] is not None:
+                d.odom_info = arr(odom[3], np.float64, (6,)).ctypes.data_as(_dp)
         _check(load().esl_graph_append(self._h, C.byref(d)), "esl_graph_append")
         if self._graph is not None:
             self._graph = _Sizes(self._graph.n_cams + d.n_new_cams, self._graph.n_objs + d.n_new_objs)

@@ -2,7 +2,8 @@
 """Generates tests/golden/mid_slam_run.npz: a WHOLE optimize(10) in SLAM mode of the CPU checker's camera-first restatement
 (oracle/esl_oracle.c ESL_ORACLE_CAMFIRST: block Cholesky along the odometry chain, dense Y, pivoted LDLT of the reduced ellipsoid
 system; numeric Jacobians at delta = 1e-6) on the mid-size synthetic graph bench.py times as `mid_2k_cams_300_ellipsoids`:
-synth.make_graph(2000, 300, 16000, seed=41, slam=True) -- 11,994 camera + 2,700 ellipsoid unknowns.  ~2 minutes on one core, which
+synth.make_graph(2000, 300, 16000, seed=41, slam=True) -- 11,994 camera + 2,700 ellipsoid unknowns -- and the same run at the
+reference's delta = 1e-9 (its own noise floor).  ~2 minutes each on one core, which
 is why the result is a fixture (inputs are regenerated from the seed by the test): tests/test_gpu_slam.py holds the GPU's sparse
 camera-first run to it, tests/test_golden_vectors.py re-runs its first iteration on the CPU.
 
@@ -28,7 +29,13 @@ def main():
     co, oo, ro = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=1e-6), solver=po.ORACLE_CAMFIRST)
     print("checker: %d iterations, trials %s, chi2 %.6f -> %.6f, stop %d, %.0f s" % (
         ro["iterations"], ro["trace_trials"], ro["chi2_initial"], ro["chi2_final"], ro["stop_reason"], time.time() - t0))
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "mid_slam_run.npz"), cams=co, objs=oo, trace_chi2=np.array(ro["trace_chi2"]),
+    # the same run at the REFERENCE's step size (g2o: delta = 1e-9): its distance from the run above is the reference's own
+    # Jacobian-noise floor on this graph -- what bounds the comparisons that are not like for like
+    t0 = time.time()
+    c9, o9, r9 = po.optimize(g, c, o, pkg.default_lm_params(numeric_delta=1e-9), solver=po.ORACLE_CAMFIRST)
+    print("checker at delta = 1e-9: %d iterations, trials %s, chi2 -> %.6f, %.0f s" % (r9["iterations"], r9["trace_trials"], r9["chi2_final"], time.time() - t0))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "mid_slam_run.npz"), cams_d9=c9, objs_d9=o9, chi2_final_d9=r9["chi2_final"],
+                        trace_trials_d9=np.array(r9["trace_trials"]), cams=co, objs=oo, trace_chi2=np.array(ro["trace_chi2"]),
                         trace_trials=np.array(ro["trace_trials"]), trace_lambda=np.array(ro["trace_lambda"]), iterations=ro["iterations"],
                         stop_reason=ro["stop_reason"], chi2_initial=ro["chi2_initial"], chi2_final=ro["chi2_final"],
                         n_edges=np.array([len(g.bbox_cam), len(g.e3d_cam), len(g.odom_i)]), numeric_delta=1e-6)

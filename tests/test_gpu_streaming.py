@@ -429,3 +429,54 @@ def test_half_turn_yaw_hypothesis_is_never_taken(pkg, po, ctx):
             assert lin.chi2 == pytest.approx(chi, rel=1e-9)
             np.testing.assert_allclose(bg, b, atol=2e-6 * np.abs(b).max() + 1e-6)
             np.testing.assert_allclose(Hg, H, atol=5e-6 * np.abs(H).max())
+
+
+def slam_graph_upto(pkg, g, f):
+    """the SLAM-mode graph of frames 0 .. f: camera 0 fixed, one odometry edge per consecutive pair (Optimizer.cpp:126-158)"""
+    mb, me, mo = g.bbox_cam <= f, g.e3d_cam <= f, g.odom_j <= f
+    return pkg.Graph(g.K, f + 1, g.n_objs, g.cam_fixed[:f + 1], g.bbox_cam[mb], g.bbox_obj[mb], g.bbox_meas.reshape(-1, 4)[mb], g.bbox_weight[mb],
+                     g.e3d_cam[me], g.e3d_obj[me], g.e3d_meas.reshape(-1, 10)[me], g.e3d_weight[me], g.grav_obj, g.grav_normal, g.grav_weight,
+                     g.odom_i[mo], g.odom_j[mo], g.odom_meas.reshape(-1, 7)[mo])
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_slam_mode_append_equals_rebuild(pkg, ctx, solver):
+    """esl_graph_append in SLAM mode (ABI 4): a frame's delta = one FREE camera, its odometry edge to the previous
+    frame and its bbox / 3-D edges, into the device-resident graph; the camera-indexed tables and the solver's lists are rebuilt from
+    the host's mirror of the layout.  After every frame the appended graph must BE the graph esl_graph_upload makes of the
+    concatenated edges: same LM trace and states (same edge order inside an ellipsoid and inside a camera -> same sums), with the
+    reduced camera system and with the camera-first elimination.  The first append re-lays the compact upload out with slack (one
+    relayout); later frames go into the slack; the stream crosses a second relayout when the slack is used up."""
+    F, N = 48, 8
+    g, c, o, _ = pkg.synth.make_graph(F, N, 14 * F, seed=9, slam=True)
+    p = pkg.default_lm_params(jacobian_mode=1, max_iters=3, linear_solver=solver)
+    f0 = 4
+    ctx.upload_graph(slam_graph_upto(pkg, g, f0)); ctx.upload_states(c[:f0 + 1], o)
+    ctx.optimize_resident(p)
+    ref = pkg.Context(0)
+    worst = dict(chi2=0.0, cams=0.0, objs=0.0)
+    try:
+        for f in range(f0 + 1, F):
+            mb, me, mo = g.bbox_cam == f, g.e3d_cam == f, g.odom_j == f
+            ctx.append_graph(new_cams=c[f:f + 1], new_cam_fixed=[0],
+                             bbox=(g.bbox_cam[mb], g.bbox_obj[mb], g.bbox_meas.reshape(-1, 4)[mb], g.bbox_weight[mb]),
+                             e3d=(g.e3d_cam[me], g.e3d_obj[me], g.e3d_meas.reshape(-1, 10)[me], g.e3d_weight[me]),
+                             odom=(g.odom_i[mo], g.odom_j[mo], g.odom_meas.reshape(-1, 7)[mo]))
+            cams_in, objs_in = ctx.download_states()
+            assert cams_in.shape == (f + 1, 7) and np.array_equal(cams_in[f], c[f])
+            ra = ctx.optimize_resident(p)
+            ca, oa = ctx.download_states()
+            assert ctx.lm_solver_used() == solver
+            ref.upload_graph(slam_graph_upto(pkg, g, f)); ref.upload_states(cams_in, objs_in)
+            rr = ref.optimize_resident(p)
+            cr, orr = ref.download_states()
+            assert ra["trace_trials"] == rr["trace_trials"] and ra["n_bbox_valid"] == rr["n_bbox_valid"], (f, ra["trace_trials"], rr["trace_trials"])
+            worst["chi2"] = max(worst["chi2"], float(np.abs(np.array(ra["trace_chi2"]) / np.array(rr["trace_chi2"]) - 1).max()))
+            worst["cams"] = max(worst["cams"], float(np.abs(ca - cr).max())); worst["objs"] = max(worst["objs"], float(np.abs(oa - orr).max()))
+        sz = ctx.graph_sizes()
+        print("SLAM-mode append vs rebuild, %d frames, solver %d: worst chi2 trace rel %.2e, cameras %.2e, ellipsoids %.2e; relayouts %d" % (
+            F - f0 - 1, solver, worst["chi2"], worst["cams"], worst["objs"], sz["relayouts"]))
+        assert sz["n_cams"] == F and sz["relayouts"] >= 1
+        assert worst["chi2"] < 1e-11 and worst["cams"] < 1e-10 and worst["objs"] < 1e-10
+    finally:
+        ref.close()
