@@ -87,6 +87,7 @@ __device__ __forceinline__ double obj_chi2(const DevGraph& g, const double* __re
     chi += g.bb_w[i] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
   }
   for (int i = g.e3_start[o] + lane; i < g.e3_start[o + 1]; i += 64) {
+    if (g.e3_obj[i] < 0) continue;   // slack slot of the appendable layout (its all-zero "measurement" has no rotation: 0 x NaN)
     const SE3 T = se3_load(cams + 7 * g.e3_cam[i]);
     const Ell m = ell_load(g.e3_meas + 10 * i);
     double r[9];

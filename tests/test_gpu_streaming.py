@@ -352,11 +352,14 @@ def test_append_new_ellipsoids_gravity_and_errors(pkg, ctx):
     assert cx.graph_sizes()["relayouts"] == r0
     rep2 = cx.optimize_resident(pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6))
     assert rep2["n_bbox_valid"] == len(g.bbox_cam) + 1 and np.isfinite(rep2["chi2_final"])
-    # SLAM-mode graphs are rejected
+    # SLAM-mode graphs are accepted since ABI 4 (test_slam_mode_append_equals_rebuild); a bad odometry index is not
     gs, cs, os_, _ = pkg.synth.make_graph(10, 2, 30, seed=1, slam=True)
     cx.upload_graph(gs); cx.upload_states(cs, os_)
-    with pytest.raises(pkg.EslError, match="mapping-mode"):
-        cx.append_graph(new_cams=cs[:1])
+    with pytest.raises(pkg.EslError, match="odometry edge index"):
+        cx.append_graph(new_cams=cs[:1], new_cam_fixed=[0], odom=([9], [11], [[0, 0, 0, 0, 0, 0, 1.0]]))
+    cx.append_graph(new_cams=cs[-1:], new_cam_fixed=[0], odom=([9], [10], [[0, 0, 0, 0, 0, 0, 1.0]]))
+    assert cx.graph_sizes()["n_cams"] == 11
+    assert np.isfinite(cx.optimize_resident(pkg.default_lm_params(jacobian_mode=1))["chi2_final"])
     cx.close()
 
 
@@ -446,7 +449,8 @@ def test_slam_mode_append_equals_rebuild(pkg, ctx, solver):
     the host's mirror of the layout.  After every frame the appended graph must BE the graph esl_graph_upload makes of the
     concatenated edges: same LM trace and states (same edge order inside an ellipsoid and inside a camera -> same sums), with the
     reduced camera system and with the camera-first elimination.  The first append re-lays the compact upload out with slack (one
-    relayout); later frames go into the slack; the stream crosses a second relayout when the slack is used up."""
+    relayout); the later frames go into the slack.  Measured (round 5): linearisation, damped solve and the whole LM run are
+    BIT-IDENTICAL on all 43 frames with both eliminations."""
     F, N = 48, 8
     g, c, o, _ = pkg.synth.make_graph(F, N, 14 * F, seed=9, slam=True)
     p = pkg.default_lm_params(jacobian_mode=1, max_iters=3, linear_solver=solver)
@@ -464,13 +468,28 @@ def test_slam_mode_append_equals_rebuild(pkg, ctx, solver):
                              odom=(g.odom_i[mo], g.odom_j[mo], g.odom_meas.reshape(-1, 7)[mo]))
             cams_in, objs_in = ctx.download_states()
             assert cams_in.shape == (f + 1, 7) and np.array_equal(cams_in[f], c[f])
+            ref.upload_graph(slam_graph_upto(pkg, g, f)); ref.upload_states(cams_in, objs_in)
+            # the linearisation and one damped solve, quantity by quantity: the appended layout must give the SAME BITS as the compact one
+            # (same edge order inside every ellipsoid, every camera and every chunk -> same sums)
+            nf = f
+            lin = []
+            for cx_ in (ctx, ref):
+                cx_.lm_begin(p)
+                part = cx_.lm_linearize()
+                tr = cx_.lm_try_step(1e-4 * part.max_diag)
+                lin.append(dict(chi2=part.chi2, max_diag=part.max_diag, Hoo=cx_.lm_download(0, N * 45), bo=cx_.lm_download(1, N * 9), Hcc=cx_.lm_download(3, nf * 36),
+                                bc=cx_.lm_download(4, nf * 6), xc=cx_.lm_download(5, nf * 6), xo=cx_.lm_download(2, N * 9), trial_chi2=tr.chi2, ok=tr.solve_ok))
+                cx_.lm_commit(False)
+            for key in ("chi2", "max_diag", "Hoo", "bo", "Hcc", "bc", "xc", "xo", "trial_chi2", "ok"):
+                a_, b_ = np.asarray(lin[0][key]), np.asarray(lin[1][key])
+                assert np.array_equal(a_, b_), "frame %d: %s of the appended graph differs from the rebuilt one by %.3e (relative to %.3e)" % (
+                    f, key, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
             ra = ctx.optimize_resident(p)
             ca, oa = ctx.download_states()
             assert ctx.lm_solver_used() == solver
-            ref.upload_graph(slam_graph_upto(pkg, g, f)); ref.upload_states(cams_in, objs_in)
             rr = ref.optimize_resident(p)
             cr, orr = ref.download_states()
-            assert ra["trace_trials"] == rr["trace_trials"] and ra["n_bbox_valid"] == rr["n_bbox_valid"], (f, ra["trace_trials"], rr["trace_trials"])
+            assert ra["trace_trials"] == rr["trace_trials"] and ra["n_bbox_valid"] == rr["n_bbox_valid"], (f, ra["trace_trials"], rr["trace_trials"], ra["trace_chi2"], rr["trace_chi2"])
             worst["chi2"] = max(worst["chi2"], float(np.abs(np.array(ra["trace_chi2"]) / np.array(rr["trace_chi2"]) - 1).max()))
             worst["cams"] = max(worst["cams"], float(np.abs(ca - cr).max())); worst["objs"] = max(worst["objs"], float(np.abs(oa - orr).max()))
         sz = ctx.graph_sizes()
