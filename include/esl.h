@@ -384,6 +384,11 @@ typedef struct esl_plane_params {
   int32_t normal_smoothing;       /* setNormalSmoothingSize(10) */
   double max_depth_change_factor; /* setMaxDepthChangeFactor(0.05) */
   int32_t min_inliers;            /* setMinInliers(100) */
+  /* ABI 4: the second half of segmentAndRefine (PlaneExtractor.cpp:82) -- PCL's OrganizedMultiPlaneSegmentation::refine: two raster
+   * passes in which a model (segment of >= min_inliers pixels) absorbs neighbouring pixels that belong to no model and lie within
+   * refine_distance of its plane.  Grows the inlier lists (sizes, labels, which candidate is the largest), not the coefficients. */
+  int32_t refine;                 /* 1 (default): as the reference; 0: segments only (the round 2-4 behaviour) */
+  double refine_distance;         /* PlaneRefinementComparator's distance threshold: 0.02 m, not depth dependent */
 } esl_plane_params;
 void esl_plane_params_default(esl_plane_params* p);
 /* PlaneExtractor::extractGroundPlane(depth, plane) (PlaneExtractor.cpp:107-183): the largest plane segment of the depth image

@@ -96,13 +96,14 @@ class EslFitSymmetry(C.Structure):
 class EslPlaneParams(C.Structure):
     """esl_plane_params (PlaneExtractorParam + the PCL constants of PlaneExtractor.cpp:57-58, 74)."""
     _fields_ = [("min_size", C.c_int32), ("angle_threshold_deg", C.c_double), ("distance_threshold", C.c_double),
-                ("normal_smoothing", C.c_int32), ("max_depth_change_factor", C.c_double), ("min_inliers", C.c_int32)]
+                ("normal_smoothing", C.c_int32), ("max_depth_change_factor", C.c_double), ("min_inliers", C.c_int32),
+                ("refine", C.c_int32), ("refine_distance", C.c_double)]
 
 
 def default_plane_params(**kw):
     """Example/param/TUM3.yaml:36-38 + PlaneExtractor.cpp:57-58, 74."""
     p = EslPlaneParams(min_size=200, angle_threshold_deg=5.0, distance_threshold=0.1, normal_smoothing=10,
-                       max_depth_change_factor=0.05, min_inliers=100)
+                       max_depth_change_factor=0.05, min_inliers=100, refine=1, refine_distance=0.02)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

@@ -17,6 +17,15 @@
 //               PlaneCoefficientComparator); a lock-free union-find over the pixel grid
 //   planes      per component of >= max(100, Plane.MinSize) pixels the least-squares plane of its points (centroid + smallest
 //               eigenvector of the covariance, moments accumulated exactly in fixed point), d >= 0 (:95-96)
+//   refinement  (round 5; the second half of segmentAndRefine, :82) PCL's OrganizedMultiPlaneSegmentation::refine: models =
+//               components of >= 100 pixels (setMinInliers); two raster passes in which a pixel carrying a model's label pulls its
+//               right / lower (second pass: left / upper) neighbour into the model when that neighbour belongs to no model and
+//               lies within 0.02 m of the model's plane (PlaneRefinementComparator) -- labels move as the scan goes, so a model grows
+//               through a whole run of such pixels.  Coefficients are NOT re-estimated (PCL does not); what grows are the inlier
+//               lists: the sizes the reference filters by (:87) and ranks the ground candidates by (:160), and GetPoints().
+//               Sequential by definition; here ONE workgroup walks the rows in order: a row's runs are disjoint, so every run is
+//               walked by its own thread, and the pull into the next row is one independent test per column.  The result does not
+//               depend on thread timing (k_plane_refine).  esl_plane_params::refine = 0 gives the segments alone.
 //   ground      among the planes whose normal is within 45 degrees of the camera's y axis (either sign, :139-146) the one with
 //               the most pixels (:160-162; ties: the component with the smaller root pixel); sign such that the camera
 //               centre is on the positive side (:165-167)
@@ -254,6 +263,86 @@ static __global__ __launch_bounds__(256) void k_plane_labels(PlaneArgs a) {
   a.labels[i] = ni[0] != ni[0] ? -1 : a.plane_of_root[uf_find(a.parent, i)];
 }
 
+// refinement pass, step 0: the label image PCL's refine() works on -- model index, -1 no label (no depth), -2 any other pixel
+static __global__ __launch_bounds__(256) void k_plane_lab_init(PlaneArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  int l = -2;
+  if (a.depth[i] == 0) l = -1;
+  else if (a.nrm[4 * (size_t)i] == a.nrm[4 * (size_t)i]) { const int m = a.plane_of_root[uf_find(a.parent, i)]; l = m >= 0 ? m : -2; }
+  a.labels[i] = l;
+}
+// OrganizedMultiPlaneSegmentation::refine (see the file header; the CPU checker runs the literal loops, oracle/esl_oracle_plane.c).
+// ONE workgroup; per row: (1) the row's labels -> LDS, (2) run starts from the labels as they are BEFORE this row's sweep (a pixel of
+// a model followed by an unlabelled-by-any-model pixel), (3) every run start walks its run -- runs end at the next pixel that is not
+// "other", so they are disjoint --, (4) the labels go back and every column tests the ONE pixel of the next row (quirk kept: not when
+// the in-row neighbour has no label).  Second pass mirrored, plus PCL's "left of column 0" = the last pixel of the row above.
+constexpr int kPlaneRefThreads = 1024;
+static __global__ __launch_bounds__(kPlaneRefThreads) void k_plane_refine(PlaneArgs a, int* __restrict__ grown, double thr) {
+  extern __shared__ int s_row[];
+  int* sL = s_row;
+  int* sF = s_row + a.w;
+  const int w = a.w, h = a.h, t = threadIdx.x;
+  auto near = [&](int m, int u, int v) {
+    float q[3];
+    px_point(a, u, v, q);
+    const double* pl = a.list + (size_t)m * 5;
+    return fabs(pl[0] * (double)q[0] + pl[1] * (double)q[1] + pl[2] * (double)q[2] + pl[3]) < thr;
+  };
+  for (int v = 0; v < h - 1; ++v) {                       // first pass: rightwards, downwards
+    int* row = a.labels + (size_t)v * w;
+    int* below = row + w;
+    for (int u = t; u < w; u += kPlaneRefThreads) sL[u] = row[u];
+    __syncthreads();
+    for (int u = t; u < w - 1; u += kPlaneRefThreads) sF[u] = (sL[u] >= 0 && sL[u + 1] == -2) ? 1 : 0;
+    __syncthreads();
+    for (int u = t; u < w - 1; u += kPlaneRefThreads)
+      if (sF[u]) {
+        const int m = sL[u];
+        int j = u + 1, n = 0;
+        while (j < w && sL[j] == -2 && near(m, j, v)) { sL[j] = m; ++j; ++n; }
+        if (n) atomicAdd(&grown[m], n);
+      }
+    __syncthreads();
+    for (int u = t; u < w; u += kPlaneRefThreads) {
+      const int cur = sL[u];
+      row[u] = cur;
+      if (u < w - 1 && cur >= 0 && sL[u + 1] != -1 && below[u] == -2 && near(cur, u, v + 1)) { below[u] = cur; atomicAdd(&grown[cur], 1); }
+    }
+    __syncthreads();
+  }
+  for (int v = h - 1; v >= 1; --v) {                      // second pass: leftwards, upwards
+    int* row = a.labels + (size_t)v * w;
+    int* above = row - w;
+    for (int u = t; u < w; u += kPlaneRefThreads) sL[u] = row[u];
+    __syncthreads();
+    for (int u = t; u < w; u += kPlaneRefThreads) sF[u] = (u >= 1 && sL[u] >= 0 && sL[u - 1] == -2) ? 1 : 0;
+    __syncthreads();
+    for (int u = t; u < w; u += kPlaneRefThreads)
+      if (sF[u]) {
+        const int m = sL[u];
+        int j = u - 1, n = 0;
+        while (j >= 0 && sL[j] == -2 && near(m, j, v)) { sL[j] = m; --j; ++n; }
+        if (n) atomicAdd(&grown[m], n);
+      }
+    __syncthreads();
+    for (int u = t; u < w; u += kPlaneRefThreads) {
+      const int cur = sL[u];
+      row[u] = cur;
+      if (u >= 1 && cur >= 0 && sL[u - 1] != -1 && above[u] == -2 && near(cur, u, v - 1)) { above[u] = cur; atomicAdd(&grown[cur], 1); }
+    }
+    __syncthreads();
+    if (t == 0) {                                          // column 0 comes last in PCL's sweep: "left" = the last pixel of the row above
+      const int cur = sL[0];
+      if (cur != -1 && above[w - 1] != -1) {
+        if (cur >= 0 && above[w - 1] == -2 && near(cur, w - 1, v - 1)) { above[w - 1] = cur; atomicAdd(&grown[cur], 1); }
+        if (cur >= 0 && above[0] == -2 && near(cur, 0, v - 1)) { above[0] = cur; atomicAdd(&grown[cur], 1); }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // one workgroup: every component of >= min_size pixels -> its plane; the ground-plane candidate with the most pixels wins
 static __global__ __launch_bounds__(256) void k_plane_select(PlaneArgs a) {
   __shared__ int s_cnt[256], s_root[256], s_np[256], s_nc[256];
@@ -296,6 +385,7 @@ extern "C" void esl_plane_params_default(esl_plane_params* p) {
   p->min_size = 200; p->angle_threshold_deg = 5; p->distance_threshold = 0.1;   // Example/param/TUM3.yaml:36-38
   p->normal_smoothing = 10; p->max_depth_change_factor = 0.05;                   // PlaneExtractor.cpp:57-58
   p->min_inliers = 100;                                                           // PlaneExtractor.cpp:74
+  p->refine = 1; p->refine_distance = 0.02;                                       // segmentAndRefine (:82); PlaneRefinementComparator's default
 }
 
 namespace esl {
@@ -310,11 +400,13 @@ namespace {
 // per call): depth u16, normal + offset 4 x f32, union-find parent i32, per-root count i32 and nine i64 moments, results, and
 // (esl_extract_planes) the root -> plane map, the plane list and the label image
 struct Buf { void* p = nullptr; };
-struct PlaneWork { Buf depth, nrm, par, cnt, mom, out, map, list, labels; };
-int plane_reserve(esl_ctx* c, size_t npx, int max_planes, PlaneWork& w) {
+struct PlaneWork { Buf depth, nrm, par, cnt, mom, out, map, list, labels, grown; int list_cap = 0; };
+int plane_reserve(esl_ctx* c, size_t npx, int max_planes, int model_min, PlaneWork& w) {
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-  const size_t sz[9] = {al(npx * 2), al(npx * 16), al(npx * 4), al(npx * 4), al(npx * 72), al(8 * sizeof(double)), al(npx * 4),
-                        al((size_t)std::max(max_planes, 1) * 5 * sizeof(double)), al(npx * 4)};
+  // the list holds PCL's MODELS when the refinement pass runs (components of >= min_inliers pixels: at most npx / min_inliers)
+  w.list_cap = std::max(std::max(max_planes, 1), model_min > 0 ? (int)(npx / (size_t)model_min) + 2 : 1);
+  const size_t sz[10] = {al(npx * 2), al(npx * 16), al(npx * 4), al(npx * 4), al(npx * 72), al(8 * sizeof(double)), al(npx * 4),
+                         al((size_t)w.list_cap * 5 * sizeof(double)), al(npx * 4), al((size_t)w.list_cap * sizeof(int))};
   size_t need = 0;
   for (size_t v : sz) need += v;
   if (need > c->plane_slab_cap) {
@@ -324,9 +416,9 @@ int plane_reserve(esl_ctx* c, size_t npx, int max_planes, PlaneWork& w) {
     ESL_HIP_TRY(hipMalloc((void**)&c->plane_slab, need));
     c->plane_slab_cap = need;
   }
-  Buf* b[9] = {&w.depth, &w.nrm, &w.par, &w.cnt, &w.mom, &w.out, &w.map, &w.list, &w.labels};
+  Buf* b[10] = {&w.depth, &w.nrm, &w.par, &w.cnt, &w.mom, &w.out, &w.map, &w.list, &w.labels, &w.grown};
   size_t off = 0;
-  for (int k = 0; k < 9; ++k) { b[k]->p = c->plane_slab + off; off += sz[k]; }
+  for (int k = 0; k < 10; ++k) { b[k]->p = c->plane_slab + off; off += sz[k]; }
   return ESL_OK;
 }
 
@@ -334,12 +426,13 @@ int plane_reserve(esl_ctx* c, size_t npx, int max_planes, PlaneWork& w) {
 int plane_segment(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5], const esl_plane_params* p,
                   PlaneWork& w, PlaneArgs& a, const char* who, int max_planes = 1) {
   if (!c || !depth || !intr || !p || width <= 0 || height <= 0) { set_error(std::string(who) + ": bad argument"); return ESL_ERR_INVALID; }
-  if (p->normal_smoothing < 2 || p->distance_threshold <= 0 || p->angle_threshold_deg <= 0 || p->max_depth_change_factor <= 0) {
+  if (p->normal_smoothing < 2 || p->distance_threshold <= 0 || p->angle_threshold_deg <= 0 || p->max_depth_change_factor <= 0 ||
+      (p->refine && (!(p->refine_distance > 0) || p->min_inliers < 1))) {
     set_error(std::string(who) + ": bad parameters"); return ESL_ERR_INVALID;
   }
   ESL_HIP_TRY(hipSetDevice(c->device));
   const size_t npx = (size_t)width * height;
-  if (const int rc = plane_reserve(c, npx, max_planes, w)) return rc;
+  if (const int rc = plane_reserve(c, npx, max_planes, p->refine ? p->min_inliers : 0, w)) return rc;
   ESL_HIP_TRY(hipMemcpyAsync(w.depth.p, depth, npx * 2, hipMemcpyHostToDevice, c->stream));
   a = PlaneArgs{};
   a.depth = (const uint16_t*)w.depth.p; a.w = width; a.h = height;
@@ -358,6 +451,51 @@ int plane_segment(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t heig
 }
 }  // namespace
 
+namespace {
+// segmentAndRefine: models (>= min_inliers) -> label image -> the two refinement passes; on the host: refined sizes, the Plane.MinSize
+// filter, the wall filter and the largest candidate (the part of extractPlanes / extractGroundPlane behind the PCL call; a handful of
+// planes).  labels_out (optional): plane index per pixel, -1 none.
+struct RefinedPlanes { std::vector<double> planes; std::vector<int> sizes; int ground = -1; };
+int plane_refined(esl_ctx* c, const esl_plane_params* p, PlaneWork& w, PlaneArgs& a, RefinedPlanes& out, int32_t* labels_out) {
+  const size_t npx = (size_t)a.w * a.h;
+  a.min_size = p->min_inliers;                         // k_plane_list: PCL's models, in raster order of their first pixel
+  a.plane_of_root = (int*)w.map.p; a.list = (double*)w.list.p; a.list_cap = w.list_cap; a.labels = (int*)w.labels.p;
+  hipLaunchKernelGGL(k_plane_list, dim3(1), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_plane_lab_init, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, a);
+  ESL_HIP_TRY(hipMemsetAsync(w.grown.p, 0, (size_t)w.list_cap * sizeof(int), c->stream));
+  if (a.w > 1 && a.h > 1)
+    hipLaunchKernelGGL(k_plane_refine, dim3(1), dim3(kPlaneRefThreads), 2 * (size_t)a.w * sizeof(int), c->stream, a, (int*)w.grown.p, p->refine_distance);
+  ESL_HIP_TRY(hipGetLastError());
+  double h[8];
+  ESL_HIP_TRY(hipMemcpyAsync(h, w.out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  const int n_models = std::min((int)h[5], w.list_cap);
+  std::vector<double> list((size_t)std::max(n_models, 1) * 5);
+  std::vector<int> grown((size_t)std::max(n_models, 1), 0), idx((size_t)std::max(n_models, 1), -1);
+  if (n_models) {
+    ESL_HIP_TRY(hipMemcpyAsync(list.data(), w.list.p, (size_t)n_models * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ESL_HIP_TRY(hipMemcpyAsync(grown.data(), w.grown.p, (size_t)n_models * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (labels_out) ESL_HIP_TRY(hipMemcpyAsync(labels_out, w.labels.p, npx * 4, hipMemcpyDeviceToHost, c->stream));
+  ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  int best_cnt = 0;
+  for (int m = 0; m < n_models; ++m) {
+    const int size = (int)list[(size_t)m * 5 + 4] + grown[m];
+    if (size < p->min_size) continue;                   // PlaneExtractor.cpp:87
+    const double* pl = &list[(size_t)m * 5];
+    idx[m] = (int)out.sizes.size();
+    out.planes.insert(out.planes.end(), pl, pl + 4);
+    out.sizes.push_back(size);
+    const double th = std::acos(pl[1] / std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]));
+    if (th > M_PI / 4 && th < 3 * M_PI / 4) continue;    // the wall filter (:139-146)
+    if (size > best_cnt) { best_cnt = size; out.ground = idx[m]; }   // most inliers (:160-162); ties: the earlier model
+  }
+  if (labels_out)
+    for (size_t i = 0; i < npx; ++i) { const int l = labels_out[i]; labels_out[i] = (l >= 0 && l < n_models) ? idx[l] : -1; }
+  return ESL_OK;
+}
+}  // namespace
+
 extern "C" int esl_extract_ground_plane(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t height, const double intr[5],
                                         const esl_plane_params* p, double plane_out[4], int32_t* ok, int32_t* n_planes, int32_t* n_pixels) {
   if (!plane_out || !ok) { set_error("esl_extract_ground_plane: bad argument"); return ESL_ERR_INVALID; }
@@ -366,6 +504,14 @@ extern "C" int esl_extract_ground_plane(esl_ctx* c, const uint16_t* depth, int32
   PlaneWork w;
   PlaneArgs a;
   if (const int rc = plane_segment(c, depth, width, height, intr, p, w, a, "esl_extract_ground_plane")) return rc;
+  if (p->refine) {
+    RefinedPlanes rp;
+    if (const int rc = plane_refined(c, p, w, a, rp, nullptr)) return rc;
+    if (n_planes) *n_planes = (int32_t)rp.sizes.size();
+    if (n_pixels) *n_pixels = rp.ground >= 0 ? rp.sizes[(size_t)rp.ground] : 0;
+    if (rp.ground >= 0) { *ok = 1; for (int k = 0; k < 4; ++k) plane_out[k] = rp.planes[(size_t)rp.ground * 4 + k]; }
+    return ESL_OK;
+  }
   hipLaunchKernelGGL(k_plane_select, dim3(1), dim3(256), 0, c->stream, a);
   ESL_HIP_TRY(hipGetLastError());
   double h[8];
@@ -386,6 +532,17 @@ extern "C" int esl_extract_planes(esl_ctx* c, const uint16_t* depth, int32_t wid
   PlaneWork w;
   PlaneArgs a;
   if (const int rc = plane_segment(c, depth, width, height, intr, p, w, a, "esl_extract_planes", max_planes)) return rc;
+  if (p->refine) {
+    RefinedPlanes rp;
+    if (const int rc = plane_refined(c, p, w, a, rp, labels_out)) return rc;
+    *n_planes = (int32_t)rp.sizes.size();
+    const int n = std::min(*n_planes, max_planes);
+    for (int i = 0; i < n; ++i) {
+      for (int k = 0; k < 4; ++k) planes_out[(size_t)i * 4 + k] = rp.planes[(size_t)i * 4 + k];
+      sizes_out[i] = rp.sizes[(size_t)i];
+    }
+    return ESL_OK;
+  }
   const size_t npx = (size_t)width * height;
   a.plane_of_root = (int*)w.map.p; a.list = (double*)w.list.p; a.list_cap = max_planes;
   hipLaunchKernelGGL(k_plane_list, dim3(1), dim3(256), 0, c->stream, a);

@@ -144,36 +144,94 @@ static int plane_core(const uint16_t* depth, int32_t w, int32_t h, const double 
       ++cnt[r];
       for (int k = 0; k < 9; ++k) mom[(size_t)r * 9 + k] += llrint(v9[k]);
     }
-  /* planes of >= min size (:87) in raster order of each segment's first pixel (= its root); wall filter; the largest one is
-   * the ground (:139-162) */
-  const int min_size = p->min_size > p->min_inliers ? p->min_size : p->min_inliers;
+  /* PCL's models: segments of >= setMinInliers(100) pixels (:74), in raster order of each segment's first pixel (= its root).
+   * Without the refinement pass a model below Plane.MinSize can never become a plane, so the list starts at max(MinSize, 100). */
+  const int refine = p->refine != 0;
+  const int model_min = refine ? p->min_inliers : (p->min_size > p->min_inliers ? p->min_size : p->min_inliers);
+  int n_models = 0;
+  for (size_t r = 0; r < npx; ++r) if (cnt[r] >= model_min && cnt[r] > 0) ++n_models;
+  int* model_of_root = (int*)malloc(npx * sizeof(int));
+  double* mpl = (double*)malloc((size_t)(n_models > 0 ? n_models : 1) * 4 * sizeof(double));
+  int* msize = (int*)malloc((size_t)(n_models > 0 ? n_models : 1) * sizeof(int));
+  int* lab = (int*)malloc(npx * sizeof(int));     /* model index; -1: no depth (never labelled); -2: any other pixel */
+  if (!model_of_root || !mpl || !msize || !lab) { free(model_of_root); free(mpl); free(msize); free(lab); free(nrm); free(parent); free(cnt); free(mom); return -1; }
+  {
+    int m = 0;
+    for (size_t r = 0; r < npx; ++r) {
+      model_of_root[r] = -1;
+      if (cnt[r] < model_min || cnt[r] <= 0) continue;
+      plane_of(mom + r * 9, cnt[r], mpl + (size_t)m * 4);
+      msize[m] = cnt[r];
+      model_of_root[r] = m++;
+    }
+  }
+  for (size_t i = 0; i < npx; ++i) {
+    if (depth[i] == 0) lab[i] = -1;
+    else if (nrm[4 * i] != nrm[4 * i]) lab[i] = -2;
+    else { const int m = model_of_root[find_root(parent, (int)i)]; lab[i] = m >= 0 ? m : -2; }
+  }
+  if (refine && n_models > 0 && w > 1 && h > 1) {
+    /* OrganizedMultiPlaneSegmentation::refine as PCL 1.8 writes it (segmentAndRefine, PlaneExtractor.cpp:82; PCL is not vendored:
+     * restated from its published source, UNPINNED): two raster passes in which a pixel of a model's label pulls its right / lower
+     * (second pass: left / upper) neighbour into the model when that neighbour belongs to NO model and lies within the refinement
+     * comparator's distance of the model's plane (PlaneRefinementComparator: |n.p + d| < 0.02 m, not depth dependent).  Labels move
+     * as the scan goes, so a model grows along the scan direction through a whole run of such pixels.  The models' COEFFICIENTS are
+     * not re-estimated (PCL does not): what changes is their inlier lists -- the size the reference filters by (:87) and ranks the
+     * ground-plane candidates by (:160) and the points GetPoints() returns.  Two quirks kept: a pixel whose right (left) neighbour
+     * has no label skips its lower (upper) neighbour too (the `continue`), and the second pass reads "the pixel to the left" of
+     * column 0, i.e. the last pixel of the row above. */
+    const double thr = p->refine_distance;
+#define ESL_PL_TRY(cur_, nxt_, u_, v_) do { \
+      const int cl_ = lab[cur_]; \
+      if (cl_ >= 0 && lab[nxt_] == -2) { \
+        float q_[3]; px_point(depth, w, (u_), (v_), intr, q_); \
+        const double* pl_ = mpl + (size_t)cl_ * 4; \
+        if (fabs(pl_[0] * (double)q_[0] + pl_[1] * (double)q_[1] + pl_[2] * (double)q_[2] + pl_[3]) < thr) { lab[nxt_] = cl_; ++msize[cl_]; } \
+      } } while (0)
+    for (int v = 0; v < h - 1; ++v)
+      for (int u = 0; u < w - 1; ++u) {
+        const size_t i = (size_t)v * w + u;
+        if (lab[i] == -1 || lab[i + 1] == -1) continue;
+        ESL_PL_TRY(i, i + 1, u + 1, v);
+        if (lab[i + w] == -1) continue;
+        ESL_PL_TRY(i, i + w, u, v + 1);
+      }
+    for (int v = h - 1; v >= 1; --v)
+      for (int u = w - 1; u >= 0; --u) {
+        const size_t i = (size_t)v * w + u;
+        const size_t l = i - 1;                                   /* u == 0: the last pixel of row v - 1 (as PCL indexes it) */
+        if (lab[i] == -1 || lab[l] == -1) continue;
+        ESL_PL_TRY(i, l, (int)(l % (size_t)w), (int)(l / (size_t)w));
+        if (lab[i - w] == -1) continue;
+        ESL_PL_TRY(i, i - w, u, v - 1);
+      }
+#undef ESL_PL_TRY
+  }
+  /* planes of >= Plane.MinSize inliers (:87), wall filter, the largest one is the ground (:139-162; ties: the earlier model) */
   int best = -1, best_cnt = 0, planes = 0;
-  int* plane_idx = labels_out ? (int*)malloc(npx * sizeof(int)) : NULL;
-  for (size_t r = 0; r < npx; ++r) {
-    if (plane_idx) plane_idx[r] = -1;
-    if (cnt[r] < min_size || cnt[r] <= 0) continue;
-    double pl[4];
-    plane_of(mom + r * 9, cnt[r], pl);
-    if (planes < max_planes && planes_out) { memcpy(planes_out + (size_t)planes * 4, pl, sizeof(pl)); sizes_out[planes] = cnt[r]; }
-    if (plane_idx) plane_idx[r] = planes;
-    ++planes;
+  int* plane_idx = (int*)malloc((size_t)(n_models > 0 ? n_models : 1) * sizeof(int));
+  for (int m = 0; m < n_models; ++m) {
+    plane_idx[m] = -1;
+    if (msize[m] < p->min_size) continue;
+    const double* pl = mpl + (size_t)m * 4;
+    if (planes < max_planes && planes_out) { memcpy(planes_out + (size_t)planes * 4, pl, 4 * sizeof(double)); sizes_out[planes] = msize[m]; }
+    plane_idx[m] = planes++;
     const double th = acos(pl[1] / sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]));
     if (th > M_PI / 4 && th < 3 * M_PI / 4) continue;
-    if (cnt[r] > best_cnt) { best_cnt = cnt[r]; best = (int)r; }
+    if (msize[m] > best_cnt) { best_cnt = msize[m]; best = m; }
   }
   if (labels_out)
-    for (size_t i = 0; i < npx; ++i)
-      labels_out[i] = nrm[4 * i] != nrm[4 * i] ? -1 : plane_idx[find_root(parent, (int)i)];
-  free(plane_idx);
+    for (size_t i = 0; i < npx; ++i) labels_out[i] = lab[i] >= 0 ? plane_idx[lab[i]] : -1;
   if (ok) *ok = 0;
   if (plane_out) for (int k = 0; k < 4; ++k) plane_out[k] = 0;
   if (n_planes) *n_planes = planes;
   if (n_pixels) *n_pixels = 0;
   if (best >= 0) {
-    if (plane_out) plane_of(mom + (size_t)best * 9, best_cnt, plane_out);   /* d >= 0: camera centre on the positive side (:165-167) */
+    if (plane_out) memcpy(plane_out, mpl + (size_t)best * 4, 4 * sizeof(double));   /* d >= 0: camera centre on the positive side (:165-167) */
     if (ok) *ok = 1;
     if (n_pixels) *n_pixels = best_cnt;
   }
+  free(plane_idx); free(model_of_root); free(mpl); free(msize); free(lab);
   free(nrm); free(parent); free(cnt); free(mom);
   return 0;
 }

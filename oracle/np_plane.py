@@ -78,7 +78,64 @@ def normals(depth, intr, smoothing=10, factor=0.05):
     return out
 
 
-def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smoothing=10, factor=0.05, min_inliers=100):
+def _refine(lab, P, mpl, thr):
+    """PCL's OrganizedMultiPlaneSegmentation::refine on a label image (model index >= 0, -1 no label, -2 any other pixel), written
+    as per-row SCANS instead of the pixel-by-pixel loops of the C restatement: inside a row a model grows through a run of "other"
+    pixels for as long as every one of them is within thr of its plane -- the source of a run is the nearest non-"other" pixel
+    behind it, the run stops at the first failure (a prefix sum of failures) -- and between rows it pulls the single pixel below
+    (second pass: above).  Same two quirks as PCL: a pixel whose in-row neighbour has no label skips the other row too, and the
+    second pass takes the last pixel of the row above for "left of column 0".  Returns the pixels absorbed per model."""
+    h, w = lab.shape
+    grown = np.zeros(len(mpl), dtype=np.int64)
+    idx = np.arange(w)
+
+    def dist_ok(m, pts):
+        pl = mpl[np.maximum(m, 0)]
+        return (np.abs(pl[:, 0] * pts[:, 0] + pl[:, 1] * pts[:, 1] + pl[:, 2] * pts[:, 2] + pl[:, 3]) < thr) & (m >= 0)
+
+    def cascade(L, pts):
+        """one in-row sweep towards increasing index; L is modified in place"""
+        other = L == -2
+        src = np.maximum.accumulate(np.where(~other, idx, -1))            # nearest non-other pixel at or before each position
+        has = src >= 0
+        m = np.where(has, L[np.maximum(src, 0)], -1)
+        ok = dist_ok(np.where(other, m, -1), pts)
+        fails = np.cumsum(other & ~ok)
+        take = other & has & (m >= 0) & (fails - fails[np.maximum(src, 0)] == 0)
+        L[take] = m[take]
+        np.add.at(grown, m[take], 1)
+
+    def pull(cur, nxt, gate, pts):
+        """the other row: nxt[k] joins cur[k]'s model where gate[k] (the quirk) allows the check"""
+        t = gate & (cur >= 0) & (nxt == -2)
+        t &= dist_ok(np.where(t, cur, -1), pts)
+        nxt[t] = cur[t]
+        np.add.at(grown, cur[t], 1)
+
+    for v in range(h - 1):                                                 # first pass: rightwards and downwards
+        L = lab[v]
+        cascade(L, P[v])
+        gate = np.zeros(w, dtype=bool)
+        gate[:-1] = (L[:-1] != -1) & (L[1:] != -1)                          # columns 0 .. w-2 only; both labelled
+        pull(L, lab[v + 1], gate & (lab[v + 1] != -1), P[v + 1])
+    for v in range(h - 1, 0, -1):                                          # second pass: leftwards and upwards
+        L = lab[v]
+        Lr = L[::-1]                                                        # a view: the sweep runs over the reversed row
+        cascade(Lr, P[v][::-1])
+        gate = np.zeros(w, dtype=bool)
+        gate[1:] = (L[1:] != -1) & (L[:-1] != -1)
+        pull(L[1:], lab[v - 1][1:], gate[1:] & (lab[v - 1][1:] != -1), P[v - 1][1:])
+        # column 0: "left" is the last pixel of the row above, then the pixel above
+        if L[0] != -1 and lab[v - 1][w - 1] != -1:
+            one = np.ones(1, dtype=bool)
+            pull(L[0:1], lab[v - 1][w - 1:w], one, P[v - 1][w - 1:w])
+            if lab[v - 1][0] != -1:
+                pull(L[0:1], lab[v - 1][0:1], one, P[v - 1][0:1])
+    return grown
+
+
+def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smoothing=10, factor=0.05, min_inliers=100, refine=True,
+                         refine_distance=0.02):
     depth = np.asarray(depth, dtype=np.uint16)
     intr = np.asarray(intr, dtype=np.float64)
     h, w = depth.shape
@@ -102,8 +159,9 @@ def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smo
     labs, first, counts = np.unique(lab[valid], return_index=True, return_counts=True)
     root = idx[valid][first]                       # smallest pixel index of each component (np.unique keeps the first)
     P = points(depth, intr).astype(np.float64)
-    need = max(min_size, min_inliers)
-    planes = []
+    # PCL's models: components of >= min_inliers pixels (without the refinement pass nothing below min_size can become a plane)
+    need = min_inliers if refine else max(min_size, min_inliers)
+    models = []
     for l, c, r in zip(labs, counts, root):
         if c < need:
             continue
@@ -115,17 +173,27 @@ def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smo
         pl = np.array([n[0], n[1], n[2], -n @ cen])
         if pl[3] < 0:
             pl = -pl
-        planes.append((int(c), int(r), pl))
+        models.append((int(c), int(r), pl, l))
+    models.sort(key=lambda t: t[1])                 # raster order of each segment's first pixel
+    mlab = np.full((h, w), -2, dtype=np.int64)
+    mlab[depth == 0] = -1
+    for k, (c, r, pl, l) in enumerate(models):
+        mlab[(lab == l) & valid] = k
+    sizes = np.array([t[0] for t in models], dtype=np.int64)
+    if refine and models and h > 1 and w > 1:
+        sizes = sizes + _refine(mlab, P, np.array([t[2] for t in models]), refine_distance)
+    keep = [k for k in range(len(models)) if sizes[k] >= min_size]
+    remap = np.full(len(models) + 1, -1, dtype=np.int32)
+    for j, k in enumerate(keep):
+        remap[k] = j
+    lab_img = np.where(mlab >= 0, remap[np.maximum(mlab, 0)], -1).astype(np.int32)
+    planes = [(int(sizes[k]), models[k][1], models[k][2]) for k in keep]
     cand = []
     for c, r, pl in planes:
         th = np.arccos(pl[1] / np.linalg.norm(pl[:3]))
         if np.pi / 4 < th < 3 * np.pi / 4:
             continue
         cand.append((c, r, pl))
-    planes.sort(key=lambda t: t[1])                 # raster order of each segment's first pixel
-    lab_img = np.full((h, w), -1, dtype=np.int32)
-    for k, (c, r, pl) in enumerate(planes):
-        lab_img[(lab == lab.reshape(-1)[r]) & valid] = k
     out = dict(ok=False, plane=np.zeros(4), n_planes=len(planes), n_pixels=0, normals=nr,
                planes=np.array([t[2] for t in planes]).reshape(-1, 4), sizes=np.array([t[0] for t in planes], dtype=np.int32), labels=lab_img)
     if cand:

@@ -2,8 +2,9 @@
 """Generates tests/golden/cabinet_plane.npz: the ground plane of two depth frames of the reference's demo clip
 (Example/dataset/cabinet, first frame and frame 30) computed by the INDEPENDENT numpy / scipy version oracle/np_plane.py.
 Run in the development container only (reads the reference's DATA files; needs scipy + PIL).  Stored: the two depth
-images (x-differenced so that deflate gets PNG-like ratios), the mocap poses of the frames, the expected plane, segment
-count, pixel count and the count of pixels with a normal.  No reference source text is stored.
+images (x-differenced so that deflate gets PNG-like ratios), the mocap poses of the frames, the expected plane, plane
+count, pixel count, the planes' sizes and the count of pixels with a normal -- with PCL's refinement pass (round 5) and, for the
+segments alone, the round 2-4 counts.  No reference source text is stored.
 
   python tests/golden/gen_golden_plane.py
 """
@@ -30,12 +31,16 @@ def main():
         depth = np.array(Image.open(REF + assoc[l[0]])).astype(np.uint16)
         diff = depth.copy()
         diff[:, 1:] = depth[:, 1:] - depth[:, :-1]
-        r = np_plane.extract_ground_plane(depth, intr)
+        r = np_plane.extract_ground_plane(depth, intr)                      # with PCL's refinement pass (the reference: segmentAndRefine)
+        r0 = np_plane.extract_ground_plane(depth, intr, refine=False)        # the segments alone (rounds 2-4)
         store[f"depth_{k}"] = diff
         store[f"pose_{k}"] = np.array(l[3:10], float)
         store[f"plane_{k}"] = r["plane"]
         store[f"counts_{k}"] = np.array([r["n_planes"], r["n_pixels"], int(np.isfinite(r["normals"][..., 0]).sum())])
-        print(li, r["plane"], r["n_planes"], r["n_pixels"])
+        store[f"sizes_{k}"] = r["sizes"]
+        store[f"counts_norefine_{k}"] = np.array([r0["n_planes"], r0["n_pixels"]])
+        assert np.array_equal(r["plane"], r0["plane"])                       # the pass grows the inlier lists, not the coefficients
+        print(li, r["plane"], r["n_planes"], r["n_pixels"], list(r["sizes"]), "| without the refinement pass:", r0["n_planes"], r0["n_pixels"])
     np.savez_compressed(OUT, **store)
     print(OUT, os.path.getsize(OUT))
 
