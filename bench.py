@@ -542,7 +542,16 @@ def ground_plane_bench(pkg, ctx, with_cpu=True):
     for _ in range(n):
         r = ctx.extract_ground_plane(sc["depth"], sc["intr"])
     out = {"ms_per_frame_host_call": 1e3 * (time.perf_counter() - t0) / n, "ok": bool(r["ok"]), "planes": int(r["n_planes"]), "pixels_of_the_plane": int(r["n_pixels"]),
-           "frame": "640x480 synthetic (ground + 3 ellipsoids)", "note": "host call incl. H2D of the depth image; buffers from a grow-only context slab (round 2: 33 MB of hipMalloc per call)"}
+           "frame": "640x480 synthetic (ground + 3 ellipsoids)",
+           "note": "host call incl. H2D of the depth image; buffers from a grow-only context slab (round 2: 33 MB of hipMalloc per call); round 5: the call now "
+                   "includes PCL's refinement pass of segmentAndRefine (PlaneExtractor.cpp:82) -- two raster passes that are sequential over the rows by "
+                   "definition, one workgroup, ~3.5 ms of the call; runs once per sequence (Tracking.cpp:498-499)"}
+    p0 = pkg.abi.default_plane_params(refine=0)
+    ctx.extract_ground_plane(sc["depth"], sc["intr"], p0)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r0 = ctx.extract_ground_plane(sc["depth"], sc["intr"], p0)
+    out["segments_only_refine_0"] = {"ms_per_frame_host_call": 1e3 * (time.perf_counter() - t0) / n, "planes": int(r0["n_planes"]), "pixels_of_the_plane": int(r0["n_pixels"])}
     if with_cpu:
         from oracle import pyoracle as po
         with pinned_to_one_core():

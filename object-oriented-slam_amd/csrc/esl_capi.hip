@@ -527,7 +527,7 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   if ((rc = up.commit())) return rc;
   if ((rc = wk.commit(c))) return rc;
   ESL_HIP_TRY(hipMemsetAsync(c->obj_part, 0, std::max<size_t>(N, 1) * 4 * sizeof(double), st));
-  if (d.n_free_cams == 0 && c->arena_solve.cap + c->arena_S.cap + c->arena_slam.cap > ((size_t)256 << 20)) {
+  if (d.n_free_cams == 0 && c->arena_solve.cap + c->arena_S.cap + c->arena_slam.cap > ((size_t)64 << 20)) {
     // a mapping-mode graph follows a SLAM-mode one: the solver blobs of the old graph (tens of GB at BASELINE configs[3]) would stay
     // pinned for the life of the context
     slam_trim(c, false);

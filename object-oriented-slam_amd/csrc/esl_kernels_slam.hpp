@@ -207,8 +207,10 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_combine(D
 }
 
 // odometry edges: Aod[e*90 ..] = Hii(21) bi(6) Hjj(21) bj(6) Hij(36, row-major i x j); od_part[e] = chi2
+// (launched with 128 threads: without the bound the compiler sizes the register file for 1,024 threads per workgroup -- 128 VGPRs --
+//  and the analytic instantiation spilt 540 B per lane, the numeric one 4.3 KB)
 template <int JAC>
-static __global__ void k_slam_odom(DevGraph g, const double* __restrict__ cams, double delta, double* __restrict__ Aod,
+static __global__ __launch_bounds__(128) void k_slam_odom(DevGraph g, const double* __restrict__ cams, double delta, double* __restrict__ Aod,
                             double* __restrict__ od_chi) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= g.n_odom) return;

@@ -529,3 +529,46 @@ def test_mid_size_slam_full_run_matches_cpu_camera_first_checker(pkg, monkeypatc
     finally:
         cx.close()
         monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
+
+
+def test_ctx_trim_releases_the_solver_blobs_and_they_come_back(pkg):
+    """esl_ctx_trim (ABI 4): the grow-only solver blobs of SLAM mode -- the camera-first set, the reduced camera system --
+    go back to the device; the next trial step builds what it needs again (index tables included) and lands on the same bits.  A
+    mapping-mode graph uploaded over a SLAM-mode one trims by itself.  S lives in a blob of its own: esl_lm_reduced_system beside a
+    camera-first run no longer re-lays that run's tables out (the pointer it returns stays valid across the next trial step)."""
+    import torch
+    g, c, o, _ = pkg.synth.make_graph(600, 120, 6000, seed=12, slam=True)
+    p2 = pkg.default_lm_params(jacobian_mode=1, linear_solver=2, max_iters=3)
+    cx = pkg.Context(0)
+    try:
+        c2, o2, r2 = cx.optimize(g, c, o, p2)
+        cx.upload_graph(g); cx.upload_states(c, o)
+        c1, o1, r1 = None, None, cx.optimize_resident(pkg.default_lm_params(jacobian_mode=1, linear_solver=1, max_iters=3))   # S: 3,594^2 doubles = 103 MB beside the camera-first set
+        free_before = torch.cuda.mem_get_info(0)[0]
+        cx.trim()
+        free_after = torch.cuda.mem_get_info(0)[0]
+        assert free_after - free_before > 100e6, (free_before, free_after)
+        cx.upload_states(c, o)
+        ca, oa = cx.download_states()
+        rb = cx.optimize_resident(p2)
+        cb, ob = cx.download_states()
+        assert rb["trace_chi2"] == r2["trace_chi2"] and np.array_equal(cb, c2) and np.array_equal(ob, o2)
+        # the reduced camera system beside a camera-first run: the pointer survives the next camera-first trial
+        cx.upload_states(c, o)
+        cx.lm_begin(p2)
+        part = cx.lm_linearize()
+        ptr, n, lda = cx.lm_reduced_system(1e-4 * part.max_diag)
+        S0 = cx.lm_download(6, lda * n)
+        tr = cx.lm_try_step(1e-4 * part.max_diag)
+        assert cx.lm_solver_used() == 2 and tr.solve_ok == 1
+        ptr2, n2, lda2 = cx.lm_reduced_system(1e-4 * part.max_diag)
+        assert (ptr2, n2, lda2) == (ptr, n, lda) and np.array_equal(cx.lm_download(6, lda * n), S0)
+        cx.lm_commit(False)
+        # a mapping-mode graph over a SLAM-mode one: the SLAM blobs go by themselves
+        gm, cm, om, _ = pkg.synth.make_graph(600, 120, 6000, seed=12, slam=False)
+        free_slam = torch.cuda.mem_get_info(0)[0]
+        cx.upload_graph(gm); cx.upload_states(cm, om)
+        assert torch.cuda.mem_get_info(0)[0] - free_slam > 100e6
+        assert np.isfinite(cx.optimize_resident(pkg.default_lm_params(jacobian_mode=1))["chi2_final"])
+    finally:
+        cx.close()
