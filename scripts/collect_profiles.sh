@@ -1,7 +1,7 @@
 # after `gpurun -- bash scripts/gpu_round_bench.sh <tag>`: copy the judged summaries from gpurun_out/<tag>/ (scratch) into profiles/
 # (tracked) under the round's name:   bash scripts/collect_profiles.sh <tag> [round-name, default r3]
-TAG=${1:-r4}
-RN=${2:-r4}
+TAG=${1:-r5}
+RN=${2:-r5}
 R=gpurun_out/$TAG
 cp $R/bench_default.json profiles/${RN}_bench_default.json
 cp $R/bench_default_kernel_stats.md profiles/${RN}_bench_default_kernel_stats.md

@@ -3,21 +3,22 @@
 #   the -m gpu test-suite, the default bench line (C4 SLAM timed + all records, with CPU baselines) and rocprofv3 kernel stats of
 #   the SAME command, PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes) of one C4 SLAM optimize and of the mapping-mode LM,
 #   C3 SLAM kernel stats, mapping kernel stats, fit kernel times, Cholesky micro-benchmark, other configs
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=gpurun_out/$TAG
 mkdir -p $R
 export TMPDIR=/tmp
 ROOT=$(pwd)
 timeout 900 python -m pytest tests -m gpu -q -s --durations=15 > $R/gputest.log 2>&1; echo rc=$? >> $R/gputest.log
-timeout 900 python bench.py > $R/bench_default.json 2> $R/bench_default.err; echo rc=$? >> $R/bench_default.err
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$R/prof_bench -- python $ROOT/bench.py > $ROOT/$R/prof_bench.json 2> $ROOT/$R/prof_bench.log)
+# the DRIVER's command (BENCH_rNN.json: `python3 bench.py --gpus 1 --steps 20 --warmup 5`), and rocprofv3 kernel stats of the same command
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/bench_default.json 2> $R/bench_default.err; echo rc=$? >> $R/bench_default.err
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$R/prof_bench -- python $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $ROOT/$R/prof_bench.json 2> $ROOT/$R/prof_bench.log)
 python profiles/summarize_rocpd.py $(ls -t $R/prof_bench/*/*_results.db | head -1) > $R/bench_default_kernel_stats.md
 rm -rf $R/prof_bench
 # HBM traffic of ONE C4 SLAM optimize (5 trials, camera-first elimination): two separate --pmc passes, kernel trace only
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $ROOT/$R/pmc_slam_$c -- python $ROOT/bench.py --no-extras --no-cpu-baseline --steps 1 --warmup 0 > $ROOT/$R/pmc_slam_$c.log 2>&1)
 done
-python scripts/pmc_summary.py $R/pmc_slam_FETCH_SIZE $R/pmc_slam_WRITE_SIZE $R/pmc_traffic_c4_slam.json k_chol_update k_cf_ k_slam_linearize k_chol_potrf k_chol_panel > $R/pmc_slam.txt 2>&1
+python scripts/pmc_summary.py $R/pmc_slam_FETCH_SIZE $R/pmc_slam_WRITE_SIZE $R/pmc_traffic_c4_slam.json k_chol_update k_chol_persist k_chol_backsub k_cf_ k_slam_linearize k_chol_potrf k_chol_panel > $R/pmc_slam.txt 2>&1
 rm -rf $R/pmc_slam_FETCH_SIZE $R/pmc_slam_WRITE_SIZE
 # ... and of the mapping-mode LM kernels
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -54,7 +55,8 @@ for f in ["bench_default", "c3_slam_camera_first", "c3_slam_reduced_camera", "c4
               "| avg launch ms", round(r.get("avg_launch_ms", 0), 5))
         for k in ("slam_reduced_camera", "mapping", "slam_c3"):
             if k in d: print("   ", k, round(d[k]["value"], 3), "it/s")
-        if "cpu_baseline" in d: print("    cpu", d["cpu_baseline"]["value"], "x", round(d.get("speedup_vs_cpu_port", 0)))
+        if "cpu_baseline" in d: print("    cpu", d["cpu_baseline"]["value"], "x", round(d.get("speedup_vs_cpu_baseline", d.get("speedup_vs_cpu_port", 0))))
+        if "secondary" in r: print("    secondary:", r["secondary"]["kernel"][:40], round(r["secondary"]["achieved"], 2), "frac", round(r["secondary"]["frac"], 4), "| trial_frac", r.get("trial_frac"), "| traffic", r.get("traffic"))
         if "fit" in d: print("    fit", {k: (round(v["ms_per_frame_kernel"], 3), round(v["ms_per_frame_host_call"], 3)) for k, v in d["fit"].items()},
                              "stream", round(d["streaming_c5"]["ms_per_frame"], 3), "ground plane", round(d["ground_plane"]["ms_per_frame_host_call"], 3))
     except Exception as e:
