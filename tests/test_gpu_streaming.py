@@ -434,6 +434,37 @@ def test_half_turn_yaw_hypothesis_is_never_taken(pkg, po, ctx):
             np.testing.assert_allclose(Hg, H, atol=5e-6 * np.abs(H).max())
 
 
+def test_all_four_yaw_hypotheses_half_turns_do_not_leave_the_edge_without_a_residual(pkg, po, ctx):
+    """the half-turn exclusion above must leave something to take.  An estimate that is the measurement turned by pi about a
+    HORIZONTAL axis (upside-down) makes E_k = Rz_k^T E_0 a half turn for EVERY yaw hypothesis; round 4's code then took hypothesis 0
+    unconditionally with best = DBL_MAX bookkeeping.  Now all four stay eligible and the first minimum as written wins -- what the
+    reference and the checker compute there.  The log of a half turn is ill-defined in the reference (a division by sin(pi)), so the
+    VALUES are not comparable; what must hold: the call returns, the edge's chi2 is either non-finite on both sides or at least
+    weight * (pi - 1e-3)^2 (a half turn is never a small residual), and an optimisation from there leaves finite states."""
+    from oracle import np_oracle as npo
+    K = pkg.synth.TUM3_K
+    cam = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
+    est = np.array([[0.2, -0.1, 2.5, 0, 0, 0, 1.0, 0.3, 0.25, 0.4]])
+    meas = est[0].copy()
+    meas[3:7] = [1.0, 0.0, 0.0, 0.0]            # the same ellipsoid turned by pi about its x axis (camera frame = world: Tcw = I)
+    g = pkg.Graph(K, 1, 1, None, e3d_cam=[0], e3d_obj=[0], e3d_meas=[meas], e3d_weight=[1e4])
+    for q in (-1, 0, 1, 2):                      # the configuration: every hypothesis is a half turn
+        a = q * np.pi / 2
+        Rz = np.eye(4); Rz[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        E = npo.T_inv(npo.obj_from10(meas)[0] @ Rz) @ npo.obj_from10(est[0])[0]
+        assert 0.5 * (np.trace(E[:3, :3]) - 1) < -1 + 1e-12
+    with np.errstate(all="ignore"):
+        r_ref = po.res_e3d(cam[0], est[0], meas)
+    for jac in (0, 1):
+        ctx.upload_graph(g); ctx.upload_states(cam, est)
+        ctx.lm_begin(pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6))
+        chi = ctx.lm_linearize().chi2
+        print("all four hypotheses half turns (jac %d): GPU chi2 %r, checker |r|^2 w %r" % (jac, chi, 1e4 * float(np.dot(r_ref, r_ref))))
+        assert (not np.isfinite(chi)) or chi >= 1e4 * (np.pi - 1e-3) ** 2
+        _, oo, rep = ctx.optimize(g, cam, est, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6))
+        assert np.all(np.isfinite(oo))
+
+
 def slam_graph_upto(pkg, g, f):
     """the SLAM-mode graph of frames 0 .. f: camera 0 fixed, one odometry edge per consecutive pair (Optimizer.cpp:126-158)"""
     mb, me, mo = g.bbox_cam <= f, g.e3d_cam <= f, g.odom_j <= f
