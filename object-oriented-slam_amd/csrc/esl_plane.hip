@@ -272,7 +272,7 @@ static __global__ __launch_bounds__(256) void k_plane_lab_init(PlaneArgs a) {
   else if (a.nrm[4 * (size_t)i] == a.nrm[4 * (size_t)i]) { const int m = a.plane_of_root[uf_find(a.parent, i)]; l = m >= 0 ? m : -2; }
   a.labels[i] = l;
 }
-// OrganizedMultiPlaneSegmentation::refine (see the file header; the CPU checker runs the literal loops, oracle/esl_oracle_plane.c).
+// OrganizedMultiPlaneSegmentation::refine (see the file header; the CPU checker under oracle/ runs the literal loops).
 // ONE workgroup; per row: (1) the row's labels -> LDS, (2) run starts from the labels as they are BEFORE this row's sweep (a pixel of
 // a model followed by an unlabelled-by-any-model pixel), (3) every run start walks its run -- runs end at the next pixel that is not
 // "other", so they are disjoint --, (4) the labels go back and every column tests the ONE pixel of the next row (quirk kept: not when
