@@ -12,5 +12,5 @@ cp $R/c3_slam_camera_first_kernel_stats.md profiles/${RN}_c3_slam_camera_first_k
 cp $R/mapping_c4_kernel_stats.md profiles/${RN}_mapping_c4_kernel_stats.md
 cp $R/cholesky_microbench.txt profiles/${RN}_cholesky_microbench.txt
 for n in slam_upload_probe fit_stage_timing fit_kernel_times; do [ -s $R/$n.txt ] && cp $R/$n.txt profiles/${RN}_$n.txt; done
-grep -v "^$" $R/gputest.log | grep -v "^\.\+$" | tail -60 > profiles/${RN}_gputest_tail.txt
+grep -v "^$" $R/gputest.log | grep -v "^\.\+$" | grep -v "^streaming frame [0-9]*: lock-step" | tail -150 > profiles/${RN}_gputest_tail.txt
 ls -la profiles
