@@ -1438,7 +1438,8 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
   const bool fuse = chol_fuse_default();
   if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0)) {
     { hipError_t e0 = hipStreamSynchronize(st); if (e0 != hipSuccess) return e0; }   // the old list / sync words may still be in use
-    chol_plan_build(n, W, /*filler*/ 128, rt.plan, fuse);
+    const char* fenv = std::getenv("ESL_CHOL_FILLER");   // (debugging: far-update tasks interleaved per chain-dependent group)
+    chol_plan_build(n, W, fenv ? std::max(1, std::atoi(fenv)) : 128, rt.plan, fuse);
     auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
       if (*cap >= need) return hipSuccess;
       if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
