@@ -266,8 +266,10 @@ int esl_lm_solver_used(esl_ctx* ctx, int32_t* solver_out);
 /* shape of the camera-first elimination of the resident graph as the last trial step ran it (zeros when it did not):
  * stats[0] form of X: 0 dense rows, 1 sparse with stored per-segment products, 2 sparse, blocks of T straight from the slabs;
  * [1] dissection stride (0: plain chain), [2] separators, [3] segments, [4] flops of the per-segment products (lower block triangles, rows from a block row's first camera on),
- * [5] bytes of the stored products, [6] bytes of the compact slabs, [7] rows of the dense MFMA update (K, padded). */
-#define ESL_SOLVER_STATS 8
+ * [5] bytes of the stored products, [6] bytes of the compact slabs, [7] rows of the dense MFMA update (K, padded),
+ * [8] flops that update executes when T's ellipsoids are ordered by first camera and the structurally zero rows above the
+ *     staircase are skipped tile by tile (0: the closed form n (n + 1) K applies), [9] 1 if T is in that order. */
+#define ESL_SOLVER_STATS 10
 int esl_lm_solver_stats(esl_ctx* ctx, double stats[ESL_SOLVER_STATS]);
 
 /* inspection (tests, debugging): copy one device array of the current linearisation to the host.

@@ -288,8 +288,12 @@ constexpr int kCfFwdCh = 16;
 //   column after the last one = the right-hand side; rows go to the segment's slab Xc (xoff / xld), acc to R at the T column.
 constexpr int kCfSyT = 128;     // tile of the per-segment product kernel (compact columns)
 constexpr int kCfSegRows = 96;   // rows of a slab: 6 (kCfFwdCh - 1) = 90, padded with zero rows to a multiple of the T kernel's row batch
+// rank / unrank (round 5, null = identity): T's ellipsoids in the order of their FIRST free camera -- column block rank[o] of T, R, Xs
+// belongs to ellipsoid o.  The separators' rows of X are then zero above a staircase (an ellipsoid no camera has seen yet has no
+// entry in any R(k)), and the dense rank-K update skips them tile by tile (esl_chol.hpp, kfirst).
 struct CfSegs {
   const int* fwork; const int* seg_start; const int* seg_obj; const long long* xoff; const int* xld;
+  const int* rank; const int* unrank;
 };
 template <int MODE>
 static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, int n_chunks, const int* __restrict__ oe_cst /* [N][n_chunks + 1] */,
@@ -310,7 +314,7 @@ static __global__ __launch_bounds__(64) void k_cf_forward(int nf_all, int n_o, i
   const bool on = j <= jr, rhs = j == jr, col = on && !rhs;
   const int oi = col ? j / 9 : 0, b = j - 9 * oi;
   const int o = (MODE == 2 && col) ? sg.seg_obj[ob + oi] : oi;
-  const long tcol = MODE == 2 ? (rhs ? (long)n_o : 9L * o + b) : (long)j;   // this lane's column of T / R
+  const long tcol = MODE == 2 ? (rhs ? (long)n_o : 9L * (sg.rank ? sg.rank[o] : o) + b) : (long)j;   // this lane's column of T / R
   const int beg = SEP ? 0 : seg * stride;
   const int nf = SEP ? nf_all : ((beg + seglen < nf_all) ? beg + seglen : nf_all);
   if (beg >= nf) return;
@@ -551,7 +555,8 @@ static __global__ __launch_bounds__(64) void k_cf_sep_rhs(int nf, int n_o, int s
 #pragma unroll
     for (int a = 0; a < 6; ++a) vs[a] = vy[(size_t)s * 6 + a];
   } else {
-    const int o = j / 9, b = j - 9 * o;
+    const int tb = j / 9, b = j - 9 * tb;
+    const int o = sg.unrank ? sg.unrank[tb] : tb;
     const int* cst = oe_cst + (size_t)o * (n_chunks + 1);
     const int ch = s / kCfFwdCh;
     for (int q = cst[ch]; q < cst[ch + 1]; ++q)
@@ -564,7 +569,8 @@ static __global__ __launch_bounds__(64) void k_cf_sep_rhs(int nf, int n_o, int s
   bool has_acc = (k + 1) * stride < nf;   // a segment behind s exists (else R(k) was never written)
   double xl[6] = {0, 0, 0, 0, 0, 0};
   if (cmap) {   // X sparse: column j is zero over a segment unless its ellipsoid is in the segment's list
-    const int ob = rhs ? N1 - 1 : j / 9, bb = rhs ? 0 : j - 9 * ob;
+    const int tb2 = j / 9, bb = rhs ? 0 : j - 9 * tb2;
+    const int ob = rhs ? N1 - 1 : (sg.unrank ? sg.unrank[tb2] : tb2);
     has_acc = has_acc && cmap[(size_t)(k + 1) * N1 + ob] >= 0;
     const int e = cmap[(size_t)k * N1 + ob];
     if (e >= 0) {
@@ -741,15 +747,17 @@ static __global__ __launch_bounds__(256) void k_cf_T_sparse(int N, int nw, const
                                                             const long long* __restrict__ xoff, const int* __restrict__ xld,
                                                             const double* __restrict__ Xc, const double* __restrict__ Hoo,
                                                             const double* __restrict__ bo, double lambda, double* __restrict__ T, long ldt,
-                                                            int o2_begin, int o2_end) {
+                                                            int o2_begin, int o2_end, const int* __restrict__ unrank) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int o1 = blockIdx.x;                    // N = the right-hand side (row 9 N of T)
+  const int t1 = blockIdx.x;                    // block row of T (its order: unrank, null = ellipsoid order); N = the right-hand side (row 9 N of T)
+  const int o1 = (t1 == N || !unrank) ? t1 : unrank[t1];
   const int r = lane & 15, kq = lane >> 4;
   const int N1 = N + 1;
   const long n_o = 9L * N;
   for (int q = wave; q < kCfTPer; q += 4) {
-    const int o2 = o2_begin + (int)blockIdx.y * kCfTPer + q;
-    if (o2 >= o2_end || o2 > o1 || o2 >= N) continue;
+    const int t2 = o2_begin + (int)blockIdx.y * kCfTPer + q;
+    if (t2 >= o2_end || t2 > t1 || t2 >= N) continue;
+    const int o2 = unrank ? unrank[t2] : t2;
     cf_d4 acc = {0, 0, 0, 0};
     for (int wd = 0; wd < nw; ++wd) {
       unsigned long long m = mask[(size_t)o1 * nw + wd] & mask[(size_t)o2 * nw + wd];
@@ -789,14 +797,14 @@ static __global__ __launch_bounds__(256) void k_cf_T_sparse(int N, int nw, const
       for (int g = 0; g < 4; ++g) {
         const int i = kq + 4 * g;
         if (o1 == N) {
-          if (i == 0) T[n_o + (9L * o2 + r) * ldt] = bo[(size_t)o2 * 9 + r] - acc[g];
+          if (i == 0) T[n_o + (9L * t2 + r) * ldt] = bo[(size_t)o2 * 9 + r] - acc[g];
         } else if (i < 9) {
           double base = 0;
           if (o1 == o2) {   // packed upper triangle of the symmetric block: (c, r) with c <= r at c * 9 - c (c - 1) / 2 + (r - c)
             const int lo = i < r ? i : r, hi = i < r ? r : i;
             base = Hoo[(size_t)o1 * 45 + lo * 9 - (lo * (lo - 1)) / 2 + (hi - lo)] + ((i == r) ? lambda : 0.0);
           }
-          T[(9L * o1 + i) + (9L * o2 + r) * ldt] = base - acc[g];
+          T[(9L * t1 + i) + (9L * t2 + r) * ldt] = base - acc[g];
         }
       }
     }
@@ -804,15 +812,16 @@ static __global__ __launch_bounds__(256) void k_cf_T_sparse(int N, int nw, const
 }
 
 // z = y - X x_o with the interior rows in the slabs: one workgroup per row (slot i, component a)
+// xo_t: x_o in T's column order (= xo unless T's ellipsoids are permuted, CfSegs::rank): what a separator's dense row meets
 static __global__ __launch_bounds__(256) void k_cf_z_sparse(int n_o, const double* __restrict__ Xs, long ldx, CfSegs sg, const double* __restrict__ Xc,
-                                                            const double* __restrict__ xo, double* __restrict__ z) {
+                                                            const double* __restrict__ xo, const double* __restrict__ xo_t, double* __restrict__ z) {
   __shared__ double red[4];
   const int t = blockIdx.x, i = t / 6, a = t - 6 * i;
   const int p = i / kCfFwdCh, pos = i - p * kCfFwdCh;
   double s = 0, y;
   if (pos == kCfFwdCh - 1) {   // separator p: a dense row
     const double* row = Xs + (size_t)(6 * p + a) * (size_t)ldx;
-    for (int o = threadIdx.x; o < n_o; o += 256) s += row[o] * xo[o];
+    for (int o = threadIdx.x; o < n_o; o += 256) s += row[o] * xo_t[o];
     y = row[n_o];
   } else {
     const int ob = sg.seg_start[p], m = 9 * (sg.seg_start[p + 1] - ob);
@@ -933,15 +942,17 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
                                                             const long long* __restrict__ boff, const long long* __restrict__ roff,
                                                             const double* __restrict__ P, const double* __restrict__ Prhs,
                                                             const double* __restrict__ Hoo, const double* __restrict__ bo, double lambda,
-                                                            double* __restrict__ T, long ldt, int o2_begin, int o2_end) {
+                                                            double* __restrict__ T, long ldt, int o2_begin, int o2_end, const int* __restrict__ unrank) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int o1 = blockIdx.x;                    // N = the right-hand side (row 9 N of T)
+  const int t1 = blockIdx.x;                    // block row of T (its order: unrank, null = ellipsoid order); N = the right-hand side (row 9 N of T)
+  const int o1 = (t1 == N || !unrank) ? t1 : unrank[t1];
   const int N1 = N + 1;
   const long n_o = 9L * N;
   const bool rhs = o1 == N;
   for (int q = wave; q < kCfTPer; q += 4) {
-    const int o2 = o2_begin + (int)blockIdx.y * kCfTPer + q;
-    if (o2 >= o2_end || o2 > o1 || o2 >= N) continue;
+    const int t2 = o2_begin + (int)blockIdx.y * kCfTPer + q;
+    if (t2 >= o2_end || t2 > t1 || t2 >= N) continue;
+    const int o2 = unrank ? unrank[t2] : t2;
     double s0 = 0, s1 = 0;                      // entries lane and 64 + lane of the 81 (column major: entry = 9 j + i)
     const int eT0 = (lane % 9) * 9 + lane / 9, eT1 = lane < 17 ? ((64 + lane) % 9) * 9 + (64 + lane) / 9 : 0;   // the same entries of the transposed block
     for (int wd = 0; wd < nw; ++wd) {
@@ -985,7 +996,7 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
       }
     }
     if (rhs) {
-      if (lane < 9) T[n_o + (9L * o2 + lane) * ldt] = bo[(size_t)o2 * 9 + lane] - s0;
+      if (lane < 9) T[n_o + (9L * t2 + lane) * ldt] = bo[(size_t)o2 * 9 + lane] - s0;
     } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -995,12 +1006,22 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
         if (o1 == o2 && i < j) continue;        // (above the diagonal: never stored, never read)
         double base = 0;
         if (o1 == o2) base = Hoo[(size_t)o1 * 45 + j * 9 - (j * (j - 1)) / 2 + (i - j)] + ((i == j) ? lambda : 0.0);
-        T[(9L * o1 + i) + (9L * o2 + j) * ldt] = base - (h ? s1 : s0);
+        T[(9L * t1 + i) + (9L * t2 + j) * ldt] = base - (h ? s1 : s0);
       }
     }
   }
 }
 
+
+// x_o arrives from the solver in T's column order; everything else (trial states, the slabs' dot products, esl_lm_download) wants it
+// by ellipsoid
+static __global__ __launch_bounds__(256) void k_cf_xo_unpermute(int N, const int* __restrict__ rank, const double* __restrict__ xo_t,
+                                                                double* __restrict__ xo) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 9 * N) return;
+  const int o = t / 9, i = t - 9 * o;
+  xo[t] = xo_t[9 * rank[o] + i];
+}
 
 // ---- the camera-first form's index tables, generated on the device (round 4) ---------------------------------------------------
 // The host ships only what it takes a sort to know (esl_slam.hip cf_ensure_impl): the per-ellipsoid lists in (slot, u) order and

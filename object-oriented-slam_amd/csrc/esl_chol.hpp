@@ -629,7 +629,8 @@ template <int BM, int BN, int WM = 4, int WN = 2>
 static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
                                                                            int kcol0, int K, long base, int ntJ, int rect,
                                                                            const double* __restrict__ Pext, long ldp,
-                                                                           double* __restrict__ part, int kper) {
+                                                                           double* __restrict__ part, int kper,
+                                                                           const int* __restrict__ kfirst = nullptr) {
   static_assert((BM == 2 * BN || BM == BN) && BM % 64 == 0, "tile shape");
   constexpr int RT = BM / BN;                     // tile row ti of the lower triangle holds RT (ti + 1) tiles
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -659,6 +660,20 @@ static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(doub
     P += (long)kbeg * ldp;
     K = (K - kbeg < kper) ? K - kbeg : kper;
     M = part + (size_t)blockIdx.y * (size_t)lda * (size_t)ncols;
+    if (K <= 0) return;
+  }
+  // kfirst (external factor only, round 5): kfirst[g] = the first row of Pext that can be non-zero in any of the columns
+  // [64 g, 64 g + 64) -- esl_cf.hpp orders T's ellipsoids by first camera, so the separators' rows of X are structurally zero above a
+  // staircase.  A product term (row r, column c) needs both factors non-zero: the tile starts at the later of its two earliest
+  // rows, rounded down to a chunk.  Only exact zeros are skipped: the result has the same bits.
+  if (kfirst) {
+    int ka = K, kb = K;
+    for (long g = i0 / 64; g < (i0 + BM) / 64; ++g) ka = kfirst[g] < ka ? kfirst[g] : ka;
+    for (long g = j0 / 64; g < (j0 + BN) / 64; ++g) kb = kfirst[g] < kb ? kfirst[g] : kb;
+    int ks = ka > kb ? ka : kb;
+    ks = (ks < K ? ks : K) & ~(kKC - 1);
+    P += (long)ks * ldp;
+    K -= ks;
     if (K <= 0) return;
   }
   // (diagnostic, ESL_CHOL_TIMING: shader clock ticks against 100 MHz wall-clock ticks over one tile of the last launch -- is the
@@ -878,8 +893,10 @@ static __global__ __launch_bounds__(256) void k_chol_splitk_reduce(double* __res
 constexpr size_t kCholLdsBig = (size_t)(2 * kKC * (256 + 16 + 128 + 16)) * sizeof(double);
 constexpr size_t kCholLdsSmall = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * sizeof(double);
 constexpr int kCholMaxSplit = 16;
+// kfirst (optional, with Pext): per group of 64 columns the first row of Pext that can be non-zero there (see the kernel); the array
+// covers rows + 256 columns.
 inline void chol_launch_update(double* M, long lda, long rows, hipStream_t stream, int kcol0, int K, long base, long col_limit,
-                               const double* Pext = nullptr, long ldp = 0, double* part = nullptr) {
+                               const double* Pext = nullptr, long ldp = 0, double* part = nullptr, const int* kfirst = nullptr) {
   // trailing region: rows [base, rows), cols [base, col_limit)
   const long nrows = rows - base, nc = col_limit - base;
   if (nrows <= 0 || nc <= 0) return;
@@ -890,7 +907,7 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
     const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
     const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
     hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), kCholLdsBig, stream, M, lda, rows, col_limit, kcol0, K,
-                       base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0);
+                       base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0, Pext ? kfirst : nullptr);
   } else {
     const long ntI = (nrows + 127) / 128, ntJ = (nc + 63) / 64;
     const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;
@@ -906,7 +923,7 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
       hipLaunchKernelGGL(k_chol_splitk_reduce, dim3((unsigned)((rows * col_limit + 255) / 256)), dim3(256), 0, stream, M, lda, rows, col_limit, part, nsplit);
     } else {
       hipLaunchKernelGGL((k_chol_update_lds<128, 64>), dim3((unsigned)nblk), dim3(512), kCholLdsSmall, stream, M, lda, rows, col_limit, kcol0, K,
-                         base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0);
+                         base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0, Pext ? kfirst : nullptr);
     }
   }
 }

@@ -239,6 +239,13 @@ struct esl_ctx {
   int* cf_twork = nullptr;
   size_t cf_p_blocks = 0, cf_prhs_len = 0;
   double *cf_P = nullptr, *cf_Prhs = nullptr;
+  // round 5: T's ellipsoids in the order of their first free camera (sparse form): column block cf_rank[o] of T / R / Xs belongs to
+  // ellipsoid o; cf_kfirst[g] = first row of Xs that can be non-zero in columns [64 g, 64 g + 64) (the rank-K update skips the rest);
+  // cf_xo_t = x_o as the solver returns it (T's order); cf_upd_flops = what the dense update executes with the staircase
+  bool cf_tperm = false;
+  int *cf_rank = nullptr, *cf_unrank = nullptr, *cf_kfirst = nullptr;
+  double* cf_xo_t = nullptr;
+  double cf_upd_flops = 0;
   int lm_solver_used = 0;   // esl_linear_solver the last trial step ran with (1 reduced camera system, 2 reduced ellipsoid system)
   // per-context runtime of the dense solver (esl_chol.hpp CholRuntime: look-ahead stream + events on THIS device, one-time
   // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context

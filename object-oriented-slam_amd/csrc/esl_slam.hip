@@ -279,6 +279,7 @@ static void cf_forget(esl_ctx* c) {
   c->cf_T = c->cf_Linv_ws = c->cf_part = nullptr;
   c->cf_Zt = c->cf_Hs = c->cf_Bs = c->cf_LfacS = c->cf_GS = c->cf_LiS = c->cf_MS = c->cf_NS = c->cf_R = nullptr;
   c->cf_Xc = c->cf_Xs = c->cf_P = c->cf_Prhs = c->cf_Xt = nullptr;
+  c->cf_rank = c->cf_unrank = c->cf_kfirst = nullptr; c->cf_xo_t = nullptr; c->cf_tperm = false; c->cf_upd_flops = 0;
   c->cf_ready = false; c->cf_sp_built = c->cf_sparse = false;
 }
 static int cf_ensure_impl(esl_ctx* c);
@@ -400,12 +401,53 @@ static int cf_ensure_impl(esl_ctx* c) {
     if (sp) sd = kCfFwdCh;
     c->cf_stride = sd; c->cf_n_sep = (int)(nf / sd); c->cf_n_seg = (int)((nf + sd - 1) / sd);
   }
+  // T's ellipsoids by first free camera (sparse form; ESL_CF_TPERM=0: ellipsoid order, A/B): rank by a counting sort over the
+  // first slot of every ellipsoid's (slot-sorted) list, ellipsoids without a free-camera edge last; kfirst per 64 columns of T: the
+  // first separator whose right-hand side R(k) can hold the column's ellipsoid is the one in FRONT of the segment of its first
+  // camera (an interior camera's segment hands its sum to the separator before it; conservative for a separator camera itself),
+  // and the right-hand side's ROW (row n_o of T, X^T y) is dense from the start
+  std::vector<int> h_rank, h_unrank, h_kfirst;
+  double upd_flops = 0;
+  const bool tperm = sp && N > 0 && !(std::getenv("ESL_CF_TPERM") && std::getenv("ESL_CF_TPERM")[0] == '0');
+  if (tperm) {
+    std::vector<int> first((size_t)N, nfi), cnt((size_t)nfi + 2, 0);
+    for (int o = 0; o < N; ++o) if (start[(size_t)o + 1] > start[o]) first[o] = os[(size_t)start[o]];
+    for (int o = 0; o < N; ++o) ++cnt[(size_t)first[o] + 1];
+    for (int s2 = 0; s2 <= nfi; ++s2) cnt[(size_t)s2 + 1] += cnt[s2];
+    h_rank.assign((size_t)N, 0); h_unrank.assign((size_t)N, 0);
+    for (int o = 0; o < N; ++o) { const int t = cnt[first[o]]++; h_rank[o] = t; h_unrank[t] = o; }
+    const int Ks = (int)((6 * (size_t)c->cf_n_sep + kKC - 1) / kKC * kKC);
+    const size_t ng = (n_o + 1 + 256) / 64 + 8;
+    h_kfirst.assign(ng, Ks);
+    for (size_t col = 0; col < n_o; ++col) {
+      const int o = h_unrank[col / 9];
+      const int k0 = std::max(0, first[o] / kCfFwdCh - 1);
+      const int row = std::min(6 * k0, Ks);
+      h_kfirst[col / 64] = std::min(h_kfirst[col / 64], row);
+    }
+    h_kfirst[n_o / 64] = 0;   // the right-hand side's row
+    // flops the update executes: per 256 x 128 tile of the lower triangle, K from the later of the tile's two earliest rows on
+    const long nti = ((long)n_o + 1 + 255) / 256;
+    for (long ti = 0; ti < nti; ++ti) {
+      int ka = Ks;
+      for (long g2 = ti * 4; g2 < ti * 4 + 4; ++g2) ka = std::min(ka, h_kfirst[(size_t)g2]);
+      for (long tj = 0; tj <= 2 * ti + 1 && tj * 128 < (long)n_o; ++tj) {
+        const int kb = std::min(h_kfirst[(size_t)(tj * 2)], h_kfirst[(size_t)(tj * 2 + 1)]);
+        const int ks = std::min(std::max(ka, kb), Ks) & ~(kKC - 1);
+        const double rows_t = (double)std::min<long>(256, (long)n_o + 1 - ti * 256), cols_t = (double)std::min<long>(128, (long)n_o - tj * 128);
+        const double in_triangle = tj < 2 * ti ? 1.0 : (tj == 2 * ti ? 0.75 : 0.25);   // the two tiles of a tile row that meet the diagonal
+        upd_flops += 2.0 * rows_t * cols_t * (double)(Ks - ks) * in_triangle;
+      }
+    }
+  }
+  c->cf_tperm = tperm; c->cf_upd_flops = upd_flops;
   const double t1 = timing ? now_us() : 0;
   // ---- layout: what the host ships first, then the device-generated tables (esl_cf.hpp k_cf_make_*), then the buffers ----
   BlobStage st;
   const int i_st = st.up(&c->cf_oe_start, start.size()), i_ou = st.up(&c->cf_oe_u, nue), i_os = st.up(&c->cf_oe_slot, nue);
   int* d_inc = nullptr; int* d_fw_off = nullptr; long long* d_tw_off = nullptr;
-  int i_inc = -1, i_ss = -1, i_xld = -1, i_xoff = -1, i_boff = -1, i_roff = -1, i_fwo = -1, i_two = -1;
+  int i_inc = -1, i_ss = -1, i_xld = -1, i_xoff = -1, i_boff = -1, i_roff = -1, i_fwo = -1, i_two = -1, i_rk = -1, i_ur = -1, i_kf = -1;
+  if (tperm) { i_rk = st.up(&c->cf_rank, h_rank.size()); i_ur = st.up(&c->cf_unrank, h_unrank.size()); i_kf = st.up(&c->cf_kfirst, h_kfirst.size()); }
   if (sp) {
     i_inc = st.up(&d_inc, 4 * n_inc); i_ss = st.up(&c->cf_seg_start, (size_t)nseg + 1); i_xld = st.up(&c->cf_xld, (size_t)nseg);
     i_xoff = st.up(&c->cf_xoff, (size_t)nseg + 1); i_boff = st.up(&c->cf_boff, (size_t)nseg + 1); i_roff = st.up(&c->cf_roff, (size_t)nseg + 1);
@@ -419,6 +461,7 @@ static int cf_ensure_impl(esl_ctx* c) {
   st.work(&c->cf_Linv, nf * 36); st.work(&c->cf_M, nf * 36); st.work(&c->cf_N, nf * 36); st.work(&c->cf_V, EU * 54);
   st.work(&c->cf_B, nf * 36); st.work(&c->cf_Lfac, nf * 21); st.work(&c->cf_G, nf * 36); st.work(&c->cf_vy, nf * 6); st.work(&c->cf_z, nf * 6);
   st.work(&c->cf_T, (size_t)c->cf_ldt * n_o); st.work(&c->cf_Linv_ws, ((n_o + kNB - 1) / kNB) * kNB * kNB);
+  if (tperm) st.work(&c->cf_xo_t, n_o);
   if (n_o <= 1024) st.work(&c->cf_part, (size_t)kCholMaxSplit * (size_t)c->cf_ldt * n_o);   // split-K workspace of small systems
   if (nd) {
     const size_t ns = (size_t)std::max(c->cf_n_sep, 1);
@@ -437,6 +480,11 @@ static int cf_ensure_impl(esl_ctx* c) {
   // ---- fill the staging blob, ship it, generate the dense tables ----
   std::memcpy(st.host<int>(i_st), start.data(), start.size() * sizeof(int));
   if (nue) { std::memcpy(st.host<int>(i_ou), ou.data(), nue * sizeof(int)); std::memcpy(st.host<int>(i_os), os.data(), nue * sizeof(int)); }
+  if (tperm) {
+    std::memcpy(st.host<int>(i_rk), h_rank.data(), h_rank.size() * sizeof(int));
+    std::memcpy(st.host<int>(i_ur), h_unrank.data(), h_unrank.size() * sizeof(int));
+    std::memcpy(st.host<int>(i_kf), h_kfirst.data(), h_kfirst.size() * sizeof(int));
+  }
   if (sp) {
     int* inc = st.host<int>(i_inc);
     if (n_inc) {
@@ -527,7 +575,7 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
         hipLaunchKernelGGL(k_cf_forward<1>, dim3(cg), dim3(64), 0, c->stream, ns, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
                            c->cf_MS, c->cf_Xt, ldx, ns, ns, (const double*)nullptr, c->cf_R, st, CfSegs{});
       } else {   // interior rows into the segments' compact slabs, the separators' dense rows into Xs (row block k = separator k)
-        const CfSegs sg{c->cf_fwork, c->cf_seg_start, c->cf_seg_obj, c->cf_xoff, c->cf_xld};
+        const CfSegs sg{c->cf_fwork, c->cf_seg_start, c->cf_seg_obj, c->cf_xoff, c->cf_xld, c->cf_rank, c->cf_unrank};
         hipLaunchKernelGGL(k_cf_forward<2>, dim3((unsigned)c->cf_n_fwork), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V,
                            c->cf_vy, c->cf_M, c->cf_Xc, ldx, st, st - 1, (const double*)c->cf_Zt, c->cf_R, st, sg);
         hipLaunchKernelGGL(k_cf_sep_rhs, dim3(cg, (unsigned)ns), dim3(64), 0, c->stream, nf, n_o, st, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
@@ -558,10 +606,10 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
         const dim3 grid((unsigned)(N + 1), (unsigned)((o2e - o2b + kCfTPer - 1) / kCfTPer));
         if (c->cf_sp_form == 1)
           hipLaunchKernelGGL(k_cf_T_gather, grid, dim3(256), 0, c->stream, N, c->cf_sp_nw, c->cf_mask, c->cf_cmap, c->cf_boff, c->cf_roff, c->cf_P, c->cf_Prhs,
-                             c->Hoo, c->bo, lambda, c->cf_T, ldt, o2b, o2e);
+                             c->Hoo, c->bo, lambda, c->cf_T, ldt, o2b, o2e, (const int*)c->cf_unrank);
         else
           hipLaunchKernelGGL(k_cf_T_sparse, grid, dim3(256), 0, c->stream, N, c->cf_sp_nw, c->cf_mask, c->cf_cmap, c->cf_xoff, c->cf_xld, c->cf_Xc, c->Hoo, c->bo,
-                             lambda, c->cf_T, ldt, o2b, o2e);
+                             lambda, c->cf_T, ldt, o2b, o2e, (const int*)c->cf_unrank);
       }
     }
     ESL_HIP_TRY(hipGetLastError());
@@ -573,26 +621,28 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
       if (dist) {
         for (int op = c->comm_rank; op < n_outer; op += c->comm_ranks) {
           const long c_begin = (long)op * Wp * kNB, c_end = std::min<long>((long)(op + 1) * Wp * kNB, (long)n_o);
-          chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, K, c_begin, c_end, Xf, ldx);
+          chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, K, c_begin, c_end, Xf, ldx, nullptr, c->cf_sparse ? c->cf_kfirst : nullptr);
         }
       } else if (K > 0) {
-        chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, K, 0, (long)n_o, Xf, ldx, c->cf_part);
+        chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, K, 0, (long)n_o, Xf, ldx, c->cf_part, c->cf_sparse ? c->cf_kfirst : nullptr);
       }
     }
     ESL_HIP_TRY(hipGetLastError());
   }
   {
     ProfScope ps(c, 3);   // dense Cholesky of the reduced ellipsoid system + the camera back-substitution
+    double* xsol = (c->cf_sparse && c->cf_tperm) ? c->cf_xo_t : c->xo;   // the solver's x_o: in T's column order
     if (cf_dist(c)) {
       CholDist d;
       if ((rc = chol_dist_fill(c, n_o, d))) return rc;
-      ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt, &d));
+      ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, xsol, c->chol_info, c->stream, rt, &d));
     } else {
-      ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, c->xo, c->chol_info, c->stream, rt));
+      ESL_HIP_TRY(chol_factor_solve(c->cf_T, ldt, n_o, c->cf_Linv_ws, c->z_ws, xsol, c->chol_info, c->stream, rt));
     }
+    if (xsol != c->xo) hipLaunchKernelGGL(k_cf_xo_unpermute, dim3((unsigned)((n_o + 255) / 256)), dim3(256), 0, c->stream, N, c->cf_rank, xsol, c->xo);
     if (c->cf_sparse)
       hipLaunchKernelGGL(k_cf_z_sparse, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, n_o, c->cf_Xs, ldx,
-                         CfSegs{c->cf_fwork, c->cf_seg_start, c->cf_seg_obj, c->cf_xoff, c->cf_xld}, c->cf_Xc, c->xo, c->cf_z);
+                         CfSegs{c->cf_fwork, c->cf_seg_start, c->cf_seg_obj, c->cf_xoff, c->cf_xld, c->cf_rank, c->cf_unrank}, c->cf_Xc, c->xo, xsol, c->cf_z);
     else
       hipLaunchKernelGGL(k_cf_z, dim3((unsigned)(6 * nf)), dim3(256), 0, c->stream, c->cf_Xt, ldx, n_o, c->xo, c->cf_z);
     if (c->cf_stride > 0 && c->cf_n_sep > 0) {
@@ -1070,6 +1120,8 @@ extern "C" int esl_lm_solver_stats(esl_ctx* c, double* st) {
     st[6] = 8.0 * (double)c->cf_xc_len;
   }
   st[7] = (double)(c->cf_sparse ? c->cf_kpad_s : c->cf_kpad);
+  st[8] = c->cf_tperm ? c->cf_upd_flops : 0.0;   // (0: the whole lower triangle times K)
+  st[9] = c->cf_tperm ? 1.0 : 0.0;
   return ESL_OK;
 }
 extern "C" int esl_lm_solver_used(esl_ctx* c, int32_t* solver_out) {

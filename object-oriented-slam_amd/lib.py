@@ -194,9 +194,10 @@ class Context:
 
     def lm_solver_stats(self):
         """Shape of the camera-first elimination as the last trial ran it (esl_lm_solver_stats)."""
-        st = (C.c_double * 8)()
+        st = (C.c_double * 10)()   # ESL_SOLVER_STATS
         _check(load().esl_lm_solver_stats(self._h, st), "esl_lm_solver_stats")
-        names = ["x_form", "stride", "separators", "segments", "product_flops", "product_bytes", "slab_bytes", "dense_update_rows"]
+        names = ["x_form", "stride", "separators", "segments", "product_flops", "product_bytes", "slab_bytes", "dense_update_rows",
+                 "dense_update_flops_executed", "t_ordered_by_first_camera"]
         return {n: float(st[i]) for i, n in enumerate(names)}
 
     def lm_reduced_system(self, lam):

@@ -536,7 +536,14 @@ def test_ctx_trim_releases_the_solver_blobs_and_they_come_back(pkg):
     go back to the device; the next trial step builds what it needs again (index tables included) and lands on the same bits.  A
     mapping-mode graph uploaded over a SLAM-mode one trims by itself.  S lives in a blob of its own: esl_lm_reduced_system beside a
     camera-first run no longer re-lays that run's tables out (the pointer it returns stays valid across the next trial step)."""
-    import torch
+    import ctypes
+
+    def free_bytes():   # hipMemGetInfo of the HIP runtime libesl_hip.so itself runs on (no second runtime in the process)
+        pkg.lib.load()
+        hip = ctypes.CDLL("libamdhip64.so.7")   # the soname libesl_hip.so is linked against: the already loaded runtime
+        fr, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0
+        return fr.value
     g, c, o, _ = pkg.synth.make_graph(600, 120, 6000, seed=12, slam=True)
     p2 = pkg.default_lm_params(jacobian_mode=1, linear_solver=2, max_iters=3)
     cx = pkg.Context(0)
@@ -544,9 +551,9 @@ def test_ctx_trim_releases_the_solver_blobs_and_they_come_back(pkg):
         c2, o2, r2 = cx.optimize(g, c, o, p2)
         cx.upload_graph(g); cx.upload_states(c, o)
         c1, o1, r1 = None, None, cx.optimize_resident(pkg.default_lm_params(jacobian_mode=1, linear_solver=1, max_iters=3))   # S: 3,594^2 doubles = 103 MB beside the camera-first set
-        free_before = torch.cuda.mem_get_info(0)[0]
+        free_before = free_bytes()
         cx.trim()
-        free_after = torch.cuda.mem_get_info(0)[0]
+        free_after = free_bytes()
         assert free_after - free_before > 100e6, (free_before, free_after)
         cx.upload_states(c, o)
         ca, oa = cx.download_states()
@@ -566,9 +573,9 @@ def test_ctx_trim_releases_the_solver_blobs_and_they_come_back(pkg):
         cx.lm_commit(False)
         # a mapping-mode graph over a SLAM-mode one: the SLAM blobs go by themselves
         gm, cm, om, _ = pkg.synth.make_graph(600, 120, 6000, seed=12, slam=False)
-        free_slam = torch.cuda.mem_get_info(0)[0]
+        free_slam = free_bytes()
         cx.upload_graph(gm); cx.upload_states(cm, om)
-        assert torch.cuda.mem_get_info(0)[0] - free_slam > 100e6
+        assert free_bytes() - free_slam > 100e6
         assert np.isfinite(cx.optimize_resident(pkg.default_lm_params(jacobian_mode=1))["chi2_final"])
     finally:
         cx.close()
