@@ -9,6 +9,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -19,8 +20,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON_DEFAULT = ["--steps", "1", "--warmup", "0", "--config", "C3", "--no-cpu-baseline", "--no-extras"]
 
 
+DRIVER_LINE_MAX = 4096
+LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
 def run_bench(extra_args, n_ranks, env_extra, port, common=None):
-    COMMON = common if common is not None else COMMON_DEFAULT
+    """returns the FULL record (the side file `--extras`), after checking the one stdout line the driver parses: < 4 KB, the
+    contract's keys, and the same numbers as the full record (a 24 KB line was dropped by the driver)"""
+    COMMON = list(common if common is not None else COMMON_DEFAULT)
+    extras = os.path.join(tempfile.mkdtemp(prefix="esl_bench_"), "extras.json")
+    COMMON += ["--extras", extras]
     env = dict(os.environ)
     env.update(env_extra)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
@@ -34,7 +43,15 @@ def run_bench(extra_args, n_ranks, env_extra, port, common=None):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])      # rank 0 prints ONE line, the other ranks nothing
-    return json.loads(lines[0])
+    assert len(lines[0]) < DRIVER_LINE_MAX, len(lines[0])
+    line = json.loads(lines[0])
+    assert LINE_KEYS <= set(line), LINE_KEYS - set(line)
+    assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert "workload" in line["config"]
+    full = json.load(open(extras))
+    for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup"):
+        assert full[k] == line[k]
+    return full
 
 
 @pytest.fixture(scope="module")
