@@ -227,7 +227,7 @@ def slam_flops(n_c, n_o, solver, stats=None):
 def _pmc_traffic(sparse, key):
     """HBM bytes per launch of one kernel of the C4 SLAM trial from the newest committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE,
     scripts/pmc_summary.py): a committed file, not this run."""
-    for tag in ("r5", "r4"):
+    for tag in ("r6", "r5", "r4"):
         try:
             path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_c4_slam.json")
             pmc = json.load(open(path))

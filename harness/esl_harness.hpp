@@ -254,7 +254,7 @@ struct Settings {   // Example/param/TUM3.yaml + src/config/Config.cpp:29-30
   double scale_3d = 10000, gravity_scale = 100;      // Optimizer.Edges.*
   bool gravity_open = true, depth_ellipsoid = true, optimization = true, symmetry = true;
   esl_fit_params fit;                                // filled by the backend's defaults, then overridden from here
-  esl_plane_params plane = {200, 5.0, 0.1, 10, 0.05, 100, 1, 0.02};   // Plane.MinSize / AngleThreshold / DistanceThreshold + PlaneExtractor.cpp:57-58, 74 + segmentAndRefine's pass (:82)
+  esl_plane_params plane = {200, 5.0, 0.1, 10, 0.05, 100, 1, 0.02, 0.001};   // Plane.MinSize / AngleThreshold / DistanceThreshold + PlaneExtractor.cpp:57-58, 74 + segmentAndRefine's pass (:82)
   bool with_association = true;                      // rgbd.cpp:73
   bool slam_mode = false;                            // Optimizer.cpp:126 bSLAM_mode (a constant false in the reference)
   bool check_visibility = false;                     // GlobalObjectGraphOptimization's last argument (false at Tracking.cpp:226)

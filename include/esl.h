@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ESL_ABI_VERSION 4   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append
+#define ESL_ABI_VERSION 5   /* 2: esl_lm_params::bbox_residual, esl_fit_frame_ex, esl_init_from_qstar / esl_init_plane_error, esl_graph_append
                              * 3: esl_linear_solver gains ESL_SOLVER_REDUCED_CAMERA / ESL_SOLVER_REDUCED_ELLIPSOID, esl_lm_solver_used,
                              *    esl_lm_solver_stats, esl_comm_set_replicated, ESL_PROF_KINDS 9
                              * 4: ESL_PROF_KINDS 10 (class 9: the dense factorisation alone), esl_ctx_trim, esl_comm_set_replicated refuses a
@@ -144,6 +144,11 @@ typedef struct {
   int32_t linear_solver;    /* esl_linear_solver (SLAM mode only; ignored when all cameras are fixed) */
   int32_t drop_nan_bbox;    /* 1: pre-evaluate bbox edges and drop those with NaN chi2 (Optimizer.cpp:234-243) */
   int32_t bbox_residual;    /* esl_bbox_residual; 0 = the reference */
+  int32_t e3d_half_turn;    /* 3-D edge, choice among the four yaw hypotheses (Ellipsoid.cpp:92-117).  0 (default): a hypothesis whose relative
+                             * rotation is within ~1.4e-6 rad of a HALF TURN is not eligible -- the reference's log has no branch for theta -> pi
+                             * (se3quat.h:229-266: 0/0, decided by the last bit of the trace), its true norm is pi and never the minimum.
+                             * 1: the minimum exactly as the reference writes it (minCoeff over the four norms, half turns included): bit-level
+                             * faithful where the log is well defined, implementation-defined where the reference itself is (ABI 5) */
 } esl_lm_params;
 
 typedef struct {
@@ -387,10 +392,14 @@ typedef struct esl_plane_params {
   double max_depth_change_factor; /* setMaxDepthChangeFactor(0.05) */
   int32_t min_inliers;            /* setMinInliers(100) */
   /* ABI 4: the second half of segmentAndRefine (PlaneExtractor.cpp:82) -- PCL's OrganizedMultiPlaneSegmentation::refine: two raster
-   * passes in which a model (segment of >= min_inliers pixels) absorbs neighbouring pixels that belong to no model and lie within
+   * passes in which a model (segment of > min_inliers pixels that passes the curvature test below) absorbs neighbouring pixels that belong to no model and lie within
    * refine_distance of its plane.  Grows the inlier lists (sizes, labels, which candidate is the largest), not the coefficients. */
   int32_t refine;                 /* 1 (default): as the reference; 0: segments only (the round 2-4 behaviour) */
   double refine_distance;         /* PlaneRefinementComparator's distance threshold: 0.02 m, not depth dependent */
+  /* ABI 5: which segments PCL's segment() keeps as MODELS -- size > min_inliers (strict) and surface curvature
+   * |lambda_min| / trace(cov) of the segment's points < maximum_curvature_ (PCL's default 0.001; the reference does not set it).  A
+   * segment that fails either test is an "other" label, which the refinement pass lets neighbouring models absorb.  <= 0: no test. */
+  double max_curvature;           /* 0.001 */
 } esl_plane_params;
 void esl_plane_params_default(esl_plane_params* p);
 /* PlaneExtractor::extractGroundPlane(depth, plane) (PlaneExtractor.cpp:107-183): the largest plane segment of the depth image

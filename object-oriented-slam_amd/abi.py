@@ -48,7 +48,7 @@ class EslLmParams(C.Structure):
     _fields_ = [
         ("max_iters", C.c_int32), ("max_trials", C.c_int32), ("tau", C.c_double),
         ("jacobian_mode", C.c_int32), ("numeric_delta", C.c_double),
-        ("linear_solver", C.c_int32), ("drop_nan_bbox", C.c_int32), ("bbox_residual", C.c_int32),
+        ("linear_solver", C.c_int32), ("drop_nan_bbox", C.c_int32), ("bbox_residual", C.c_int32), ("e3d_half_turn", C.c_int32),
     ]
 
 
@@ -97,13 +97,13 @@ class EslPlaneParams(C.Structure):
     """esl_plane_params (PlaneExtractorParam + the PCL constants of PlaneExtractor.cpp:57-58, 74)."""
     _fields_ = [("min_size", C.c_int32), ("angle_threshold_deg", C.c_double), ("distance_threshold", C.c_double),
                 ("normal_smoothing", C.c_int32), ("max_depth_change_factor", C.c_double), ("min_inliers", C.c_int32),
-                ("refine", C.c_int32), ("refine_distance", C.c_double)]
+                ("refine", C.c_int32), ("refine_distance", C.c_double), ("max_curvature", C.c_double)]
 
 
 def default_plane_params(**kw):
     """Example/param/TUM3.yaml:36-38 + PlaneExtractor.cpp:57-58, 74."""
     p = EslPlaneParams(min_size=200, angle_threshold_deg=5.0, distance_threshold=0.1, normal_smoothing=10,
-                       max_depth_change_factor=0.05, min_inliers=100, refine=1, refine_distance=0.02)
+                       max_depth_change_factor=0.05, min_inliers=100, refine=1, refine_distance=0.02, max_curvature=0.001)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -118,7 +118,7 @@ def default_lm_params(**kw):
     """Reference settings: optimize(10) (Optimizer.cpp:291), tau 1e-5, 10 trials
     (optimization_algorithm_levenberg.cpp:45-49), delta 1e-9 (base_binary_edge.hpp:147)."""
     p = EslLmParams(max_iters=10, max_trials=10, tau=1e-5, jacobian_mode=0, numeric_delta=1e-9,
-                    linear_solver=0, drop_nan_bbox=1, bbox_residual=0)
+                    linear_solver=0, drop_nan_bbox=1, bbox_residual=0, e3d_half_turn=0)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

@@ -194,6 +194,7 @@ void esl_lm_params_default(esl_lm_params* p) {
   p->linear_solver = ESL_SOLVER_AUTO;
   p->drop_nan_bbox = 1;
   p->bbox_residual = ESL_BBOX_REPROJECTION;
+  p->e3d_half_turn = 0;
 }
 
 int esl_ctx_create(int device_id, esl_ctx** out) {
@@ -1151,6 +1152,7 @@ static int lm_begin_enqueue(esl_ctx* c, const esl_lm_params* p, bool validate_in
   ESL_HIP_TRY(hipSetDevice(c->device));
   c->lm.p = *p;
   c->g.bbox_mode = p->bbox_residual == ESL_BBOX_TANGENCY ? 1 : 0;
+  c->g.yt.as_written = p->e3d_half_turn ? 1 : 0;
   c->lm.slam = c->g.n_free_cams > 0;
   c->lm.have_trial = false;
   int* cnt = c->chol_info + 2;
@@ -1391,6 +1393,7 @@ int esl_optimize_resident(esl_ctx* c, const esl_lm_params* p, esl_lm_report* out
     set_error("esl_lm_params::linear_solver: unknown solver"); return ESL_ERR_INVALID;
   }
   if (p->bbox_residual != ESL_BBOX_REPROJECTION && p->bbox_residual != ESL_BBOX_TANGENCY) { set_error("esl_lm_params::bbox_residual: unknown mode"); return ESL_ERR_INVALID; }
+  if (p->e3d_half_turn != 0 && p->e3d_half_turn != 1) { set_error("esl_lm_params::e3d_half_turn: 0 (half turns not eligible) or 1 (as the reference writes it)"); return ESL_ERR_INVALID; }
   std::memset(out, 0, sizeof(*out));
   if (c->graph_loaded) { const int rcr = comm_check_replicated(c); if (rcr) return rcr; }
   if (c->graph_loaded && c->g.n_free_cams == 0) {   // mapping mode: the LM runs on the device, nothing waits on the host

@@ -559,6 +559,29 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
       if (!skip) {
         const double* Ab = As + buf * kKC * kLdA + wi * SM + r;
         const double* Bb = Bs + buf * kKC * kLdB + wj * SN + r;
+        if constexpr (WM * WN <= 4) {
+          // one wave per SIMD (accumulators in AGPRs): nothing but this wave's own instruction stream hides the LDS latency, so the
+          // fragments of k-step s + 1 are requested before the MFMAs of k-step s issue (two register sets)
+          double a[2][MI], bq[2][NJ];
+#pragma unroll
+          for (int m = 0; m < MI; ++m) a[0][m] = Ab[kq * kLdA + m * 16];
+#pragma unroll
+          for (int m = 0; m < NJ; ++m) bq[0][m] = Bb[kq * kLdB + m * 16];
+#pragma unroll
+          for (int kk = 0; kk < kKC; kk += 4) {
+            const int cur = (kk >> 2) & 1;
+            if (kk + 4 < kKC) {
+#pragma unroll
+              for (int m = 0; m < MI; ++m) a[cur ^ 1][m] = Ab[(kk + 4 + kq) * kLdA + m * 16];
+#pragma unroll
+              for (int m = 0; m < NJ; ++m) bq[cur ^ 1][m] = Bb[(kk + 4 + kq) * kLdB + m * 16];
+            }
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) acc[nj][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[cur][nj], a[cur][mi], acc[nj][mi], 0, 0, 0);
+          }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < kKC; kk += 4) {
           double a[MI], bq[NJ];
@@ -570,6 +593,7 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
           for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[nj][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[nj], a[mi], acc[nj][mi], 0, 0, 0);
+        }
         }
       }
       if (more) sstore(buf ^ 1);
@@ -626,7 +650,7 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
 }
 
 template <int BM, int BN, int WM = 4, int WN = 2>
-static __global__ __launch_bounds__(64 * WM * WN, 2) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
+static __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 1 : 2)) void k_chol_update_lds(double* __restrict__ M, long lda, long rows, long ncols,
                                                                            int kcol0, int K, long base, int ntJ, int rect,
                                                                            const double* __restrict__ Pext, long ldp,
                                                                            double* __restrict__ part, int kper,
@@ -906,6 +930,11 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
   if (big_tiles >= 1024) {   // (square 128 x 128 tiles, two workgroups per CU, measured at n = 32,768: 238.7 vs 231.6 ms -- dropped)
     const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
     const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
+    static const int waves4 = [] { const char* e = std::getenv("ESL_UPD_WAVES"); return (e && std::atoi(e) == 4) ? 1 : 0; }();
+    if (waves4)   // (experiment, round 6) four waves of 128 x 64, one per SIMD, accumulators in AGPRs
+      hipLaunchKernelGGL((k_chol_update_lds<256, 128, 2, 2>), dim3((unsigned)nblk), dim3(256), kCholLdsBig, stream, M, lda, rows, col_limit, kcol0, K,
+                         base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0, Pext ? kfirst : nullptr);
+    else
     hipLaunchKernelGGL((k_chol_update_lds<256, 128>), dim3((unsigned)nblk), dim3(512), kCholLdsBig, stream, M, lda, rows, col_limit, kcol0, K,
                        base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0, Pext ? kfirst : nullptr);
   } else {
@@ -1422,6 +1451,8 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
   e = hipFuncSetAttribute((const void*)k_chol_potrf2_512<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBig);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_chol_update_lds<256, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBig);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_chol_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBsLds);
   if (e != hipSuccess) return e;

@@ -504,8 +504,9 @@ ESL_HD void jac_box_edge(int mode, const SE3& Tcw, const Ell& e, const double K[
 // ------------------------------------------------------------------------------------------------
 // sin/cos of yaw/2 for yaw = k*pi/2, k = -1,0,1,2, and the entries of the yaw rotation matrix Rz built from the
 // NORMALISED quaternion (0,0,s,c) exactly as q_to_R would: cy = 1 - 2 z^2, sy = 2 z w.  Filled once on the host.
-struct YawTable { double s[4], c[4], cy[4], sy[4]; };
+struct YawTable { double s[4], c[4], cy[4], sy[4]; int as_written; /* esl_lm_params::e3d_half_turn of the current run */ };
 ESL_HD void yaw_table_fill(YawTable& yt, const double half_sin[4], const double half_cos[4]) {
+  yt.as_written = 0;
   for (int k = 0; k < 4; ++k) {
     const Quat q = q_normalize_pos(Quat{0, 0, half_sin[k], half_cos[k]});
     yt.s[k] = half_sin[k]; yt.c[k] = half_cos[k];
@@ -578,7 +579,7 @@ ESL_HD void res_e3d_from_E0(const SE3& E0, const double est_s[3], const double m
     // to the measurement's yaw exactly and keeps a tilt residual eps, and Rz(pi) R_tilt(eps) is a half turn for ANY eps.  Its true
     // norm is pi (never the minimum over the four yaws); measured on the streaming sequence, frame 11: this code took it at 7e-13
     // where the checker's (and the numpy restatement's) arithmetic lands on the other side and keeps the true minimum 1.88e-2.
-    const double nn = (all_half || h.a.d > -1.0 + 1e-12) ? sqrt(n2) : 1.7976931348623157e308;
+    const double nn = (yt.as_written || all_half || h.a.d > -1.0 + 1e-12) ? sqrt(n2) : 1.7976931348623157e308;   // (as_written: esl_lm_params::e3d_half_turn = 1, the reference's minCoeff)
     const bool take = (k == 0) || (nn < best);
     best = take ? nn : best;
 #pragma unroll

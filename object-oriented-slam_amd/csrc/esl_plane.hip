@@ -42,6 +42,7 @@ struct PlaneArgs {
   const uint16_t* depth; int w, h;
   double fx, fy, cx, cy, scale;
   int R; double depth_factor, cos_ang, dist_th; int min_size;
+  int min_inliers; double max_curv;   // PCL's model test (segment()): size > min_inliers, curvature < max_curv (<= 0: no test); min_size: an extra >= when no refinement follows
   float* nrm;            // 4 per pixel: nx ny nz d ; nx = NaN: no normal
   int* parent;           // union-find forest over the pixels
   int* cnt;              // pixels per root
@@ -51,6 +52,7 @@ struct PlaneArgs {
   double* list;          // esl_extract_planes: 5 per plane (a b c d pixels), in raster order of each segment's first pixel
   int list_cap;
   int* labels;           // esl_extract_planes: plane index per pixel, -1 = none
+  int* blk;              // k_plane_flag / _scan / _emit: models per block of 256 roots, then their exclusive scan
 };
 constexpr double kFix1 = 4294967296.0;     // first moments in 2^-32 m   (65 m x 2^19 pixels x 2^32 < 2^63)
 constexpr double kFix2 = 1073741824.0;     // second moments in 2^-30 m^2 (4300 m^2 x 2^19 pixels x 2^30 < 2^63)
@@ -208,7 +210,8 @@ __device__ void smallest_eigvec3(const double C[9], double n[3]) {
   for (int k = 0; k < 3; ++k) n[k] = V[k * 3 + m];
 }
 
-__device__ void plane_from_moments(const long long* m, int cnt, double pl[4]) {
+// returns PCL's surface curvature of the segment: |lambda_min| / trace(cov) (lambda_min as the Rayleigh quotient of the unit normal)
+__device__ double plane_from_moments(const long long* m, int cnt, double pl[4]) {
   const double inv = 1.0 / (double)cnt;
   const double cx = (double)m[0] / kFix1 * inv, cy = (double)m[1] / kFix1 * inv, cz = (double)m[2] / kFix1 * inv;
   const double C[9] = {(double)m[3] / kFix2 * inv - cx * cx, (double)m[4] / kFix2 * inv - cx * cy, (double)m[5] / kFix2 * inv - cx * cz,
@@ -220,41 +223,76 @@ __device__ void plane_from_moments(const long long* m, int cnt, double pl[4]) {
   pl[0] = n[0] / nn; pl[1] = n[1] / nn; pl[2] = n[2] / nn;
   pl[3] = -(pl[0] * cx + pl[1] * cy + pl[2] * cz);
   if (pl[3] < 0) for (int k = 0; k < 4; ++k) pl[k] = -pl[k];   // camera centre on the positive side (PlaneExtractor.cpp:95-96, 165-167)
+  double lmin = 0;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lmin += pl[i] * C[3 * i + j] * pl[j];
+  const double tr = C[0] + C[4] + C[8];
+  return tr != 0 ? fabs(lmin / tr) : 0.0;
+}
+// PCL's model test (OrganizedMultiPlaneSegmentation::segment): more than min_inliers pixels (strict) and curvature below
+// maximum_curvature_; a.min_size: an additional >= (the Plane.MinSize filter folded in where no refinement pass can grow a segment)
+__device__ __forceinline__ bool plane_is_model(const PlaneArgs& a, int r, int c, double pl[4]) {
+  if (!(c > a.min_inliers && c >= a.min_size && c > 0)) return false;
+  const double curv = plane_from_moments(a.mom + (size_t)r * 9, c, pl);
+  return !(a.max_curv > 0) || curv < a.max_curv;
 }
 
-// one workgroup: the planes of all segments of >= min_size pixels in raster order of their first pixel (= their root: the
-// union-find keeps the smallest index on top), as extractPlanes stores them (PlaneExtractor.cpp:85-103)
-static __global__ __launch_bounds__(256) void k_plane_list(PlaneArgs a) {
-  __shared__ int s_scan[256];
-  __shared__ int s_base;
-  if (threadIdx.x == 0) s_base = 0;
+// the MODELS (plane_is_model) in raster order of their first pixel (= their root: the union-find keeps the smallest index on top), as
+// extractPlanes stores them (PlaneExtractor.cpp:85-103).  Round 6: three small launches over all roots instead of ONE workgroup
+// scanning 307,200 roots 256 at a time (1.5 ms): flags + per-block counts, a scan of the 1,200 counts, the emit.
+static __global__ __launch_bounds__(256) void k_plane_flag(PlaneArgs a) {
+  __shared__ int s_n;
+  if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  const int N = a.w * a.h;
-  for (int r0 = 0; r0 < N; r0 += 256) {
-    const int r = r0 + threadIdx.x;
-    const int c = r < N ? a.cnt[r] : 0;
-    const int flag = c >= a.min_size && c > 0;
-    s_scan[threadIdx.x] = flag;
+  const int N = a.w * a.h, r = blockIdx.x * 256 + threadIdx.x;
+  const int c = r < N ? a.cnt[r] : 0;
+  double pl[4];
+  const int flag = (r < N && plane_is_model(a, r, c, pl)) ? 1 : 0;
+  if (r < N) a.plane_of_root[r] = flag;
+  if (flag) atomicAdd(&s_n, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) a.blk[blockIdx.x] = s_n;
+}
+static __global__ __launch_bounds__(1024) void k_plane_scan(PlaneArgs a, int nb) {
+  __shared__ int s_part[1024];
+  const int t = threadIdx.x, per = (nb + 1023) / 1024, b0 = t * per;
+  int sum = 0;
+  for (int b = b0; b < b0 + per && b < nb; ++b) sum += a.blk[b];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? s_part[t - off] : 0;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      const int v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
-      __syncthreads();
-      s_scan[threadIdx.x] += v;
-      __syncthreads();
-    }
-    const int idx = s_base + s_scan[threadIdx.x] - flag;
-    if (r < N) a.plane_of_root[r] = flag ? idx : -1;
-    if (flag && idx < a.list_cap) {
-      double pl[4];
-      plane_from_moments(a.mom + (size_t)r * 9, c, pl);
-      for (int k = 0; k < 4; ++k) a.list[(size_t)idx * 5 + k] = pl[k];
-      a.list[(size_t)idx * 5 + 4] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 255) s_base += s_scan[255];
+    s_part[t] += v;
     __syncthreads();
   }
-  if (threadIdx.x == 0) a.out[5] = s_base;
+  int run = s_part[t] - sum;
+  for (int b = b0; b < b0 + per && b < nb; ++b) { const int v = a.blk[b]; a.blk[b] = run; run += v; }
+  if (t == 1023) a.out[5] = s_part[1023];
+}
+static __global__ __launch_bounds__(256) void k_plane_emit(PlaneArgs a) {
+  __shared__ int s_w[4];
+  const int N = a.w * a.h, r = blockIdx.x * 256 + threadIdx.x;
+  const int flag = r < N ? a.plane_of_root[r] : 0;
+  const unsigned long long bal = __ballot(flag != 0);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) s_w[wv] = __popcll(bal);
+  __syncthreads();
+  int idx = a.blk[blockIdx.x] + __popcll(bal & ((1ull << lane) - 1ull));
+  for (int k = 0; k < wv; ++k) idx += s_w[k];
+  if (r < N) a.plane_of_root[r] = flag ? idx : -1;
+  if (flag && idx < a.list_cap) {
+    double pl[4];
+    const int c = a.cnt[r];
+    (void)plane_from_moments(a.mom + (size_t)r * 9, c, pl);
+    for (int k = 0; k < 4; ++k) a.list[(size_t)idx * 5 + k] = pl[k];
+    a.list[(size_t)idx * 5 + 4] = c;
+  }
+}
+static void plane_list_launch(const PlaneArgs& a, hipStream_t st) {
+  const int nb = (a.w * a.h + 255) / 256;
+  hipLaunchKernelGGL(k_plane_flag, dim3((unsigned)nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_plane_scan, dim3(1), dim3(1024), 0, st, a, nb);
+  hipLaunchKernelGGL(k_plane_emit, dim3((unsigned)nb), dim3(256), 0, st, a);
 }
 static __global__ __launch_bounds__(256) void k_plane_labels(PlaneArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -278,69 +316,99 @@ static __global__ __launch_bounds__(256) void k_plane_lab_init(PlaneArgs a) {
 // "other", so they are disjoint --, (4) the labels go back and every column tests the ONE pixel of the next row (quirk kept: not when
 // the in-row neighbour has no label).  Second pass mirrored, plus PCL's "left of column 0" = the last pixel of the row above.
 constexpr int kPlaneRefThreads = 1024;
+// Round 6: the two rows a step works on -- labels AND depths -- live in LDS, the row after them is in flight in registers while the
+// step runs, and a finished row leaves once: no global load sits on the serial path any more (round 5 re-read every row's labels
+// and, inside the run walk, one depth per step from global memory: 2.3 us per row, 2.2 ms per image).
 static __global__ __launch_bounds__(kPlaneRefThreads) void k_plane_refine(PlaneArgs a, int* __restrict__ grown, double thr) {
   extern __shared__ int s_row[];
-  int* sL = s_row;
-  int* sF = s_row + a.w;
   const int w = a.w, h = a.h, t = threadIdx.x;
-  auto near = [&](int m, int u, int v) {
-    float q[3];
-    px_point(a, u, v, q);
+  int* sLab[2] = {s_row, s_row + w};
+  int* sF = s_row + 2 * w;
+  unsigned short* sDep[2] = {reinterpret_cast<unsigned short*>(s_row + 3 * w), reinterpret_cast<unsigned short*>(s_row + 3 * w) + w};
+  constexpr int kPer = 2;                                  // columns per thread of the prefetch (w <= 2048)
+  auto near = [&](int m, int u, int v, unsigned short d) {
+    const float z = (float)((double)d / a.scale);
+    const float qx = (float)(((double)u - a.cx) * (double)z / a.fx), qy = (float)(((double)v - a.cy) * (double)z / a.fy);
     const double* pl = a.list + (size_t)m * 5;
-    return fabs(pl[0] * (double)q[0] + pl[1] * (double)q[1] + pl[2] * (double)q[2] + pl[3]) < thr;
+    return fabs(pl[0] * (double)qx + pl[1] * (double)qy + pl[2] * (double)z + pl[3]) < thr;
   };
-  for (int v = 0; v < h - 1; ++v) {                       // first pass: rightwards, downwards
-    int* row = a.labels + (size_t)v * w;
-    int* below = row + w;
-    for (int u = t; u < w; u += kPlaneRefThreads) sL[u] = row[u];
-    __syncthreads();
+  int pl_[kPer]; unsigned short pd_[kPer];
+  auto fetch = [&](int v) {                                 // row v -> registers (rows outside the image: nothing)
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int u = t + q * kPlaneRefThreads;
+      const bool in = v >= 0 && v < h && u < w;
+      pl_[q] = in ? a.labels[(size_t)v * w + u] : -1;
+      pd_[q] = in ? a.depth[(size_t)v * w + u] : (unsigned short)0;
+    }
+  };
+  auto park = [&](int b) {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) { const int u = t + q * kPlaneRefThreads; if (u < w) { sLab[b][u] = pl_[q]; sDep[b][u] = pd_[q]; } }
+  };
+  // ---- first pass: rightwards, downwards
+  fetch(0); park(0); fetch(1); park(1);
+  __syncthreads();
+  for (int v = 0; v < h - 1; ++v) {
+    int* sL = sLab[v & 1]; int* sN = sLab[(v + 1) & 1];
+    const unsigned short* sD = sDep[v & 1]; const unsigned short* sDN = sDep[(v + 1) & 1];
+    fetch(v + 2);
     for (int u = t; u < w - 1; u += kPlaneRefThreads) sF[u] = (sL[u] >= 0 && sL[u + 1] == -2) ? 1 : 0;
     __syncthreads();
     for (int u = t; u < w - 1; u += kPlaneRefThreads)
       if (sF[u]) {
         const int m = sL[u];
         int j = u + 1, n = 0;
-        while (j < w && sL[j] == -2 && near(m, j, v)) { sL[j] = m; ++j; ++n; }
+        while (j < w && sL[j] == -2 && near(m, j, v, sD[j])) { sL[j] = m; ++j; ++n; }
         if (n) atomicAdd(&grown[m], n);
       }
     __syncthreads();
     for (int u = t; u < w; u += kPlaneRefThreads) {
       const int cur = sL[u];
-      row[u] = cur;
-      if (u < w - 1 && cur >= 0 && sL[u + 1] != -1 && below[u] == -2 && near(cur, u, v + 1)) { below[u] = cur; atomicAdd(&grown[cur], 1); }
+      a.labels[(size_t)v * w + u] = cur;
+      if (u < w - 1 && cur >= 0 && sL[u + 1] != -1 && sN[u] == -2 && near(cur, u, v + 1, sDN[u])) { sN[u] = cur; atomicAdd(&grown[cur], 1); }
     }
     __syncthreads();
-  }
-  for (int v = h - 1; v >= 1; --v) {                      // second pass: leftwards, upwards
-    int* row = a.labels + (size_t)v * w;
-    int* above = row - w;
-    for (int u = t; u < w; u += kPlaneRefThreads) sL[u] = row[u];
+    park(v & 1);                                            // row v + 2 takes the finished row's place
     __syncthreads();
+  }
+  for (int u = t; u < w; u += kPlaneRefThreads) a.labels[(size_t)(h - 1) * w + u] = sLab[(h - 1) & 1][u];
+  __syncthreads();
+  // ---- second pass: leftwards, upwards (plus PCL's "left of column 0" = the last pixel of the row above)
+  fetch(h - 1); park((h - 1) & 1); fetch(h - 2); park((h - 2) & 1);
+  __syncthreads();
+  for (int v = h - 1; v >= 1; --v) {
+    int* sL = sLab[v & 1]; int* sN = sLab[(v - 1) & 1];
+    const unsigned short* sD = sDep[v & 1]; const unsigned short* sDN = sDep[(v - 1) & 1];
+    fetch(v - 2);
     for (int u = t; u < w; u += kPlaneRefThreads) sF[u] = (u >= 1 && sL[u] >= 0 && sL[u - 1] == -2) ? 1 : 0;
     __syncthreads();
     for (int u = t; u < w; u += kPlaneRefThreads)
       if (sF[u]) {
         const int m = sL[u];
         int j = u - 1, n = 0;
-        while (j >= 0 && sL[j] == -2 && near(m, j, v)) { sL[j] = m; --j; ++n; }
+        while (j >= 0 && sL[j] == -2 && near(m, j, v, sD[j])) { sL[j] = m; --j; ++n; }
         if (n) atomicAdd(&grown[m], n);
       }
     __syncthreads();
     for (int u = t; u < w; u += kPlaneRefThreads) {
       const int cur = sL[u];
-      row[u] = cur;
-      if (u >= 1 && cur >= 0 && sL[u - 1] != -1 && above[u] == -2 && near(cur, u, v - 1)) { above[u] = cur; atomicAdd(&grown[cur], 1); }
+      a.labels[(size_t)v * w + u] = cur;
+      if (u >= 1 && cur >= 0 && sL[u - 1] != -1 && sN[u] == -2 && near(cur, u, v - 1, sDN[u])) { sN[u] = cur; atomicAdd(&grown[cur], 1); }
     }
     __syncthreads();
     if (t == 0) {                                          // column 0 comes last in PCL's sweep: "left" = the last pixel of the row above
       const int cur = sL[0];
-      if (cur != -1 && above[w - 1] != -1) {
-        if (cur >= 0 && above[w - 1] == -2 && near(cur, w - 1, v - 1)) { above[w - 1] = cur; atomicAdd(&grown[cur], 1); }
-        if (cur >= 0 && above[0] == -2 && near(cur, 0, v - 1)) { above[0] = cur; atomicAdd(&grown[cur], 1); }
+      if (cur != -1 && sN[w - 1] != -1) {
+        if (cur >= 0 && sN[w - 1] == -2 && near(cur, w - 1, v - 1, sDN[w - 1])) { sN[w - 1] = cur; atomicAdd(&grown[cur], 1); }
+        if (cur >= 0 && sN[0] == -2 && near(cur, 0, v - 1, sDN[0])) { sN[0] = cur; atomicAdd(&grown[cur], 1); }
       }
     }
     __syncthreads();
+    park(v & 1);                                            // row v - 2 takes the finished row's place
+    __syncthreads();
   }
+  for (int u = t; u < w; u += kPlaneRefThreads) a.labels[u] = sLab[0][u];
 }
 
 // one workgroup: every component of >= min_size pixels -> its plane; the ground-plane candidate with the most pixels wins
@@ -352,10 +420,9 @@ static __global__ __launch_bounds__(256) void k_plane_select(PlaneArgs a) {
     const int c = a.cnt[r];
     if (c <= 0) continue;
     ++n_comp;
-    if (c < a.min_size) continue;
-    ++n_planes;
     double n[4];
-    plane_from_moments(a.mom + (size_t)r * 9, c, n);
+    if (!plane_is_model(a, r, c, n)) continue;
+    ++n_planes;
     // wall filter: the angle between the normal and the camera's y axis must not lie in (pi/4, 3 pi/4)
     const double th = acos(n[1] / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]));
     if (th > M_PI / 4 && th < 3 * M_PI / 4) continue;
@@ -372,7 +439,7 @@ static __global__ __launch_bounds__(256) void k_plane_select(PlaneArgs a) {
   a.out[5] = n_planes; a.out[7] = n_comp;
   if (best_root < 0) return;
   double pl[4];
-  plane_from_moments(a.mom + (size_t)best_root * 9, best_cnt, pl);
+  (void)plane_from_moments(a.mom + (size_t)best_root * 9, best_cnt, pl);
   for (int k = 0; k < 4; ++k) a.out[k] = pl[k];
   a.out[4] = 1; a.out[6] = best_cnt;
 }
@@ -386,6 +453,7 @@ extern "C" void esl_plane_params_default(esl_plane_params* p) {
   p->normal_smoothing = 10; p->max_depth_change_factor = 0.05;                   // PlaneExtractor.cpp:57-58
   p->min_inliers = 100;                                                           // PlaneExtractor.cpp:74
   p->refine = 1; p->refine_distance = 0.02;                                       // segmentAndRefine (:82); PlaneRefinementComparator's default
+  p->max_curvature = 0.001;                                                       // PCL's maximum_curvature_ default (the reference does not set it)
 }
 
 namespace esl {
@@ -400,13 +468,13 @@ namespace {
 // per call): depth u16, normal + offset 4 x f32, union-find parent i32, per-root count i32 and nine i64 moments, results, and
 // (esl_extract_planes) the root -> plane map, the plane list and the label image
 struct Buf { void* p = nullptr; };
-struct PlaneWork { Buf depth, nrm, par, cnt, mom, out, map, list, labels, grown; int list_cap = 0; };
+struct PlaneWork { Buf depth, nrm, par, cnt, mom, out, map, list, labels, grown, blk; int list_cap = 0; };
 int plane_reserve(esl_ctx* c, size_t npx, int max_planes, int model_min, PlaneWork& w) {
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   // the list holds PCL's MODELS when the refinement pass runs (components of >= min_inliers pixels: at most npx / min_inliers)
   w.list_cap = std::max(std::max(max_planes, 1), model_min > 0 ? (int)(npx / (size_t)model_min) + 2 : 1);
-  const size_t sz[10] = {al(npx * 2), al(npx * 16), al(npx * 4), al(npx * 4), al(npx * 72), al(8 * sizeof(double)), al(npx * 4),
-                         al((size_t)w.list_cap * 5 * sizeof(double)), al(npx * 4), al((size_t)w.list_cap * sizeof(int))};
+  const size_t sz[11] = {al(npx * 2), al(npx * 16), al(npx * 4), al(npx * 4), al(npx * 72), al(8 * sizeof(double)), al(npx * 4),
+                         al((size_t)w.list_cap * 5 * sizeof(double)), al(npx * 4), al((size_t)w.list_cap * sizeof(int)), al(((npx + 255) / 256 + 1) * sizeof(int))};
   size_t need = 0;
   for (size_t v : sz) need += v;
   if (need > c->plane_slab_cap) {
@@ -416,9 +484,9 @@ int plane_reserve(esl_ctx* c, size_t npx, int max_planes, int model_min, PlaneWo
     ESL_HIP_TRY(hipMalloc((void**)&c->plane_slab, need));
     c->plane_slab_cap = need;
   }
-  Buf* b[10] = {&w.depth, &w.nrm, &w.par, &w.cnt, &w.mom, &w.out, &w.map, &w.list, &w.labels, &w.grown};
+  Buf* b[11] = {&w.depth, &w.nrm, &w.par, &w.cnt, &w.mom, &w.out, &w.map, &w.list, &w.labels, &w.grown, &w.blk};
   size_t off = 0;
-  for (int k = 0; k < 10; ++k) { b[k]->p = c->plane_slab + off; off += sz[k]; }
+  for (int k = 0; k < 11; ++k) { b[k]->p = c->plane_slab + off; off += sz[k]; }
   return ESL_OK;
 }
 
@@ -439,8 +507,8 @@ int plane_segment(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t heig
   a.fx = intr[0]; a.fy = intr[1]; a.cx = intr[2]; a.cy = intr[3]; a.scale = intr[4];
   a.R = p->normal_smoothing / 2; a.depth_factor = p->max_depth_change_factor;
   a.cos_ang = std::cos(p->angle_threshold_deg * 0.017453);   // the reference's degree-to-radian constant (PlaneExtractor.cpp:75)
-  a.dist_th = p->distance_threshold; a.min_size = std::max(p->min_size, p->min_inliers);
-  a.nrm = (float*)w.nrm.p; a.parent = (int*)w.par.p; a.cnt = (int*)w.cnt.p; a.mom = (long long*)w.mom.p; a.out = (double*)w.out.p;
+  a.dist_th = p->distance_threshold; a.min_size = p->min_size; a.min_inliers = p->min_inliers; a.max_curv = p->max_curvature;
+  a.nrm = (float*)w.nrm.p; a.parent = (int*)w.par.p; a.cnt = (int*)w.cnt.p; a.mom = (long long*)w.mom.p; a.out = (double*)w.out.p; a.blk = (int*)w.blk.p;
   const unsigned nb = (unsigned)((npx + 255) / 256);
   hipLaunchKernelGGL(k_plane_normals, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_plane_init, dim3(nb), dim3(256), 0, c->stream, a);
@@ -458,13 +526,14 @@ namespace {
 struct RefinedPlanes { std::vector<double> planes; std::vector<int> sizes; int ground = -1; };
 int plane_refined(esl_ctx* c, const esl_plane_params* p, PlaneWork& w, PlaneArgs& a, RefinedPlanes& out, int32_t* labels_out) {
   const size_t npx = (size_t)a.w * a.h;
-  a.min_size = p->min_inliers;                         // k_plane_list: PCL's models, in raster order of their first pixel
+  if (a.w > 2 * kPlaneRefThreads) { set_error("plane refinement: images wider than 2048 pixels are not supported"); return ESL_ERR_INVALID; }
+  a.min_size = 0;                                      // PCL's models (plane_is_model), in raster order of their first pixel; Plane.MinSize applies to the REFINED sizes below
   a.plane_of_root = (int*)w.map.p; a.list = (double*)w.list.p; a.list_cap = w.list_cap; a.labels = (int*)w.labels.p;
-  hipLaunchKernelGGL(k_plane_list, dim3(1), dim3(256), 0, c->stream, a);
+  plane_list_launch(a, c->stream);
   hipLaunchKernelGGL(k_plane_lab_init, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, a);
   ESL_HIP_TRY(hipMemsetAsync(w.grown.p, 0, (size_t)w.list_cap * sizeof(int), c->stream));
   if (a.w > 1 && a.h > 1)
-    hipLaunchKernelGGL(k_plane_refine, dim3(1), dim3(kPlaneRefThreads), 2 * (size_t)a.w * sizeof(int), c->stream, a, (int*)w.grown.p, p->refine_distance);
+    hipLaunchKernelGGL(k_plane_refine, dim3(1), dim3(kPlaneRefThreads), 4 * (size_t)a.w * sizeof(int), c->stream, a, (int*)w.grown.p, p->refine_distance);
   ESL_HIP_TRY(hipGetLastError());
   double h[8];
   ESL_HIP_TRY(hipMemcpyAsync(h, w.out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -545,7 +614,7 @@ extern "C" int esl_extract_planes(esl_ctx* c, const uint16_t* depth, int32_t wid
   }
   const size_t npx = (size_t)width * height;
   a.plane_of_root = (int*)w.map.p; a.list = (double*)w.list.p; a.list_cap = max_planes;
-  hipLaunchKernelGGL(k_plane_list, dim3(1), dim3(256), 0, c->stream, a);
+  plane_list_launch(a, c->stream);
   if (labels_out) {
     a.labels = (int*)w.labels.p;
     hipLaunchKernelGGL(k_plane_labels, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, a);

@@ -54,7 +54,10 @@ static void unite(int* parent, int a, int b) {
   if (a < b) parent[b] = a; else parent[a] = b;
 }
 
-static void plane_of(const long long* m, int cnt, double pl[4]) {
+/* least-squares plane of a segment from its exact moments; returns PCL's surface curvature of the segment, |lambda_min| / trace(cov)
+ * (OrganizedMultiPlaneSegmentation::segment: eigen_value / eig_sum of the 3 x 3 covariance; lambda_min as the Rayleigh quotient of the
+ * unit normal) */
+static double plane_of(const long long* m, int cnt, double pl[4]) {
   const double f1 = 4294967296.0, f = 1073741824.0, inv = 1.0 / (double)cnt;   /* fixed point: 2^-32 m, 2^-30 m^2 */
   const double cx = (double)m[0] / f1 * inv, cy = (double)m[1] / f1 * inv, cz = (double)m[2] / f1 * inv;
   const double C[9] = {(double)m[3] / f * inv - cx * cx, (double)m[4] / f * inv - cx * cy, (double)m[5] / f * inv - cx * cz,
@@ -66,6 +69,10 @@ static void plane_of(const long long* m, int cnt, double pl[4]) {
   pl[0] = n[0] / nn; pl[1] = n[1] / nn; pl[2] = n[2] / nn;
   pl[3] = -(pl[0] * cx + pl[1] * cy + pl[2] * cz);
   if (pl[3] < 0) for (int k = 0; k < 4; ++k) pl[k] = -pl[k];          /* PlaneExtractor.cpp:95-96 */
+  double lmin = 0;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lmin += pl[i] * C[3 * i + j] * pl[j];
+  const double tr = C[0] + C[4] + C[8];
+  return tr != 0 ? fabs(lmin / tr) : 0.0;
 }
 
 static int plane_core(const uint16_t* depth, int32_t w, int32_t h, const double intr[5], const esl_plane_params* p,
@@ -144,26 +151,33 @@ static int plane_core(const uint16_t* depth, int32_t w, int32_t h, const double 
       ++cnt[r];
       for (int k = 0; k < 9; ++k) mom[(size_t)r * 9 + k] += llrint(v9[k]);
     }
-  /* PCL's models: segments of >= setMinInliers(100) pixels (:74), in raster order of each segment's first pixel (= its root).
-   * Without the refinement pass a model below Plane.MinSize can never become a plane, so the list starts at max(MinSize, 100). */
+  /* PCL's models (OrganizedMultiPlaneSegmentation::segment, PCL 1.8 -- restated from its published source, UNPINNED):
+   * segments of MORE than setMinInliers(100) pixels (:74; the test is a strict >) whose surface curvature is below maximum_curvature_
+   * (0.001, PCL's default: the reference does not set it), in raster order of each segment's first pixel (= its root).  Anything else is
+   * an "other" label that the refinement pass lets neighbouring models absorb.  Without the refinement pass a model below
+   * Plane.MinSize can never become a plane, so the list then also starts at MinSize. */
   const int refine = p->refine != 0;
-  const int model_min = refine ? p->min_inliers : (p->min_size > p->min_inliers ? p->min_size : p->min_inliers);
-  int n_models = 0;
-  for (size_t r = 0; r < npx; ++r) if (cnt[r] >= model_min && cnt[r] > 0) ++n_models;
+  const int extra_min = refine ? 0 : p->min_size;
   int* model_of_root = (int*)malloc(npx * sizeof(int));
+  if (!model_of_root) { free(nrm); free(parent); free(cnt); free(mom); return -1; }
+  int n_models = 0;
+  for (size_t r = 0; r < npx; ++r) {
+    model_of_root[r] = -1;
+    if (!(cnt[r] > p->min_inliers && cnt[r] >= extra_min)) continue;
+    double pl4[4];
+    const double curv = plane_of(mom + r * 9, cnt[r], pl4);
+    if (p->max_curvature > 0 && !(curv < p->max_curvature)) continue;
+    model_of_root[r] = n_models++;
+  }
   double* mpl = (double*)malloc((size_t)(n_models > 0 ? n_models : 1) * 4 * sizeof(double));
   int* msize = (int*)malloc((size_t)(n_models > 0 ? n_models : 1) * sizeof(int));
   int* lab = (int*)malloc(npx * sizeof(int));     /* model index; -1: no depth (never labelled); -2: any other pixel */
-  if (!model_of_root || !mpl || !msize || !lab) { free(model_of_root); free(mpl); free(msize); free(lab); free(nrm); free(parent); free(cnt); free(mom); return -1; }
-  {
-    int m = 0;
-    for (size_t r = 0; r < npx; ++r) {
-      model_of_root[r] = -1;
-      if (cnt[r] < model_min || cnt[r] <= 0) continue;
-      plane_of(mom + r * 9, cnt[r], mpl + (size_t)m * 4);
-      msize[m] = cnt[r];
-      model_of_root[r] = m++;
-    }
+  if (!mpl || !msize || !lab) { free(model_of_root); free(mpl); free(msize); free(lab); free(nrm); free(parent); free(cnt); free(mom); return -1; }
+  for (size_t r = 0; r < npx; ++r) {
+    const int m = model_of_root[r];
+    if (m < 0) continue;
+    (void)plane_of(mom + r * 9, cnt[r], mpl + (size_t)m * 4);
+    msize[m] = cnt[r];
   }
   for (size_t i = 0; i < npx; ++i) {
     if (depth[i] == 0) lab[i] = -1;

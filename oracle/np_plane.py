@@ -135,7 +135,7 @@ def _refine(lab, P, mpl, thr):
 
 
 def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smoothing=10, factor=0.05, min_inliers=100, refine=True,
-                         refine_distance=0.02):
+                         refine_distance=0.02, max_curvature=0.001):
     depth = np.asarray(depth, dtype=np.uint16)
     intr = np.asarray(intr, dtype=np.float64)
     h, w = depth.shape
@@ -159,17 +159,19 @@ def extract_ground_plane(depth, intr, min_size=200, angle_deg=5.0, dist=0.1, smo
     labs, first, counts = np.unique(lab[valid], return_index=True, return_counts=True)
     root = idx[valid][first]                       # smallest pixel index of each component (np.unique keeps the first)
     P = points(depth, intr).astype(np.float64)
-    # PCL's models: components of >= min_inliers pixels (without the refinement pass nothing below min_size can become a plane)
-    need = min_inliers if refine else max(min_size, min_inliers)
+    # PCL's models (OrganizedMultiPlaneSegmentation::segment): components of MORE than min_inliers pixels whose surface curvature
+    # lambda_min / trace(cov) is below maximum_curvature_ (0.001); without the refinement pass nothing below min_size can become a plane
     models = []
     for l, c, r in zip(labs, counts, root):
-        if c < need:
+        if not (c > min_inliers and (refine or c >= min_size)):
             continue
         pts = P[(lab == l) & valid]
         cen = pts.mean(axis=0)
         C = (pts - cen).T @ (pts - cen) / len(pts)
         wv, V = np.linalg.eigh(C)
         n = V[:, 0]
+        if max_curvature > 0 and np.trace(C) != 0 and not abs(wv[0] / np.trace(C)) < max_curvature:
+            continue
         pl = np.array([n[0], n[1], n[2], -n @ cen])
         if pl[3] < 0:
             pl = -pl

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Generates tests/golden/cabinet_plane.npz: the ground plane of two depth frames of the reference's demo clip
-(Example/dataset/cabinet, first frame and frame 30) computed by the INDEPENDENT numpy / scipy version oracle/np_plane.py.
+(Example/dataset/cabinet, first frame and frame 35; round 6: frame 30, used until then, has floor and cabinet chained into ONE segment of curvature 0.034, which PCL's maximum_curvature_ = 0.001 drops -- no ground plane there) computed by the INDEPENDENT numpy / scipy version oracle/np_plane.py.
 Run in the development container only (reads the reference's DATA files; needs scipy + PIL).  Stored: the two depth
 images (x-differenced so that deflate gets PNG-like ratios), the mocap poses of the frames, the expected plane, plane
 count, pixel count, the planes' sizes and the count of pixels with a normal -- with PCL's refinement pass (round 5) and, for the
@@ -26,7 +26,7 @@ def main():
     lines = [l.split() for l in open(REF + "associateGroundtruth.txt")]
     assoc = {a.split()[0]: a.split()[3] for a in open(REF + "associate.txt")}
     store = dict(intr=intr)
-    for k, li in enumerate((0, 30)):
+    for k, li in enumerate((0, 35)):
         l = lines[li]
         depth = np.array(Image.open(REF + assoc[l[0]])).astype(np.uint16)
         diff = depth.copy()

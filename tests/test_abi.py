@@ -26,10 +26,11 @@ def test_header_symbols_exported(pkg):
 
 def test_abi_version_and_struct_sizes(pkg):
     L = pkg.lib.load()
-    assert L.esl_abi_version() == 4
+    assert L.esl_abi_version() == 5
+    assert ctypes.sizeof(pkg.abi.EslLmParams) == 48   # ABI 5: + e3d_half_turn
     p = pkg.abi.EslLmParams()
     L.esl_lm_params_default(ctypes.byref(p))
-    assert (p.max_iters, p.max_trials, p.tau, p.numeric_delta, p.drop_nan_bbox) == (10, 10, 1e-5, 1e-9, 1)
+    assert (p.max_iters, p.max_trials, p.tau, p.numeric_delta, p.drop_nan_bbox, p.bbox_residual, p.e3d_half_turn) == (10, 10, 1e-5, 1e-9, 1, 0, 0)
     f = pkg.abi.EslFitParams()
     L.esl_fit_params_default(ctypes.byref(f))
     assert (f.stride, f.depth_scale, f.voxel_leaf, f.min_cluster_size) == (3, 5000.0, 0.01, 100)

@@ -447,25 +447,26 @@ def test_sparse_interior_rows_on_awkward_structures(pkg, monkeypatch):
 def test_sparse_camera_first_trial_matches_cpu_camera_first_checker(pkg, po, monkeypatch):
     """The sparse camera-first path (nested dissection of a 2,047-camera chain into 128 segments of 16 slots, X kept sparse,
     per-segment products, separators' rows on the MFMA update: every piece of esl_cf.hpp live, as at BASELINE configs[3]) against the
-    CPU checker at a size the checker reaches: ONE LM iteration from the same start, numeric Jacobians at delta = 1e-6 on both
-    sides.  The checker eliminates the cameras first too, but as the PLAIN chain with a dense Y and a pivoted LDLT
+    CPU checker at a size the checker reaches: ONE LM iteration from the same start, numeric Jacobians at delta = 1e-4 on both
+    sides (round 6: at 1e-6 the checker's central differences carry ~1e-7 of roundoff noise, which was the whole 7.9e-6 this test
+    used to measure on the cameras -- see test_mid_size_slam_full_run_matches_cpu_camera_first_checker).  The checker eliminates the cameras first too, but as the PLAIN chain with a dense Y and a pivoted LDLT
     (oracle/esl_oracle.c solve_camfirst; tests/test_oracle_cross.py holds it to the faithful dense LDLT of the whole system) --
     none of the dissection / sparsity machinery."""
     g, c, o, _ = pkg.synth.make_graph(2048, 150, 8 * 2048, seed=43, slam=True)
-    p1 = pkg.default_lm_params(numeric_delta=1e-6, max_iters=1)
+    p1 = pkg.default_lm_params(numeric_delta=1e-4, max_iters=1)
     co, oo, ro = po.optimize(g, c, o, p1, solver=po.ORACLE_CAMFIRST)
     monkeypatch.setenv("ESL_CF_SPARSE", "1")
     cx = pkg.Context(0)
     try:
         for jac in (0, 1):
-            cg, og, rg = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-6, max_iters=1, linear_solver=2))
+            cg, og, rg = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=1e-4, max_iters=1, linear_solver=2))
             st = cx.lm_solver_stats()
             assert cx.lm_solver_used() == 2 and st["x_form"] == 1 and st["stride"] == 16 and st["separators"] == 127
             print("2,048-camera chain, sparse camera-first trial (jac %d) vs CPU camera-first checker: chi2 rel %.2e, cameras %.2e, ellipsoids %.2e, trials %s / %s"
                   % (jac, abs(rg["chi2_final"] / ro["chi2_final"] - 1), cam_err(cg, co), obj_rel(og, oo), rg["trace_trials"], ro["trace_trials"]))
             assert rg["trace_trials"] == ro["trace_trials"]
-            assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-6)
-            assert cam_err(cg, co) < 1e-5 and obj_rel(og, oo) < 1e-5
+            assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-8)
+            assert cam_err(cg, co) < 2e-6 and obj_rel(og, oo) < 1e-6
     finally:
         cx.close()
         monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
@@ -475,17 +476,25 @@ def test_mid_size_slam_full_run_matches_cpu_camera_first_checker(pkg, monkeypatc
     """A WHOLE optimize(10) in SLAM mode on the form BASELINE configs[3] runs (chain dissected into 16-slot segments, X kept sparse,
     stored per-segment products, separators' rows on the MFMA update, dense factorisation of the 2,700 ellipsoid unknowns) against the
     CPU checker's camera-first restatement (plain chain, dense Y, pivoted LDLT: none of that machinery) -- 11,994 camera + 2,700
-    ellipsoid unknowns, the graph bench.py times as `mid_2k_cams_300_ellipsoids` (the gap between "C3 whole run"
-    and "C4 one trial / residual only").  The checker's run is a committed fixture (two minutes on one core:
-    tests/golden/gen_golden_mid_slam.py; tests/test_golden_vectors.py re-runs its first iteration on the CPU).  Like for like: numeric
-    Jacobians at delta = 1e-6 on both sides -> same trial counts, same chi2 trace, same states.  Then the product default (analytic
-    Jacobians) and the reference's delta = 1e-9 against that run at north_star's 1e-4."""
+    ellipsoid unknowns, the graph bench.py times as `mid_2k_cams_300_ellipsoids`.  The checker's runs are a committed fixture (2.5
+    minutes each on one core: tests/golden/gen_golden_mid_slam.py; tests/test_golden_vectors.py re-runs a first iteration on the CPU).
+
+    Round 6 ("resolve the 1.08e-4 camera discrepancy instead of widening the assert").  It was the CHECKER's
+    numeric-Jacobian roundoff, not the elimination: (a) the checker's camera-first solve agrees with a dense Cholesky solve of its own
+    (H + lambda I) x = b refined in long double to 7e-14 (scripts/debug/camfirst_checker_precision.py), so its linear algebra is
+    exact; (b) its central differences carry a noise ~ eps_f / delta (error functions good to ~1e-13): re-run at delta = 1e-5 and
+    1e-4 the checker moves 1.1e-4 away from its own delta = 1e-6 run on the cameras -- and TOWARD the GPU: the GPU (analytic or
+    numeric at any delta, either elimination: 2e-7 among themselves) is 1.08e-4 / 4.2e-6 / 8e-7 from the checker at 1e-6 / 1e-5 / 1e-4.
+    The like-for-like step is therefore delta = 1e-4 on both sides, held to 5e-6 on the cameras and 2e-7 on the ellipsoids
+    (north_star: 1e-4); the older steps stay in the fixture and the sequence above is asserted."""
     import os
     sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_golden_mid_slam", os.path.join(sys_path, "gen_golden_mid_slam.py"))
     gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
     G = np.load(os.path.join(sys_path, "mid_slam_run.npz"))
+    delta = float(G["numeric_delta"])
+    assert delta == gen.DELTA == 1e-4
     g, c, o, _ = pkg.synth.make_graph(**gen.ARGS)
     assert list(G["n_edges"]) == [len(g.bbox_cam), len(g.e3d_cam), len(g.odom_i)]
     co, oo = G["cams"], G["objs"]
@@ -495,37 +504,42 @@ def test_mid_size_slam_full_run_matches_cpu_camera_first_checker(pkg, monkeypatc
     monkeypatch.setenv("ESL_CF_SPARSE", "1")
     cx = pkg.Context(0)
     try:
-        cg, og, rg = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, linear_solver=2))
+        cg, og, rg = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=delta, linear_solver=2))
         st = cx.lm_solver_stats()
         assert cx.lm_solver_used() == 2 and st["x_form"] == 1 and st["stride"] == 16 and st["separators"] == 1999 // 16
         tr = float(np.abs(np.array(rg["trace_chi2"]) / np.array(ro["trace_chi2"]) - 1).max()) if rg["trace_trials"] == ro["trace_trials"] else float("nan")
-        print("2,000 cams / 300 ellipsoids, full SLAM run, sparse camera-first (numeric 1e-6) vs CPU camera-first checker: %d iterations, trials %s / %s, "
-              "chi2 trace rel %.2e, final chi2 rel %.2e, cameras %.2e, ellipsoids %.2e" % (
-                  rg["iterations"], rg["trace_trials"], ro["trace_trials"], tr, abs(rg["chi2_final"] / ro["chi2_final"] - 1), cam_err(cg, co), obj_rel(og, oo)))
+        print("2,000 cams / 300 ellipsoids, full SLAM run, sparse camera-first (numeric %g) vs CPU camera-first checker at the same step: %d iterations, "
+              "trials %s / %s, chi2 trace rel %.2e, final chi2 rel %.2e, cameras %.2e, ellipsoids %.2e" % (
+                  delta, rg["iterations"], rg["trace_trials"], ro["trace_trials"], tr, abs(rg["chi2_final"] / ro["chi2_final"] - 1), cam_err(cg, co), obj_rel(og, oo)))
         assert [int(t) for t in rg["trace_trials"]] == [int(t) for t in ro["trace_trials"]] and rg["stop_reason"] == ro["stop_reason"]
         assert rg["chi2_initial"] == pytest.approx(ro["chi2_initial"], rel=1e-9)
-        # measured on MI355X (round 5): chi2 trace 7.3e-10, ellipsoids 7.6e-7, cameras 1.1e-4 -- the objective and the ellipsoids are held to
-        # 1e-8 / 5e-6; the cameras of this graph are gauge-soft (8 edges per camera: some hang on the odometry chain alone), two EXACT
-        # eliminations land 1e-4 apart on them while agreeing on chi2 to ten digits -- shown by the GPU's own two eliminations below
-        np.testing.assert_allclose(rg["trace_chi2"], ro["trace_chi2"], rtol=1e-8)
-        assert obj_rel(og, oo) < 5e-6 and cam_err(cg, co) < 5e-4
-        c1, o1, r1 = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-6, linear_solver=1))
+        # measured on MI355X (round 6): chi2 final 8.7e-13, cameras 9.4e-7, ellipsoids 1e-8
+        np.testing.assert_allclose(rg["trace_chi2"], ro["trace_chi2"], rtol=1e-9)
+        assert obj_rel(og, oo) < 2e-7 and cam_err(cg, co) < 5e-6
+        c1, o1, r1 = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=delta, linear_solver=1))
         print("   the GPU's reduced-camera elimination on the same graph: vs its camera-first run chi2 rel %.2e cameras %.2e ellipsoids %.2e | vs the checker "
               "cameras %.2e ellipsoids %.2e" % (abs(r1["chi2_final"] / rg["chi2_final"] - 1), cam_err(c1, cg), obj_rel(o1, og), cam_err(c1, co), obj_rel(o1, oo)))
-        assert r1["trace_trials"] == rg["trace_trials"] and r1["chi2_final"] == pytest.approx(rg["chi2_final"], rel=1e-8)
-        assert obj_rel(o1, oo) < 5e-6 and cam_err(c1, co) < 5e-4
-        # the product default and the reference's own step size: NOT like for like -- the distance is the reference's Jacobian-noise floor,
-        # measured by the checker against itself (delta = 1e-9 vs 1e-6, in the fixture): the GPU may be no further from the checker than
-        # twice that, and within north_star's 1e-4 on the objective and the ellipsoids
-        floor_c, floor_o = cam_err(G["cams_d9"], co), obj_rel(G["objs_d9"], oo)
-        print("   checker against itself, delta 1e-9 vs 1e-6: final chi2 rel %.2e, cameras %.2e, ellipsoids %.2e" % (
-            abs(float(G["chi2_final_d9"]) / ro["chi2_final"] - 1), floor_c, floor_o))
-        for jac, delta, tag in ((1, 1e-6, "analytic"), (0, 1e-9, "numeric 1e-9 (g2o's)")):
-            ca, oa, ra = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=jac, numeric_delta=delta, linear_solver=2))
-            print("   %s Jacobians vs that checker run: %d iterations, final chi2 rel %.2e, cameras %.2e, ellipsoids %.2e" % (
-                tag, ra["iterations"], abs(ra["chi2_final"] / ro["chi2_final"] - 1), cam_err(ca, co), obj_rel(oa, oo)))
-            assert ra["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-4)
-            assert obj_rel(oa, oo) < max(1e-4, 2 * floor_o) and cam_err(ca, co) < max(5e-4, 2 * floor_c)
+        assert r1["trace_trials"] == rg["trace_trials"] and r1["chi2_final"] == pytest.approx(rg["chi2_final"], rel=1e-9)
+        assert cam_err(c1, cg) < 1e-6 and obj_rel(o1, oo) < 2e-7 and cam_err(c1, co) < 5e-6
+        # the product default (analytic Jacobians) against the checker at its three finite steps: the checker converges to it as its
+        # own roundoff noise (~ 1 / delta) goes down; and the checker against itself, which is that noise
+        ca, oa, ra = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=1, linear_solver=2))
+        seq = [(sfx, cam_err(ca, G["cams" + sfx]), obj_rel(oa, G["objs" + sfx]), abs(ra["chi2_final"] / float(G["chi2_final" + sfx]) - 1)) for sfx in ("_d6", "_d5", "")]
+        print("   analytic Jacobians (%d iterations) vs the checker at delta 1e-6 / 1e-5 / 1e-4: cameras %s, ellipsoids %s, final chi2 %s" % (
+            ra["iterations"], " / ".join("%.2e" % s[1] for s in seq), " / ".join("%.2e" % s[2] for s in seq), " / ".join("%.1e" % s[3] for s in seq)))
+        print("   checker against itself: delta 1e-6 vs 1e-4 cameras %.2e, 1e-5 vs 1e-4 %.2e, 1e-9 (g2o's) vs 1e-4 %.2e (ellipsoids %.2e)" % (
+            cam_err(G["cams_d6"], co), cam_err(G["cams_d5"], co), cam_err(G["cams_d9"], co), obj_rel(G["objs_d9"], oo)))
+        assert seq[0][1] > seq[1][1] > seq[2][1]                       # monotone: the distance IS the checker's noise
+        assert seq[0][1] < 2e-4 and seq[1][1] < 2e-5 and seq[2][1] < 5e-6 and seq[2][2] < 2e-7
+        assert cam_err(G["cams_d6"], co) > 10 * seq[2][1]               # the checker is further from itself (1e-6 vs 1e-4) than the GPU is from its 1e-4 run
+        assert ra["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-8)
+        # the reference's own step (delta = 1e-9) on the GPU: its distance from everything else is the GPU's own Jacobian noise at that step,
+        # two orders below the checker's (1.7e-2 on the cameras) -- inside north_star's 1e-4 on the objective and the ellipsoids
+        c9, o9, r9 = cx.optimize(g, c, o, pkg.default_lm_params(jacobian_mode=0, numeric_delta=1e-9, linear_solver=2))
+        print("   numeric 1e-9 (g2o's step) on the GPU vs the checker at 1e-4: %d iterations, final chi2 rel %.2e, cameras %.2e, ellipsoids %.2e" % (
+            r9["iterations"], abs(r9["chi2_final"] / ro["chi2_final"] - 1), cam_err(c9, co), obj_rel(o9, oo)))
+        assert r9["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-6)
+        assert obj_rel(o9, oo) < 1e-4 and cam_err(c9, co) < 1e-3 and cam_err(c9, co) < 0.1 * cam_err(G["cams_d9"], co)
     finally:
         cx.close()
         monkeypatch.delenv("ESL_CF_SPARSE", raising=False)
