@@ -23,9 +23,11 @@
 //               lies within 0.02 m of the model's plane (PlaneRefinementComparator) -- labels move as the scan goes, so a model grows
 //               through a whole run of such pixels.  Coefficients are NOT re-estimated (PCL does not); what grows are the inlier
 //               lists: the sizes the reference filters by (:87) and ranks the ground candidates by (:160), and GetPoints().
-//               Sequential by definition; here ONE workgroup walks the rows in order: a row's runs are disjoint, so every run is
-//               walked by its own thread, and the pull into the next row is one independent test per column.  The result does not
+//               Sequential by definition; here ONE WAVE walks the rows in order: a row's runs are disjoint, so every run is
+//               walked by its own lane, and the pull into the next row is one independent test per column.  The result does not
 //               depend on thread timing (k_plane_refine).  esl_plane_params::refine = 0 gives the segments alone.
+//   models      (round 6) what PCL's segment() keeps: components of MORE than 100 pixels whose surface curvature
+//               |lambda_min| / trace(cov) is below maximum_curvature_ = 0.001; the rest are "other" pixels a model may absorb
 //   ground      among the planes whose normal is within 45 degrees of the camera's y axis (either sign, :139-146) the one with
 //               the most pixels (:160-162; ties: the component with the smaller root pixel); sign such that the camera
 //               centre is on the positive side (:165-167)
@@ -315,100 +317,131 @@ static __global__ __launch_bounds__(256) void k_plane_lab_init(PlaneArgs a) {
 // a model followed by an unlabelled-by-any-model pixel), (3) every run start walks its run -- runs end at the next pixel that is not
 // "other", so they are disjoint --, (4) the labels go back and every column tests the ONE pixel of the next row (quirk kept: not when
 // the in-row neighbour has no label).  Second pass mirrored, plus PCL's "left of column 0" = the last pixel of the row above.
+// Round 6.  What a row cost in round 5's form (2.3 us, 2.2 ms per image) was the global-memory round trip of its labels and depths in
+// front of every step, not the step: (a) a single wave without any barrier takes 7 us per row (ten columns per lane, every one a
+// dependent LDS round trip), 256 threads 2.6 us, 1,024 threads 2.1 us; (b) with the next ROW prefetched one step ahead the step still
+// waits, because a step is shorter than a memory round trip.  So: a ring of 2 x kPlaneRefB rows (labels AND depths) in LDS, the
+// kPlaneRefB rows after them in flight in registers for a whole block of steps, a finished row leaves once, growth counts in LDS.
+// Rows beyond the two a step works on are never modified before their turn, so the prefetched values are the ones the serial sweep
+// would read.
+// (c) what remained after that (1.7 ms) was the point of a tested pixel: three IEEE double divisions per test (px_point's, kept bit
+// for bit), ~500 cycles on the one lane the whole workgroup waits for, once or twice per row and once per pixel of a run.  The
+// points of a row are now computed by ALL threads when the row is parked in the ring (same expressions, same bits); a test is four
+// multiply-adds.
 constexpr int kPlaneRefThreads = 1024;
-// Round 6: the two rows a step works on -- labels AND depths -- live in LDS, the row after them is in flight in registers while the
-// step runs, and a finished row leaves once: no global load sits on the serial path any more (round 5 re-read every row's labels
-// and, inside the run walk, one depth per step from global memory: 2.3 us per row, 2.2 ms per image).
-static __global__ __launch_bounds__(kPlaneRefThreads) void k_plane_refine(PlaneArgs a, int* __restrict__ grown, double thr) {
+constexpr int kPlaneRefMaxW = 4096;                        // (B = 1; the B = 4 ring fits images up to kPlaneRefRingW columns)
+constexpr int kPlaneRefRingW = 1152;
+constexpr int kPlaneRefGrown = 2048;                       // models whose growth is counted in LDS (beyond: global atomics)
+static size_t plane_refine_lds(int B, int w) { return ((size_t)(2 * B) * w * 4 + (size_t)w + kPlaneRefGrown) * sizeof(int); }
+// B: rows per prefetch block; the ring holds 2 B rows
+template <int B>
+static __global__ __launch_bounds__(kPlaneRefThreads) void k_plane_refine(PlaneArgs a, int* __restrict__ grown, double thr, int n_cap) {
   extern __shared__ int s_row[];
   const int w = a.w, h = a.h, t = threadIdx.x;
-  int* sLab[2] = {s_row, s_row + w};
-  int* sF = s_row + 2 * w;
-  unsigned short* sDep[2] = {reinterpret_cast<unsigned short*>(s_row + 3 * w), reinterpret_cast<unsigned short*>(s_row + 3 * w) + w};
-  constexpr int kPer = 2;                                  // columns per thread of the prefetch (w <= 2048)
-  auto near = [&](int m, int u, int v, unsigned short d) {
-    const float z = (float)((double)d / a.scale);
-    const float qx = (float)(((double)u - a.cx) * (double)z / a.fx), qy = (float)(((double)v - a.cy) * (double)z / a.fy);
+  constexpr int RING = 2 * B;
+  int* sLab = s_row;                                       // [RING][w]
+  float* sPt = reinterpret_cast<float*>(s_row + RING * w); // [RING][3][w]: the pixel's point, as px_point computes it
+  int* sF = s_row + 4 * RING * w;
+  int* sG = sF + w;                                        // [kPlaneRefGrown]
+  constexpr int kPer = (B == 1 ? kPlaneRefMaxW : kPlaneRefRingW + kPlaneRefThreads - 1) / kPlaneRefThreads;
+  auto near = [&](int m, const float* P, int u) {           // P: the row's points
     const double* pl = a.list + (size_t)m * 5;
-    return fabs(pl[0] * (double)qx + pl[1] * (double)qy + pl[2] * (double)z + pl[3]) < thr;
+    return fabs(pl[0] * (double)P[u] + pl[1] * (double)P[w + u] + pl[2] * (double)P[2 * w + u] + pl[3]) < thr;
   };
-  int pl_[kPer]; unsigned short pd_[kPer];
-  auto fetch = [&](int v) {                                 // row v -> registers (rows outside the image: nothing)
+  auto grow = [&](int m, int n) { if (m < kPlaneRefGrown) atomicAdd(&sG[m], n); else atomicAdd(&grown[m], n); };
+  for (int m = t; m < kPlaneRefGrown; m += kPlaneRefThreads) sG[m] = 0;
+  // LOGICAL rows: i = 0 .. h - 1 in sweep order (pass 1: image row i; pass 2: image row h - 1 - i); step i works on rows i and i + 1
+  int pl_[B][kPer]; unsigned short pd_[B][kPer];
+  auto fetch = [&](int i0, bool down) {                    // logical rows i0 .. i0 + B - 1 -> registers (rows outside the image: nothing)
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      const int u = t + q * kPlaneRefThreads;
-      const bool in = v >= 0 && v < h && u < w;
-      pl_[q] = in ? a.labels[(size_t)v * w + u] : -1;
-      pd_[q] = in ? a.depth[(size_t)v * w + u] : (unsigned short)0;
-    }
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int i = i0 + r, v = down ? i : h - 1 - i, u = t + q * kPlaneRefThreads;
+        const bool in = i >= 0 && i < h && u < w;
+        pl_[r][q] = in ? a.labels[(size_t)v * w + u] : -1;
+        pd_[r][q] = in ? a.depth[(size_t)v * w + u] : (unsigned short)0;
+      }
   };
-  auto park = [&](int b) {
+  auto park = [&](int i0, bool down) {
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) { const int u = t + q * kPlaneRefThreads; if (u < w) { sLab[b][u] = pl_[q]; sDep[b][u] = pd_[q]; } }
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int i = i0 + r, v = down ? i : h - 1 - i, u = t + q * kPlaneRefThreads, sl = (i % RING) * w;
+        if (u < w) {
+          sLab[sl + u] = pl_[r][q];
+          const float z = (float)((double)pd_[r][q] / a.scale);   // px_point, expression for expression
+          sPt[3 * sl + u] = (float)(((double)u - a.cx) * (double)z / a.fx);
+          sPt[3 * sl + w + u] = (float)(((double)v - a.cy) * (double)z / a.fy);
+          sPt[3 * sl + 2 * w + u] = z;
+        }
+      }
   };
   // ---- first pass: rightwards, downwards
-  fetch(0); park(0); fetch(1); park(1);
+  fetch(0, true); park(0, true); fetch(B, true); park(B, true);
   __syncthreads();
   for (int v = 0; v < h - 1; ++v) {
-    int* sL = sLab[v & 1]; int* sN = sLab[(v + 1) & 1];
-    const unsigned short* sD = sDep[v & 1]; const unsigned short* sDN = sDep[(v + 1) & 1];
-    fetch(v + 2);
+    if (v % B == 0) fetch(v + 2 * B, true);                 // the block after the ring's two: in flight for B steps
+    int* sL = sLab + (v % RING) * w; int* sN = sLab + ((v + 1) % RING) * w;
+    const float* sP = sPt + 3 * (v % RING) * w; const float* sPN = sPt + 3 * ((v + 1) % RING) * w;
     for (int u = t; u < w - 1; u += kPlaneRefThreads) sF[u] = (sL[u] >= 0 && sL[u + 1] == -2) ? 1 : 0;
     __syncthreads();
     for (int u = t; u < w - 1; u += kPlaneRefThreads)
       if (sF[u]) {
         const int m = sL[u];
         int j = u + 1, n = 0;
-        while (j < w && sL[j] == -2 && near(m, j, v, sD[j])) { sL[j] = m; ++j; ++n; }
-        if (n) atomicAdd(&grown[m], n);
+        while (j < w && sL[j] == -2 && near(m, sP, j)) { sL[j] = m; ++j; ++n; }
+        if (n) grow(m, n);
       }
     __syncthreads();
     for (int u = t; u < w; u += kPlaneRefThreads) {
       const int cur = sL[u];
       a.labels[(size_t)v * w + u] = cur;
-      if (u < w - 1 && cur >= 0 && sL[u + 1] != -1 && sN[u] == -2 && near(cur, u, v + 1, sDN[u])) { sN[u] = cur; atomicAdd(&grown[cur], 1); }
+      if (u < w - 1 && cur >= 0 && sL[u + 1] != -1 && sN[u] == -2 && near(cur, sPN, u)) { sN[u] = cur; grow(cur, 1); }
     }
     __syncthreads();
-    park(v & 1);                                            // row v + 2 takes the finished row's place
-    __syncthreads();
+    if (v % B == B - 1) { park(v + 1 + B, true); __syncthreads(); }   // rows v + 1 - B .. v are finished: their slots take the block that was in flight
   }
-  for (int u = t; u < w; u += kPlaneRefThreads) a.labels[(size_t)(h - 1) * w + u] = sLab[(h - 1) & 1][u];
+  for (int u = t; u < w; u += kPlaneRefThreads) a.labels[(size_t)(h - 1) * w + u] = sLab[((h - 1) % RING) * w + u];
+  __threadfence_block();
   __syncthreads();
-  // ---- second pass: leftwards, upwards (plus PCL's "left of column 0" = the last pixel of the row above)
-  fetch(h - 1); park((h - 1) & 1); fetch(h - 2); park((h - 2) & 1);
+  // ---- second pass: leftwards, upwards (plus PCL's "left of column 0" = the last pixel of the row above); logical row i = image row h - 1 - i
+  fetch(0, false); park(0, false); fetch(B, false); park(B, false);
   __syncthreads();
-  for (int v = h - 1; v >= 1; --v) {
-    int* sL = sLab[v & 1]; int* sN = sLab[(v - 1) & 1];
-    const unsigned short* sD = sDep[v & 1]; const unsigned short* sDN = sDep[(v - 1) & 1];
-    fetch(v - 2);
+  for (int i = 0; i < h - 1; ++i) {
+    const int v = h - 1 - i;
+    if (i % B == 0) fetch(i + 2 * B, false);
+    int* sL = sLab + (i % RING) * w; int* sN = sLab + ((i + 1) % RING) * w;
+    const float* sP = sPt + 3 * (i % RING) * w; const float* sPN = sPt + 3 * ((i + 1) % RING) * w;
     for (int u = t; u < w; u += kPlaneRefThreads) sF[u] = (u >= 1 && sL[u] >= 0 && sL[u - 1] == -2) ? 1 : 0;
     __syncthreads();
     for (int u = t; u < w; u += kPlaneRefThreads)
       if (sF[u]) {
         const int m = sL[u];
         int j = u - 1, n = 0;
-        while (j >= 0 && sL[j] == -2 && near(m, j, v, sD[j])) { sL[j] = m; --j; ++n; }
-        if (n) atomicAdd(&grown[m], n);
+        while (j >= 0 && sL[j] == -2 && near(m, sP, j)) { sL[j] = m; --j; ++n; }
+        if (n) grow(m, n);
       }
     __syncthreads();
     for (int u = t; u < w; u += kPlaneRefThreads) {
       const int cur = sL[u];
       a.labels[(size_t)v * w + u] = cur;
-      if (u >= 1 && cur >= 0 && sL[u - 1] != -1 && sN[u] == -2 && near(cur, u, v - 1, sDN[u])) { sN[u] = cur; atomicAdd(&grown[cur], 1); }
+      if (u >= 1 && cur >= 0 && sL[u - 1] != -1 && sN[u] == -2 && near(cur, sPN, u)) { sN[u] = cur; grow(cur, 1); }
     }
     __syncthreads();
     if (t == 0) {                                          // column 0 comes last in PCL's sweep: "left" = the last pixel of the row above
       const int cur = sL[0];
       if (cur != -1 && sN[w - 1] != -1) {
-        if (cur >= 0 && sN[w - 1] == -2 && near(cur, w - 1, v - 1, sDN[w - 1])) { sN[w - 1] = cur; atomicAdd(&grown[cur], 1); }
-        if (cur >= 0 && sN[0] == -2 && near(cur, 0, v - 1, sDN[0])) { sN[0] = cur; atomicAdd(&grown[cur], 1); }
+        if (cur >= 0 && sN[w - 1] == -2 && near(cur, sPN, w - 1)) { sN[w - 1] = cur; grow(cur, 1); }
+        if (cur >= 0 && sN[0] == -2 && near(cur, sPN, 0)) { sN[0] = cur; grow(cur, 1); }
       }
     }
     __syncthreads();
-    park(v & 1);                                            // row v - 2 takes the finished row's place
-    __syncthreads();
+    if (i % B == B - 1) { park(i + 1 + B, false); __syncthreads(); }
   }
-  for (int u = t; u < w; u += kPlaneRefThreads) a.labels[u] = sLab[0][u];
+  for (int u = t; u < w; u += kPlaneRefThreads) a.labels[u] = sLab[((h - 1) % RING) * w + u];
+  for (int m = t; m < kPlaneRefGrown && m < n_cap; m += kPlaneRefThreads) if (sG[m]) atomicAdd(&grown[m], sG[m]);
 }
 
 // one workgroup: every component of >= min_size pixels -> its plane; the ground-plane candidate with the most pixels wins
@@ -526,14 +559,23 @@ namespace {
 struct RefinedPlanes { std::vector<double> planes; std::vector<int> sizes; int ground = -1; };
 int plane_refined(esl_ctx* c, const esl_plane_params* p, PlaneWork& w, PlaneArgs& a, RefinedPlanes& out, int32_t* labels_out) {
   const size_t npx = (size_t)a.w * a.h;
-  if (a.w > 2 * kPlaneRefThreads) { set_error("plane refinement: images wider than 2048 pixels are not supported"); return ESL_ERR_INVALID; }
+  if (a.w > kPlaneRefMaxW) { set_error("plane refinement: images wider than 4096 pixels are not supported"); return ESL_ERR_INVALID; }
   a.min_size = 0;                                      // PCL's models (plane_is_model), in raster order of their first pixel; Plane.MinSize applies to the REFINED sizes below
   a.plane_of_root = (int*)w.map.p; a.list = (double*)w.list.p; a.list_cap = w.list_cap; a.labels = (int*)w.labels.p;
   plane_list_launch(a, c->stream);
   hipLaunchKernelGGL(k_plane_lab_init, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, a);
   ESL_HIP_TRY(hipMemsetAsync(w.grown.p, 0, (size_t)w.list_cap * sizeof(int), c->stream));
-  if (a.w > 1 && a.h > 1)
-    hipLaunchKernelGGL(k_plane_refine, dim3(1), dim3(kPlaneRefThreads), 4 * (size_t)a.w * sizeof(int), c->stream, a, (int*)w.grown.p, p->refine_distance);
+  if (a.w > 1 && a.h > 1) {
+    if (a.w <= kPlaneRefRingW) {
+      const size_t lds = plane_refine_lds(4, a.w);
+      ESL_HIP_TRY(hipFuncSetAttribute((const void*)k_plane_refine<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_plane_refine<4>, dim3(1), dim3(kPlaneRefThreads), lds, c->stream, a, (int*)w.grown.p, p->refine_distance, w.list_cap);
+    } else {
+      const size_t lds = plane_refine_lds(1, a.w);
+      ESL_HIP_TRY(hipFuncSetAttribute((const void*)k_plane_refine<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_plane_refine<1>, dim3(1), dim3(kPlaneRefThreads), lds, c->stream, a, (int*)w.grown.p, p->refine_distance, w.list_cap);
+    }
+  }
   ESL_HIP_TRY(hipGetLastError());
   double h[8];
   ESL_HIP_TRY(hipMemcpyAsync(h, w.out.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));

@@ -466,7 +466,7 @@ def test_sparse_camera_first_trial_matches_cpu_camera_first_checker(pkg, po, mon
                   % (jac, abs(rg["chi2_final"] / ro["chi2_final"] - 1), cam_err(cg, co), obj_rel(og, oo), rg["trace_trials"], ro["trace_trials"]))
             assert rg["trace_trials"] == ro["trace_trials"]
             assert rg["chi2_final"] == pytest.approx(ro["chi2_final"], rel=1e-8)
-            assert cam_err(cg, co) < 2e-6 and obj_rel(og, oo) < 1e-6
+            assert cam_err(cg, co) < 1e-6 and obj_rel(og, oo) < 5e-7   # measured (round 6): 1.7e-7 / 7.8e-8
     finally:
         cx.close()
         monkeypatch.delenv("ESL_CF_SPARSE", raising=False)

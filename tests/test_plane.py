@@ -227,7 +227,8 @@ def test_gpu_ground_plane_matches_checker_and_fixture(ctx):
 @pytest.mark.gpu
 def test_gpu_all_planes_match_checker(ctx):
     intr, frames = fixture()
-    cases = [(f[0], intr) for f in frames] + [scene(noise=3.0, seed=5)[:2], scene(h=123, w=211, noise=2.0)[:2]]
+    cases = [(f[0], intr) for f in frames] + [scene(noise=3.0, seed=5)[:2], scene(h=123, w=211, noise=2.0)[:2],
+                                                  scene(h=90, w=1300, noise=2.0, seed=2)[:2]]   # (wider than the refinement kernel's LDS ring: its two-row form)
     for depth, it in cases:
         g, r = ctx.extract_planes(depth, it), po.extract_planes(depth, it)
         assert g["n_planes"] == r["n_planes"] and np.array_equal(g["sizes"], r["sizes"]) and np.array_equal(g["labels"], r["labels"])
