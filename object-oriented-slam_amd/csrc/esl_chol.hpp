@@ -1008,6 +1008,7 @@ struct CholTask { int type, a, b, c; };
 struct CholPlan {
   int n = 0, np = 0, W = 0, n_outer = 0, nR = 0;
   int fuse = 0;          // the chain solves the two strips under its diagonal block and updates the next diagonal block itself (below)
+  int merge = 1;         // far updates of a tile taken `merge` outer panels at a time (round 6: one visit with K = merge x W x 128)
   std::vector<CholTask> tasks;
   std::vector<int> ns;   // [np][nR]
 };
@@ -1025,9 +1026,10 @@ __host__ __device__ inline bool chol_quarter_live(int R, int J, int h, int g, lo
   const long i0 = 256L * R + 128L * h, j0 = 128L * J + 64L * g;
   return i0 < rows && j0 < n && i0 + 127 >= j0;
 }
-inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = false) {
+inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = false, int merge = 1) {
   const long rows = (long)n + 1;
   pl.fuse = fuse ? 1 : 0;
+  pl.merge = merge < 1 ? 1 : merge;
   pl.n = n; pl.W = W; pl.np = (n + kNB - 1) / kNB; pl.n_outer = (pl.np + W - 1) / W; pl.nR = (int)((rows + 255) / 256);
   const int np = pl.np, nR = pl.nR;
   pl.ns.assign((size_t)np * nR, 0);
@@ -1076,9 +1078,19 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
     pl.tasks.insert(pl.tasks.end(), prevB.begin() + bpos, prevB.end());
     prevA.clear(); prevB.clear();
     const int ne = std::min(np, ke + W);
+    // Round 6: a tile's FAR updates -- those of outer panels o <= J / W - 2, which only fill the workers' time -- are taken `merge` outer
+    // panels at a time: one visit of the tile with K = merge x W x 128 instead of `merge` visits (each visit pays ~22 us of task
+    // hand-off, first-chunk staging and the read-modify-write of C beside ~127 us of K loop).  A group [g0, g0 + cnt) goes into the
+    // list when its LAST outer panel is solved; the update of the outer panel right in front of the tile's own (o = J / W - 1, the one
+    // the chain waits for) stays a visit of its own.  c = J | cnt << 16; sequence number g0 -> g0 + cnt.
     for (int J = ke; J < np; ++J)
       for (int R = J / 2; R < nR; ++R)
-        if (live(R, J) && !(J == ke && R == ke / 2)) (J < ne ? prevA : prevB).push_back(CholTask{2, o, R, J});   // (the special tile: see chol_tile_special)
+        if (live(R, J) && !(J == ke && R == ke / 2)) {   // (the special tile: see chol_tile_special)
+          if (J < ne) { prevA.push_back(CholTask{2, o, R, J | (1 << 16)}); continue; }
+          const int far = J / W - 1;                     // far updates of this tile: o = 0 .. far - 1 (this o is one of them: J >= ne)
+          const int g0 = (o / pl.merge) * pl.merge, ge = std::min(g0 + pl.merge, far) - 1;
+          if (o == ge) prevB.push_back(CholTask{2, g0, R, J | ((ge - g0 + 1) << 16)});
+        }
   }
 }
 // sync words: [0] task counter, [1] abort, [2] arrival tickets (0 = the chain), [4 ..) pdone[np], sdone[np][nR], ver[nR][np], quarters done [nR][np]
@@ -1337,7 +1349,8 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         ok = chol_wait_ge<100>(&pdone[k], 1, sync + 1, info) && chol_wait_ge<100>(&ver[(size_t)R * np + k], chol_tile_final(R, k, W), sync + 1, info);
       } else {
         const int R = tk.b, J = tk.c & 0xffff;
-        const int ke = (tk.type != 2) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
+        const int cnt = (tk.type == 2) ? (tk.c >> 16) : 1;   // type 2: outer panels [a, a + cnt) in one visit
+        const int ke = (tk.type != 2) ? tk.a + 1 : (((tk.a + cnt) * W < np) ? (tk.a + cnt) * W : np);
         // the LAST panel's strips of a row tile are solved only after every earlier panel of the same outer panel has solved its own
         // there and updated them (S waits for its tile to be final): one pair of words stands for all W panels
         // the three words are fetched TOGETHER first (agent-scope loads go to the fabric, ~1.5 us each one after the other; most
@@ -1364,14 +1377,15 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
         chol_panel_body<true>(M, lda, rows, k0, nb, Linv_ws + (size_t)k * kNB * kNB, (long)tk.b);
       } else {
-        const int kb = (tk.type != 2) ? tk.a : tk.a * W, ke = (tk.type != 2) ? tk.a + 1 : ((tk.a * W + W < np) ? tk.a * W + W : np);
+        const int cnt = (tk.type == 2) ? (tk.c >> 16) : 1;
+        const int kb = (tk.type != 2) ? tk.a : tk.a * W, ke = (tk.type != 2) ? tk.a + 1 : (((tk.a + cnt) * W < np) ? (tk.a + cnt) * W : np);
         const long c0 = (long)kb * kNB;
         const int K = (int)(((long)ke * kNB < n ? (long)ke * kNB : (long)n) - c0);
         if (tk.type == 3)
           chol_update_tile<128, 64, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b + 128L * ((tk.c >> 16) & 1),
                                                 128L * (tk.c & 0xffff) + 64L * ((tk.c >> 17) & 1), false);
         else
-          chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * tk.c, false);
+          chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * (tk.c & 0xffff), false);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
@@ -1389,7 +1403,8 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         if (old + 1 == full * (tk.a % W) + mine)
           __hip_atomic_store(&ver[(size_t)tk.b * np + J], chol_tile_nU(tk.b, J, W) + tk.a % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        __hip_atomic_store(&ver[(size_t)tk.b * np + tk.c], ((tk.type == 1) ? tk.c / W + tk.a % W : tk.a) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int J = tk.c & 0xffff;
+        __hip_atomic_store(&ver[(size_t)tk.b * np + J], (tk.type == 1) ? J / W + tk.a % W + 1 : tk.a + (tk.c >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (stats) { lstat[1] += (long long)wall_clock64() - lstat[4]; lstat[2] += 1; }
     }
@@ -1478,16 +1493,27 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
 }
 
 inline bool chol_fuse_default() { const char* e = std::getenv("ESL_CHOL_FUSE"); return !(e && e[0] == '0'); }
+// Far updates of a tile per visit (chol_plan_build).  Measured on MI355X (round 6, scripts/chol_bench.py; 1 / 2 / 4 / 8 outer panels per
+// visit): n = 8,192 7.22 / 7.53 / 7.76 / 8.65 ms, 12,000 15.6 / 15.6 / 16.2 / 18.5, 18,000 39.5 / 39.1 / 38.9 / 40.4, 24,000 87.6 / 85.4 / 84.5 / 87.0:
+// the workers' time in task bodies falls as predicted (n = 18,000: 36.5 -> 34.1 ms), part of it comes back as waiting (2.7 -> 3.8 ms: a
+// group enters the list one to three outer panels later than its first member did), and small systems have no slack to give.
+// Default: 4 from n = 16,384, else 1 (the round 4-5 list); ESL_CHOL_MERGE overrides.
+inline int chol_merge_default(int n) {
+  const char* e = std::getenv("ESL_CHOL_MERGE");
+  const int m = e ? std::atoi(e) : (n >= 16384 ? 4 : 1);
+  return m < 1 ? 1 : (m > 16 ? 16 : m);
+}
 // the persistent kernel on the caller's stream (one launch; the sync words are cleared in front of it)
 inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Linv_ws, int* info, hipStream_t st, CholRuntime& rt) {
   const char* wenv = std::getenv("ESL_CHOL_W");   // (debugging: outer-panel width of the persistent form)
   const int W = wenv ? std::max(1, std::atoi(wenv)) : chol_outer_panels(n);
   // ESL_CHOL_FUSE=0: strips under the diagonal block and the next block's update as worker tasks (the first form of round 4; A/B)
   const bool fuse = chol_fuse_default();
-  if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0)) {
+  const int merge = chol_merge_default(n);
+  if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0) || rt.plan.merge != merge) {
     { hipError_t e0 = hipStreamSynchronize(st); if (e0 != hipSuccess) return e0; }   // the old list / sync words may still be in use
     const char* fenv = std::getenv("ESL_CHOL_FILLER");   // (debugging: far-update tasks interleaved per chain-dependent group)
-    chol_plan_build(n, W, fenv ? std::max(1, std::atoi(fenv)) : 128, rt.plan, fuse);
+    chol_plan_build(n, W, fenv ? std::max(1, std::atoi(fenv)) : 128, rt.plan, fuse, merge);
     auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
       if (*cap >= need) return hipSuccess;
       if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }

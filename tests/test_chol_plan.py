@@ -129,8 +129,10 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
             M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
             sdone[k, R] += 1
         else:
-            R, J = bb, c
-            ks = [a] if ty == 1 else list(range(a * W, min(np_, a * W + W)))
+            # type 2 (round 6): c = J | cnt << 16 -- the tile takes the rank-(W x 128) updates of outer panels [a, a + cnt) in ONE visit
+            R, J, cnt = bb, c & 0xFFFF, (c >> 16) if ty == 2 else 1
+            assert cnt >= 1
+            ks = [a] if ty == 1 else list(range(a * W, min(np_, (a + cnt) * W)))
             seq = (J // W + a % W) if ty == 1 else a
             # (the device code polls the LAST panel's words only: S waits for its tile to be final, so the last panel's strips of a
             #  row tile are solved after every earlier panel of the outer panel has solved its own there -- asserted here for all)
@@ -141,7 +143,8 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
                 if ty == 1:
                     assert k // W == J // W and J > k and R not in (J // 2, (J + 1) // 2)   # (the diagonal tile and the one under an odd panel's block take their rank-128 updates in quarters)
                 else:
-                    assert J >= min(np_, a * W + W) and not (special(R, J) and J // W == a + 1)
+                    assert J >= min(np_, (a + cnt) * W) and not (special(R, J) and J // W == a + cnt)
+                    assert cnt == 1 or a + cnt <= J // W - 1, "only FAR updates are merged: the one in front of the tile's own outer panel is a visit of its own"
             assert ver[R, J] == seq, ("update out of sequence", ty, a, R, J, ver[R, J], seq)
             c0, c1 = 128 * ks[0], min(128 * (ks[-1] + 1), n)
             i0, i1 = 256 * R, min(256 * R + 256, rows); j0, j1 = 128 * J, min(128 * J + 128, n)
@@ -151,7 +154,7 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
             mask = rr >= cc                        # the kernel writes the lower triangle only (row n = the right-hand side's row)
             blk = M[i0:i1, j0:j1]
             blk[mask] -= upd[mask]
-            ver[R, J] = seq + 1
+            ver[R, J] = seq + cnt
     advance_chain()
     assert chain_k[0] == np_, "the chain never got its last blocks"
     # every word at its final value
@@ -184,6 +187,21 @@ def test_task_list_without_the_fused_chain(pkg, monkeypatch, n, W, filler):
     assert counts[0] == int(pl["ns"].sum())
 
 
+@pytest.mark.parametrize("n,W,filler,merge", [(3000, 4, 128, 2), (2500, 4, 16, 2), (2994, 2, 128, 3), (2500, 2, 7, 4), (4000, 4, 128, 4)])
+def test_task_list_with_merged_far_updates(pkg, monkeypatch, n, W, filler, merge):
+    """ESL_CHOL_MERGE (round 6): a tile's far rank-(W x 128) updates taken `merge` outer panels per visit -- still a schedule, still a
+    Cholesky factorisation, fewer type-2 tasks for the same flops"""
+    monkeypatch.setenv("ESL_CHOL_MERGE", "1")
+    base = pkg.lib.chol_plan(n, W, filler)
+    monkeypatch.setenv("ESL_CHOL_MERGE", str(merge))
+    pl, counts, _ = replay(pkg, n, W, filler)
+    t, t0 = pl["tasks"], base["tasks"]
+    k2 = lambda tt: int((tt[tt[:, 0] == 2][:, 3] >> 16).sum())
+    assert k2(t) == k2(t0) == int((t0[:, 0] == 2).sum())          # the same outer-panel contributions ...
+    assert int((t[:, 0] == 2).sum()) < int((t0[:, 0] == 2).sum())  # ... in fewer visits
+    assert int((t[:, 0] == 2).sum() + 0) == counts[2] and (t[t[:, 0] == 2][:, 3] >> 16).max() == merge
+
+
 def test_look_ahead_order_of_the_list(pkg):
     """the next outer panel's chain-dependent tasks must not queue behind ALL far updates of the previous one (that would be the
     launch-per-step order without any look-ahead): the first strip of panel W comes before the last far update of outer panel 0"""
@@ -191,6 +209,6 @@ def test_look_ahead_order_of_the_list(pkg):
     t = pl["tasks"]
     first_s = int(np.nonzero((t[:, 0] == 0) & (t[:, 1] == 4))[0][0])
     far0 = np.nonzero((t[:, 0] == 2) & (t[:, 1] == 0))[0]
-    look0 = far0[t[far0, 3] < 8]
+    look0 = far0[(t[far0, 3] & 0xFFFF) < 8]
     assert look0.max() < first_s < far0.max()
-    assert len(t) > 50000 and pl["np"] == 141 and pl["nR"] == 71
+    assert len(t) > 40000 and pl["np"] == 141 and pl["nR"] == 71   # (round 6: far updates four outer panels per visit from n = 16,384: 87,651 -> 48,056 tasks)
