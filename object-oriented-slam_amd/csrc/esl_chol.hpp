@@ -1088,7 +1088,11 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
         if (live(R, J) && !(J == ke && R == ke / 2)) {   // (the special tile: see chol_tile_special)
           if (J < ne) { prevA.push_back(CholTask{2, o, R, J | (1 << 16)}); continue; }
           const int far = J / W - 1;                     // far updates of this tile: o = 0 .. far - 1 (this o is one of them: J >= ne)
-          const int g0 = (o / pl.merge) * pl.merge, ge = std::min(g0 + pl.merge, far) - 1;
+          // the groups of different tiles are STAGGERED (boundaries shifted by a hash of the tile): with one grid of boundaries for all
+          // tiles every far task of `merge` outer panels enters the list at once and the panels in between have no filler work at all
+          // (measured: waiting 2.7 -> 3.8 ms while the bodies fell 36.5 -> 34.1)
+          const int shift = (R + 2 * J) % pl.merge, q = (o + shift) / pl.merge;
+          const int g0 = std::max(0, q * pl.merge - shift), ge = std::min((q + 1) * pl.merge - shift, far) - 1;
           if (o == ge) prevB.push_back(CholTask{2, g0, R, J | ((ge - g0 + 1) << 16)});
         }
   }
@@ -1493,14 +1497,15 @@ inline hipError_t chol_set_attributes(CholRuntime& rt) {   // dynamic-LDS limits
 }
 
 inline bool chol_fuse_default() { const char* e = std::getenv("ESL_CHOL_FUSE"); return !(e && e[0] == '0'); }
-// Far updates of a tile per visit (chol_plan_build).  Measured on MI355X (round 6, scripts/chol_bench.py; 1 / 2 / 4 / 8 outer panels per
-// visit): n = 8,192 7.22 / 7.53 / 7.76 / 8.65 ms, 12,000 15.6 / 15.6 / 16.2 / 18.5, 18,000 39.5 / 39.1 / 38.9 / 40.4, 24,000 87.6 / 85.4 / 84.5 / 87.0:
-// the workers' time in task bodies falls as predicted (n = 18,000: 36.5 -> 34.1 ms), part of it comes back as waiting (2.7 -> 3.8 ms: a
-// group enters the list one to three outer panels later than its first member did), and small systems have no slack to give.
-// Default: 4 from n = 16,384, else 1 (the round 4-5 list); ESL_CHOL_MERGE overrides.
+// Far updates of a tile per visit (chol_plan_build).  Measured on MI355X (round 6, scripts/chol_bench.py).  With ONE grid of group
+// boundaries for all tiles (1 / 2 / 4 / 8 outer panels per visit): n = 8,192 7.22 / 7.53 / 7.76 / 8.65 ms, 18,000 39.5 / 39.1 / 38.9 / 40.4 -- the
+// time in task bodies falls as predicted (36.5 -> 34.1 ms) but the far work arrives in bursts and the waiting grows (2.7 -> 3.8 ms).
+// With the boundaries STAGGERED by tile (1 / 2 / 3 / 4 / 6 per visit): n = 4,096 2.97 / 2.93 / 2.98, 8,192 7.35 / 7.12 / 7.18 / 7.70, 12,000
+// 15.35 / 14.85 / 15.64 / 16.7, 18,000 39.38 / 37.94 / 37.67 / 38.0 / 39.2, 24,000 87.7 / 83.9 / 83.5 / 84.7 / 86.3.
+// Default: 3 from n = 16,384, else 2; ESL_CHOL_MERGE overrides (1 = the round 4-5 list).
 inline int chol_merge_default(int n) {
   const char* e = std::getenv("ESL_CHOL_MERGE");
-  const int m = e ? std::atoi(e) : (n >= 16384 ? 4 : 1);
+  const int m = e ? std::atoi(e) : (n >= 16384 ? 3 : 2);
   return m < 1 ? 1 : (m > 16 ? 16 : m);
 }
 // the persistent kernel on the caller's stream (one launch; the sync words are cleared in front of it)
