@@ -1009,6 +1009,7 @@ struct CholPlan {
   int n = 0, np = 0, W = 0, n_outer = 0, nR = 0;
   int fuse = 0;          // the chain solves the two strips under its diagonal block and updates the next diagonal block itself (below)
   int merge = 1;         // far updates of a tile taken `merge` outer panels at a time (round 6: one visit with K = merge x W x 128)
+  int strip_merge = 0;   // the strips of a row tile away from the diagonal as one task (round 6)
   std::vector<CholTask> tasks;
   std::vector<int> ns;   // [np][nR]
 };
@@ -1026,15 +1027,17 @@ __host__ __device__ inline bool chol_quarter_live(int R, int J, int h, int g, lo
   const long i0 = 256L * R + 128L * h, j0 = 128L * J + 64L * g;
   return i0 < rows && j0 < n && i0 + 127 >= j0;
 }
-inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = false, int merge = 1) {
+inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = false, int merge = 1, bool strip_merge = false) {
   const long rows = (long)n + 1;
   pl.fuse = fuse ? 1 : 0;
   pl.merge = merge < 1 ? 1 : merge;
+  pl.strip_merge = strip_merge ? 1 : 0;
   pl.n = n; pl.W = W; pl.np = (n + kNB - 1) / kNB; pl.n_outer = (pl.np + W - 1) / W; pl.nR = (int)((rows + 255) / 256);
   const int np = pl.np, nR = pl.nR;
   pl.ns.assign((size_t)np * nR, 0);
   pl.tasks.clear();
   auto live = [&](int R, int J) { return 256L * R + 255 >= 128L * J && 256L * R < rows; };   // the tile meets the lower triangle (or the b row)
+  auto k0s = [&](int k) { const long k0 = 128L * k; return k0 + std::min<long>(kNB, n - k0); };   // first row under panel k's diagonal block
   auto strips = [&](int k) { const long k0 = 128L * k, nb = std::min<long>(kNB, n - k0), below = rows - (k0 + nb); return (int)(below > 0 ? (below + 63) / 64 : 0); };
   for (int k = 0; k < np; ++k) {
     const long k0 = 128L * k, nb = std::min<long>(kNB, n - k0);
@@ -1048,7 +1051,18 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
     auto fill = [&]() { const size_t e = std::min(prevB.size(), bpos + (size_t)filler); pl.tasks.insert(pl.tasks.end(), prevB.begin() + bpos, prevB.begin() + e); bpos = e; };
     for (int k = kb; k < ke; ++k) {
       fill();                                              // (work for the others while the chain factors block k)
-      for (int i = fuse ? 2 : 0; i < strips(k); ++i) pl.tasks.push_back(CholTask{0, k, i, 0});   // (fused: strips 0, 1 are the chain's)
+      // (fused: strips 0, 1 are the chain's.)  Round 6: the strips of ONE row tile are one task where nobody is waiting for the first
+      // of them alone -- every consumer of a solved row tile waits for all of its strips (sdone == ns) anyway, and a strip is ~9 us of
+      // work behind ~20 us of task hand-off.  The row tiles next to the diagonal block keep their 64-row strips: they feed the quarters
+      // of the next diagonal tiles, i.e. the chain, and four workgroups finish them sooner than one.  c = strips in the task.
+      for (int i = fuse ? 2 : 0; i < strips(k);) {
+        const long R = (k0s(k) + 64L * i) / 256;
+        int cnt = 1;
+        if (pl.strip_merge && R >= k0s(k) / 256 + 2)
+          while (i + cnt < strips(k) && (k0s(k) + 64L * (i + cnt)) / 256 == R) ++cnt;
+        pl.tasks.push_back(CholTask{0, k, i, cnt});
+        i += cnt;
+      }
       bool any = false;
       auto quarters = [&](int R, int J) {
         // (q & 1 = h: which 128 rows, q >> 1 = g: which 64 columns.)  Fused chain: panel J - 1's update of the diagonal BLOCK of
@@ -1264,7 +1278,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
   const long rows = (long)n + 1;
   // the chain is whichever workgroup gets here FIRST (a ticket in sync[2]), not blockIdx 0: the workers' waits end only if the chain
   // is resident, and nothing guarantees that the dispatcher starts with block 0 (guide G16: no dispatch-order assumption)
-  if (t == 0) slot[2] = __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == 0) { slot[2] = __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); slot[14] = 0; slot[15] = 0; }
   __syncthreads();
   const bool is_chain = slot[2] == 0;
   if (is_chain) {   // ---- the chain: diagonal blocks in order
@@ -1337,16 +1351,20 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
   for (;;) {               // ---- a worker: the next task of the list
     // (nothing but the kernel arguments is live across a task body: the task is re-read from the list afterwards -- with the
     //  descriptor, the publish address and the diagnostics kept in registers the update tile's 212 spilled 60 B per lane)
-    if (t == 0) slot[0] = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {
+      if (slot[14] > 0) { slot[14] -= 1; slot[15] += 1; }   // the next strip of the task in hand: no new task, no waits, no publish in between
+      else { slot[0] = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); slot[15] = 0; }
+    }
     __syncthreads();
     if (slot[0] >= n_tasks) {
       if (stats && t == 0) { const int me = slot[2] < kPwGrid ? slot[2] : kPwGrid - 1; for (int q = 0; q < 4; ++q) g_chol_stats[5 * me + q] = lstat[q]; g_chol_stats[5 * me + 4] = (long long)wall_clock64(); }
       return;
     }
-    if (t == 0) {
+    if (t == 0 && slot[15] == 0) {
       const CholTask tk = tasks[slot[0]];
       bool ok = true;
       const long long tw = stats ? (long long)wall_clock64() : 0;
+      slot[14] = (tk.type == 0 && tk.c > 1) ? tk.c - 1 : 0;   // strips of this task after the first
       if (tk.type == 0) {
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
         const int R = (int)(((long)k0 + nb + 64L * tk.b) / 256);
@@ -1379,7 +1397,9 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       const CholTask tk = tasks[slot[0]];
       if (tk.type == 0) {
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
-        chol_panel_body<true>(M, lda, rows, k0, nb, Linv_ws + (size_t)k * kNB * kNB, (long)tk.b);
+        // (a task of several strips -- tk.c, one row tile's -- comes back here once per strip without leaving the task: slot[15] = the strip
+        //  it is at.  A loop around this body cost the merged kernel 540 B of scratch per lane, K loops included: 37.7 -> 46.7 ms.)
+        chol_panel_body<true>(M, lda, rows, k0, nb, Linv_ws + (size_t)k * kNB * kNB, (long)(tk.b + slot[15]));
       } else {
         const int cnt = (tk.type == 2) ? (tk.c >> 16) : 1;
         const int kb = (tk.type != 2) ? tk.a : tk.a * W, ke = (tk.type != 2) ? tk.a + 1 : (((tk.a + cnt) * W < np) ? (tk.a + cnt) * W : np);
@@ -1394,11 +1414,11 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
     __syncthreads();
-    if (t == 0) {                                         // ... then ONE lane publishes
+    if (t == 0 && slot[14] == 0) {                        // ... then ONE lane publishes (a task of several strips: after its last)
       const CholTask tk = tasks[slot[0]];
       if (tk.type == 0) {
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
-        __hip_atomic_fetch_add(&sdone[(size_t)k * nR + (size_t)(((long)k0 + nb + 64L * tk.b) / 256)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&sdone[(size_t)k * nR + (size_t)(((long)k0 + nb + 64L * tk.b) / 256)], tk.c > 1 ? tk.c : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (tk.type == 3) {
         // quarters of ONE update run side by side; the one that completes the set moves the tile's sequence number on.  (The counter
         // only grows: panel a is the (a % W + 1)-th rank-128 update of this tile, which belongs to a's own outer panel.)
@@ -1503,6 +1523,10 @@ inline bool chol_fuse_default() { const char* e = std::getenv("ESL_CHOL_FUSE"); 
 // With the boundaries STAGGERED by tile (1 / 2 / 3 / 4 / 6 per visit): n = 4,096 2.97 / 2.93 / 2.98, 8,192 7.35 / 7.12 / 7.18 / 7.70, 12,000
 // 15.35 / 14.85 / 15.64 / 16.7, 18,000 39.38 / 37.94 / 37.67 / 38.0 / 39.2, 24,000 87.7 / 83.9 / 83.5 / 84.7 / 86.3.
 // Default: 3 from n = 16,384, else 2; ESL_CHOL_MERGE overrides (1 = the round 4-5 list).
+// The strips of a row tile away from the diagonal as ONE task (ESL_CHOL_STRIPS=1): measured and NOT the default -- n = 4,096 2.95 -> 3.57 ms,
+// 8,192 7.00 -> 8.31, 12,000 15.0 -> 17.2, 18,000 37.7 -> 38.9, 24,000 83.4 -> 84.7: four workgroups finish a row tile's solve sooner than
+// one, and every trailing update of that row tile waits for it.
+inline bool chol_strip_merge_default() { const char* e = std::getenv("ESL_CHOL_STRIPS"); return e && e[0] == '1'; }
 inline int chol_merge_default(int n) {
   const char* e = std::getenv("ESL_CHOL_MERGE");
   const int m = e ? std::atoi(e) : (n >= 16384 ? 3 : 2);
@@ -1515,10 +1539,11 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
   // ESL_CHOL_FUSE=0: strips under the diagonal block and the next block's update as worker tasks (the first form of round 4; A/B)
   const bool fuse = chol_fuse_default();
   const int merge = chol_merge_default(n);
-  if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0) || rt.plan.merge != merge) {
+  const bool smerge = chol_strip_merge_default();
+  if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0) || rt.plan.merge != merge || rt.plan.strip_merge != (smerge ? 1 : 0)) {
     { hipError_t e0 = hipStreamSynchronize(st); if (e0 != hipSuccess) return e0; }   // the old list / sync words may still be in use
     const char* fenv = std::getenv("ESL_CHOL_FILLER");   // (debugging: far-update tasks interleaved per chain-dependent group)
-    chol_plan_build(n, W, fenv ? std::max(1, std::atoi(fenv)) : 128, rt.plan, fuse, merge);
+    chol_plan_build(n, W, fenv ? std::max(1, std::atoi(fenv)) : 128, rt.plan, fuse, merge, smerge);
     auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
       if (*cap >= need) return hipSuccess;
       if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }

@@ -121,13 +121,19 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
                 ver[R, J] = seq + 1
             continue
         if ty == 0:
-            k, i = a, bb; k0, nb = 128 * k, nb_of(k)
-            r0 = k0 + nb + 64 * i; r1 = min(r0 + 64, rows); R = r0 // 256
-            assert r0 < rows and (i >= 2 or not fuse), "strips 0, 1 are the fused chain's"
-            assert pdone[k] == 1, ("S before its diagonal block", k, i)
-            assert ver[R, k] == final(R, k), ("S on a tile that is not final", k, i, ver[R, k], final(R, k))
-            M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
-            sdone[k, R] += 1
+            # (round 6) c = strips in the task: i .. i + c - 1, all of ONE row tile that is not next to the diagonal block
+            k, i, scnt = a, bb, max(int(c), 1); k0, nb = 128 * k, nb_of(k)
+            counts[0] += scnt - 1
+            R = (k0 + nb + 64 * i) // 256
+            assert scnt == 1 or R >= (k0 + nb) // 256 + 2, "strips next to the diagonal block stay single"
+            for q in range(i, i + scnt):
+                r0 = k0 + nb + 64 * q; r1 = min(r0 + 64, rows)
+                assert r0 // 256 == R
+                assert r0 < rows and (q >= 2 or not fuse), "strips 0, 1 are the fused chain's"
+                assert pdone[k] == 1, ("S before its diagonal block", k, q)
+                assert ver[R, k] == final(R, k), ("S on a tile that is not final", k, q, ver[R, k], final(R, k))
+                M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
+                sdone[k, R] += 1
         else:
             # type 2 (round 6): c = J | cnt << 16 -- the tile takes the rank-(W x 128) updates of outer panels [a, a + cnt) in ONE visit
             R, J, cnt = bb, c & 0xFFFF, (c >> 16) if ty == 2 else 1
@@ -202,6 +208,15 @@ def test_task_list_with_merged_far_updates(pkg, monkeypatch, n, W, filler, merge
     assert int((t[:, 0] == 2).sum() + 0) == counts[2] and (t[t[:, 0] == 2][:, 3] >> 16).max() == merge
 
 
+@pytest.mark.parametrize("n,W,filler", [(2500, 4, 16), (4000, 4, 128)])
+def test_task_list_with_row_tile_strip_tasks(pkg, monkeypatch, n, W, filler):
+    """ESL_CHOL_STRIPS=1 (round 6; measured slower, not the default): the strips of a row tile away from the diagonal block as one task"""
+    monkeypatch.setenv("ESL_CHOL_STRIPS", "1")
+    pl, counts, _ = replay(pkg, n, W, filler)
+    t = pl["tasks"]
+    assert (t[t[:, 0] == 0][:, 3] > 1).any()
+
+
 def test_look_ahead_order_of_the_list(pkg):
     """the next outer panel's chain-dependent tasks must not queue behind ALL far updates of the previous one (that would be the
     launch-per-step order without any look-ahead): the first strip of panel W comes before the last far update of outer panel 0"""
@@ -211,4 +226,4 @@ def test_look_ahead_order_of_the_list(pkg):
     far0 = np.nonzero((t[:, 0] == 2) & (t[:, 1] == 0))[0]
     look0 = far0[(t[far0, 3] & 0xFFFF) < 8]
     assert look0.max() < first_s < far0.max()
-    assert len(t) > 40000 and pl["np"] == 141 and pl["nR"] == 71   # (round 6: far updates four outer panels per visit from n = 16,384: 87,651 -> 48,056 tasks)
+    assert len(t) > 25000 and pl["np"] == 141 and pl["nR"] == 71   # (round 6: far updates three outer panels per visit, far strips per row tile: 87,651 -> ~37,000 tasks)
