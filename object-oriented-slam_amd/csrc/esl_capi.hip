@@ -312,6 +312,23 @@ int esl_ctx_synchronize(esl_ctx* c) {
 // ---------------------------------------------------------------------------------------------------
 // graph upload: validate, sort edges by ellipsoid (stable), build CSR
 // ---------------------------------------------------------------------------------------------------
+// order-independent structure fingerprint (comm_check_replicated): a 64-bit hash per edge / flag, summed
+static inline unsigned long long fp_hash(unsigned long long a, unsigned long long b, unsigned long long c3) {
+  unsigned long long h = 1469598103934665603ull;
+  h = (h ^ a) * 1099511628211ull; h = (h ^ b) * 1099511628211ull; h = (h ^ c3) * 1099511628211ull;
+  h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+  return h;
+}
+static unsigned long long fp_edges(int tag, int n, const int32_t* a, const int32_t* b) {
+  unsigned long long s = 0;
+  for (int i = 0; i < n; ++i) s += fp_hash((unsigned long long)tag, (unsigned)a[i], (unsigned)b[i]);
+  return s;
+}
+static unsigned long long fp_fixed(int first_cam, int n, const uint8_t* fixed) {   // null = all fixed
+  unsigned long long s = 0;
+  for (int i = 0; i < n; ++i) s += fp_hash(4, (unsigned)(first_cam + i), fixed ? (fixed[i] ? 1u : 0u) : 1u);
+  return s;
+}
 static int validate_graph(const esl_graph* g) {
   if (!g || g->n_cams < 0 || g->n_objs < 0 || g->n_bbox < 0 || g->n_e3d < 0 || g->n_grav < 0 || g->n_odom < 0) {
     set_error("esl_graph: null or negative size");
@@ -368,6 +385,8 @@ int esl_graph_upload(esl_ctx* c, const esl_graph* g) {
   if (rc) return rc;
   ESL_HIP_TRY(hipSetDevice(c->device));
   free_graph(c);
+  c->graph_fp = fp_edges(1, g->n_bbox, g->bbox_cam, g->bbox_obj) + fp_edges(2, g->n_e3d, g->e3d_cam, g->e3d_obj) + fp_edges(3, g->n_odom, g->odom_i, g->odom_j) +
+                fp_fixed(0, g->n_cams, g->cam_fixed);
   DevGraph& d = c->g;
   hipStream_t st = c->stream;
   // every array of the device-resident graph goes into ONE staging blob -> one H2D copy into a grow-only arena;
@@ -731,12 +750,6 @@ static int slam_tables_refresh(esl_ctx* c, const HostImage& im) {
   c->h_od_i = im.od_i; c->h_od_j = im.od_j;
   c->h_bb_cam.assign(im.bb_cam.begin(), im.bb_cam.begin() + (long)im.used_bb); c->h_bb_obj.assign(im.bb_obj.begin(), im.bb_obj.begin() + (long)im.used_bb);
   c->h_e3_cam.assign(im.e3_cam.begin(), im.e3_cam.begin() + (long)im.used_e3); c->h_e3_obj.assign(im.e3_obj.begin(), im.e3_obj.begin() + (long)im.used_e3);
-  if (!im.appendable) {   // the compact layout of esl_graph_upload has no free slots, and its image does not mark any
-    for (int o = 0; o < N; ++o) {
-      for (int k = im.bb_cnt[o]; k < im.bb_cap[o]; ++k) c->h_bb_obj[(size_t)im.bb_begin[o] + k] = -1;
-      for (int k = im.e3_cnt[o]; k < im.e3_cap[o]; ++k) c->h_e3_obj[(size_t)im.e3_begin[o] + k] = -1;
-    }
-  }
   slam_forget(c);
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));   // the staging block is free again (slam_alloc stages through its own blob)
   if (nf > 0 && (rc = slam_alloc(c))) return rc;
@@ -861,6 +874,9 @@ int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
     if (dl->grav_obj[i] < 0 || dl->grav_obj[i] >= N) { set_error("esl_graph_delta: gravity edge index out of range"); return ESL_ERR_INVALID; }
   for (int i = 0; i < dl->n_odom; ++i)
     if (dl->odom_i[i] < 0 || dl->odom_i[i] >= F || dl->odom_j[i] < 0 || dl->odom_j[i] >= F) { set_error("esl_graph_delta: odometry edge index out of range"); return ESL_ERR_INVALID; }
+  c->graph_fp += fp_edges(1, dl->n_bbox, dl->bbox_cam, dl->bbox_obj) + fp_edges(2, dl->n_e3d, dl->e3d_cam, dl->e3d_obj) + fp_edges(3, dl->n_odom, dl->odom_i, dl->odom_j) +
+                 fp_fixed(im.n_cams, dl->n_new_cams, dl->new_cam_fixed);
+  c->repl_checked = false;
   auto add_cameras_and_odometry = [&](HostImage& I) {   // the delta's camera flags and odometry edges into an image whose n_cams is already F
     I.cam_fixed.resize((size_t)F, 1);
     for (int i = 0; i < dl->n_new_cams; ++i) I.cam_fixed[(size_t)(F - dl->n_new_cams + i)] = dl->new_cam_fixed ? (dl->new_cam_fixed[i] ? 1 : 0) : 1;
@@ -985,7 +1001,13 @@ int esl_graph_append(esl_ctx* c, const esl_graph_delta* dl) {
   dev_free(&c->cams_snap); dev_free(&c->objs_snap);
   c->cams_match_snap = false;
   c->lm.begun = false;
-  if (im.slam()) return slam_tables_refresh(c, im);   // the camera-indexed tables + the solver's lists (SLAM mode)
+  if (im.slam()) {   // the camera-indexed tables + the solver's lists (SLAM mode)
+    // Not failure-atomic by itself: records, states and the host image are committed above, the camera tables are rebuilt here.  If
+    // that fails (out of memory in arena_reserve / slam_alloc) the device tables may be freed or describe the old graph -- drop the
+    // graph altogether, so that the next call is an error ("upload graph first") and never a read of stale tables.
+    const int rcs = slam_tables_refresh(c, im);
+    if (rcs) { const std::string msg = esl_last_error(); free_graph(c); set_error(msg + " (esl_graph_append: the graph was dropped, upload it again)"); return rcs; }
+  }
   return ESL_OK;
 }
 
@@ -1176,6 +1198,8 @@ static int lm_begin_enqueue(esl_ctx* c, const esl_lm_params* p, bool validate_in
 
 int esl_lm_begin(esl_ctx* c, const esl_lm_params* p, int32_t* n_valid, int32_t* n_dropped) {
   if (!c || !p) return ESL_ERR_INVALID;
+  // the replicated-graph promise is checked on the step API as well (once per uploaded graph; the same point of every rank's sequence)
+  if (c->graph_loaded) { const int rcr = comm_check_replicated(c); if (rcr) return rcr; }
   int rc = lm_begin_enqueue(c, p);
   if (rc) return rc;
   int dropped = 0;

@@ -741,7 +741,7 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
 
 // ---- backward substitution L^T x = y in ONE launch (round 4) ---------------------------------------------------------------
 // The launch-per-panel form above is 2 x ceil(n / 128) dependent launches whose kernels are each a few microseconds of work
-// (n = 18,000: 282 launches, ~6 ms of a 46 ms solve).  Here panel p belongs to workgroup (np - 1 - p) mod G; the workgroup streams
+// (n = 18,000: 282 launches, ~6 ms of a 46 ms solve).  Here a workgroup owns one panel p at a time (claimed from a counter, see below); it streams
 // the blocks L[panel r, panel p] for r = np - 1 .. p + 1 in the order the x_r appear, keeps per-lane partial sums of
 // z_p = y_p - sum_r L_rp^T x_r in registers (ONE cross-lane reduction at the end, fixed order => bit-reproducible), then
 // x_p = Linv_p^T z_p from an LDS copy of Linv_p staged at the start, and publishes x_p.  Block r - 1 is fetched before the
@@ -751,10 +751,12 @@ static __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __r
 // drains its stores, one lane stores the flag; the consumer polls the flag relaxed from ONE lane and reads x_r with sc1 loads
 // (L1 bypassed: no acquire fence on the chain).  Flags are zeroed by a memset in front of every launch.  Every spin is bounded:
 // on a timeout bit 1 of info is set and every waiter gives up (the host reports an error instead of hanging the device).
-// Workgroup b only ever waits for panels owned by workgroups with a LOWER index or for its own earlier panels, and b is an ARRIVAL
-// TICKET (flags[np], round 5), not blockIdx: whoever holds a lower ticket has started, i.e. is resident -- no assumption
-// about dispatch order or about all G workgroups fitting the device at once (a CU-partitioned or shared device runs the late
-// arrivals when the early ones are done, and they then find every flag they need already set).  G = min(np, CUs of the device).
+// Panels are CLAIMED, last panel first, from one counter (flags[np]; round 6): a workgroup takes the next unclaimed panel
+// when it arrives and again whenever it has finished one.  Panel p waits only for panels > p, and every one of those was claimed
+// earlier by a workgroup that had already started, i.e. is resident and will finish it -- no assumption about dispatch order, about
+// all G workgroups fitting the device at once, or about a second round of a workgroup's own panels (round 5's static
+// `p -= gridDim.x` made ticket b's second panel wait for first-round panels of tickets that might not have started on a CU-masked
+// device).  G = min(np, CUs of the device).
 // Read a word other workgroups of the SAME launch write: a device-scope atomic ADD OF ZERO, written as inline assembly.
 // Measured on MI355X (round 4): an agent-scope (sc1) LOAD in a poll loop -- and every atomic the compiler or the L2 can treat as a
 // read: fetch_or 0 is folded into a load, a compare-and-swap that fails writes nothing -- can keep returning the value the line had
@@ -798,12 +800,14 @@ static __global__ __launch_bounds__(kBsThreads) void k_chol_backsub(const double
   bool aborted = false;            // (thread 0 only; no static __shared__ here: it would shift the 16-byte alignment of sm, guide G17)
   const int c0 = 16 * wave;                                                   // this wave's 16 columns of the panel
   const int vcol = c0 + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);   // bs_reduce16: whose total this lane ends up with
-  if (t == 0) reinterpret_cast<int*>(zs)[0] = atomicAdd(&flags[np], 1);       // arrival ticket (the word behind the np panel flags)
-  __syncthreads();
-  const int ticket = reinterpret_cast<const int*>(zs)[0];                     // (zs is first written behind the loop's leading barrier)
-  for (int p = np - 1 - ticket; p >= 0; p -= (int)gridDim.x) {
-    const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
+  for (;;) {
     __syncthreads();                                                           // the previous panel's readers of Li / zs are done
+    if (t == 0) reinterpret_cast<int*>(zs)[0] = atomicAdd(&flags[np], 1);     // claim the next panel (the word behind the np panel flags)
+    __syncthreads();
+    const int p = np - 1 - reinterpret_cast<const int*>(zs)[0];
+    __syncthreads();                                                           // everybody holds p before zs is written again
+    if (p < 0) break;
+    const int k0 = p * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
     {
       const double2_t* src = reinterpret_cast<const double2_t*>(Linv_ws + (size_t)p * kNB * kNB);
       double2_t* dst = reinterpret_cast<double2_t*>(Li);
@@ -1595,7 +1599,14 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   const size_t lds = (size_t)(kNB * kLdsPad + 96 * kSB + kNB) * sizeof(double);
   int np = (n + kNB - 1) / kNB;
   { hipError_t e = chol_set_attributes(rt); if (e != hipSuccess) return e; }
-  if (rt.prof_mark) rt.prof_mark(rt.prof_user, 1);
+  // the bracket closes on EVERY way out of the factorisation, error returns included (an early return used to leave the
+  // scope open, and later brackets were skipped or mis-paired)
+  struct ProfBracket {
+    CholRuntime& r; bool open;
+    explicit ProfBracket(CholRuntime& rr) : r(rr), open(rr.prof_mark != nullptr) { if (open) r.prof_mark(r.prof_user, 1); }
+    void close() { if (open) { r.prof_mark(r.prof_user, 0); open = false; } }
+    ~ProfBracket() { close(); }
+  } bracket(rt);
   auto launch_update = [&](hipStream_t stream, int kcol0, int K, long base, long col_limit) {
     chol_launch_update(M, lda, rows, stream, kcol0, K, base, col_limit);
   };
@@ -1787,7 +1798,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   }
   if (trail_pending) { hipError_t e = hipStreamWaitEvent(st, ev_trail[n_outer - 2], 0); if (e != hipSuccess) return e; }
   }
-  if (rt.prof_mark) rt.prof_mark(rt.prof_user, 0);
+  bracket.close();
   if (rt.sw_backsub < 0) { const char* sw = std::getenv("ESL_CHOL_BACKSUB_LAUNCHES"); rt.sw_backsub = (sw && sw[0] == '1') ? 1 : 0; }
   // the one-launch form reads the factor as 16-byte pairs: even leading dimension, 16-byte aligned base
   if (rt.sw_backsub == 0 && (lda & 1) == 0 && ((uintptr_t)M & 15) == 0 && ((uintptr_t)Linv_ws & 15) == 0) {

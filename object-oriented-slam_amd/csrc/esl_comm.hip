@@ -234,8 +234,9 @@ int esl_comm_set_replicated(esl_ctx* c, int replicated) {
 }  // extern "C"
 namespace esl {
 // Replicated-graph communicator: "every rank holds the same whole graph" is the caller's promise; the first optimisation of a
-// graph checks it -- a 60-bit fingerprint of the graph's structure (sizes, every edge's camera and ellipsoid in the uploaded
-// order, the fixed flags) as three 20-bit words a_k, all-reduced as {a_k, a_k^2}: all ranks agree <=> R sum a_k^2 == (sum a_k)^2
+// graph checks it (esl_optimize_resident and esl_lm_begin: the step API runs it too) -- a 60-bit fingerprint of the graph's structure
+// (sizes + esl_ctx::graph_fp: every edge's camera and ellipsoid, the fixed flags, the odometry pairs, hashed per edge from the
+// caller's arrays and summed, so the order of the edges does not matter) as three 20-bit words a_k, all-reduced as {a_k, a_k^2}: all ranks agree <=> R sum a_k^2 == (sum a_k)^2
 // (exact in doubles).  One 48-byte collective per uploaded graph, at the same point of every rank's call sequence.
 int comm_check_replicated(esl_ctx* c) {
   if (!c->comm || !c->comm_replicated || c->comm_ranks < 2 || c->repl_checked) return ESL_OK;
@@ -244,13 +245,7 @@ int comm_check_replicated(esl_ctx* c) {
   const DevGraph& g = c->g;
   mix((unsigned long long)g.n_cams); mix((unsigned long long)g.n_objs); mix((unsigned long long)g.n_bbox); mix((unsigned long long)g.n_e3d);
   mix((unsigned long long)g.n_odom); mix((unsigned long long)g.n_free_cams);
-  for (int v : c->h_bb_cam) mix((unsigned)v);
-  for (int v : c->h_bb_obj) mix((unsigned)v);
-  for (int v : c->h_e3_cam) mix((unsigned)v);
-  for (int v : c->h_e3_obj) mix((unsigned)v);
-  for (int v : c->h_cam_slot) mix((unsigned)v);
-  for (int v : c->h_od_i) mix((unsigned)v);
-  for (int v : c->h_od_j) mix((unsigned)v);
+  mix(c->graph_fp);   // every edge's (type, camera, ellipsoid), the fixed flags, the odometry pairs: summed per edge at upload / append
   double w[6];
   for (int k = 0; k < 3; ++k) { w[k] = (double)((h >> (20 * k)) & 0xFFFFFull); w[3 + k] = w[k] * w[k]; }
   double* dev = nullptr;

@@ -251,6 +251,7 @@ struct esl_ctx {
   // kernel attributes of this device) and of the Schur kernel; created on first use, released with the context
   void* chol_rt = nullptr;
   void* chol_prof_scope = nullptr;   // the open ProfScope (class 9) around a dense factorisation (esl_slam.hip chol_prof_mark)
+  unsigned long long graph_fp = 0;   // order-independent fingerprint of the uploaded graph's structure (esl_graph_upload / _append; comm_check_replicated)
   bool repl_checked = false;         // replicated-graph communicator: this graph's fingerprint has been compared across the ranks
   double *chol_pack = nullptr, *chol_pack2 = nullptr;   // staging buffers of the distributed factorisation's panel messages (esl_chol.hpp CholDist)
   size_t chol_pack_len = 0;

@@ -691,6 +691,7 @@ static CholRuntime& chol_rt(esl_ctx* c) {
   return *(CholRuntime*)c->chol_rt;
 }
 void slam_release_runtime(esl_ctx* c) {
+  if (c->chol_prof_scope) { delete (ProfScope*)c->chol_prof_scope; c->chol_prof_scope = nullptr; }
   if (!c->chol_rt) return;
   ((CholRuntime*)c->chol_rt)->release();
   delete (CholRuntime*)c->chol_rt;
