@@ -61,6 +61,148 @@ template <bool WT>
 __device__ __forceinline__ void chol_store(double* p, double v) {
   if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
 }
+// ---- the triangular inverse of the factored diagonal block, in place in the LDS copy (see chol_potrf2_body) -------------------------------
+// A function of its own, NOT inlined (round 6): inlined into k_chol_persist its register pressure (two tile columns of double4 accumulators)
+// moved the merged kernel's allocation and the chain's fused row solve picked up spills -- 15.5 -> 24.7 us per panel, which ate the
+// 8 us the inverse had gained.  The LDS copy is reached through the kernel's one dynamic-LDS symbol (offset 0), not through a pointer
+// argument (that would decay to flat addressing).
+template <int NT>
+static __device__ __attribute__((noinline)) void chol_inv_levels() {
+  extern __shared__ __attribute__((aligned(16))) double sm_inv[];
+  double* L = sm_inv;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#define LL(i, j) L[(i) + (j) * kLdsPad]
+  // ---- Linv = L^-1 IN PLACE by recursive doubling: the inverse of [A 0; C D] is [A^-1 0; -D^-1 C A^-1  D^-1].  Level b merges
+  // pairs of adjacent b x b diagonal inverses; C (original L) is overwritten by its block of the inverse, which no later level
+  // reads as L.  Rounds 3-5: b = 4, 8 one thread per output entry; b = 16, 32, 64 two MFMA products, the intermediate T = C A^-1 parked
+  // in the (unused) block above the diagonal that mirrors C; 8 barriers in all, against the 32-step triangular inverses of
+  // the four 32 x 32 sub-blocks + 3 dependent block columns of the blocked form (25.6 -> 16.4 us; n = 2,994 2.86 -> 2.60 ms).
+  // Round 6: every level on the matrix cores, and no intermediate through LDS.  In the f64 MFMA layout the D fragment of the first product
+  // (T = C A^-1: lane (r, kq), register g = T[kq + 4 g][r]) IS the B fragment of k-step g of the second (X = D^-1 T wants T[4 g + kq][r]):
+  // a wave that computes a tile column of T keeps it in registers and goes straight on to the same tile column of X.
+  //   levels 4, 8   wave s < 8 owns the 16 x 16 diagonal super-block s; the level's C / A^-1 / D^-1 positions are selected by index masks
+  //                 and the two products are 4 + 4 MFMAs on the whole super-block (block-diagonal operands), wave-local: no barrier
+  //                 between the two levels (LDS operations of one wave complete in order)
+  //   level 16      four groups, one wave each: 4 + 4 MFMAs
+  //   levels 32, 64 (group, tile column) per wave: the column's tiles of T, then of X, all in registers; one barrier before C is overwritten
+  // 16.4 -> ~6 us (the one-entry-per-thread loops of levels 4, 8 were 5.1 us, the per-MFMA LDS round trips of the others 10.9).
+  {
+    const int r = lane & 15, kq = lane >> 4;
+    if (wave < 8) {
+      const int s0 = 16 * wave;
+#pragma unroll
+      for (int b = 4; b <= 8; b *= 2) {
+        // position classes of the level inside the super-block: same 2b-group, (upper | lower) half of it
+        auto grp = [b](int i) { return i / (2 * b); };
+        auto low = [b](int i) { return (i / b) & 1; };
+        double4_t tt = {0, 0, 0, 0}, xx = {0, 0, 0, 0};
+        double av[4], bv[4], dv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int k = 4 * g + kq;
+          const bool cpos = grp(r) == grp(k) && low(r) == 1 && low(k) == 0;             // C(i = r, k)
+          const bool apos = grp(k) == grp(r) && low(k) == 0 && low(r) == 0 && k >= r;   // A^-1(k, j = r), lower
+          const bool dpos = grp(r) == grp(k) && low(r) == 1 && low(k) == 1 && k <= r;   // D^-1(i = r, m = k), lower
+          const double vc = LL(s0 + r, s0 + k), va = LL(s0 + k, s0 + r);
+          av[g] = cpos ? vc : 0.0; bv[g] = apos ? va : 0.0; dv[g] = dpos ? vc : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bv[g], tt, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xx = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[g], tt[g], xx, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int i = kq + 4 * g;
+          if (grp(i) == grp(r) && low(i) == 1 && low(r) == 0) LL(s0 + i, s0 + r) = -xx[g];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own writes, before its own reads of the next level)
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    if (t == 0) g_potrf_clk[14] = (long long)wall_clock64();   // (diagnostic: end of levels 4, 8)
+    if (wave < 4) {   // level 16: group `wave`, rows / columns [32 wave, 32 wave + 32)
+      const int r0 = 32 * wave;
+      double4_t tt = {0, 0, 0, 0}, xx = {0, 0, 0, 0};
+      double av[4], bv[4], dv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int k = 4 * g + kq;
+        av[g] = LL(r0 + 16 + r, r0 + k);
+        const double va = LL(r0 + k, r0 + r), vd = LL(r0 + 16 + r, r0 + 16 + k);
+        bv[g] = (k >= r) ? va : 0.0; dv[g] = (k <= r) ? vd : 0.0;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bv[g], tt, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xx = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[g], tt[g], xx, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) LL(r0 + 16 + kq + 4 * g, r0 + r) = -xx[g];   // (C's own wave: nobody else reads this group)
+    }
+    __syncthreads();
+    if (t == 0) g_potrf_clk[15] = (long long)wall_clock64();   // (diagnostic: end of level 16)
+    auto level_cols = [&](auto bc) {
+      constexpr int B = decltype(bc)::value, NTL = B / 16;   // (kNB / (2 B)) x NTL = 4 wave tasks at both levels
+      double4_t X[NTL];
+      const int mg = wave / NTL, jb = wave % NTL, r0 = mg * 2 * B;
+      if (wave < 4) {
+        double4_t Tc[NTL];
+#pragma unroll
+        for (int m = 0; m < NTL; ++m) { Tc[m] = double4_t{0, 0, 0, 0}; X[m] = double4_t{0, 0, 0, 0}; }
+        const int j = jb * 16 + r;
+        // T(:, jb) = C(:, k) A^-1(k, jb), k from the column's own tile on (A^-1 is lower); operands of step kk + 4 in flight under step kk
+        double an[NTL], bn, ac[NTL], bc2;
+        {
+          const int k = jb * 16 + kq;
+          const double va = LL(r0 + k, r0 + j);
+          bc2 = (k >= j) ? va : 0.0;
+#pragma unroll
+          for (int m = 0; m < NTL; ++m) ac[m] = LL(r0 + B + m * 16 + r, r0 + k);
+        }
+        for (int kk = jb * 16; kk < B; kk += 4) {
+          const int k = (kk + 4 < B ? kk + 4 : kk) + kq;
+          const double va = LL(r0 + k, r0 + j);
+          bn = (k >= j) ? va : 0.0;
+#pragma unroll
+          for (int m = 0; m < NTL; ++m) an[m] = LL(r0 + B + m * 16 + r, r0 + k);
+#pragma unroll
+          for (int m = 0; m < NTL; ++m) Tc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[m], bc2, Tc[m], 0, 0, 0);
+          bc2 = bn;
+#pragma unroll
+          for (int m = 0; m < NTL; ++m) ac[m] = an[m];
+        }
+        // X(ib, jb) = D^-1(ib, m) T(m, jb), m <= ib
+#pragma unroll
+        for (int ib = 0; ib < NTL; ++ib) {
+          const int i = ib * 16 + r;
+#pragma unroll
+          for (int m = 0; m <= ib; ++m) {
+            double dv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int mm = m * 16 + 4 * g + kq;
+              const double vd = LL(r0 + B + i, r0 + B + mm);
+              dv[g] = (mm <= i) ? vd : 0.0;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) X[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[g], Tc[m][g], X[ib], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();   // every column's reads of C are done
+      if (wave < 4) {
+#pragma unroll
+        for (int ib = 0; ib < NTL; ++ib)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) LL(r0 + B + ib * 16 + kq + 4 * g, r0 + jb * 16 + r) = -X[ib][g];
+      }
+      __syncthreads();
+    };
+    level_cols(std::integral_constant<int, 32>{});
+    level_cols(std::integral_constant<int, 64>{});
+  }
+#undef LL
+}
 // NT = 640: every one of the 528 blocks has its own thread (the stand-alone kernel).  NT = 512 (the persistent kernel's workgroup
 // shape): threads 0..15 own TWO blocks one after the other -- their first one lies in block column 0 and is final after step 0, so
 // they store it there and then (global memory + the LDS copy) and take over blocks 512..527 (block columns 26..31, which only see
@@ -72,8 +214,7 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
   double* L = sm;                          // kNB x kNB, column stride kLdsPad: the factor, later its inverse
   double* T = sm + kNB * kLdsPad;          // 96 x 32 temporary of the inverse; the column buffers of the factorisation before that
   double* dinv = T + 96 * kSB;             // kNB reciprocals of the diagonal
-  constexpr int NW = NT / 64;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x;
 #define LL(i, j) L[(i) + (j) * kLdsPad]
   POTRF_MARK(0);
   // the thread's 4 x 4 block (bi >= bj) of the 32 x 32 grid of blocks, enumerated column by column: the blocks of the first
@@ -238,68 +379,7 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
   }
   __syncthreads();
   POTRF_MARK(5); POTRF_MARK(6); POTRF_MARK(7);
-  // ---- Linv = L^-1 IN PLACE by recursive doubling: the inverse of [A 0; C D] is [A^-1 0; -D^-1 C A^-1  D^-1].  Level b merges
-  // pairs of adjacent b x b diagonal inverses; C (original L) is overwritten by its block of the inverse, which no later level
-  // reads as L.  b = 4, 8: one thread per output entry; b = 16, 32, 64: two MFMA products, the intermediate T = C A^-1 parked
-  // in the (unused) block above the diagonal that mirrors C.  8 barriers in all, against the 32-step triangular inverses of
-  // the four 32 x 32 sub-blocks + 3 dependent block columns of the blocked form (25.6 -> 16.4 us; n = 2,994 2.86 -> 2.60 ms).
-#pragma unroll 1
-  for (int b = 4; b <= 8; b *= 2) {
-    const int per = b * b, total = (kNB / (2 * b)) * per;
-    for (int e = t; e < total; e += NT) {
-      const int mg = e / per, ij = e - mg * per, i = ij / b, j = ij - i * b;
-      const int r0 = mg * 2 * b;
-      double acc = 0;
-      for (int m = 0; m <= i; ++m) {                 // D^-1 lower
-        double s2 = 0;
-        for (int k = j; k < b; ++k) s2 += LL(r0 + b + m, r0 + k) * LL(r0 + k, r0 + j);   // C(m,k) A^-1(k,j), A^-1 lower
-        acc += LL(r0 + b + i, r0 + b + m) * s2;
-      }
-      T[e] = -acc;                                   // every output of the level first (C is still being read)
-    }
-    __syncthreads();
-    for (int e = t; e < total; e += NT) {
-      const int mg = e / per, ij = e - mg * per, i = ij / b, j = ij - i * b;
-      LL(mg * 2 * b + b + i, mg * 2 * b + j) = T[e];
-    }
-    __syncthreads();
-    if (t == 0) g_potrf_clk[b == 4 ? 14 : 15] = (long long)wall_clock64();   // (diagnostic: end of the b = 4 / b = 8 level)
-  }
-#pragma unroll 1
-  for (int b = 16; b <= 64; b *= 2) {
-    const int nt = b / 16, tiles = (kNB / (2 * b)) * nt * nt;
-    const int r = lane & 15, kq = lane >> 4;
-    // T = C A^-1  -> parked at LL(r0 + i, r0 + b + j)
-    for (int tl = wave; tl < tiles; tl += NW) {
-      const int mg = tl / (nt * nt), ij = tl - mg * nt * nt, ib = ij / nt, jb = ij - ib * nt;
-      const int r0 = mg * 2 * b;
-      double4_t acc = {0, 0, 0, 0};
-      for (int kk = jb * 16; kk < b; kk += 4) {      // A^-1(k, j) = 0 for k < j
-        const int k = kk + kq, j = jb * 16 + r;
-        const double av = LL(r0 + b + ib * 16 + r, r0 + k);
-        const double bv = (k >= j) ? LL(r0 + k, r0 + j) : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) LL(r0 + ib * 16 + kq + 4 * g, r0 + b + jb * 16 + r) = acc[g];   // D: row = (lane >> 4) + 4 g, col = lane & 15
-    }
-    __syncthreads();
-    // X21 = -D^-1 T  -> in C's place
-    for (int tl = wave; tl < tiles; tl += NW) {
-      const int mg = tl / (nt * nt), ij = tl - mg * nt * nt, ib = ij / nt, jb = ij - ib * nt;
-      const int r0 = mg * 2 * b;
-      double4_t acc = {0, 0, 0, 0};
-      for (int mm = 0; mm < (ib + 1) * 16; mm += 4) {   // D^-1(i, m) = 0 for m > i
-        const int m = mm + kq, i = ib * 16 + r;
-        const double av = (m <= i) ? LL(r0 + b + i, r0 + b + m) : 0.0;
-        const double bv = LL(r0 + m, r0 + b + jb * 16 + r);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) LL(r0 + b + ib * 16 + kq + 4 * g, r0 + jb * 16 + r) = -acc[g];
-    }
-    __syncthreads();
-  }
+  chol_inv_levels<NT>();
   POTRF_MARK(8);
   for (int idx = t; idx < kNB * kNB; idx += NT) {
     const int i = idx % kNB, j = idx / kNB;

@@ -1093,7 +1093,7 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
       static const char* names[9] = {"load", "rank-4 steps", "-", "-", "-", "store L", "-", "inverse", "store Linv"};
       fprintf(stderr, "[k_chol_potrf2, last launch, us into the rank-4 loop at step 1 / 8 / 16 / 24: %.1f %.1f %.1f %.1f]\n", (double)(clk[10] - clk[1]) * 0.01,
               (double)(clk[11] - clk[1]) * 0.01, (double)(clk[12] - clk[1]) * 0.01, (double)(clk[13] - clk[1]) * 0.01);
-      fprintf(stderr, "[k_chol_potrf2, last launch, triangular inverse: level 4 %.1f us, level 8 %.1f us, levels 16 - 64 %.1f us]\n", (double)(clk[14] - clk[7]) * 0.01,
+      fprintf(stderr, "[k_chol_potrf2, last launch, triangular inverse: levels 4 + 8 %.1f us, level 16 %.1f us, levels 32 + 64 %.1f us]\n", (double)(clk[14] - clk[7]) * 0.01,
               (double)(clk[15] - clk[14]) * 0.01, (double)(clk[8] - clk[15]) * 0.01);
       fprintf(stderr, "[k_chol_potrf2, last launch, us]");
       for (int k = 0; k < 9; ++k) fprintf(stderr, " %s=%.1f", names[k], (double)(clk[k + 1] - clk[k]) * 0.01);
