@@ -789,6 +789,175 @@ static __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 1 : 2)) void k
   if (clk_on) { g_upd_clk[0] = (long long)clock64() - c0; g_upd_clk[1] = (long long)wall_clock64() - w0; g_upd_clk[2] = K; g_upd_clk[3] = BM; }
 }
 
+// ---- small systems: factor + both substitutions in ONE workgroup, the whole lower triangle in registers (round 6) ---------------
+// An order-180 system (20 ellipsoids: BASELINE configs[4] in SLAM mode) is two diagonal blocks of the blocked path: 2 x potrf2 + 2 panel
+// solves + 1 update + the back-substitution = 6 dependent launches, ~170 us, with fewer than 1e7 flops in them.  Here 1024 threads own
+// the 4 x 4 blocks of the lower triangle (and of the right-hand side's row, a block row of its own under the padded matrix) for the
+// whole solve -- up to two blocks per thread, enumerated column by column, so n <= 248 -- and run the rank-4 steps of k_chol_potrf2
+// over ALL block columns: (a) the diagonal block's owner factors it and publishes the inverse of its factor, (b) the blocks under it
+// become X = A L_JJ^-T and publish their four columns, (c) every block to the right subtracts its rank-4 product.  y = L^-1 b rides
+// along as the last block row.  L^T x = y runs on the same registers, block row by block row from the last: the diagonal owner forms
+// x_J = L_JJ^-T z_J, the blocks (J, j < J) subtract L(J, j)^T x_J from z_j (one writer per entry and step: no atomics, fixed order).
+// Only x leaves the kernel (nobody reads the factor of these systems afterwards; the panels' inverses are not formed at all).
+constexpr int kCsThreads = 1024, kCsKB = 2, kCsMaxRows = 256;
+__host__ __device__ inline int chol_small_blocks(int n) { const int nbc = (n + 3) / 4; return nbc * (nbc + 1) / 2 + nbc; }
+inline bool chol_small_fits(int n) { return n >= 1 && chol_small_blocks(n) <= kCsThreads * kCsKB && 4 * ((n + 3) / 4 + 1) <= kCsMaxRows; }
+static __global__ __launch_bounds__(kCsThreads) void k_chol_small(const double* __restrict__ M, long lda, int n, double* __restrict__ x,
+                                                                  int* __restrict__ info) {
+  __shared__ double colbuf[4 * kCsMaxRows];   // [k][4 bi + r]: the four columns of the current block column
+  __shared__ double dblk[12];                 // inverse of the current diagonal block's factor, packed rows
+  __shared__ double zs[kCsMaxRows];           // back-substitution: what is left of y
+  __shared__ double xs[4];
+  const int t = threadIdx.x;
+  const int NBC = (n + 3) / 4, NBR = NBC + 1, total = chol_small_blocks(n);
+  int bi[kCsKB], bj[kCsKB];
+  bool own[kCsKB];
+  double a[kCsKB][4][4];
+#pragma unroll
+  for (int q = 0; q < kCsKB; ++q) {
+    const int idx = t + q * kCsThreads;
+    own[q] = idx < total;
+    int off = 0, c = 0;
+    if (own[q]) while (off + (NBR - c) <= idx) { off += NBR - c; ++c; }
+    bj[q] = c; bi[q] = own[q] ? c + (idx - off) : 0;
+    const bool rhs = bi[q] == NBC;              // the right-hand side's row: local row 0 of the last block row
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * bi[q] + r, j = 4 * bj[q] + c2;
+        const bool valid = own[q] && j < n && (rhs ? r == 0 : (i < n && i >= j));
+        const long row = rhs ? (long)n : (long)i;
+        const double v = valid ? M[row + (long)j * lda] : 0.0;
+        a[q][r][c2] = valid ? v : ((!rhs && i == j) ? 1.0 : 0.0);   // identity padding behind the matrix
+      }
+  }
+  // 4 x 4 Cholesky of block q (lower, in place); the block is REPLACED by the inverse of its factor (all that is needed afterwards)
+  auto factor_diag = [&](double (&b)[4][4]) {
+    double is[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double d = b[c][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) d -= b[c][k] * b[c][k];
+      if (!(d > 0)) atomicOr(info, 1);
+      double rq = __builtin_amdgcn_rsq(d);
+      rq = rq * (1.5 - 0.5 * d * rq * rq);
+      rq = rq * (1.5 - 0.5 * d * rq * rq);
+      is[c] = rq;
+      b[c][c] = d * rq;
+#pragma unroll
+      for (int rr = c + 1; rr < 4; ++rr) {
+        double v = b[rr][c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= b[rr][k] * b[c][k];
+        b[rr][c] = v * rq;
+      }
+    }
+    double xi[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      xi[c][c] = is[c];
+#pragma unroll
+      for (int rr = c + 1; rr < 4; ++rr) {
+        double v = 0;
+#pragma unroll
+        for (int k = c; k < rr; ++k) v += b[rr][k] * xi[k][c];
+        xi[rr][c] = -v * is[rr];
+      }
+    }
+    int p = 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        b[rr][c] = c <= rr ? xi[rr][c] : 0.0;
+        if (c <= rr) dblk[p++] = xi[rr][c];
+      }
+  };
+  if (t == 0) factor_diag(a[0]);   // block (0, 0) is thread 0's first
+  __syncthreads();
+  for (int J = 0; J < NBC; ++J) {
+#pragma unroll
+    for (int q = 0; q < kCsKB; ++q)
+      if (own[q] && bj[q] == J && bi[q] > J) {   // (b) X = A L_JJ^-T
+        double li[10];
+#pragma unroll
+        for (int p = 0; p < 10; ++p) li[p] = dblk[p];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double a0 = a[q][r][0], a1 = a[q][r][1], a2 = a[q][r][2], a3 = a[q][r][3];
+          a[q][r][0] = a0 * li[0];
+          a[q][r][1] = a0 * li[1] + a1 * li[2];
+          a[q][r][2] = a0 * li[3] + a1 * li[4] + a2 * li[5];
+          a[q][r][3] = a0 * li[6] + a1 * li[7] + a2 * li[8] + a3 * li[9];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) colbuf[c * kCsMaxRows + 4 * bi[q] + r] = a[q][r][c];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kCsKB; ++q)
+      if (own[q] && bj[q] > J) {                 // (c) rank-4 update
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double rv[4], cv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { rv[r] = colbuf[k * kCsMaxRows + 4 * bi[q] + r]; cv[r] = colbuf[k * kCsMaxRows + 4 * bj[q] + r]; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[q][r][c] -= rv[r] * cv[c];
+        }
+        if (bi[q] == bj[q] && bj[q] == J + 1) factor_diag(a[q]);   // (a) of the next step
+      }
+    __syncthreads();
+  }
+  // ---- L^T x = y.  zs <- y (local row 0 of the last block row); diagonal blocks hold the inverses of their factors
+#pragma unroll
+  for (int q = 0; q < kCsKB; ++q)
+    if (own[q] && bi[q] == NBC) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) zs[4 * bj[q] + c] = a[q][0][c];
+    }
+  __syncthreads();
+  for (int J = NBC - 1; J >= 0; --J) {
+#pragma unroll
+    for (int q = 0; q < kCsKB; ++q)
+      if (own[q] && bi[q] == J && bj[q] == J) {   // x_J = L_JJ^-T z_J
+        double z[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[r] = zs[4 * J + r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = 0;
+#pragma unroll
+          for (int r = c; r < 4; ++r) v += a[q][r][c] * z[r];
+          xs[c] = v;
+          if (4 * J + c < n) x[4 * J + c] = v;
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kCsKB; ++q)
+      if (own[q] && bi[q] == J && bj[q] < J) {    // z_j -= L(J, j)^T x_J
+        double xv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = xs[r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = zs[4 * bj[q] + c];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v -= a[q][r][c] * xv[r];
+          zs[4 * bj[q] + c] = v;
+        }
+      }
+    __syncthreads();
+  }
+}
+
 // ---- backward substitution L^T x = y, panel by panel from the last ------------------------------------------
 // z[c] = y[k0+c] - sum_{i >= k0+nb}^{n-1} L[i][k0+c] x[i]   (one workgroup per column: contiguous dot product)
 static __global__ __launch_bounds__(256) void k_chol_backdot(const double* __restrict__ M, long lda, int n, int k0, int nb,
@@ -1540,6 +1709,7 @@ struct CholRuntime {
   int stats_on = 0;                                         // g_chol_stats_on as last written (ESL_CHOL_TIMING)
   int sw_potrf512 = -1;                                     // ESL_CHOL_POTRF512=1: diagnostic kernel shape in the launch path
   int sw_backsub = -1;                                      // ESL_CHOL_BACKSUB_LAUNCHES=1 keeps the launch-per-panel form (A/B)
+  int sw_small = -1;                                        // ESL_CHOL_SMALL=0: orders <= 248 on the blocked path too (A/B)
   int n_cu = 0;                                             // hipDeviceProp_t::multiProcessorCount of the context's device (grids of the one-launch forms)
   int fallbacks = 0;                                        // trials redone launch-per-step after a device-side hand-off timed out (esl_slam.hip)
   // optional event bracket around the FACTORISATION alone (not the back-substitution): mark(user, 1) before, mark(user, 0) after
@@ -1696,6 +1866,16 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
   // Look-ahead: that update is split -- the columns of the NEXT outer panel are updated on the caller's stream, the rest on a
   // second stream, so the next outer panel's potrf / panel solves (single-workgroup and short kernels that leave the chip
   // empty) run underneath the big update instead of in front of it.
+  // small systems on one GPU: one workgroup, one launch (k_chol_small; ESL_CHOL_SMALL=0 keeps the blocked path: A/B and the tests
+  // that compare the two)
+  if (rt.sw_persistent < 0) { const char* sw = std::getenv("ESL_CHOL_PERSISTENT"); rt.sw_persistent = sw ? (sw[0] == '1' ? 1 : 0) : 2; }
+  if (!(dist && dist->n_ranks > 1) && chol_small_fits(n)) {
+    if (rt.sw_small < 0) { const char* sw = std::getenv("ESL_CHOL_SMALL"); rt.sw_small = (sw && sw[0] == '0') ? 0 : 1; }
+    if (rt.sw_small == 1 && rt.sw_persistent != 1) {   // (ESL_CHOL_PERSISTENT=1 asks for that kernel at every size: the tests of its chain)
+      hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(kCsThreads), 0, st, (const double*)M, lda, n, x, info);
+      return hipGetLastError();
+    }
+  }
   hipStream_t& side = rt.side;
   std::vector<hipEvent_t>& ev_panel = rt.ev_panel;
   std::vector<hipEvent_t>& ev_trail = rt.ev_trail;
@@ -1834,8 +2014,7 @@ inline hipError_t chol_factor_solve(double* M, long lda, int n, double* Linv_ws,
         launch_update(st, c_begin, c_end - c_begin, b2, e2);
       }
     }
-  } else if (([&]() { if (rt.sw_persistent < 0) { const char* sw = std::getenv("ESL_CHOL_PERSISTENT"); rt.sw_persistent = sw ? (sw[0] == '1' ? 1 : 0) : 2; }
-                      // by size, measured on MI355X (profiles/r4_cholesky_microbench.txt), one launch vs launch per step: n = 2,994 2.43 vs
+  } else if (([&]() { // by size, measured on MI355X (profiles/r4_cholesky_microbench.txt), one launch vs launch per step: n = 2,994 2.43 vs
                       // 2.24 ms, 4,096 3.23 vs 3.24, 6,000 4.88 vs 5.75, 8,192 7.94 vs 8.95, 12,000 15.9 vs 17.9, 18,000 40.3 vs 43.9,
                       // 24,000 88.0 vs 91.8, 32,768 214.4 vs 214.5 (a draw: the launch path is kept there, it is the form that has run the
                       // order-59,994 reduced camera system since round 1)

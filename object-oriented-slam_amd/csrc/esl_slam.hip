@@ -390,11 +390,14 @@ static int cf_ensure_impl(esl_ctx* c) {
     if (!c->cf_sparse) c->cf_sp_built = false;   // (none of the sparse-form tables are shipped)
   }
   const bool sp = c->cf_sparse;
-  // nested dissection of the camera chain from 128 free cameras on: stride = 16 x round(sqrt(nf) / 16) in [16, 128] (a multiple
+  // nested dissection of the camera chain from 48 free cameras on: stride = 16 x round(sqrt(nf) / 16) in [16, 128] (a multiple
   // of the forward substitution's chunk, so that segments start on chunk boundaries), kCfFwdCh when X is kept sparse;
   // ESL_CF_NO_ND=1 keeps the plain chain (A/B)
   c->cf_stride = 0; c->cf_n_sep = 0; c->cf_n_seg = 1;
-  const bool nd = nf >= 128 && !std::getenv("ESL_CF_NO_ND");
+  // (ESL_CF_ND_MIN: first free-camera count that is dissected -- default 48, three segments; 128 until round 6: at 119 free cameras the
+  //  plain chain's two serial sweeps, k_cf_chain 72 us + k_cf_forward 69 us, were a quarter of a streaming-size trial)
+  static const size_t nd_min = [] { const char* e = std::getenv("ESL_CF_ND_MIN"); const int v = e ? std::atoi(e) : 48; return (size_t)std::max(v, 2 * kCfFwdCh); }();
+  const bool nd = nf >= nd_min && !std::getenv("ESL_CF_NO_ND");
   if (nd) {
     int sd = 16 * (int)std::max(1.0, std::floor(std::sqrt((double)nf) / 16.0 + 0.5));
     sd = std::min(sd, kCfMaxStride);
@@ -1080,6 +1083,14 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
           if (c) fprintf(stderr, " %.0f/%.0f", f / c * 0.01, g / c * 0.01);
         }
         fprintf(stderr, "\n");
+        {   // the same over the last three eighths (where the chain sets the pace), by the panel's position in its outer panel
+          const int Wp = chol_outer_panels(n);
+          std::vector<double> f(Wp, 0), g(Wp, 0); std::vector<int> cn(Wp, 0);
+          for (int k = 5 * npl / 8; k < npl - 1; ++k) { f[k % Wp] += (double)(cl[2 * k + 1] - cl[2 * k]); g[k % Wp] += (double)(cl[2 * k + 2] - cl[2 * k + 1]); ++cn[k % Wp]; }
+          fprintf(stderr, "[k_chol_persist chain, last 3/8 of the panels, us by k mod W: potrf / gap]");
+          for (int q = 0; q < Wp; ++q) if (cn[q]) fprintf(stderr, " %.0f/%.0f", f[q] / cn[q] * 0.01, g[q] / cn[q] * 0.01);
+          fprintf(stderr, "\n");
+        }
       }
     }
     {

@@ -4,7 +4,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("object-oriented-slam_amd")
-for (F, N, E) in ((120, 20, 2400), (500, 50, 5000)):
+import os
+SIZES = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(120, 20, 2400), (500, 50, 5000)]
+for (F, N, E) in SIZES:
     g, c, o, _ = pkg.synth.make_graph(F, N, E, seed=3, slam=True)
     ctx = pkg.Context(0)
     ctx.upload_graph(g); ctx.upload_states(c, o); ctx.snapshot_states()

@@ -182,6 +182,28 @@ def test_dense_cholesky_selftest_residual(ctx, n):
     assert ms >= 0
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 17, 64, 127, 128, 129, 180, 181, 182, 183, 247, 248])
+def test_small_dense_cholesky_one_workgroup(pkg, monkeypatch, n):
+    """k_chol_small (round 6): orders <= 248 are factored and solved by ONE workgroup with the lower triangle in registers (rank-4 steps
+    over all block columns, y = L^-1 b as a block row of its own, L^T x = y on the same registers).  Residual at round-off at sizes
+    around the 4-wide blocks, the second block per thread (from 181 on) and the limit; the blocked path (ESL_CHOL_SMALL=0: potrf2 +
+    panel + update launches) gives the same x to round-off on the same generated system (their residuals agree in magnitude, and both
+    are checked here -- the blocked path has no other test at these sizes now)."""
+    cx = pkg.Context(0)
+    try:
+        ms, res = cx.selftest_cholesky(n)
+    finally:
+        cx.close()
+    monkeypatch.setenv("ESL_CHOL_SMALL", "0")
+    cx = pkg.Context(0)
+    try:
+        ms0, res0 = cx.selftest_cholesky(n)
+    finally:
+        cx.close()
+    print("one-workgroup solve n = %d: %.3f ms, residual %.2e | blocked path %.3f ms, residual %.2e" % (n, ms, res, ms0, res0))
+    assert res < 5e-15 and res0 < 5e-15, (n, res, res0)
+
+
 @pytest.mark.parametrize("n", [1, 7, 129, 130, 257, 777, 1153, 3000, 4097, 5000, 8192, 9001, 18000])
 def test_persistent_dense_cholesky_selftest_residual(pkg, monkeypatch, n):
     """the persistent form of the dense factorisation (k_chol_persist: ONE launch, workgroup 0 walks the diagonal blocks, the others
