@@ -1263,6 +1263,7 @@ struct CholPlan {
   int fuse = 0;          // the chain solves the two strips under its diagonal block and updates the next diagonal block itself (below)
   int merge = 1;         // far updates of a tile taken `merge` outer panels at a time (round 6: one visit with K = merge x W x 128)
   int strip_merge = 0;   // the strips of a row tile away from the diagonal as one task (round 6)
+  int sp = 1;            // leading column panels of an outer panel whose chain tiles are fed rank-128 updates panel by panel (chol_tile_special)
   std::vector<CholTask> tasks;
   std::vector<int> ns;   // [np][nR]
 };
@@ -1272,19 +1273,34 @@ struct CholPlan {
 // previous outer panel's contribution as W rank-128 updates (in quarters), one per panel as that panel is solved, instead of
 // inside U(o - 1) -- otherwise the chain's step across an outer-panel boundary waits for a whole rank-512 tile update (~150 us)
 // that cannot start before the LAST panel of the outer panel is solved.
-__host__ __device__ __forceinline__ bool chol_tile_special(int R, int J, int W) { return J >= W && J % W == 0 && R == J / 2; }
-__host__ __device__ __forceinline__ int chol_tile_nU(int R, int J, int W) { return J / W - (chol_tile_special(R, J, W) ? 1 : 0); }
-__host__ __device__ __forceinline__ int chol_tile_final(int R, int J, int W) { return chol_tile_nU(R, J, W) + (chol_tile_special(R, J, W) ? W : J % W); }
+// Round 6: SP leading column panels of every outer panel are special in this sense (default 2), in the diagonal tile's row AND the row tile
+// under it (R == J / 2 + 1: its strips of panel J are what the next panels' chain tiles wait for).  Measured with SP = 1, R == J / 2
+// only, by the panel's position in its outer panel over the chain-bound part: gap to the next block 60 / 36 / 27 / 27 us at n = 8,192
+// against 26 us of the chain's own work -- at the first panel of an outer panel the fused stage waited ~34 us for the rank-(W x 128)
+// update of the NEXT diagonal tile (ke / 2, ke + 1), which cannot start before the outer panel's last solve.  Making only that tile
+// special moved the stall to the next step (27 / 68 / 27 / 27): there the chain waits for tile (ke / 2 + 1, ke + 1), whose update by panel
+// ke needs panel ke's strips in row tile ke / 2 + 1, which wait for tile (ke / 2 + 1, ke) to be final -- another 150 us rank-512 update.
+// A special tile receives, in this order: the rank-(W x 128) updates of outer panels 0 .. J / W - 2, then W rank-128 updates from the
+// panels of outer panel J / W - 1, then J % W rank-128 updates from the earlier panels of its own outer panel.
+__host__ __device__ __forceinline__ bool chol_tile_special(int R, int J, int W, int SP) { return J >= W && (J % W) < SP && (R == J / 2 || R == J / 2 + 1); }
+__host__ __device__ __forceinline__ int chol_tile_nU(int R, int J, int W, int SP) { return J / W - (chol_tile_special(R, J, W, SP) ? 1 : 0); }
+// index, among the rank-128 updates tile (R, J) receives, of the one from panel a (a in J's outer panel or, special tiles, the one before)
+__host__ __device__ __forceinline__ int chol_tile_ridx(int R, int J, int W, int SP, int a) { return ((a / W == J / W && chol_tile_special(R, J, W, SP)) ? W : 0) + a % W; }
+// sequence number of that update: the value of ver[R][J] it waits for (and leaves at + 1)
+__host__ __device__ __forceinline__ int chol_tile_seq(int R, int J, int W, int SP, int a) { return chol_tile_nU(R, J, W, SP) + chol_tile_ridx(R, J, W, SP, a); }
+__host__ __device__ __forceinline__ int chol_tile_final(int R, int J, int W, int SP) { return chol_tile_nU(R, J, W, SP) + (chol_tile_special(R, J, W, SP) ? W : 0) + J % W; }
 // quarter (h, g) of tile (R, J): rows 256 R + 128 h .. + 128, columns 128 J + 64 g .. + 64
 __host__ __device__ inline bool chol_quarter_live(int R, int J, int h, int g, long rows, int n) {
   const long i0 = 256L * R + 128L * h, j0 = 128L * J + 64L * g;
   return i0 < rows && j0 < n && i0 + 127 >= j0;
 }
-inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = false, int merge = 1, bool strip_merge = false) {
+inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = false, int merge = 1, bool strip_merge = false, int sp = 1) {
   const long rows = (long)n + 1;
   pl.fuse = fuse ? 1 : 0;
   pl.merge = merge < 1 ? 1 : merge;
   pl.strip_merge = strip_merge ? 1 : 0;
+  pl.sp = sp < 1 ? 1 : (sp > W ? W : sp);
+  const int SP = pl.sp;
   pl.n = n; pl.W = W; pl.np = (n + kNB - 1) / kNB; pl.n_outer = (pl.np + W - 1) / W; pl.nR = (int)((rows + 255) / 256);
   const int np = pl.np, nR = pl.nR;
   pl.ns.assign((size_t)np * nR, 0);
@@ -1330,7 +1346,9 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
       };
       // the next outer panel's first diagonal tile takes this panel's rank-128 contribution now (chol_tile_special); of all of the
       // panel's updates it is the one the chain will wait for soonest when k is the outer panel's last, so it goes first
-      if (ke < np && live(ke / 2, ke)) { fill(); any = true; quarters(ke / 2, ke); }
+      for (int J = ke; J < std::min(np, ke + W); ++J)
+        for (int R = J / 2; R <= J / 2 + 1; ++R)
+          if (chol_tile_special(R, J, W, SP) && live(R, J)) { if (!any) { fill(); any = true; } quarters(R, J); }
       for (int J = k + 1; J < ke; ++J)
         for (int R = J / 2; R < nR; ++R)
           if (live(R, J)) {
@@ -1352,7 +1370,7 @@ inline void chol_plan_build(int n, int W, int filler, CholPlan& pl, bool fuse = 
     // the chain waits for) stays a visit of its own.  c = J | cnt << 16; sequence number g0 -> g0 + cnt.
     for (int J = ke; J < np; ++J)
       for (int R = J / 2; R < nR; ++R)
-        if (live(R, J) && !(J == ke && R == ke / 2)) {   // (the special tile: see chol_tile_special)
+        if (live(R, J) && !(J < ne && chol_tile_special(R, J, W, SP))) {   // (special tiles took this outer panel's contribution panel by panel)
           if (J < ne) { prevA.push_back(CholTask{2, o, R, J | (1 << 16)}); continue; }
           const int far = J / W - 1;                     // far updates of this tile: o = 0 .. far - 1 (this o is one of them: J >= ne)
           // the groups of different tiles are STAGGERED (boundaries shifted by a hash of the tile): with one grid of boundaries for all
@@ -1517,7 +1535,7 @@ constexpr size_t kPwLds = kP2Lds + 64;   // + the task slot words and the diagno
 // diagonal-block role needs make every workgroup the only tenant of its CU -- which the 104 KB of the update role did anyway.
 static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __restrict__ M, long lda, int n, int np, int W, int nR,
                                                                    double* __restrict__ Linv_ws, const CholTask* __restrict__ tasks,
-                                                                   int n_tasks, const int* __restrict__ ns, int* sync, int* info, int fuse) {
+                                                                   int n_tasks, const int* __restrict__ ns, int* sync, int* info, int fuse, int SP) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   int* slot = reinterpret_cast<int*>(sm + kP2Lds / sizeof(double));   // (behind the roles' LDS: no static __shared__, guide G17)
   long long* lstat = reinterpret_cast<long long*>(slot + 4);           // diagnostics accumulate in LDS, not in registers (see below)
@@ -1540,7 +1558,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       const int k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
       if (t == 0) {
         const long long tw = stats ? (long long)wall_clock64() : 0;
-        const bool ok = have_next || chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], chol_tile_final(k / 2, k, W), sync + 1, info);   // every update of the diagonal block's tile is in
+        const bool ok = have_next || chol_wait_ge<2>(&ver[(size_t)(k / 2) * np + k], chol_tile_final(k / 2, k, W, SP), sync + 1, info);   // every update of the diagonal block's tile is in
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         slot[0] = ok ? 1 : 0;
         if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; lstat[4] = now; if (k < 1024) g_chol_chain_log[2 * k] = now; }
@@ -1564,8 +1582,8 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         const bool next = k + 1 < np;
         if (t == 0) {
           const long long tw = stats ? (long long)wall_clock64() : 0;
-          bool ok = chol_wait_ge<2>(&ver[(size_t)R1 * np + k], chol_tile_final(R1, k, W), sync + 1, info);
-          if (ok && next) ok = chol_wait_ge<2>(&ver[(size_t)((k + 1) / 2) * np + k + 1], chol_tile_nU((k + 1) / 2, k + 1, W) + k % W, sync + 1, info);
+          bool ok = chol_wait_ge<2>(&ver[(size_t)R1 * np + k], chol_tile_final(R1, k, W, SP), sync + 1, info);
+          if (ok && next) ok = chol_wait_ge<2>(&ver[(size_t)((k + 1) / 2) * np + k + 1], chol_tile_seq((k + 1) / 2, k + 1, W, SP, k), sync + 1, info);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           slot[0] = ok ? 1 : 0;
           if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; g_chol_fuse_ticks[0] += now - tw; lstat[4] = now; }
@@ -1592,7 +1610,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
             const int J = k + 1, R = J / 2;
             int mine = 0;
             for (int q = 0; q < 4; ++q) if ((q & 1) != (J & 1) && chol_quarter_live(R, J, q & 1, q >> 1, rows, n)) ++mine;
-            if (mine == 0) __hip_atomic_store(&ver[(size_t)R * np + J], chol_tile_nU(R, J, W) + k % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine == 0) __hip_atomic_store(&ver[(size_t)R * np + J], chol_tile_seq(R, J, W, SP, k) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         have_next = next;
@@ -1621,7 +1639,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       if (tk.type == 0) {
         const int k = tk.a, k0 = k * kNB, nb = (n - k0 < kNB) ? (n - k0) : kNB;
         const int R = (int)(((long)k0 + nb + 64L * tk.b) / 256);
-        ok = chol_wait_ge<100>(&pdone[k], 1, sync + 1, info) && chol_wait_ge<100>(&ver[(size_t)R * np + k], chol_tile_final(R, k, W), sync + 1, info);
+        ok = chol_wait_ge<100>(&pdone[k], 1, sync + 1, info) && chol_wait_ge<100>(&ver[(size_t)R * np + k], chol_tile_final(R, k, W, SP), sync + 1, info);
       } else {
         const int R = tk.b, J = tk.c & 0xffff;
         const int cnt = (tk.type == 2) ? (tk.c >> 16) : 1;   // type 2: outer panels [a, a + cnt) in one visit
@@ -1634,7 +1652,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         int* w1 = &sdone[(size_t)(ke - 1) * nR + J / 2];
         int* w2 = &ver[(size_t)R * np + J];
         const int want0 = ns[(size_t)(ke - 1) * nR + R], want1 = ns[(size_t)(ke - 1) * nR + J / 2];
-        const int seq = (tk.type != 2) ? chol_tile_nU(R, J, W) + tk.a % W : tk.a;
+        const int seq = (tk.type != 2) ? chol_tile_seq(R, J, W, SP, tk.a) : tk.a;
         const int v0 = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                   v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = (v0 >= want0 || chol_wait_ge<100>(w0, want0, sync + 1, info)) && (v1 >= want1 || chol_wait_ge<100>(w1, want1, sync + 1, info)) &&
@@ -1677,11 +1695,11 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         // only grows: panel a is the (a % W + 1)-th rank-128 update of this tile, which belongs to a's own outer panel.)
         const int J = tk.c & 0xffff, mine = (tk.c >> 18) & 7, full = (tk.c >> 21) & 7;
         const int old = __hip_atomic_fetch_add(&qdone[(size_t)tk.b * np + J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == full * (tk.a % W) + mine)
-          __hip_atomic_store(&ver[(size_t)tk.b * np + J], chol_tile_nU(tk.b, J, W) + tk.a % W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == full * chol_tile_ridx(tk.b, J, W, SP, tk.a) + mine)
+          __hip_atomic_store(&ver[(size_t)tk.b * np + J], chol_tile_seq(tk.b, J, W, SP, tk.a) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         const int J = tk.c & 0xffff;
-        __hip_atomic_store(&ver[(size_t)tk.b * np + J], (tk.type == 1) ? J / W + tk.a % W + 1 : tk.a + (tk.c >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ver[(size_t)tk.b * np + J], (tk.type == 1) ? chol_tile_seq(tk.b, J, W, SP, tk.a) + 1 : tk.a + (tk.c >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (stats) { lstat[1] += (long long)wall_clock64() - lstat[4]; lstat[2] += 1; }
     }
@@ -1781,6 +1799,8 @@ inline bool chol_fuse_default() { const char* e = std::getenv("ESL_CHOL_FUSE"); 
 // 8,192 7.00 -> 8.31, 12,000 15.0 -> 17.2, 18,000 37.7 -> 38.9, 24,000 83.4 -> 84.7: four workgroups finish a row tile's solve sooner than
 // one, and every trailing update of that row tile waits for it.
 inline bool chol_strip_merge_default() { const char* e = std::getenv("ESL_CHOL_STRIPS"); return e && e[0] == '1'; }
+// leading column panels of an outer panel with special chain tiles (chol_tile_special): ESL_CHOL_SPECIAL, default 2 (1 = rounds 4-5)
+inline int chol_special_default() { const char* e = std::getenv("ESL_CHOL_SPECIAL"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }
 inline int chol_merge_default(int n) {
   const char* e = std::getenv("ESL_CHOL_MERGE");
   const int m = e ? std::atoi(e) : (n >= 16384 ? 3 : 2);
@@ -1794,10 +1814,11 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
   const bool fuse = chol_fuse_default();
   const int merge = chol_merge_default(n);
   const bool smerge = chol_strip_merge_default();
-  if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0) || rt.plan.merge != merge || rt.plan.strip_merge != (smerge ? 1 : 0)) {
+  const int spc = std::min(chol_special_default(), W);
+  if (rt.plan.n != n || rt.plan.W != W || rt.plan.fuse != (fuse ? 1 : 0) || rt.plan.merge != merge || rt.plan.strip_merge != (smerge ? 1 : 0) || rt.plan.sp != spc) {
     { hipError_t e0 = hipStreamSynchronize(st); if (e0 != hipSuccess) return e0; }   // the old list / sync words may still be in use
     const char* fenv = std::getenv("ESL_CHOL_FILLER");   // (debugging: far-update tasks interleaved per chain-dependent group)
-    chol_plan_build(n, W, fenv ? std::max(1, std::atoi(fenv)) : 128, rt.plan, fuse, merge, smerge);
+    chol_plan_build(n, W, fenv ? std::max(1, std::atoi(fenv)) : 128, rt.plan, fuse, merge, smerge, spc);
     auto grow = [](void** p, size_t* cap, size_t need) -> hipError_t {
       if (*cap >= need) return hipSuccess;
       if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
@@ -1836,7 +1857,7 @@ inline hipError_t chol_factor_persistent(double* M, long lda, int n, double* Lin
   // one workgroup per CU of THIS device (the kernel is correct for any grid >= 2: the first arrival is the chain, the others pull tasks)
   const int grid = std::max(2, std::min(rt.n_cu > 0 ? rt.n_cu : kPwGrid, kPwGrid));
   hipLaunchKernelGGL(k_chol_persist, dim3((unsigned)grid), dim3(kPwThreads), kPwLds, st, M, lda, n, pl.np, pl.W, pl.nR, Linv_ws, (const CholTask*)rt.d_tasks,
-                     (int)pl.tasks.size(), (const int*)rt.d_ns, rt.d_sync, info, pl.fuse);
+                     (int)pl.tasks.size(), (const int*)rt.d_ns, rt.d_sync, info, pl.fuse, pl.sp);
   return hipGetLastError();
 }
 

@@ -1148,7 +1148,7 @@ extern "C" int esl_debug_chol_plan(int32_t n, int32_t W, int32_t filler, int32_t
                                    int32_t* ns_out /* np x nR */, int64_t cap_ns, int32_t meta_out[5] /* np, n_outer, nR, n_tasks, W */) {
   if (n < 1 || W < 1 || !meta_out) return ESL_ERR_INVALID;
   esl::CholPlan pl;
-  esl::chol_plan_build(n, W, filler, pl, esl::chol_fuse_default(), esl::chol_merge_default(n), esl::chol_strip_merge_default());
+  esl::chol_plan_build(n, W, filler, pl, esl::chol_fuse_default(), esl::chol_merge_default(n), esl::chol_strip_merge_default(), std::min(esl::chol_special_default(), (int)W));
   meta_out[0] = pl.np; meta_out[1] = pl.n_outer; meta_out[2] = pl.nR; meta_out[3] = (int32_t)pl.tasks.size(); meta_out[4] = pl.W;
   if (tasks_out) {
     if ((int64_t)pl.tasks.size() > cap_tasks) return ESL_ERR_INVALID;

@@ -31,9 +31,15 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
     chain_k = [0]
     # what a tile receives before its panel is factored (csrc/esl_chol.hpp chol_tile_special / _nU / _final): the diagonal tile of an
     # outer panel's first column panel takes the previous outer panel's contribution as W rank-128 updates instead of one rank-(128 W)
-    special = lambda R, J: J >= W and J % W == 0 and R == J // 2
+    # (round 6: the first SP column panels of every outer panel, ESL_CHOL_SPECIAL, default 2; the diagonal tile's row and the row tile under it.
+    #  A special tile takes its W rank-128 updates of the previous outer panel first, then the J % W of its own outer panel.)
+    import os
+    SP = max(1, min(int(os.environ.get("ESL_CHOL_SPECIAL", "2")), W))
+    special = lambda R, J: J >= W and (J % W) < SP and R in (J // 2, J // 2 + 1)
     n_big = lambda R, J: J // W - (1 if special(R, J) else 0)
-    final = lambda R, J: n_big(R, J) + (W if special(R, J) else J % W)
+    final = lambda R, J: n_big(R, J) + (W if special(R, J) else 0) + J % W
+    ridx = lambda R, J, a: (W if (a // W == J // W and special(R, J)) else 0) + a % W     # which of the tile's rank-128 updates panel a's is
+    seq_of = lambda R, J, a: n_big(R, J) + ridx(R, J, a)
     nb_of = lambda k: min(128, n - 128 * k)
 
     chain_stage = [0]      # 0: block chain_k is next to be factored; 1 (fused): factored, its rows below and the next block's update pending
@@ -64,11 +70,11 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
             below = rows - r0; nstr = 2 if below > 64 else 1
             if ver[R1, k] < final(R1, k):
                 return
-            if nxt and ver[(k + 1) // 2, k + 1] < n_big((k + 1) // 2, k + 1) + k % W:
+            if nxt and ver[(k + 1) // 2, k + 1] < seq_of((k + 1) // 2, k + 1, k):
                 return
             assert ver[R1, k] == final(R1, k)
             if nxt:
-                assert nb == 128 and ver[(k + 1) // 2, k + 1] == n_big((k + 1) // 2, k + 1) + k % W, "the next diagonal tile is not at the chain's sequence number"
+                assert nb == 128 and ver[(k + 1) // 2, k + 1] == seq_of((k + 1) // 2, k + 1, k), "the next diagonal tile is not at the chain's sequence number"
             M[r0:r1, k0:k0 + nb] = M[r0:r1, k0:k0 + nb] @ Linv[k].T
             sdone[k, R1] += nstr
             if nxt:
@@ -82,7 +88,7 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
                 J = k + 1; R = J // 2
                 mine = sum(1 for hh in (0, 1) for gg in (0, 1) if hh != (J & 1) and quarter_live(R, J, hh, gg))
                 if mine == 0:
-                    ver[R, J] = n_big(R, J) + k % W + 1
+                    ver[R, J] = seq_of(R, J, k) + 1
             have_next[0] = nxt
             chain_stage[0] = 0
             chain_k[0] += 1
@@ -98,9 +104,9 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
             R, J, h, g, cnt, full = bb, c & 0xFFFF, (c >> 16) & 1, (c >> 17) & 1, (c >> 18) & 7, (c >> 21) & 7
             k = a
             chains = fuse and k == J - 1 and R == J // 2     # the chain applies this update to the diagonal block (the half h == J & 1) itself
-            assert R in (J // 2, (J + 1) // 2) and J > k and 1 <= cnt <= full <= 4
+            assert (R in (J // 2, (J + 1) // 2) or special(R, J)) and J > k and 1 <= cnt <= full <= 4
             assert (k // W == J // W) or (special(R, J) and k // W == J // W - 1)
-            seq = n_big(R, J) + a % W
+            seq = seq_of(R, J, a)
             assert sdone[k, R] == ns[k, R] and sdone[k, J // 2] == ns[k, J // 2], ("quarter before its operands", a, R, J)
             assert ver[R, J] == seq, ("quarter out of sequence", a, R, J, ver[R, J], seq)
             i0 = 256 * R + 128 * h; j0 = 128 * J + 64 * g
@@ -117,7 +123,7 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
             live_q = [(hh, gg) for hh in (0, 1) for gg in (0, 1) if quarter_live(R, J, hh, gg)]
             task_q = [(hh, gg) for hh, gg in live_q if not (chains and hh == (J & 1))]
             assert full == len(live_q) and cnt == len(task_q) and (h, g) in task_q
-            if qdone[R, J] == full * (a % W) + cnt:
+            if qdone[R, J] == full * ridx(R, J, a) + cnt:
                 ver[R, J] = seq + 1
             continue
         if ty == 0:
@@ -139,7 +145,7 @@ def replay(pkg, n, W, filler, seed=0, fuse=True):
             R, J, cnt = bb, c & 0xFFFF, (c >> 16) if ty == 2 else 1
             assert cnt >= 1
             ks = [a] if ty == 1 else list(range(a * W, min(np_, (a + cnt) * W)))
-            seq = (J // W + a % W) if ty == 1 else a
+            seq = seq_of(R, J, a) if ty == 1 else a
             # (the device code polls the LAST panel's words only: S waits for its tile to be final, so the last panel's strips of a
             #  row tile are solved after every earlier panel of the outer panel has solved its own there -- asserted here for all)
             assert ns[ks[-1], R] > 0 and ns[ks[-1], J // 2] > 0
