@@ -1161,6 +1161,11 @@ static int map_combine(esl_ctx* c) {
 // step API
 // ---------------------------------------------------------------------------------------------------
 static int read_parts(esl_ctx* c, double out[4]) {
+  if (c->parts_fresh) {   // (slam_try_step copied them together with the dense solver's flag: one wait per trial)
+    c->parts_fresh = false;
+    for (int i = 0; i < 4; ++i) out[i] = c->host_part[i];
+    return ESL_OK;
+  }
   ESL_HIP_TRY(hipMemcpyAsync(c->host_part, c->dev_part, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   for (int i = 0; i < 4; ++i) out[i] = c->host_part[i];

@@ -640,6 +640,23 @@ static __global__ __launch_bounds__(256) void k_cf_T_init(int n_objs, const doub
   }
 }
 
+// the whole of T in one launch (X dense: no memset in front): thread = entry (row, column) of the (n_o + 1) x n_o array
+static __global__ __launch_bounds__(256) void k_cf_T_init_full(int n_objs, const double* __restrict__ Hoo, const double* __restrict__ bo,
+                                                               double lambda, double* __restrict__ T, long ldt, long n_o) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long col = t / ldt, row = t - col * ldt;
+  if (col >= n_o) return;
+  double v = 0;
+  const long o = col / 9;
+  const int c = (int)(col - 9 * o);
+  if (row == n_o) v = bo[(size_t)o * 9 + c];
+  else if (row < n_o && row / 9 == o && row >= col) {
+    const int r = (int)(row - 9 * o);
+    v = Hoo[(size_t)o * 45 + c * 9 - (c * (c - 1)) / 2 + (r - c)] + ((r == c) ? lambda : 0.0);
+  }
+  T[t] = v;
+}
+
 // ---- z = y - X x_o: one workgroup per row of X (a contiguous row of Xt) -----------------------------------------------------------
 static __global__ __launch_bounds__(256) void k_cf_z(const double* __restrict__ Xt, long ldx, int n_o, const double* __restrict__ xo,
                                                      double* __restrict__ z) {
@@ -706,10 +723,8 @@ static __global__ __launch_bounds__(64) void k_cf_tridiag_back(int nf_all, const
 }
 
 // ---- trial ellipsoids from x_o (the solution of the reduced ellipsoid system); scale partial of computeScale -------------------
-static __global__ __launch_bounds__(256) void k_cf_obj_update(DevGraph g, double lambda, const double* __restrict__ objs,
-                                                              const double* __restrict__ bo, const double* __restrict__ xo,
-                                                              double* __restrict__ objs_trial, double* __restrict__ part) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void cf_obj_update_one(const DevGraph& g, double lambda, const double* __restrict__ objs, const double* __restrict__ bo,
+                                                  const double* __restrict__ xo, double* __restrict__ objs_trial, double* __restrict__ part, int o) {
   if (o >= g.n_objs) return;
   const Ell e = ell_load(objs + 10 * o);
   const bool active = (g.bb_start[o + 1] > g.bb_start[o]) || (g.e3_start[o + 1] > g.e3_start[o]) || g.gr_cnt[o] > 0;
@@ -724,6 +739,11 @@ static __global__ __launch_bounds__(256) void k_cf_obj_update(DevGraph g, double
   for (int i = 0; i < 9; ++i) { x[i] = xo[(size_t)o * 9 + i]; scale += x[i] * (lambda * x[i] + bo[(size_t)o * 9 + i]); }
   ell_store(ell_oplus(e, x), objs_trial + 10 * o);
   part[o * 4 + 2] = scale;
+}
+static __global__ __launch_bounds__(256) void k_cf_obj_update(DevGraph g, double lambda, const double* __restrict__ objs,
+                                                              const double* __restrict__ bo, const double* __restrict__ xo,
+                                                              double* __restrict__ objs_trial, double* __restrict__ part) {
+  cf_obj_update_one(g, lambda, objs, bo, xo, objs_trial, part, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- sparse interior rows of X (round 3) ---------------------------------------------------------------------------------------------

@@ -182,6 +182,7 @@ struct esl_ctx {
   char* fit_out = nullptr; size_t fit_out_cap = 0;
   char* plane_slab = nullptr; size_t plane_slab_cap = 0;    // esl_extract_ground_plane / esl_extract_planes (esl_plane.hip)
   void* fit_graph_cache = nullptr;                          // captured launch sequences (std::vector<FitGraphEntry>)
+  bool parts_fresh = false;      // host_part holds the last trial's scalars already (slam_try_step fetched them with the solver's flag)
   bool cams_match_snap = false;  // cameras untouched since the snapshot: esl_states_restore skips their copy
   int n_grav_edges = 0;
   void* lm_dev = nullptr;        // device-resident LM state (LmCore[2], esl_kernels_chunk.hpp)

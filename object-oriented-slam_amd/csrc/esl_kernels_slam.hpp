@@ -575,10 +575,8 @@ static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_backsub(
 }
 
 // one lane per camera: trial camera = exp(x_c) * Tcw for free cameras; scale partial
-static __global__ void k_slam_cam_update(DevGraph g, double lambda, const double* __restrict__ cams,
-                                  const double* __restrict__ xc, const double* __restrict__ bc,
-                                  double* __restrict__ cams_trial, double* __restrict__ cam_part) {
-  const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void slam_cam_update_one(const DevGraph& g, double lambda, const double* __restrict__ cams, const double* __restrict__ xc,
+                                                    const double* __restrict__ bc, double* __restrict__ cams_trial, double* __restrict__ cam_part, int cidx) {
   if (cidx >= g.n_cams) return;
   const SE3 T = se3_load(cams + 7 * cidx);
   const int slot = g.cam_slot[cidx];
@@ -593,6 +591,11 @@ static __global__ void k_slam_cam_update(DevGraph g, double lambda, const double
     se3_store(cam_oplus(T, u), cams_trial + 7 * cidx);
   }
   cam_part[cidx * 4 + 0] = 0; cam_part[cidx * 4 + 1] = 0; cam_part[cidx * 4 + 2] = scale; cam_part[cidx * 4 + 3] = 1;
+}
+static __global__ void k_slam_cam_update(DevGraph g, double lambda, const double* __restrict__ cams,
+                                  const double* __restrict__ xc, const double* __restrict__ bc,
+                                  double* __restrict__ cams_trial, double* __restrict__ cam_part) {
+  slam_cam_update_one(g, lambda, cams, xc, bc, cams_trial, cam_part, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // chi2 of the trial states: ellipsoid-attached edges (wave per ellipsoid) ...
@@ -632,6 +635,85 @@ static __global__ __launch_bounds__(256) void k_sum_into(const double* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) out[0] += s[0];
+}
+
+// ---- one launch for the trial's scalars (round 6): the two k_reduce_parts launches and k_sum_into of reduce_all, in the same order and
+// with the same trees (same bits), plus the fold of the dense solver's pivot flag into the "ok" partial -- at streaming sizes a
+// trial is ~30 dependent launches of a few microseconds each, and these were four of them and a host round trip.
+//   out[0..3] = {sum chi2, max maxdiag, sum scale, min ok} over the ellipsoids' and the cameras' partials, out[0] += sum of od_part
+//   info != null: out[3] = 0 if bit 0 of *info is set (non-positive pivot: the step is rejected), out[4] = *info as a double
+static __global__ __launch_bounds__(256) void k_slam_reduce_all(const double* __restrict__ obj_part, int n_objs, const double* __restrict__ cam_part, int n_cams,
+                                                                const double* __restrict__ od_part, int n_od, double* __restrict__ out,
+                                                                const int* __restrict__ info) {
+  __shared__ double s0[256], s1[256], s2[256], s3[256];
+  double r[4] = {0, 0, 0, 1};
+  for (int pass = 0; pass < 3; ++pass) {
+    const double* part = pass == 0 ? obj_part : (pass == 1 ? cam_part : od_part);
+    const int n = pass == 0 ? n_objs : (pass == 1 ? n_cams : n_od);
+    double a = 0, b = 0, c = 0, d = 1;
+    if (pass < 2) {
+      for (int i = threadIdx.x; i < n; i += 256) {
+        a += part[i * 4 + 0];
+        b = fmax(b, part[i * 4 + 1]);
+        c += part[i * 4 + 2];
+        d = fmin(d, part[i * 4 + 3]);
+      }
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+    }
+    __syncthreads();   // (the previous pass's readers of the trees)
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b; s2[threadIdx.x] = c; s3[threadIdx.x] = d;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        s0[threadIdx.x] += s0[threadIdx.x + s];
+        s1[threadIdx.x] = fmax(s1[threadIdx.x], s1[threadIdx.x + s]);
+        s2[threadIdx.x] += s2[threadIdx.x + s];
+        s3[threadIdx.x] = fmin(s3[threadIdx.x], s3[threadIdx.x + s]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (pass == 0) { r[0] = s0[0]; r[1] = s1[0]; r[2] = s2[0]; r[3] = s3[0]; }
+      else if (pass == 1) { r[0] += s0[0]; r[1] = fmax(r[1], s1[0]); r[2] += s2[0]; r[3] = fmin(r[3], s3[0]); }
+      else if (n > 0) r[0] += s0[0];
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (info) { const int f = info[0]; if (f & 1) r[3] = 0; out[4] = (double)f; }
+    out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
+  }
+}
+// the pivot flag alone (runs where the flag is only final after a collective: replicated-graph ranks)
+static __global__ void k_slam_fold_info(const int* __restrict__ info, double* __restrict__ out) {
+  const int f = info[0];
+  if (f & 1) out[3] = 0;
+  out[4] = (double)f;
+}
+
+// chi2 of the trial states in ONE launch: blocks [0, nb_obj) are k_slam_chi2_obj's (a wave per ellipsoid), the rest k_slam_chi2_odom's
+static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_chi2_all(DevGraph g, int nb_obj, const double* __restrict__ cams,
+                                                                                const double* __restrict__ objs, double* __restrict__ part,
+                                                                                double* __restrict__ od_chi) {
+  if ((int)blockIdx.x < nb_obj) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (o >= g.n_objs) return;
+    const Ell e = ell_load(objs + 10 * o);
+    const double chi = obj_chi2(g, cams, e, o, lane);
+    if (lane == 0) part[o * 4 + 0] = chi;
+    return;
+  }
+  const int e = ((int)blockIdx.x - nb_obj) * (kWave * kWavesPerBlock) + threadIdx.x;
+  if (e >= g.n_odom) return;
+  const int vi = g.od_i[e], vj = g.od_j[e];
+  if (g.cam_slot[vi] < 0 && g.cam_slot[vj] < 0) { od_chi[e] = 0; return; }
+  double r[6];
+  res_odom(se3_load(cams + 7 * vi), se3_load(cams + 7 * vj), se3_load(g.od_meas + 7 * e), r);
+  double chi = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) chi += r[k] * g.od_info[6 * e + k] * r[k];
+  od_chi[e] = chi;
 }
 
 // xc <- solution vector x (n doubles) : plain copy kernel not needed (same layout: slot*6 + a)

@@ -16,6 +16,16 @@
 
 namespace esl {
 
+// trial ellipsoids AND trial cameras of the camera-first form in one launch (round 6): blocks [0, nb_obj) are k_cf_obj_update's, the
+// rest k_slam_cam_update's
+static __global__ __launch_bounds__(256) void k_cf_updates(DevGraph g, int nb_obj, double lambda, const double* __restrict__ objs, const double* __restrict__ bo,
+                                                           const double* __restrict__ xo, double* __restrict__ objs_trial, double* __restrict__ obj_part,
+                                                           const double* __restrict__ cams, const double* __restrict__ xc, const double* __restrict__ bc,
+                                                           double* __restrict__ cams_trial, double* __restrict__ cam_part) {
+  if ((int)blockIdx.x < nb_obj) cf_obj_update_one(g, lambda, objs, bo, xo, objs_trial, obj_part, blockIdx.x * 256 + threadIdx.x);
+  else slam_cam_update_one(g, lambda, cams, xc, bc, cams_trial, cam_part, ((int)blockIdx.x - nb_obj) * 256 + threadIdx.x);
+}
+
 template <class T>
 static int al(T** dst, size_t n) {
   if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
@@ -591,9 +601,8 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     // distributed factorisation below expects them)
     const int Wp = chol_outer_panels(n_o), n_outer = ((n_o + kNB - 1) / kNB + Wp - 1) / Wp;
     const bool dist = cf_dist(c);
-    if (!c->cf_sparse) {
-      ESL_HIP_TRY(hipMemsetAsync(c->cf_T, 0, (size_t)ldt * (size_t)n_o * sizeof(double), c->stream));
-      hipLaunchKernelGGL(k_cf_T_init, dim3((unsigned)(((long)N * 90 + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
+    if (!c->cf_sparse) {   // (one launch writes every entry: D's lower blocks, b_o's row, zeros)
+      hipLaunchKernelGGL(k_cf_T_init_full, dim3((unsigned)((ldt * (long)n_o + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
     } else {   // T = D - (interior rows)^T (interior rows), block by block (every block on and below the diagonal is written)
       ProfScope pk(c, 8);
       if (c->cf_sp_form == 1)   // the segments' products (all of them on every rank: 3 % of a trial)
@@ -660,12 +669,12 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
   }
   {
     ProfScope ps(c, 1);
-    hipLaunchKernelGGL(k_cf_obj_update, dim3((N + 255) / 256), dim3(256), 0, c->stream, g, lambda, c->objs, c->bo, c->xo, c->objs_trial, c->obj_part);
-    hipLaunchKernelGGL(k_slam_cam_update, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, lambda, c->cams, c->xc, c->bc, c->cams_trial, c->cam_part);
-    const dim3 grid((N + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-    hipLaunchKernelGGL(k_slam_chi2_obj, grid, block, 0, c->stream, g, c->cams_trial, c->objs_trial, c->obj_part);
-    if (g.n_odom)
-      hipLaunchKernelGGL(k_slam_chi2_odom, dim3((g.n_odom + 127) / 128), dim3(128), 0, c->stream, g, c->cams_trial, c->od_part);
+    const int nb_obj = (N + 255) / 256, nb_cam = (F + 255) / 256;
+    hipLaunchKernelGGL(k_cf_updates, dim3((unsigned)(nb_obj + nb_cam)), dim3(256), 0, c->stream, g, nb_obj, lambda, c->objs, c->bo, c->xo, c->objs_trial, c->obj_part,
+                       c->cams, c->xc, c->bc, c->cams_trial, c->cam_part);
+    const int nb_co = (N + kWavesPerBlock - 1) / kWavesPerBlock, nb_od = (g.n_odom + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
+    hipLaunchKernelGGL(k_slam_chi2_all, dim3((unsigned)(nb_co + nb_od)), dim3(kWave * kWavesPerBlock), 0, c->stream, g, nb_co, c->cams_trial, c->objs_trial, c->obj_part,
+                       c->od_part);
     ESL_HIP_TRY(hipGetLastError());
   }
   return ESL_OK;
@@ -702,16 +711,18 @@ void slam_release_runtime(esl_ctx* c) {
   c->schur_attr_set = false;
 }
 
-static int reduce_all(esl_ctx* c) {
+// info: the dense solver's flag word, folded into the "ok" partial and handed on as out[4] (null: no fold -- linearisation, or a
+// replicated-graph run, where the flag is only final after its collective: k_slam_fold_info there)
+static int reduce_all(esl_ctx* c, const int* info = nullptr) {
   const DevGraph& g = c->g;
-  hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->obj_part, g.n_objs, c->dev_part, 0);
-  hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->cam_part, g.n_cams, c->dev_part, 1);
-  if (g.n_odom && g.shard_rank == 0) hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(256), 0, c->stream, c->od_part, g.n_odom, c->dev_part);
+  hipLaunchKernelGGL(k_slam_reduce_all, dim3(1), dim3(256), 0, c->stream, c->obj_part, g.n_objs, c->cam_part, g.n_cams, c->od_part,
+                     (g.n_odom && g.shard_rank == 0) ? g.n_odom : 0, c->dev_part, info);
   ESL_HIP_TRY(hipGetLastError());
   return ESL_OK;
 }
 
 int slam_linearize(esl_ctx* c) {
+  c->parts_fresh = false;
   const DevGraph& g = c->g;
   const int N = g.n_objs, F = g.n_cams;
   const bool an = c->lm.p.jacobian_mode == ESL_JAC_ANALYTIC;
@@ -813,6 +824,7 @@ int slam_build_reduced(esl_ctx* c, double lambda, bool full_sum, void** dev_ptr,
 }
 
 int slam_try_step(esl_ctx* c, double lambda) {
+  c->parts_fresh = false;
   const DevGraph& g = c->g;
   const int N = g.n_objs, F = g.n_cams;
   int solver = slam_pick_solver(c);
@@ -852,29 +864,34 @@ int slam_try_step(esl_ctx* c, double lambda) {
                          c->objs_trial, c->obj_part);
     hipLaunchKernelGGL(k_slam_cam_update, dim3((F + 127) / 128), dim3(128), 0, c->stream, g, lambda, c->cams, c->xc, c->bc,
                        c->cams_trial, c->cam_part);
-    if (N > 0) hipLaunchKernelGGL(k_slam_chi2_obj, grid, block, 0, c->stream, g, c->cams_trial, c->objs_trial, c->obj_part);
-    if (g.n_odom)
-      hipLaunchKernelGGL(k_slam_chi2_odom, dim3((g.n_odom + 127) / 128), dim3(128), 0, c->stream, g, c->cams_trial, c->od_part);
+    const int nb_co = (N + kWavesPerBlock - 1) / kWavesPerBlock, nb_od = (g.n_odom + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
+    if (nb_co + nb_od > 0)
+      hipLaunchKernelGGL(k_slam_chi2_all, dim3((unsigned)(nb_co + nb_od)), dim3(kWave * kWavesPerBlock), 0, c->stream, g, nb_co, c->cams_trial, c->objs_trial,
+                         c->obj_part, c->od_part);
   }
   ESL_HIP_TRY(hipGetLastError());
   }
+  const bool info_by_collective = c->comm && c->comm_replicated && c->comm_ranks > 1;
   {
     ProfScope ps2(c, 4);
-    if ((rc = reduce_all(c))) return rc;
+    if ((rc = reduce_all(c, info_by_collective ? nullptr : c->chol_info))) return rc;
   }
-  if (c->comm && c->comm_replicated && c->comm_ranks > 1) {
+  if (info_by_collective) {
     // replicated-graph run: no LM scalars are exchanged, so the pivot check of the panels' OWNERS has to reach every rank here
     // (one 8-byte all-reduce per trial) -- otherwise the owner would reject the step on its flag and the others on the NaNs that
     // came with the broadcast panel, two different exits of the trial loop
     hipLaunchKernelGGL(k_info_to_double, dim3(1), dim3(1), 0, c->stream, c->chol_info, c->dev_scal + 6);
     if ((rc = comm_allreduce_sum(c, c->dev_scal + 6, 1))) return rc;
     hipLaunchKernelGGL(k_double_to_info, dim3(1), dim3(1), 0, c->stream, c->dev_scal + 6, c->chol_info);
+    hipLaunchKernelGGL(k_slam_fold_info, dim3(1), dim3(1), 0, c->stream, (const int*)c->chol_info, c->dev_part);
     ESL_HIP_TRY(hipGetLastError());
   }
-  // fold the Cholesky pivot check into the "ok" partial
-  int info = 0;
-  ESL_HIP_TRY(hipMemcpyAsync(&info, c->chol_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  // the trial's four scalars and the solver's flag in ONE copy and ONE wait (the flag is already folded into the "ok" partial on the
+  // device); esl_lm_try_step's read_parts finds them in the pinned block (parts_fresh)
+  ESL_HIP_TRY(hipMemcpyAsync(c->host_part, c->dev_part, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   ESL_HIP_TRY(hipStreamSynchronize(c->stream));
+  const int info = (int)c->host_part[4];
+  c->parts_fresh = true;
   if (info & 2) {
     // A spin of the one-launch forms ran into its wall-clock bound (3 s): the kernel was preempted or time-sliced for that long
     // (two processes on one GPU, a debugger, a profiler) or a producer never became resident.  The factorisation itself is not
@@ -887,12 +904,8 @@ int slam_try_step(esl_ctx* c, double lambda) {
     rt.sw_persistent = 0; rt.sw_backsub = 1; rt.fallbacks += 1;
     fprintf(stderr, "[libesl_hip] a device-side hand-off of the dense solver timed out; this context now uses the launch-per-step form\n");
     ESL_HIP_TRY(hipMemsetAsync(c->chol_info, 0, sizeof(int), c->stream));
+    c->parts_fresh = false;
     return slam_try_step(c, lambda);
-  }
-  if (info) {
-    const double zero = 0.0;
-    ESL_HIP_TRY(hipMemcpyAsync(c->dev_part + 3, &zero, sizeof(double), hipMemcpyHostToDevice, c->stream));
-    ESL_HIP_TRY(hipStreamSynchronize(c->stream));
   }
   return ESL_OK;
 }
