@@ -43,7 +43,9 @@ extern "C" {
                              * 3: esl_linear_solver gains ESL_SOLVER_REDUCED_CAMERA / ESL_SOLVER_REDUCED_ELLIPSOID, esl_lm_solver_used,
                              *    esl_lm_solver_stats, esl_comm_set_replicated, ESL_PROF_KINDS 9
                              * 4: ESL_PROF_KINDS 10 (class 9: the dense factorisation alone), esl_ctx_trim, esl_comm_set_replicated refuses a
-                             *    mode change under a resident graph, esl_graph_append accepts SLAM-mode graphs (free cameras + odometry) */
+                             *    mode change under a resident graph, esl_graph_append accepts SLAM-mode graphs (free cameras + odometry)
+                             * 5: esl_lm_params::e3d_half_turn (1 = the yaw-hypothesis minimum exactly as Ellipsoid.cpp:92-117 writes it),
+                             *    esl_plane_params::max_curvature (PCL's maximum_curvature_ model test; min_inliers is a strict >) */
 #define ESL_MAX_TRACE 32
 
 typedef enum {
