@@ -691,17 +691,28 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
   // cost more than the whole K loop of the tile.
   const bool full = (iw + SM <= rows) && (jw + SN <= ncols) && (jw + SN - 1 <= iw);
   if (full) {
+    // Round 6: the loads of column group nj + 1 are issued BEFORE the stores of group nj (two register sets).  Written as "load 16,
+    // store 16" per group the compiler keeps every group's loads behind the previous group's stores (same array), i.e. NJ exposed
+    // round trips to a tile another CU wrote last -- ~2 us each, in a task that is visited 216 times per worker at n = 18,000.
+    // Launch-path kernels only (n = 32,768: 215.9 -> 213.6 ms): the persistent kernel owns all 256 registers of its two waves per SIMD
+    // and the second register set went to scratch there (128 -> 224 B, task bodies 33.6 -> 34.3 ms) -- it keeps the one-set form.
+    constexpr int NSET = WT ? 1 : 2;
+    double cv[NSET][MI][4];
+    auto load_group = [&](int nj, double (&dst)[MI][4]) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[mi][g] = assign ? 0.0 : M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda];
+    };
+    if constexpr (NSET == 2) load_group(0, cv[0]);
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
-      double cv[MI][4];
+      if constexpr (NSET == 2) { if (nj + 1 < NJ) load_group(nj + 1, cv[(nj + 1) & 1]); }
+      else load_group(nj, cv[0]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cv[mi][g] = assign ? 0.0 : M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) chol_store<WT>(&M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda], cv[mi][g] - acc[nj][mi][g]);
+        for (int g = 0; g < 4; ++g) chol_store<WT>(&M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda], cv[nj & (NSET - 1)][mi][g] - acc[nj][mi][g]);
     }
     return;
   }
