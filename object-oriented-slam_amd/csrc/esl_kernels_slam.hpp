@@ -78,6 +78,66 @@ __device__ __forceinline__ void store_cam_terms(const double* Jc, const double* 
   }
 }
 
+// The 3-D edge's Jacobians are structured: wrt the ellipsoid [[Jp 6x6, 0], [0, I3]], wrt the camera [[Jcp = Jp Ad 6x6], [0 3x6]] (the scale
+// rows s - s_k do not see the camera).  W = Jc^T w Jo is therefore [Jcp^T w Jp | 0 (6 x 3)], A and g sum over the six pose rows only: the
+// same values as store_cam_terms<9> on the padded 9 x 9 / 9 x 6 arrays (the dropped terms are exact zeros), from 36 + 36 + 9 live doubles
+// instead of 81 + 54 + 9 (round 6: the padded form kept both arrays in scratch, 1,104 B per lane).
+__device__ __forceinline__ void store_cam_terms_e3d(const double* Jcp, const double* Jp, const double* r, double w,
+                                                    double* __restrict__ W, double* __restrict__ A, long EU, long u) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      double s = 0;
+      if (b < 6) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += Jcp[k * 6 + a] * w * Jp[k * 6 + b];
+      }
+      W[(long)(a * 9 + b) * EU + u] = s;
+    }
+  int p = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = a; c < 6; ++c) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += Jcp[k * 6 + a] * w * Jcp[k * 6 + c];
+      A[u * kARec + (p++)] = s;
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += Jcp[k * 6 + a] * (w * r[k]);
+    A[u * kARec + 21 + a] = -s;
+  }
+}
+// 64-lane form of reduce_group_e3d_lds (one chunk per wave): the group's 18 entries from the structured Jacobian, then the LDS transpose
+template <int G>
+__device__ __forceinline__ void reduce_group_lds_e3d64(const double* Jp, const double* r, double w, int lane, double* __restrict__ out,
+                                                       double* __restrict__ tr) {
+  double v[18];
+  fill_group_e3d<G>(v, Jp, r, w, std::make_integer_sequence<int, 18>{});
+#pragma unroll
+  for (int k = 0; k < 18; ++k) tr[k * kTrStride + lane] = v[k];
+  __builtin_amdgcn_wave_barrier();
+  const int k = lane % 18, p = lane / 18;
+  double s0 = 0, s1 = 0;
+  if (lane < 54) {
+    const double* row = tr + k * kTrStride + p * 22;
+    const int n = (p == 2) ? 20 : 22;
+#pragma unroll
+    for (int i = 0; i < 22; i += 2) {
+      if (i < n) { s0 += row[i]; s1 += row[i + 1]; }
+    }
+  }
+  double s = s0 + s1;
+  const double sa = __shfl_down(s, 18, 64), sb = __shfl_down(s, 36, 64);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 18) out[G * 18 + lane] = (s + sa) + sb;
+}
+
 // One wave per CHUNK (<= 64 bbox edges or <= 32 3-D edges of one ellipsoid: the decomposition of mapping mode, built at upload),
 // lane = edge: residual, Jacobians wrt ellipsoid AND camera, W / A of the edge to HBM, the 45 + 9 entries of the ellipsoid's
 // J^T w J / -J^T w r summed over the wave through the LDS transpose of esl_kernels_chunk.hpp into a chunk partial (row of
@@ -113,7 +173,8 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_slam_linearize_chunks
       w = g.bb_w[i];
       double Jc[24];
       if (JAC == ESL_JAC_ANALYTIC) {
-        jac_box_edge(g.bbox_mode, T, e, g.K, meas, r, Jo, cam_free ? Jc : nullptr);
+        // (Jc always, and through the entry without null tests: a select or a comparison of an array's address keeps it in scratch)
+        jac_box_edge_both(g.bbox_mode, T, e, g.K, meas, r, Jo, Jc);
       } else {
         res_box_edge(g.bbox_mode, T, e, g.K, meas, r);
         numeric_jac_obj(e, delta, 4, Jo, [&](const Ell& ep, double* o4) { res_box_edge(g.bbox_mode, T, ep, g.K, meas, o4); });
@@ -125,6 +186,43 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_slam_linearize_chunks
     reduce_group_lds<4, 0>(Jo, r, w, lane, out, tr);
     reduce_group_lds<4, 1>(Jo, r, w, lane, out, tr);
     reduce_group_lds<4, 2>(Jo, r, w, lane, out, tr);
+  } else if (JAC == ESL_JAC_ANALYTIC) {   // structured Jacobians (see store_cam_terms_e3d)
+    double r[9], Jp[36], w = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Jp[k] = 0;
+    if (in) {
+      const int ci = g.e3_cam[i];
+      const SE3 T = se3_load(cams + 7 * ci);
+      const bool cam_free = g.cam_slot[ci] >= 0;
+      const Ell m = ell_load(g.e3_meas + 10 * i);
+      w = g.e3_w[i];
+      E3dHyp h;
+      res_e3d(T, e, m, g.yt, r, &h);
+      dlog_right_R(h.R, h.t, h.a, Jp);
+      double cc = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cc += r[k] * r[k];
+      chi = w * cc;
+      if (cam_free) {   // exp(d) Tcw == right perturbation of E by Ad((Tcw T_est)^-1) d  (jac_e3d)
+        double Ad[36], Jcp[36];
+        se3_adj(se3_inv(se3_mul(T, e.pose)), Ad);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sacc += Jp[a * 6 + k] * Ad[k * 6 + b];
+            Jcp[a * 6 + b] = sacc;
+          }
+        store_cam_terms_e3d(Jcp, Jp, r, w, W, A, EU, (long)g.n_bbox + i);
+      }
+    }
+    reduce_group_lds_e3d64<0>(Jp, r, w, lane, out, tr);
+    reduce_group_lds_e3d64<1>(Jp, r, w, lane, out, tr);
+    reduce_group_lds_e3d64<2>(Jp, r, w, lane, out, tr);
   } else {
     double r[9], Jo[81], w = 0;
 #pragma unroll

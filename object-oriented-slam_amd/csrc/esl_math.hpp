@@ -491,6 +491,12 @@ ESL_HD void jac_bbox(const SE3& Tcw, const Ell& e, const double K[4], const doub
   else if (Jc) jac_bbox_t<false, true>(Tcw, e, K, meas, r, nullptr, Jc);
   else res_bbox(Tcw, e, K, meas, r);
 }
+// both Jacobians, no null tests on the arrays (`if (Jo && Jc)` on two private arrays is not folded by the compiler -- null is a valid
+// private address -- and an array whose address is compared stays in scratch memory: 496 B per lane in k_slam_linearize_chunks, round 6)
+ESL_HD void jac_box_edge_both(int mode, const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4], double* Jo, double* Jc) {
+  if (!mode) jac_bbox_t<true, true>(Tcw, e, K, meas, r, Jo, Jc);
+  else jac_tangency_t<true, true>(Tcw, e, K, meas, r, Jo, Jc);
+}
 ESL_HD void jac_box_edge(int mode, const SE3& Tcw, const Ell& e, const double K[4], const double meas[4], double r[4], double* Jo, double* Jc) {
   if (!mode) { jac_bbox(Tcw, e, K, meas, r, Jo, Jc); return; }
   if (Jo && Jc) jac_tangency_t<true, true>(Tcw, e, K, meas, r, Jo, Jc);
