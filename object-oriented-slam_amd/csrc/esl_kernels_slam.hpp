@@ -43,6 +43,27 @@ __device__ __forceinline__ void numeric_jac_cam(const SE3& T, double delta, int 
   }
 }
 
+// the same for a 6-row residual with ONE loop body (six trips, the column placed by a select chain): the odometry edge's two
+// Jacobians cost 24 fully inlined evaluations and 2,612 B of scratch per lane in the unrolled form (round 6)
+template <class F>
+__device__ __forceinline__ void numeric_jac_cam6_loop(const SE3& T, double delta, double* J, F&& eval) {
+  const double scalar = 1.0 / (2 * delta);
+  for (int d = 0; d < 6; ++d) {   // not unrolled
+    double u[6], rp[6], rm[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) u[q] = (q == d) ? delta : 0.0;
+    eval(cam_oplus(T, u), rp);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) u[q] = (q == d) ? -delta : 0.0;
+    eval(cam_oplus(T, u), rm);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) if (q == d) J[k * 6 + q] = scalar * (rp[k] - rm[k]);
+    }
+  }
+}
+
 // per-edge camera-side products: W = Jc^T w Jo written SoA (index k * EU + u); the camera terms A = Jc^T w Jc (21 packed) and
 // g = -Jc^T w r (6) as a per-edge record ([u][27]: the camera gather reads a record as one coalesced row, lane = entry); Y and the
 // pull kernel's copy of W are per-edge records ([u][54])
@@ -165,6 +186,17 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_slam_linearize_chunks
     double r[4] = {0, 0, 0, 0}, Jo[36], w = 0;
 #pragma unroll
     for (int k = 0; k < 36; ++k) Jo[k] = 0;
+    if (JAC == ESL_JAC_NUMERIC) {
+      // as the mapping-mode kernel (esl_kernels_chunk.hpp): the 18 states ell_oplus(e, +-delta e_d) are the same for every edge of the
+      // chunk -- 18 lanes compute one each into the wave's LDS tile
+      if (lane < 18) {
+        double u[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) u[q] = (q == (lane >> 1)) ? ((lane & 1) ? -delta : delta) : 0.0;
+        ell_store(ell_oplus(e, u), tr + 10 * lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     if (in && g.bb_valid[i]) {
       const int ci = g.bb_cam[i];
       const SE3 T = se3_load(cams + 7 * ci);
@@ -176,13 +208,42 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_slam_linearize_chunks
         // (Jc always, and through the entry without null tests: a select or a comparison of an array's address keeps it in scratch)
         jac_box_edge_both(g.bbox_mode, T, e, g.K, meas, r, Jo, Jc);
       } else {
+        // one loop body per Jacobian, not 18 + 12 inlined evaluations (round 6); same perturbed states, same differences
         res_box_edge(g.bbox_mode, T, e, g.K, meas, r);
-        numeric_jac_obj(e, delta, 4, Jo, [&](const Ell& ep, double* o4) { res_box_edge(g.bbox_mode, T, ep, g.K, meas, o4); });
-        if (cam_free) numeric_jac_cam(T, delta, 4, Jc, [&](const SE3& Tp, double* o4) { res_box_edge(g.bbox_mode, Tp, e, g.K, meas, o4); });
+        const double scalar = 1.0 / (2 * delta);
+        for (int d = 0; d < 9; ++d) {   // not unrolled
+          double rp[4], rm[4];
+          res_box_edge(g.bbox_mode, T, ell_load(tr + 20 * d), g.K, meas, rp);
+          res_box_edge(g.bbox_mode, T, ell_load(tr + 20 * d + 10), g.K, meas, rm);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) if (q == d) Jo[k * 9 + q] = scalar * (rp[k] - rm[k]);
+          }
+        }
+        if (cam_free) {
+#pragma unroll
+          for (int k = 0; k < 24; ++k) Jc[k] = 0;
+          for (int d = 0; d < 6; ++d) {   // not unrolled
+            double u[6], rp[4], rm[4];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) u[q] = (q == d) ? delta : 0.0;
+            res_box_edge(g.bbox_mode, cam_oplus(T, u), e, g.K, meas, rp);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) u[q] = (q == d) ? -delta : 0.0;
+            res_box_edge(g.bbox_mode, cam_oplus(T, u), e, g.K, meas, rm);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) if (q == d) Jc[k * 6 + q] = scalar * (rp[k] - rm[k]);
+            }
+          }
+        }
       }
       chi = w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
       if (cam_free) store_cam_terms<4>(Jc, Jo, r, w, W, A, EU, (long)i);
     }
+    if (JAC == ESL_JAC_NUMERIC) __builtin_amdgcn_wave_barrier();   // the perturbed states have been read; the tile is reused
     reduce_group_lds<4, 0>(Jo, r, w, lane, out, tr);
     reduce_group_lds<4, 1>(Jo, r, w, lane, out, tr);
     reduce_group_lds<4, 2>(Jo, r, w, lane, out, tr);
@@ -224,34 +285,67 @@ static __global__ __launch_bounds__(64 * kLinWaves) void k_slam_linearize_chunks
     reduce_group_lds_e3d64<1>(Jp, r, w, lane, out, tr);
     reduce_group_lds_e3d64<2>(Jp, r, w, lane, out, tr);
   } else {
-    double r[9], Jo[81], w = 0;
+    // g2o's central differences, in the structured form of the analytic branch and of the mapping-mode kernel (esl_kernels_chunk.hpp):
+    // the six pose columns of the ellipsoid's Jacobian from E_0 exp(+-delta e_d) (the ellipsoid is perturbed on the right, so E_0 is
+    // formed once), its scale block exactly the identity, the camera's six columns from exp(+-delta e_d) Tcw; both loops NOT
+    // unrolled (one body, six trips; the column is placed by a select chain).  Round 6: the 30 fully inlined evaluations on padded
+    // 9 x 9 / 9 x 6 arrays cost 6,596 B of scratch per lane and 0.40 ms per linearisation at C3 (analytic: 0.06).
+    double r[9], Jp[36], w = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) r[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 81; ++k) Jo[k] = 0;
+    for (int k = 0; k < 36; ++k) Jp[k] = 0;
     if (in) {
       const int ci = g.e3_cam[i];
       const SE3 T = se3_load(cams + 7 * ci);
       const bool cam_free = g.cam_slot[ci] >= 0;
       const Ell m = ell_load(g.e3_meas + 10 * i);
       w = g.e3_w[i];
-      double Jc[54];
-      if (JAC == ESL_JAC_ANALYTIC) {
-        jac_e3d(T, e, m, g.yt, r, Jo, cam_free ? Jc : nullptr);
-      } else {
-        res_e3d(T, e, m, g.yt, r);
-        numeric_jac_obj(e, delta, 9, Jo, [&](const Ell& ep, double* o9) { res_e3d(T, ep, m, g.yt, o9); });
-        if (cam_free) numeric_jac_cam(T, delta, 9, Jc, [&](const SE3& Tp, double* o9) { res_e3d(Tp, e, m, g.yt, o9); });
+      const SE3 E0 = e3d_E0(T, e, m);
+      res_e3d_from_E0(E0, e.s, m.s, g.yt, r);
+      const double scalar = 1.0 / (2 * delta);
+      for (int d = 0; d < 6; ++d) {   // not unrolled
+        double u[6], rp[9], rm[9];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) u[q] = (q == d) ? delta : 0.0;
+        res_e3d_from_E0(se3_mul(E0, se3_exp(u)), e.s, m.s, g.yt, rp);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) u[q] = (q == d) ? -delta : 0.0;
+        res_e3d_from_E0(se3_mul(E0, se3_exp(u)), e.s, m.s, g.yt, rm);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) if (q == d) Jp[k * 6 + q] = scalar * (rp[k] - rm[k]);
+        }
       }
       double cc = 0;
 #pragma unroll
       for (int k = 0; k < 9; ++k) cc += r[k] * r[k];
       chi = w * cc;
-      if (cam_free) store_cam_terms<9>(Jc, Jo, r, w, W, A, EU, (long)g.n_bbox + i);
+      if (cam_free) {
+        double Jcp[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) Jcp[k] = 0;
+        for (int d = 0; d < 6; ++d) {   // not unrolled
+          double u[6], rp[9], rm[9];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) u[q] = (q == d) ? delta : 0.0;
+          res_e3d_from_E0(e3d_E0(cam_oplus(T, u), e, m), e.s, m.s, g.yt, rp);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) u[q] = (q == d) ? -delta : 0.0;
+          res_e3d_from_E0(e3d_E0(cam_oplus(T, u), e, m), e.s, m.s, g.yt, rm);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if (q == d) Jcp[k * 6 + q] = scalar * (rp[k] - rm[k]);
+          }
+        }
+        store_cam_terms_e3d(Jcp, Jp, r, w, W, A, EU, (long)g.n_bbox + i);
+      }
     }
-    reduce_group_lds<9, 0>(Jo, r, w, lane, out, tr);
-    reduce_group_lds<9, 1>(Jo, r, w, lane, out, tr);
-    reduce_group_lds<9, 2>(Jo, r, w, lane, out, tr);
+    reduce_group_lds_e3d64<0>(Jp, r, w, lane, out, tr);
+    reduce_group_lds_e3d64<1>(Jp, r, w, lane, out, tr);
+    reduce_group_lds_e3d64<2>(Jp, r, w, lane, out, tr);
   }
   chi = wave_sum(chi);
   if (lane == 0) out[54] = chi;
@@ -326,31 +420,41 @@ static __global__ __launch_bounds__(128) void k_slam_odom(DevGraph g, const doub
     jac_odom(Ti, Tj, Z, r, Ji, Jj);
   } else {
     res_odom(Ti, Tj, Z, r);
-    numeric_jac_cam(Ti, delta, 6, Ji, [&](const SE3& Tp, double* o6) { res_odom(Tp, Tj, Z, o6); });
-    numeric_jac_cam(Tj, delta, 6, Jj, [&](const SE3& Tp, double* o6) { res_odom(Ti, Tp, Z, o6); });
+#pragma unroll
+    for (int k = 0; k < 36; ++k) { Ji[k] = 0; Jj[k] = 0; }
+    numeric_jac_cam6_loop(Ti, delta, Ji, [&](const SE3& Tp, double* o6) { res_odom(Tp, Tj, Z, o6); });
+    numeric_jac_cam6_loop(Tj, delta, Jj, [&](const SE3& Tp, double* o6) { res_odom(Ti, Tp, Z, o6); });
   }
   double w[6], chi = 0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) { w[k] = g.od_info[6 * e + k]; chi += r[k] * w[k] * r[k]; }
   od_chi[e] = chi;
   int p = 0;
+#pragma unroll
   for (int a = 0; a < 6; ++a)
+#pragma unroll
     for (int c = a; c < 6; ++c) {
       double s = 0, t = 0;
+#pragma unroll
       for (int k = 0; k < 6; ++k) { s += Ji[k * 6 + a] * w[k] * Ji[k * 6 + c]; t += Jj[k * 6 + a] * w[k] * Jj[k * 6 + c]; }
       out[p] = fi ? s : 0.0;
       out[27 + p] = fj ? t : 0.0;
       ++p;
     }
+#pragma unroll
   for (int a = 0; a < 6; ++a) {
     double s = 0, t = 0;
+#pragma unroll
     for (int k = 0; k < 6; ++k) { s += Ji[k * 6 + a] * w[k] * r[k]; t += Jj[k * 6 + a] * w[k] * r[k]; }
     out[21 + a] = fi ? -s : 0.0;
     out[48 + a] = fj ? -t : 0.0;
   }
+#pragma unroll
   for (int a = 0; a < 6; ++a)
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
       double s = 0;
+#pragma unroll
       for (int k = 0; k < 6; ++k) s += Ji[k * 6 + a] * w[k] * Jj[k * 6 + c];
       out[54 + a * 6 + c] = (fi && fj) ? s : 0.0;
     }
