@@ -169,9 +169,11 @@ static __global__ __launch_bounds__(64) void k_cf_chain(int nf_all, const double
 
 // stride > 0 (nested dissection): slots with i % stride == stride - 1 are separators (not touched here), the first camera of a
 // segment has no predecessor (M = 0) and the last none to hand its x to (N = 0; its G couples it to the separator instead)
+// scat (round 6; the separator chain's call): L_ii^-1 of chain position i ALSO goes to scat[(i scat_stride + scat_stride - 1) * 36 ..], the
+// per-slot array the other kernels read (was a launch of its own, k_cf_sep_scatter)
 static __global__ __launch_bounds__(64) void k_cf_factor_blocks(int nf, const double* __restrict__ Lfac, const double* __restrict__ Gfac,
                                                                 double* __restrict__ Linv, double* __restrict__ Mm, double* __restrict__ Nn,
-                                                                int stride) {
+                                                                int stride, double* __restrict__ scat = nullptr, int scat_stride = 0) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= nf) return;
   const int pos = stride > 0 ? i % stride : i;
@@ -193,6 +195,10 @@ static __global__ __launch_bounds__(64) void k_cf_factor_blocks(int nf, const do
     }
 #pragma unroll
   for (int k = 0; k < 36; ++k) Linv[(size_t)i * 36 + k] = Li[k];
+  if (scat) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) scat[(size_t)(i * scat_stride + scat_stride - 1) * 36 + k] = Li[k];
+  }
   // M_i = Li Lo, Lo = L_{i,i-1} = G_{i-1}^T (zero for the first camera)
   double Lo[36];
 #pragma unroll
@@ -225,12 +231,11 @@ static __global__ __launch_bounds__(64) void k_cf_factor_blocks(int nf, const do
 // thread = (list entry k, ellipsoid column b) or, behind those, one per free camera.  Records in LIST order ([k][b][a], a = camera
 // row): the forward substitution finds the record of entry k of column b without going through the edge id.  bbox edges dropped by
 // the NaN / visibility pre-check get V = 0 (the lists still hold them).
-static __global__ __launch_bounds__(256) void k_cf_edge_scale(DevGraph g, int n_list, const int* __restrict__ oe_u, const int* __restrict__ oe_slot,
-                                                              const double* __restrict__ W, const double* __restrict__ Linv,
-                                                              const double* __restrict__ bc, double* __restrict__ V,
-                                                              double* __restrict__ vy) {
+__device__ __forceinline__ void cf_edge_scale_one(const DevGraph& g, int n_list, const int* __restrict__ oe_u, const int* __restrict__ oe_slot,
+                                                  const double* __restrict__ W, const double* __restrict__ Linv,
+                                                  const double* __restrict__ bc, double* __restrict__ V,
+                                                  double* __restrict__ vy, long t) {
   const long EU = (long)g.n_bbox + g.n_e3d;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t < (long)n_list * 9) {
     const long k = t / 9;
     const int b = (int)(t - k * 9);
@@ -263,6 +268,12 @@ static __global__ __launch_bounds__(256) void k_cf_edge_scale(DevGraph g, int n_
       vy[(size_t)s * 6 + a] = v;
     }
   }
+}
+static __global__ __launch_bounds__(256) void k_cf_edge_scale(DevGraph g, int n_list, const int* __restrict__ oe_u, const int* __restrict__ oe_slot,
+                                                              const double* __restrict__ W, const double* __restrict__ Linv,
+                                                              const double* __restrict__ bc, double* __restrict__ V,
+                                                              double* __restrict__ vy) {
+  cf_edge_scale_one(g, n_list, oe_u, oe_slot, W, Linv, bc, V, vy, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- X = L^-1 [W | b_c]: one lane per column (9 per ellipsoid + the right-hand side), sequential over the cameras -----------
@@ -529,13 +540,6 @@ static __global__ __launch_bounds__(256) void k_cf_sep_assemble(int nf, int stri
   }
   Bs[t] = w;
 }
-// the separators' L_ii^-1 into the per-slot array the other kernels read
-static __global__ __launch_bounds__(256) void k_cf_sep_scatter(int stride, int n_sep, const double* __restrict__ LiS, double* __restrict__ Linv) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int k = t / 36;
-  if (k >= n_sep) return;
-  Linv[(size_t)(k * stride + stride - 1) * 36 + (t - k * 36)] = LiS[t];
-}
 
 // right-hand sides of the separator rows of X: R(k) <- V_s - LiS_k (G_l^T X_l + acc), acc = what the forward kernel left in R(k);
 // grid (column groups, separators), lane = column
@@ -621,29 +625,10 @@ static __global__ __launch_bounds__(256) void k_cf_back_prep(int nf, int stride,
   z[t] -= v;
 }
 
-// ---- T <- D (block diagonal, lower triangle) and row n_o <- b_o^T; the rest of T was cleared by a memset -----------------------
-static __global__ __launch_bounds__(256) void k_cf_T_init(int n_objs, const double* __restrict__ Hoo, const double* __restrict__ bo,
-                                                          double lambda, double* __restrict__ T, long ldt, long n_o) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const long o = t / 90;
-  if (o >= n_objs) return;
-  const int e = (int)(t - o * 90);
-  if (e < 81) {
-    const int r = e / 9, c = e - 9 * r;
-    if (r < c) return;
-    // packed upper triangle of the symmetric block: (c, r) with c <= r at c * 9 - c (c - 1) / 2 + (r - c)
-    const double v = Hoo[(size_t)o * 45 + c * 9 - (c * (c - 1)) / 2 + (r - c)] + ((r == c) ? lambda : 0.0);
-    T[(9 * o + r) + (9 * o + c) * ldt] = v;
-  } else {
-    const int c = e - 81;
-    T[n_o + (9 * o + c) * ldt] = bo[(size_t)o * 9 + c];
-  }
-}
-
+// ---- T <- D (block diagonal, lower triangle), row n_o <- b_o^T, zeros elsewhere ------------------------------------------------------------
 // the whole of T in one launch (X dense: no memset in front): thread = entry (row, column) of the (n_o + 1) x n_o array
-static __global__ __launch_bounds__(256) void k_cf_T_init_full(int n_objs, const double* __restrict__ Hoo, const double* __restrict__ bo,
-                                                               double lambda, double* __restrict__ T, long ldt, long n_o) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void cf_T_init_full_one(const double* __restrict__ Hoo, const double* __restrict__ bo, double lambda,
+                                                   double* __restrict__ T, long ldt, long n_o, long t) {
   const long col = t / ldt, row = t - col * ldt;
   if (col >= n_o) return;
   double v = 0;
@@ -655,6 +640,15 @@ static __global__ __launch_bounds__(256) void k_cf_T_init_full(int n_objs, const
     v = Hoo[(size_t)o * 45 + c * 9 - (c * (c - 1)) / 2 + (r - c)] + ((r == c) ? lambda : 0.0);
   }
   T[t] = v;
+}
+// V = Li W, vy = Li b_c AND the whole of T in one launch (X dense): blocks [0, nb_es) are k_cf_edge_scale's, the rest write T
+static __global__ __launch_bounds__(256) void k_cf_edge_scale_T(DevGraph g, int nb_es, int n_list, const int* __restrict__ oe_u, const int* __restrict__ oe_slot,
+                                                                const double* __restrict__ W, const double* __restrict__ Linv,
+                                                                const double* __restrict__ bc, double* __restrict__ V, double* __restrict__ vy,
+                                                                const double* __restrict__ Hoo, const double* __restrict__ bo, double lambda,
+                                                                double* __restrict__ T, long ldt, long n_o) {
+  if ((int)blockIdx.x < nb_es) cf_edge_scale_one(g, n_list, oe_u, oe_slot, W, Linv, bc, V, vy, (long)blockIdx.x * 256 + threadIdx.x);
+  else cf_T_init_full_one(Hoo, bo, lambda, T, ldt, n_o, (long)(blockIdx.x - nb_es) * 256 + threadIdx.x);
 }
 
 // ---- z = y - X x_o: one workgroup per row of X (a contiguous row of Xt) -----------------------------------------------------------

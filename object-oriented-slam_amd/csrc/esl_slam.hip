@@ -562,11 +562,21 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     const bool nd = st > 0 && ns > 0;
     const unsigned cg = (unsigned)((n_o + 1 + 63) / 64);
     const long nt = (long)c->cf_n_list * 9 + nf;
+    // V = Li W, vy = Li b_c; X dense: the same launch writes the whole of T (D's lower blocks, b_o's row, zeros) -- nothing reads T before
+    // the rank-K update further down
+    auto launch_edge_scale = [&]() {
+      const int nb_es = (int)((nt + 255) / 256);
+      if (!c->cf_sparse)
+        hipLaunchKernelGGL(k_cf_edge_scale_T, dim3((unsigned)(nb_es + (int)((ldt * (long)n_o + 255) / 256))), dim3(256), 0, c->stream, g, nb_es, c->cf_n_list, c->cf_oe_u,
+                           c->cf_oe_slot, c->Wbb, c->cf_Linv, c->bc, c->cf_V, c->cf_vy, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
+      else
+        hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)nb_es), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb, c->cf_Linv, c->bc,
+                           c->cf_V, c->cf_vy);
+    };
     if (!nd) {
       hipLaunchKernelGGL(k_cf_chain, dim3(1), dim3(64), 0, c->stream, nf, c->Hcc, c->cf_B, lambda, c->cf_Lfac, c->cf_G, c->chol_info, nf, nf);
       hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, c->stream, nf, c->cf_Lfac, c->cf_G, c->cf_Linv, c->cf_M, c->cf_N, 0);
-      hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
-                         c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
+      launch_edge_scale();
       hipLaunchKernelGGL(k_cf_forward<0>, dim3(cg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V, c->cf_vy,
                          c->cf_M, c->cf_Xt, ldx, nf, nf, (const double*)nullptr, (double*)nullptr, 0, CfSegs{});
     } else {   // nested dissection (esl_cf.hpp): segments in parallel, then the separators' own short chain
@@ -576,10 +586,9 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
       hipLaunchKernelGGL(k_cf_sep_assemble, dim3((unsigned)((ns * 36 + 255) / 256)), dim3(256), 0, c->stream, nf, st, ns, c->Hcc, lambda, c->cf_G, c->cf_Zt,
                          c->cf_Hs, c->cf_Bs);
       hipLaunchKernelGGL(k_cf_chain, dim3(1), dim3(64), 0, c->stream, ns, c->cf_Hs, c->cf_Bs, 0.0, c->cf_LfacS, c->cf_GS, c->chol_info, ns, ns);
-      hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, c->stream, ns, c->cf_LfacS, c->cf_GS, c->cf_LiS, c->cf_MS, c->cf_NS, 0);
-      hipLaunchKernelGGL(k_cf_sep_scatter, dim3((unsigned)((ns * 36 + 255) / 256)), dim3(256), 0, c->stream, st, ns, c->cf_LiS, c->cf_Linv);
-      hipLaunchKernelGGL(k_cf_edge_scale, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream, g, c->cf_n_list, c->cf_oe_u, c->cf_oe_slot, c->Wbb,
-                         c->cf_Linv, c->bc, c->cf_V, c->cf_vy);
+      hipLaunchKernelGGL(k_cf_factor_blocks, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, c->stream, ns, c->cf_LfacS, c->cf_GS, c->cf_LiS, c->cf_MS, c->cf_NS, 0,
+                         c->cf_Linv, st);   // (+ the separators' L_ii^-1 into the per-slot array: was k_cf_sep_scatter)
+      launch_edge_scale();
       if (!c->cf_sparse) {
         hipLaunchKernelGGL(k_cf_forward<0>, dim3(cg, (unsigned)nseg), dim3(64), 0, c->stream, nf, n_o, c->cf_n_chunks, c->cf_oe_cst, c->cf_oe_slot, c->cf_V,
                            c->cf_vy, c->cf_M, c->cf_Xt, ldx, st, st - 1, (const double*)c->cf_Zt, c->cf_R, st, CfSegs{});
@@ -601,8 +610,7 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     // distributed factorisation below expects them)
     const int Wp = chol_outer_panels(n_o), n_outer = ((n_o + kNB - 1) / kNB + Wp - 1) / Wp;
     const bool dist = cf_dist(c);
-    if (!c->cf_sparse) {   // (one launch writes every entry: D's lower blocks, b_o's row, zeros)
-      hipLaunchKernelGGL(k_cf_T_init_full, dim3((unsigned)((ldt * (long)n_o + 255) / 256)), dim3(256), 0, c->stream, N, c->Hoo, c->bo, lambda, c->cf_T, ldt, (long)n_o);
+    if (!c->cf_sparse) {   // (T was written whole by the edge-scale launch)
     } else {   // T = D - (interior rows)^T (interior rows), block by block (every block on and below the diagonal is written)
       ProfScope pk(c, 8);
       if (c->cf_sp_form == 1)   // the segments' products (all of them on every rank: 3 % of a trial)
