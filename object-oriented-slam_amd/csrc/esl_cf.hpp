@@ -734,11 +734,6 @@ __device__ __forceinline__ void cf_obj_update_one(const DevGraph& g, double lamb
   ell_store(ell_oplus(e, x), objs_trial + 10 * o);
   part[o * 4 + 2] = scale;
 }
-static __global__ __launch_bounds__(256) void k_cf_obj_update(DevGraph g, double lambda, const double* __restrict__ objs,
-                                                              const double* __restrict__ bo, const double* __restrict__ xo,
-                                                              double* __restrict__ objs_trial, double* __restrict__ part) {
-  cf_obj_update_one(g, lambda, objs, bo, xo, objs_trial, part, blockIdx.x * 256 + threadIdx.x);
-}
 
 // ---- sparse interior rows of X (round 3) ---------------------------------------------------------------------------------------------
 // Column o of X = G^-1 W is zero over segment p unless a camera INSIDE p sees ellipsoid o (the recurrence X_j = V_j - M_j X_{j-1}

@@ -129,35 +129,4 @@ static __global__ void k_append_tables(AppendCopies cp) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cp.count[k]; i += gridDim.x * blockDim.x) cp.dst[k][i] = cp.src[k][i];
 }
 
-// ---- deterministic reduction of the per-vertex partials: out = {sum chi2, max maxdiag, sum scale, min ok}
-static __global__ __launch_bounds__(256) void k_reduce_parts(const double* __restrict__ part, int n, double* __restrict__ out,
-                                                      int accumulate) {
-  __shared__ double s0[256], s1[256], s2[256], s3[256];
-  double a = 0, b = 0, c = 0, d = 1;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    a += part[i * 4 + 0];
-    b = fmax(b, part[i * 4 + 1]);
-    c += part[i * 4 + 2];
-    d = fmin(d, part[i * 4 + 3]);
-  }
-  s0[threadIdx.x] = a; s1[threadIdx.x] = b; s2[threadIdx.x] = c; s3[threadIdx.x] = d;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      s0[threadIdx.x] += s0[threadIdx.x + s];
-      s1[threadIdx.x] = fmax(s1[threadIdx.x], s1[threadIdx.x + s]);
-      s2[threadIdx.x] += s2[threadIdx.x + s];
-      s3[threadIdx.x] = fmin(s3[threadIdx.x], s3[threadIdx.x + s]);
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    if (accumulate) {
-      out[0] += s0[0]; out[1] = fmax(out[1], s1[0]); out[2] += s2[0]; out[3] = fmin(out[3], s3[0]);
-    } else {
-      out[0] = s0[0]; out[1] = s1[0]; out[2] = s2[0]; out[3] = s3[0];
-    }
-  }
-}
-
 }  // namespace esl

@@ -21,7 +21,7 @@
 //   dense Cholesky     esl_chol.hpp (FP64 MFMA)
 //   k_slam_backsub     one wave per ellipsoid: x_o, retraction, trial states
 //   k_slam_cam_update  one lane per camera: retraction exp(x_c) * Tcw
-//   chi2 of the trial  k_slam_chi2_obj (wave per ellipsoid) + k_slam_chi2_odom
+//   chi2 of the trial  k_slam_chi2_all (a wave per ellipsoid + a lane per odometry edge, one launch)
 #pragma once
 #include "esl_kernels_chunk.hpp"
 
@@ -800,46 +800,7 @@ static __global__ void k_slam_cam_update(DevGraph g, double lambda, const double
   slam_cam_update_one(g, lambda, cams, xc, bc, cams_trial, cam_part, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// chi2 of the trial states: ellipsoid-attached edges (wave per ellipsoid) ...
-static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_chi2_obj(DevGraph g, const double* __restrict__ cams,
-                                                                        const double* __restrict__ objs,
-                                                                        double* __restrict__ part) {
-  const int lane = threadIdx.x & 63;
-  const int o = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (o >= g.n_objs) return;
-  const Ell e = ell_load(objs + 10 * o);
-  const double chi = obj_chi2(g, cams, e, o, lane);
-  if (lane == 0) part[o * 4 + 0] = chi;
-}
-// ... and odometry edges
-static __global__ void k_slam_chi2_odom(DevGraph g, const double* __restrict__ cams, double* __restrict__ od_chi) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= g.n_odom) return;
-  const int vi = g.od_i[e], vj = g.od_j[e];
-  if (g.cam_slot[vi] < 0 && g.cam_slot[vj] < 0) { od_chi[e] = 0; return; }
-  double r[6];
-  res_odom(se3_load(cams + 7 * vi), se3_load(cams + 7 * vj), se3_load(g.od_meas + 7 * e), r);
-  double chi = 0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) chi += r[k] * g.od_info[6 * e + k] * r[k];
-  od_chi[e] = chi;
-}
-
-// deterministic sum of a plain array into out[0] (accumulate)
-static __global__ __launch_bounds__(256) void k_sum_into(const double* __restrict__ v, int n, double* __restrict__ out) {
-  __shared__ double s[256];
-  double a = 0;
-  for (int i = threadIdx.x; i < n; i += 256) a += v[i];
-  s[threadIdx.x] = a;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] += s[0];
-}
-
-// ---- one launch for the trial's scalars (round 6): the two k_reduce_parts launches and k_sum_into of reduce_all, in the same order and
+// ---- one launch for the trial's scalars (round 6): the two 4-tuple reductions and the odometry sum reduce_all used to launch (rounds 3-5: k_reduce_parts x 2, k_sum_into), in the same order and
 // with the same trees (same bits), plus the fold of the dense solver's pivot flag into the "ok" partial -- at streaming sizes a
 // trial is ~30 dependent launches of a few microseconds each, and these were four of them and a host round trip.
 //   out[0..3] = {sum chi2, max maxdiag, sum scale, min ok} over the ellipsoids' and the cameras' partials, out[0] += sum of od_part
@@ -893,7 +854,7 @@ static __global__ void k_slam_fold_info(const int* __restrict__ info, double* __
   out[4] = (double)f;
 }
 
-// chi2 of the trial states in ONE launch: blocks [0, nb_obj) are k_slam_chi2_obj's (a wave per ellipsoid), the rest k_slam_chi2_odom's
+// chi2 of the trial states in ONE launch: blocks [0, nb_obj) take a wave per ellipsoid (its bbox, 3-D and gravity edges), the rest a lane per odometry edge
 static __global__ __launch_bounds__(kWave* kWavesPerBlock) void k_slam_chi2_all(DevGraph g, int nb_obj, const double* __restrict__ cams,
                                                                                 const double* __restrict__ objs, double* __restrict__ part,
                                                                                 double* __restrict__ od_chi) {
