@@ -68,6 +68,65 @@ __device__ __forceinline__ bool px_point(const PlaneArgs& a, int u, int v, float
   return d != 0;
 }
 
+// Round 6: the tile's points staged once.  The direct form below recomputes the point of every pixel of the (2R+1)^2 window four times
+// per centre pixel -- three IEEE double divisions each, ~1,500 divisions per output pixel: 0.35-0.41 ms per 640 x 480 image, all of it
+// the divider.  Here a workgroup computes the points of its 16 x 16 tile + halo (R + 1) ONCE into LDS (same expressions: same bits) and
+// the validity test and the window sums read them there, in the same order.  Dynamic LDS: (16 + 2 (R + 1))^2 x 20 bytes (R = 5: 15.7 KB).
+static __global__ __launch_bounds__(256) void k_plane_normals_lds(PlaneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int R = a.R, H = R + 1, side = 16 + 2 * H, np = side * side;
+  double* zz = reinterpret_cast<double*>(lds_raw);   // depth in metres, as the validity test forms it; 0: no depth or outside the image
+  float* pxs = reinterpret_cast<float*>(zz + np);
+  float* pys = pxs + np;
+  float* pzs = pys + np;
+  const int u0 = blockIdx.x * 16 - H, v0 = blockIdx.y * 16 - H;
+  for (int i = threadIdx.x; i < np; i += 256) {
+    const int lx = i % side, ly = i / side, x = u0 + lx, y = v0 + ly;
+    double z = 0;
+    float p[3] = {0, 0, 0};
+    if (x >= 0 && y >= 0 && x < a.w && y < a.h) {
+      const uint16_t d = a.depth[(size_t)y * a.w + x];
+      if (d != 0) { z = (double)d / a.scale; (void)px_point(a, x, y, p); }
+    }
+    zz[i] = z; pxs[i] = p[0]; pys[i] = p[1]; pzs[i] = p[2];
+  }
+  __syncthreads();
+  const int tu = threadIdx.x & 15, tv = threadIdx.x >> 4;
+  const int u = blockIdx.x * 16 + tu, v = blockIdx.y * 16 + tv;
+  if (u >= a.w || v >= a.h) return;
+  float* o = a.nrm + 4 * ((size_t)v * a.w + u);
+  const float qnan = __builtin_nanf("");
+  o[0] = qnan; o[1] = o[2] = o[3] = 0;
+  if (u - R - 1 < 0 || v - R - 1 < 0 || u + R + 1 >= a.w || v + R + 1 >= a.h) return;
+  const int c0 = (tv + H) * side + (tu + H);        // this pixel in the tile
+  // validity of the (2R+3)^2 neighbourhood: every depth present, no jump between horizontal / vertical neighbours
+  for (int dy = -H; dy <= H; ++dy)
+    for (int dx = -H; dx <= H; ++dx) {
+      const int i = c0 + dy * side + dx;
+      const double z = zz[i];
+      if (z == 0) return;                           // (a depth of 0 is "no point"; any other depth is a positive number)
+      if (dx + 1 <= H) { const double z2 = zz[i + 1]; if (fabs(z2 - z) > a.depth_factor * z) return; }
+      if (dy + 1 <= H) { const double z2 = zz[i + side]; if (fabs(z2 - z) > a.depth_factor * z) return; }
+    }
+  double dh[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+  for (int dy = -R; dy <= R; ++dy)
+    for (int dx = -R; dx <= R; ++dx) {
+      const int i = c0 + dy * side + dx;
+      dh[0] += (double)pxs[i + 1] - (double)pxs[i - 1]; dv[0] += (double)pxs[i + side] - (double)pxs[i - side];
+      dh[1] += (double)pys[i + 1] - (double)pys[i - 1]; dv[1] += (double)pys[i + side] - (double)pys[i - side];
+      dh[2] += (double)pzs[i + 1] - (double)pzs[i - 1]; dv[2] += (double)pzs[i + side] - (double)pzs[i - side];
+    }
+  double n[3] = {dv[1] * dh[2] - dv[2] * dh[1], dv[2] * dh[0] - dv[0] * dh[2], dv[0] * dh[1] - dv[1] * dh[0]};
+  const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  if (!(nn > 0)) return;
+  const float p[3] = {pxs[c0], pys[c0], pzs[c0]};
+  double s = 1.0 / nn;
+  if ((n[0] * p[0] + n[1] * p[1] + n[2] * p[2]) * s > 0) s = -s;   // towards the camera at the origin
+  const float nx = (float)(n[0] * s), ny = (float)(n[1] * s), nz = (float)(n[2] * s);
+  o[0] = nx; o[1] = ny; o[2] = nz;
+  o[3] = -(nx * p[0] + ny * p[1] + nz * p[2]);
+}
+// the direct form (tiles whose halo does not fit LDS: very wide smoothing windows)
 static __global__ __launch_bounds__(256) void k_plane_normals(PlaneArgs a) {
   const int u = blockIdx.x * 16 + (threadIdx.x & 15), v = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (u >= a.w || v >= a.h) return;
@@ -132,6 +191,65 @@ static __global__ __launch_bounds__(256) void k_plane_init(PlaneArgs a) {
   a.parent[i] = i; a.cnt[i] = 0;
   for (int k = 0; k < 9; ++k) a.mom[(size_t)i * 9 + k] = 0;
 }
+// Round 6: two levels.  The one-level kernel below sends every pixel's two unions through global atomics (0.52 ms per 640 x 480 image:
+// pointer chasing over a forest that 300k threads rewrite at once).  Here a workgroup first unites the pixels of its 32 x 32 tile in LDS
+// (the same lock-free union-find on local indices -- row-major inside the tile, so "smaller local index" is "smaller pixel index" and the
+// root of a local component is its first pixel, as in the global forest), writes every pixel's parent as its local root's pixel index (a
+// forest of stars), and k_plane_union_borders then unites across the tile borders only (one pixel in 16).  The final roots are the
+// components' first pixels either way: same segments, same order.
+constexpr int kPlaneTile = 32;
+__device__ __forceinline__ int uf_find_lds(int* parent, int i) {
+  while (true) {
+    const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (p == i) return i;
+    const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gp != p) (void)atomicCAS(&parent[i], p, gp);
+    i = p;
+  }
+}
+__device__ __forceinline__ void uf_union_lds(int* parent, int x, int y) {
+  while (true) {
+    x = uf_find_lds(parent, x); y = uf_find_lds(parent, y);
+    if (x == y) return;
+    if (x < y) { const int t = x; x = y; y = t; }
+    if (atomicCAS(&parent[x], x, y) == x) return;
+  }
+}
+static __global__ __launch_bounds__(256) void k_plane_union_tiles(PlaneArgs a) {
+  __shared__ int lp[kPlaneTile * kPlaneTile];
+  const int u0 = blockIdx.x * kPlaneTile, v0 = blockIdx.y * kPlaneTile;
+  for (int l = threadIdx.x; l < kPlaneTile * kPlaneTile; l += 256) lp[l] = l;
+  __syncthreads();
+  for (int l = threadIdx.x; l < kPlaneTile * kPlaneTile; l += 256) {
+    const int lx = l % kPlaneTile, ly = l / kPlaneTile, u = u0 + lx, v = v0 + ly;
+    if (u >= a.w || v >= a.h) continue;
+    const size_t i = (size_t)v * a.w + u;
+    const float* ni = a.nrm + 4 * i;
+    if (ni[0] != ni[0]) continue;
+    if (lx + 1 < kPlaneTile && u + 1 < a.w && same_plane(a, ni, a.nrm + 4 * (i + 1))) uf_union_lds(lp, l, l + 1);
+    if (ly + 1 < kPlaneTile && v + 1 < a.h && same_plane(a, ni, a.nrm + 4 * (i + a.w))) uf_union_lds(lp, l, l + kPlaneTile);
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < kPlaneTile * kPlaneTile; l += 256) {
+    const int lx = l % kPlaneTile, ly = l / kPlaneTile, u = u0 + lx, v = v0 + ly;
+    if (u >= a.w || v >= a.h) continue;
+    const int rt = uf_find_lds(lp, l);
+    a.parent[(size_t)v * a.w + u] = (v0 + rt / kPlaneTile) * a.w + (u0 + rt % kPlaneTile);
+  }
+}
+// unions across the tile borders: thread = (tile row boundary pixel | tile column boundary pixel)
+static __global__ __launch_bounds__(256) void k_plane_union_borders(PlaneArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.w * a.h) return;
+  const int u = i % a.w, v = i / a.w;
+  const bool right_edge = (u % kPlaneTile) == kPlaneTile - 1, bottom_edge = (v % kPlaneTile) == kPlaneTile - 1;
+  if (!right_edge && !bottom_edge) return;
+  const float* ni = a.nrm + 4 * (size_t)i;
+  if (ni[0] != ni[0]) return;
+  if (right_edge && u + 1 < a.w && same_plane(a, ni, a.nrm + 4 * (size_t)(i + 1))) uf_union(a.parent, i, i + 1);
+  if (bottom_edge && v + 1 < a.h && same_plane(a, ni, a.nrm + 4 * (size_t)(i + a.w))) uf_union(a.parent, i, i + a.w);
+}
+// the one-level form (kept: ESL_PLANE_UNION=0, A/B)
 static __global__ __launch_bounds__(256) void k_plane_union(PlaneArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.w * a.h) return;
@@ -543,9 +661,20 @@ int plane_segment(esl_ctx* c, const uint16_t* depth, int32_t width, int32_t heig
   a.dist_th = p->distance_threshold; a.min_size = p->min_size; a.min_inliers = p->min_inliers; a.max_curv = p->max_curvature;
   a.nrm = (float*)w.nrm.p; a.parent = (int*)w.par.p; a.cnt = (int*)w.cnt.p; a.mom = (long long*)w.mom.p; a.out = (double*)w.out.p; a.blk = (int*)w.blk.p;
   const unsigned nb = (unsigned)((npx + 255) / 256);
-  hipLaunchKernelGGL(k_plane_normals, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, c->stream, a);
+  {
+    const int side = 16 + 2 * (a.R + 1);
+    const size_t lds = (size_t)side * side * 20;
+    if (lds <= 48 * 1024) hipLaunchKernelGGL(k_plane_normals_lds, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), lds, c->stream, a);
+    else hipLaunchKernelGGL(k_plane_normals, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, c->stream, a);
+  }
   hipLaunchKernelGGL(k_plane_init, dim3(nb), dim3(256), 0, c->stream, a);
-  hipLaunchKernelGGL(k_plane_union, dim3(nb), dim3(256), 0, c->stream, a);
+  static const int tiled = [] { const char* e = std::getenv("ESL_PLANE_UNION"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (tiled) {
+    hipLaunchKernelGGL(k_plane_union_tiles, dim3((width + kPlaneTile - 1) / kPlaneTile, (height + kPlaneTile - 1) / kPlaneTile), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_plane_union_borders, dim3(nb), dim3(256), 0, c->stream, a);
+  } else {
+    hipLaunchKernelGGL(k_plane_union, dim3(nb), dim3(256), 0, c->stream, a);
+  }
   hipLaunchKernelGGL(k_plane_moments, dim3(nb), dim3(256), 0, c->stream, a);
   ESL_HIP_TRY(hipGetLastError());
   return ESL_OK;
