@@ -628,6 +628,30 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
 #pragma unroll
     for (int q = 0; q < QB; ++q) rb[q] = *reinterpret_cast<const double2_t*>(pB[q] + (long)kc * ldp);
   };
+  // Round 6, persistent kernel only: the C tile's lines are requested (one dword per line and lane group, into a register nobody
+  // reads) under the LAST chunk's MFMAs.  The tile was written write-through by whichever CU visited it last, usually on another
+  // XCD: the epilogue's NJ dependent load groups each paid a fabric round trip (~2 us) in a task visited 216 times per worker at
+  // n = 18,000.  The loads are older than the epilogue's, and loads complete in order, so the dummy register is dead by the time the
+  // first real C value arrives (it is kept allocated until then).
+  int c_dummy = 0;
+  auto c_prefetch = [&]() {
+    const long iw0 = i0 + wi * SM, jw0 = j0 + wj * SN;
+    const bool full_sub = !assign && (iw0 + SM <= rows) && (jw0 + SN <= ncols) && (jw0 + SN - 1 <= iw0);
+    if (full_sub) {
+      // ONE pointer walks the sub-tile's column groups (column jw0 + kq + 4 c, c = 0 .. 4 NJ - 1), the MI row groups are immediate
+      // offsets: 64 separately formed addresses took the merged kernel's scratch from 144 to 656 B
+      const double* pc = &M[(iw0 + r) + (jw0 + kq) * lda];
+#pragma unroll 1
+      for (int c2 = 0; c2 < 4 * NJ; ++c2) {
+        if constexpr (MI == 4)
+          asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:128\n\tglobal_load_dword %0, %1, off offset:256\n\t"
+                       "global_load_dword %0, %1, off offset:384" : "+v"(c_dummy) : "v"(pc) : "memory");
+        else if constexpr (MI == 2)
+          asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:128" : "+v"(c_dummy) : "v"(pc) : "memory");
+        pc += 4 * lda;
+      }
+    }
+  };
   auto mainloop = [&](auto fast) {
     if constexpr (decltype(fast)::value) gload_fast(0); else gload(0);
     sstore(0);
@@ -636,6 +660,9 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
     for (int kc = 0; kc < K; kc += kKC) {
       const bool more = kc + kKC < K;
       if (more) { if constexpr (decltype(fast)::value) gload_fast(kc + kKC); else gload(kc + kKC); }
+#ifndef ESL_NO_CPREFETCH
+      else if constexpr (WT) c_prefetch();
+#endif   // (the last chunk has no operands to fetch: its MFMAs cover the C tile's way into this XCD's L2)
       if (!skip) {
         const double* Ab = As + buf * kKC * kLdA + wi * SM + r;
         const double* Bb = Bs + buf * kKC * kLdB + wj * SN + r;
@@ -713,6 +740,7 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int g = 0; g < 4; ++g) chol_store<WT>(&M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda], cv[nj & (NSET - 1)][mi][g] - acc[nj][mi][g]);
+      if (nj == 0) asm volatile("" :: "v"(c_dummy));   // (the prefetch's destination register: allocated until the first real C values are in)
     }
     return;
   }
