@@ -828,6 +828,208 @@ static __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 1 : 2)) void k
   if (clk_on) { g_upd_clk[0] = (long long)clock64() - c0; g_upd_clk[1] = (long long)wall_clock64() - w0; g_upd_clk[2] = K; g_upd_clk[3] = BM; }
 }
 
+// ---- round 6: the update tile in the shape the part's own DGEMM library runs (scripts/debug/rocblas_dgemm_probe.py) ------------------
+// The vendor DGEMM reaches 89 - 96 % of the FP64-MFMA peak at these sizes where the 256 x 128 tile above reaches 79 %.  Its kernels
+// (the dispatched symbols name the shape: MT128x128x16, four waves of 32 x 128, one operand "direct to VGPR") differ in two ways that
+// matter here: (1) a workgroup is FOUR waves, one per SIMD, and TWO workgroups share a CU -- when one of them sits in its barrier the
+// other one's wave on the same SIMD owns the matrix core, where the eight waves of the big tile all wait together; (2) the operand
+// no other wave needs (this wave's 32 rows) never touches LDS: every lane loads its own MFMA fragment from global memory (a lane's
+// fragment of the f64 16x16x4 MFMA is ONE element: row r = lane & 15, k = lane >> 4), only the 128-column operand the four waves share
+// is staged.  Half the LDS stores and half the LDS fragment reads per MFMA.
+// Tile: rows [i0, i0 + 128) x columns [j0, j0 + 128); wave w owns rows i0 + 32 w .. + 31, interleaved in pairs -- lane r holds rows
+// 2 r and 2 r + 1 (one 16-byte load per k-step, and the C tile's read-modify-write is 16-byte accesses too).  Same product
+// orientation as above (D rows = tile columns, D columns = tile rows), the same k order inside and across MFMAs: the same bits.
+constexpr int kVT = 128, kVLd = kVT + 16;
+constexpr size_t kCholLdsV = (size_t)(2 * kKC * kVLd) * sizeof(double);
+template <bool WT>
+__device__ __forceinline__ void chol_update_tile_v(double* __restrict__ sm, double* __restrict__ M, long lda, long rows, long ncols,
+                                                   const double* __restrict__ P, long ldp, int K, long i0, long j0, bool assign) {
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  constexpr int NT = 256, NJ = kVT / 16, QB = kVT * kKC / 2 / NT;   // 8 column blocks; 4 double2 of the shared operand per thread and chunk
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, kq = lane >> 4;
+  const long iw = i0 + wave * 32;
+  const bool interior = (i0 + kVT <= rows) && (K % kKC == 0);
+  // the shared operand: thread t stages rows j0 + 2 (e % 64), k = e / 64 (e = t + 256 q)
+  const double* pB[QB];
+#pragma unroll
+  for (int q = 0; q < QB; ++q) { const int e = t + NT * q; pB[q] = P + j0 + 2 * (e % (kVT / 2)) + (long)(e / (kVT / 2)) * ldp; }
+  // this lane's own fragments: rows iw + 2 r, iw + 2 r + 1 at k = kc + 4 s + kq
+  const double* pA = P + iw + 2 * r + (long)kq * ldp;
+  double2_t rb[QB];
+  auto gload_b = [&](int kc, auto fast) {
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      if constexpr (decltype(fast)::value) rb[q] = *reinterpret_cast<const double2_t*>(pB[q] + (long)kc * ldp);
+      else {
+        const int e = t + NT * q, k = e / (kVT / 2);
+        const long row = j0 + 2 * (e % (kVT / 2));
+        const bool kv = (kc + k) < K;
+        const long kcl = kv ? (long)(kc + k) : (long)(K - 1);
+        const double v0 = P[(row < rows ? row : rows - 1) + kcl * ldp], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * ldp];
+        rb[q] = double2_t{(kv && row < rows) ? v0 : 0.0, (kv && row + 1 < rows) ? v1 : 0.0};
+      }
+    }
+  };
+  auto gload_a = [&](double2_t (&a)[4], int kc, auto fast) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (decltype(fast)::value) a[s] = *reinterpret_cast<const double2_t*>(pA + (long)(kc + 4 * s) * ldp);
+      else {
+        const long row = iw + 2 * r;
+        const int k = kc + 4 * s + kq;
+        const bool kv = k < K;
+        const long kcl = kv ? (long)k : (long)(K - 1);
+        const double v0 = P[(row < rows ? row : rows - 1) + kcl * ldp], v1 = P[(row + 1 < rows ? row + 1 : rows - 1) + kcl * ldp];
+        a[s] = double2_t{(kv && row < rows) ? v0 : 0.0, (kv && row + 1 < rows) ? v1 : 0.0};
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int e = t + NT * q;
+      *reinterpret_cast<double2_t*>(sm + (buf * kKC + e / (kVT / 2)) * kVLd + 2 * (e % (kVT / 2))) = rb[q];
+    }
+  };
+  double4_t acc[NJ][2];
+#pragma unroll
+  for (int x = 0; x < NJ; ++x) { acc[x][0] = double4_t{0, 0, 0, 0}; acc[x][1] = double4_t{0, 0, 0, 0}; }
+  // one chunk: MFMAs on a_cur and LDS buffer `buf`; the operands of chunk `kn` (the next one; the last chunk names itself) are
+  // requested first and the shared one goes into the other LDS buffer behind the MFMAs.  No branch around the loads or the stores:
+  // with `if (more)` the compiler's wait-count pass joins the two paths at the first MFMA and waits for the loads it has just issued
+  // (vmcnt(3) with twelve in flight: one exposed memory round trip per chunk).
+  auto chunk = [&](double2_t (&a_cur)[4], double2_t (&a_nxt)[4], int kn, int buf, auto fast) {
+    gload_b(kn, fast);
+    gload_a(a_nxt, kn, fast);
+    const double* Bb = sm + buf * kKC * kVLd + r;
+    double bq[2][NJ];
+#pragma unroll
+    for (int m = 0; m < NJ; ++m) bq[0][m] = Bb[kq * kVLd + m * 16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) {
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) bq[(s + 1) & 1][m] = Bb[(4 * (s + 1) + kq) * kVLd + m * 16];
+      }
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        acc[nj][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[s & 1][nj], a_cur[s].x, acc[nj][0], 0, 0, 0);
+        acc[nj][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[s & 1][nj], a_cur[s].y, acc[nj][1], 0, 0, 0);
+      }
+    }
+    // (the stores stay behind the MFMAs: hoisted to the middle of the chunk, as the scheduler likes to, they wait for loads that are
+    //  half a chunk old -- 19.1 vs 18.7 ms on the rank-3,744 update)
+    __builtin_amdgcn_sched_barrier(0);
+    sstore(buf ^ 1);
+    __syncthreads();
+  };
+  auto mainloop = [&](auto fast) {
+    double2_t a0[4], a1[4];
+    gload_b(0, fast); gload_a(a0, 0, fast);
+    sstore(0);
+    __syncthreads();
+    const int klast = ((K + kKC - 1) / kKC - 1) * kKC;   // first k of the last chunk
+    int kc = 0;
+    for (; kc + kKC <= klast; kc += 2 * kKC) {
+      chunk(a0, a1, kc + kKC, 0, fast);
+      chunk(a1, a0, kc + 2 * kKC <= klast ? kc + 2 * kKC : klast, 1, fast);
+    }
+    if (kc <= klast) chunk(a0, a1, klast, 0, fast);   // (an odd number of chunks)
+  };
+  if (interior) mainloop(std::true_type{}); else mainloop(std::false_type{});
+  if (iw >= rows || j0 >= ncols) return;
+  // C -= acc: acc[nj][mi][g] is row iw + 2 r + mi, column j0 + 16 nj + kq + 4 g
+  const bool full = (iw + 32 <= rows) && (j0 + kVT <= ncols) && (j0 + kVT - 1 <= iw) && ((lda & 1) == 0) && (((iw & 1) == 0));
+  if (full) {
+    double2_t cv[2][4];
+    auto load_group = [&](int nj, double2_t (&dst)[4]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        dst[g] = assign ? double2_t{0.0, 0.0} : *reinterpret_cast<const double2_t*>(&M[(iw + 2 * r) + (j0 + nj * 16 + kq + 4 * g) * lda]);
+    };
+    load_group(0, cv[0]);
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      if (nj + 1 < NJ) load_group(nj + 1, cv[(nj + 1) & 1]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        double* p = &M[(iw + 2 * r) + (j0 + nj * 16 + kq + 4 * g) * lda];
+        const double2_t v = double2_t{cv[nj & 1][g].x - acc[nj][0][g], cv[nj & 1][g].y - acc[nj][1][g]};
+        if constexpr (WT) { chol_store<true>(p, v.x); chol_store<true>(p + 1, v.y); } else *reinterpret_cast<double2_t*>(p) = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    double cv[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long col = j0 + nj * 16 + kq + 4 * g, row = iw + 2 * r + mi;
+        cv[mi][g] = assign ? 0.0 : M[(row < rows ? row : rows - 1) + (col < ncols ? col : ncols - 1) * lda];
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const long col = j0 + nj * 16 + kq + 4 * g, row = iw + 2 * r + mi;
+        if (row < rows && col < ncols && row >= col) chol_store<WT>(&M[row + col * lda], cv[mi][g] - acc[nj][mi][g]);
+      }
+  }
+}
+// the launch: same arguments and tile enumeration as k_chol_update_lds<128, 128> (square tiles: tile row ti holds ti + 1 tiles)
+// Tile order (whole-triangle launches): workgroups are dealt to the eight XCDs round-robin, and each XCD has an L2 of its own.  Row-major
+// over the triangle, the ~64 tiles an XCD holds at one time are 64 different tile columns of one tile row: 1 + 64 operand panels stream
+// through that L2.  `sb` > 0: ids are dealt so that XCD x works on a block of sb x sb tiles (2 sb panels) -- workgroup b belongs to
+// super-block 8 (b / (8 sb sb)) + b % 8, tile (b % (8 sb sb)) / 8 of it; super-blocks in row-major order over their own triangle.
+__host__ __device__ inline long chol_v_grid(long ntI, int sb) {
+  if (sb <= 0) return ntI * (ntI + 1) / 2;
+  const long nS = (ntI + sb - 1) / sb, nSB = nS * (nS + 1) / 2;
+  return (nSB + 7) / 8 * 8 * sb * sb;
+}
+static __global__ __launch_bounds__(256, 2) void k_chol_update_v(double* __restrict__ M, long lda, long rows, long ncols, int kcol0, int K, long base, int ntJ,
+                                                                 int rect, const double* __restrict__ Pext, long ldp,
+                                                                 const int* __restrict__ kfirst = nullptr, int sb = 0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const long b = blockIdx.x;
+  long ti, tj;
+  if (rect) {
+    ti = b / ntJ; tj = b - ti * ntJ;
+    if (tj > ti) return;
+  } else if (sb > 0) {
+    const long per = 8L * sb * sb, B = 8 * (b / per) + (b & 7), e = (b % per) >> 3;
+    long sI = (long)((sqrt(1.0 + 8.0 * (double)B) - 1.0) * 0.5);
+    while (sI * (sI + 1) / 2 > B) --sI;
+    while ((sI + 1) * (sI + 2) / 2 <= B) ++sI;
+    const long sJ = B - sI * (sI + 1) / 2;
+    ti = sI * sb + e / sb; tj = sJ * sb + e % sb;
+    if (tj > ti || tj >= ntJ) return;
+  } else {
+    ti = (long)((sqrt(1.0 + 8.0 * (double)b) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > b) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    tj = b - ti * (ti + 1) / 2;
+    if (tj >= ntJ) return;
+  }
+  const long i0 = base + ti * kVT, j0 = base + tj * kVT;
+  if (i0 >= rows || j0 >= ncols) return;
+  const double* P = Pext ? Pext : M + (long)kcol0 * lda;
+  if (!Pext) ldp = lda;
+  if (kfirst) {   // (the staircase of esl_cf.hpp, as in k_chol_update_lds)
+    int ka = K, kb = K;
+    for (long g = i0 / 64; g < (i0 + kVT) / 64; ++g) ka = kfirst[g] < ka ? kfirst[g] : ka;
+    for (long g = j0 / 64; g < (j0 + kVT) / 64; ++g) kb = kfirst[g] < kb ? kfirst[g] : kb;
+    int ks = ka > kb ? ka : kb;
+    ks = (ks < K ? ks : K) & ~(kKC - 1);
+    P += (long)ks * ldp;
+    K -= ks;
+    if (K <= 0) return;
+  }
+  chol_update_tile_v<false>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, false);
+}
+
 // ---- small systems: factor + both substitutions in ONE workgroup, the whole lower triangle in registers (round 6) ---------------
 // An order-180 system (20 ellipsoids: BASELINE configs[4] in SLAM mode) is two diagonal blocks of the blocked path: 2 x potrf2 + 2 panel
 // solves + 1 update + the back-substitution = 6 dependent launches, ~170 us, with fewer than 1e7 flops in them.  Here 1024 threads own
@@ -1223,6 +1425,15 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
     const long ntI = (nrows + 255) / 256, ntJ = (nc + 127) / 128;
     const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
     static const int waves4 = [] { const char* e = std::getenv("ESL_UPD_WAVES"); return (e && std::atoi(e) == 4) ? 1 : 0; }();
+    // round 6: the vendor-shaped 128 x 128 tile, two four-wave workgroups per CU (k_chol_update_v; ESL_UPD_V=0: the 256 x 128 tile).  Same bits.
+    static const int use_v = [] { const char* e = std::getenv("ESL_UPD_V"); return (e && std::atoi(e) == 0) ? 0 : 1; }();
+    if (use_v && !waves4 && (lda & 1) == 0 && (base & 1) == 0 && (!Pext || (ldp & 1) == 0)) {
+      const long vI = (nrows + kVT - 1) / kVT, vJ = (nc + kVT - 1) / kVT;
+      const long vblk = whole ? chol_v_grid(vI, 0) : vI * vJ;
+      hipLaunchKernelGGL(k_chol_update_v, dim3((unsigned)vblk), dim3(256), kCholLdsV, stream, M, lda, rows, col_limit, kcol0, K, base, (int)vJ, whole ? 0 : 1, Pext, ldp,
+                         Pext ? kfirst : nullptr, 0);
+      return;
+    }
     if (waves4)   // (experiment, round 6) four waves of 128 x 64, one per SIMD, accumulators in AGPRs
       hipLaunchKernelGGL((k_chol_update_lds<256, 128, 2, 2>), dim3((unsigned)nblk), dim3(256), kCholLdsBig, stream, M, lda, rows, col_limit, kcol0, K,
                          base, (int)ntJ, whole ? 0 : 1, Pext, ldp, (double*)nullptr, 0, Pext ? kfirst : nullptr);
