@@ -840,26 +840,51 @@ static __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 1 : 2)) void k
 // 2 r and 2 r + 1 (one 16-byte load per k-step, and the C tile's read-modify-write is 16-byte accesses too).  Same product
 // orientation as above (D rows = tile columns, D columns = tile rows), the same k order inside and across MFMAs: the same bits.
 constexpr int kVT = 128, kVLd = kVT + 16;
+// a value every lane holds alike, as the compiler cannot know (it came through LDS or a vector load): into scalar registers
+__device__ __forceinline__ int chol_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long chol_uniform(long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffL)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)v >> 32));
+  return (long)(((unsigned long)hi << 32) | lo);
+}
 constexpr size_t kCholLdsV = (size_t)(2 * kKC * kVLd) * sizeof(double);
-template <bool WT>
+// HV = 1 (the persistent factorisation, one 512-thread workgroup per CU): the workgroup's two halves -- waves 0-3 and 4-7, one wave per
+// SIMD each (measured: the eight waves of a workgroup sit on SIMDs 3 0 2 1 3 0 2 1) -- run this function side by side on the upper and
+// the lower 128 rows of a 256 x 128 tile, each with its own LDS buffers and its own barrier: a counter in LDS (`bar`, zeroed by the
+// caller behind a workgroup barrier) that the four waves of a half bump and poll.  The piecewise probe (scripts/debug/tile_probe_v.hip):
+// 86.4 % of the FP64-MFMA peak for the eight-wave 256 x 128 loop, 92.3 % for two four-wave workgroups, 89.7 % for two halves of one
+// workgroup behind the LDS-counter barrier.
+template <bool WT, int HV = 0>
 __device__ __forceinline__ void chol_update_tile_v(double* __restrict__ sm, double* __restrict__ M, long lda, long rows, long ncols,
-                                                   const double* __restrict__ P, long ldp, int K, long i0, long j0, bool assign) {
+                                                   const double* __restrict__ P, long ldp, int K, long i0, long j0, bool assign, int* bar = nullptr) {
   typedef double double2_t __attribute__((ext_vector_type(2)));
   constexpr int NT = 256, NJ = kVT / 16, QB = kVT * kKC / 2 / NT;   // 8 column blocks; 4 double2 of the shared operand per thread and chunk
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, kq = lane >> 4;
+  const int t = HV ? (int)(threadIdx.x & 255) : (int)threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, kq = lane >> 4;
   const long iw = i0 + wave * 32;
-  const bool interior = (i0 + kVT <= rows) && (K % kKC == 0);
-  // the shared operand: thread t stages rows j0 + 2 (e % 64), k = e / 64 (e = t + 256 q)
-  const double* pB[QB];
-#pragma unroll
-  for (int q = 0; q < QB; ++q) { const int e = t + NT * q; pB[q] = P + j0 + 2 * (e % (kVT / 2)) + (long)(e / (kVT / 2)) * ldp; }
-  // this lane's own fragments: rows iw + 2 r, iw + 2 r + 1 at k = kc + 4 s + kq
-  const double* pA = P + iw + 2 * r + (long)kq * ldp;
+  const bool interior = (i0 + kVT <= rows) && (K % (2 * kKC) == 0);
+  const bool skipw = (j0 > iw + 31) || iw >= rows;   // this wave's rows lie above the diagonal / under the matrix: staging and barriers only
+  int phase = 0;
+  auto sync = [&]() {
+    if constexpr (HV == 0) __syncthreads();
+    else {
+      phase += 4;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase) __builtin_amdgcn_s_sleep(0);
+      asm volatile("" ::: "memory");
+    }
+  };
+  // the shared operand: thread t stages rows j0 + 2 (e % 64), k = e / 64 (e = t + 256 q), i.e. k = t / 64 + 4 q; this lane's own
+  // fragments: rows iw + 2 r, iw + 2 r + 1 at k = kc + 4 s + kq.  Addresses = a wave-uniform base (scalar registers) + ONE 32-bit
+  // per-lane byte offset each (eight 64-bit pointers per lane went to scratch in the persistent kernel)
+  const char* PBu = reinterpret_cast<const char*>(P + j0);
+  const char* PAu = reinterpret_cast<const char*>(P + i0);
+  const unsigned offB = (unsigned)((2 * (t % (kVT / 2)) + (long)(t / (kVT / 2)) * ldp) * (long)sizeof(double));
+  const unsigned offA = (unsigned)((wave * 32 + 2 * r + (long)kq * ldp) * (long)sizeof(double));
   double2_t rb[QB];
   auto gload_b = [&](int kc, auto fast) {
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-      if constexpr (decltype(fast)::value) rb[q] = *reinterpret_cast<const double2_t*>(pB[q] + (long)kc * ldp);
+      if constexpr (decltype(fast)::value) rb[q] = *reinterpret_cast<const double2_t*>(PBu + (long)(kc + 4 * q) * ldp * (long)sizeof(double) + offB);
       else {
         const int e = t + NT * q, k = e / (kVT / 2);
         const long row = j0 + 2 * (e % (kVT / 2));
@@ -873,7 +898,7 @@ __device__ __forceinline__ void chol_update_tile_v(double* __restrict__ sm, doub
   auto gload_a = [&](double2_t (&a)[4], int kc, auto fast) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if constexpr (decltype(fast)::value) a[s] = *reinterpret_cast<const double2_t*>(pA + (long)(kc + 4 * s) * ldp);
+      if constexpr (decltype(fast)::value) a[s] = *reinterpret_cast<const double2_t*>(PAu + (long)(kc + 4 * s) * ldp * (long)sizeof(double) + offA);
       else {
         const long row = iw + 2 * r;
         const int k = kc + 4 * s + kq;
@@ -894,6 +919,20 @@ __device__ __forceinline__ void chol_update_tile_v(double* __restrict__ sm, doub
   double4_t acc[NJ][2];
 #pragma unroll
   for (int x = 0; x < NJ; ++x) { acc[x][0] = double4_t{0, 0, 0, 0}; acc[x][1] = double4_t{0, 0, 0, 0}; }
+  const bool full = !skipw && (iw + 32 <= rows) && (j0 + kVT <= ncols) && (j0 + kVT - 1 <= iw) && ((lda & 1) == 0) && (((iw & 1) == 0));
+  // persistent kernel: the C sub-tile's lines requested under the LAST chunk's MFMAs (see chol_update_tile: the tile was written
+  // write-through by another CU, usually on another XCD; one dword per 128-byte line and lane group into a register nobody reads)
+  int c_dummy = 0;
+  auto c_prefetch = [&]() {
+    if (full && !assign) {
+      const double* pc = &M[(iw + 2 * r) + (j0 + kq) * lda];
+#pragma unroll 1
+      for (int c2 = 0; c2 < 4 * NJ; ++c2) {
+        asm volatile("global_load_dword %0, %1, off" : "+v"(c_dummy) : "v"(pc) : "memory");
+        pc += 4 * lda;
+      }
+    }
+  };
   // one chunk: MFMAs on a_cur and LDS buffer `buf`; the operands of chunk `kn` (the next one; the last chunk names itself) are
   // requested first and the shared one goes into the other LDS buffer behind the MFMAs.  No branch around the loads or the stores:
   // with `if (more)` the compiler's wait-count pass joins the two paths at the first MFMA and waits for the loads it has just issued
@@ -901,45 +940,57 @@ __device__ __forceinline__ void chol_update_tile_v(double* __restrict__ sm, doub
   auto chunk = [&](double2_t (&a_cur)[4], double2_t (&a_nxt)[4], int kn, int buf, auto fast) {
     gload_b(kn, fast);
     gload_a(a_nxt, kn, fast);
-    const double* Bb = sm + buf * kKC * kVLd + r;
-    double bq[2][NJ];
+    if (!skipw) {
+      const double* Bb = sm + buf * kKC * kVLd + r;
+      double bq[2][NJ];
 #pragma unroll
-    for (int m = 0; m < NJ; ++m) bq[0][m] = Bb[kq * kVLd + m * 16];
+      for (int m = 0; m < NJ; ++m) bq[0][m] = Bb[kq * kVLd + m * 16];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) {
+      for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
 #pragma unroll
-        for (int m = 0; m < NJ; ++m) bq[(s + 1) & 1][m] = Bb[(4 * (s + 1) + kq) * kVLd + m * 16];
-      }
+          for (int m = 0; m < NJ; ++m) bq[(s + 1) & 1][m] = Bb[(4 * (s + 1) + kq) * kVLd + m * 16];
+        }
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) {
-        acc[nj][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[s & 1][nj], a_cur[s].x, acc[nj][0], 0, 0, 0);
-        acc[nj][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[s & 1][nj], a_cur[s].y, acc[nj][1], 0, 0, 0);
+        for (int nj = 0; nj < NJ; ++nj) {
+          acc[nj][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[s & 1][nj], a_cur[s].x, acc[nj][0], 0, 0, 0);
+          acc[nj][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[s & 1][nj], a_cur[s].y, acc[nj][1], 0, 0, 0);
+        }
       }
     }
     // (the stores stay behind the MFMAs: hoisted to the middle of the chunk, as the scheduler likes to, they wait for loads that are
     //  half a chunk old -- 19.1 vs 18.7 ms on the rank-3,744 update)
     __builtin_amdgcn_sched_barrier(0);
     sstore(buf ^ 1);
-    __syncthreads();
+    sync();
   };
   auto mainloop = [&](auto fast) {
     double2_t a0[4], a1[4];
     gload_b(0, fast); gload_a(a0, 0, fast);
     sstore(0);
-    __syncthreads();
-    const int klast = ((K + kKC - 1) / kKC - 1) * kKC;   // first k of the last chunk
-    int kc = 0;
-    for (; kc + kKC <= klast; kc += 2 * kKC) {
-      chunk(a0, a1, kc + kKC, 0, fast);
-      chunk(a1, a0, kc + 2 * kKC <= klast ? kc + 2 * kKC : klast, 1, fast);
+    sync();
+    if constexpr (decltype(fast)::value) {
+      // an even number of whole chunks: ONE copy of the chunk pair (separate copies for the last chunks cost the persistent kernel
+      // 80 scratch stores + 35 reloads per visit around them); the last chunk fetches nothing new -- its own operands again
+      for (int kc = 0; kc < K; kc += 2 * kKC) {
+        const bool last = kc + 2 * kKC >= K;
+        if constexpr (WT) { if (last) c_prefetch(); }
+        chunk(a0, a1, kc + kKC, 0, fast);
+        chunk(a1, a0, last ? kc + kKC : kc + 2 * kKC, 1, fast);
+      }
+    } else {
+      const int klast = ((K + kKC - 1) / kKC - 1) * kKC;   // first k of the last chunk
+      int kc = 0;
+      for (; kc + kKC <= klast; kc += 2 * kKC) {
+        chunk(a0, a1, kc + kKC, 0, fast);
+        chunk(a1, a0, kc + 2 * kKC <= klast ? kc + 2 * kKC : klast, 1, fast);
+      }
+      if (kc <= klast) chunk(a0, a1, klast, 0, fast);   // (an odd number of chunks)
     }
-    if (kc <= klast) chunk(a0, a1, klast, 0, fast);   // (an odd number of chunks)
   };
   if (interior) mainloop(std::true_type{}); else mainloop(std::false_type{});
-  if (iw >= rows || j0 >= ncols) return;
+  if (skipw || j0 >= ncols) return;
   // C -= acc: acc[nj][mi][g] is row iw + 2 r + mi, column j0 + 16 nj + kq + 4 g
-  const bool full = (iw + 32 <= rows) && (j0 + kVT <= ncols) && (j0 + kVT - 1 <= iw) && ((lda & 1) == 0) && (((iw & 1) == 0));
   if (full) {
     double2_t cv[2][4];
     auto load_group = [&](int nj, double2_t (&dst)[4]) {
@@ -955,8 +1006,14 @@ __device__ __forceinline__ void chol_update_tile_v(double* __restrict__ sm, doub
       for (int g = 0; g < 4; ++g) {
         double* p = &M[(iw + 2 * r) + (j0 + nj * 16 + kq + 4 * g) * lda];
         const double2_t v = double2_t{cv[nj & 1][g].x - acc[nj][0][g], cv[nj & 1][g].y - acc[nj][1][g]};
-        if constexpr (WT) { chol_store<true>(p, v.x); chol_store<true>(p + 1, v.y); } else *reinterpret_cast<double2_t*>(p) = v;
+        // write-through as ONE 16-byte sc1 store: 8-byte sc1 stores cost 2.7 x per byte (the guide's store table; n = 18,000 37.25 ->
+        // 36.37 ms, 24,000 80.7 -> 79.4 against two 8-byte atomic stores).  Inline assembly, so the compiler sees neither the store's
+        // place in the vmcnt queue nor its hazard: a VALU write to the data registers of a store wider than 8 bytes needs wait states
+        // behind it (the hazard recognizer pads its own stores; without the s_nop the next address computation landed in the stored data)
+        if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+        else *reinterpret_cast<double2_t*>(p) = v;
       }
+      if (nj == 0) asm volatile("" :: "v"(c_dummy));   // (the prefetch's destination register: allocated until the first real C values are in)
     }
     return;
   }
@@ -1023,11 +1080,16 @@ static __global__ __launch_bounds__(256, 2) void k_chol_update_v(double* __restr
     for (long g = j0 / 64; g < (j0 + kVT) / 64; ++g) kb = kfirst[g] < kb ? kfirst[g] : kb;
     int ks = ka > kb ? ka : kb;
     ks = (ks < K ? ks : K) & ~(kKC - 1);
+    if (((K - ks) & kKC) != 0 && ks >= kKC) ks -= kKC;   // (the tile's unguarded loop takes chunks in pairs: an odd count sent half the tiles down the guarded path)
     P += (long)ks * ldp;
     K -= ks;
     if (K <= 0) return;
   }
+#ifdef ESL_V_FORCE_WT
+  chol_update_tile_v<true>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, false);
+#else
   chol_update_tile_v<false>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, false);
+#endif
 }
 
 // ---- small systems: factor + both substitutions in ONE workgroup, the whole lower triangle in registers (round 6) ---------------
@@ -1777,7 +1839,8 @@ constexpr int kPwThreads = 512, kPwGrid = 256;
 __device__ long long g_chol_stats[kPwGrid * 5];
 __device__ long long g_chol_chain_log[2 * 1024];
 __device__ long long g_chol_fuse_ticks[4];   // fused chain stage, totals of the last launch: waits, row solve, next-block update, drain + publish   // per diagonal block: tick its tile was final, tick its factor was published
-constexpr size_t kPwLds = kP2Lds + 64;   // + the task slot words and the diagnostics accumulators
+constexpr size_t kPwLds = kP2Lds + 64 + 256;   // + the task slot words and the diagnostics accumulators + the two halves' barrier counters (slot[16], slot[48])
+static_assert(2 * kCholLdsV <= kP2Lds, "two halves' staging buffers");
 // ONE kernel, two roles (round 4, second form): workgroup 0 is the chain, workgroups 1..255 the workers.  (The first form ran the two
 // roles as two kernels on two streams: correct and as fast -- but whether two queues of one process run side by side or in turns
 // is the scheduler's business: creating or destroying any stream while the pair ran made it time-slice them, each role then only
@@ -1910,6 +1973,7 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       slot[1] = ok ? 1 : 0;
+      slot[16] = 0; slot[48] = 0;   // the halves' barrier counters (chol_update_tile_v<.., 1>): every wave of the previous task is behind its last barrier
       if (stats) { const long long now = (long long)wall_clock64(); lstat[0] += now - tw; lstat[4] = now; }
     }
     __syncthreads();
@@ -1929,8 +1993,24 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
         if (tk.type == 3)
           chol_update_tile<128, 64, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b + 128L * ((tk.c >> 16) & 1),
                                                 128L * (tk.c & 0xffff) + 64L * ((tk.c >> 17) & 1), false);
-        else
+        else {
+#ifdef ESL_PERSIST_TILE_LDS
           chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * (tk.c & 0xffff), false);
+#else
+#ifdef ESL_PERSIST_MIX
+          if (chol_uniform(tk.type) == 1) {
+            chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * (tk.c & 0xffff), false);
+          } else
+#endif
+          {
+          // round 6: the two halves of the workgroup take the tile's upper and lower 128 rows independently (chol_update_tile_v, HV = 1)
+          const int hv = chol_uniform(t >> 8), Ku = chol_uniform(K);
+          const long ih = 256L * chol_uniform(tk.b) + 128L * hv, jh = 128L * chol_uniform(tk.c & 0xffff), c0u = chol_uniform(c0);
+          if (ih < rows && jh <= ih + 127)   // (a half under the matrix or above the diagonal has nothing to do)
+            chol_update_tile_v<true, 1>(sm + hv * (2 * kKC * kVLd), M, lda, rows, (long)n, M + c0u * lda, lda, Ku, ih, jh, false, slot + 16 + 32 * hv);
+          }
+#endif
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   long diff = 0, changed = 0; double maxd = 0;
   for (long c = 0; c < n; ++c) for (long r = c; r < rows; ++r) {
     const size_t i = (size_t)c * lda + r;
-    if (memcmp(&r1[i], &r2[i], 8)) { ++diff; maxd = std::max(maxd, std::abs(r1[i] - r2[i])); }
+    if (memcmp(&r1[i], &r2[i], 8)) { if (diff < 12) printf("first differing: row %ld col %ld  lds %.17g  v %.17g  before %.17g\n", r, c, r1[i], r2[i], hM[i]); ++diff; maxd = std::max(maxd, std::abs(r1[i] - r2[i])); }
     if (r1[i] != hM[i]) ++changed;
   }
   long above = 0;
