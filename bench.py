@@ -268,14 +268,14 @@ def slam_roofline(prof, n_c, n_o, solver, trials, stats=None, dt=None):
         ch_avg = ch["total_ms"] / max(ch["count"], 1)
         sparse = bool(stats and stats.get("x_form", 0) > 0)
         c4 = n_c == 59994 and n_o == 18000
-        tile = "256,128" if n_o >= 8192 else "128,64 (split-K)"
+        tile = None if n_o >= 8192 else "128,64 (split-K)"
         k_rows = int(fl["rank_k_rows"])
         sp = prof.get("sparse_block_products", dict(count=0, total_ms=0.0))
         sp_avg = sp["total_ms"] / max(sp["count"], 1)
         rk_traffic, rk_src = _pmc_traffic(sparse, "rank_k_update_launch") if c4 else (None, None)
         fa_traffic, fa_src = _pmc_traffic(sparse, "k_chol_persist") if (c4 and one_launch) else (None, None)
-        rec_rk = {"kernel": "k_chol_update_lds<%s>, the launch that carries the rank-%d update T -= X^T X of the reduced ellipsoid system (order %d)%s" % (
-                      tile, k_rows, n_o, "; X kept sparse: these are the separators' rows, the interior rows go through the per-segment products"
+        rec_rk = {"kernel": "%s, the launch that carries the rank-%d update T -= X^T X of the reduced ellipsoid system (order %d)%s" % (
+                      ("k_chol_update_lds<%s>" % tile) if tile else "k_chol_update_v (128 x 128 tiles, two four-wave workgroups per CU)", k_rows, n_o, "; X kept sparse: these are the separators' rows, the interior rows go through the per-segment products"
                       if sparse else ""),
                   "bound": "mfma", "achieved": rk_ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": rk_ach / FP64_MFMA_PEAK_TF,
                   "traffic": rk_traffic, "traffic_source": rk_src, "algorithmic_flops_per_launch": fl["rank_k_update"], "avg_launch_ms": rk_avg,
@@ -284,7 +284,7 @@ def slam_roofline(prof, n_c, n_o, solver, trials, stats=None, dt=None):
                                  "staircase are skipped tile by tile (closed form without the skip: %.4g)" % fl["rank_k_closed_form"])
                   if fl["rank_k_update"] != fl["rank_k_closed_form"] else "closed form n_o (n_o + 1) K"}
         rec_fa = {"kernel": ("k_chol_persist: the whole dense Cholesky factorisation of the reduced ellipsoid system T (order %d) in ONE launch" % n_o) if one_launch
-                  else ("dense Cholesky factorisation of T (order %d): k_chol_potrf2 + k_chol_panel + k_chol_update_lds, a launch per step" % n_o),
+                  else ("dense Cholesky factorisation of T (order %d): k_chol_potrf2 + k_chol_panel + k_chol_update_v / _lds, a launch per step" % n_o),
                   "bound": "mfma", "achieved": fa_ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fa_ach / FP64_MFMA_PEAK_TF,
                   "traffic": fa_traffic, "traffic_source": fa_src, "algorithmic_flops_per_launch": fac_flops, "avg_launch_ms": fa_avg,
                   "launches": fa["count"], "ms_per_trial": fa["total_ms"] / max(ch["count"], 1),
@@ -319,7 +319,7 @@ def slam_roofline(prof, n_c, n_o, solver, trials, stats=None, dt=None):
     fac_flops = n_c ** 3 / 3.0 if fa["count"] else fl["cholesky"]
     ach = fac_flops / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
     return {"kernel": "dense Cholesky factorisation of the reduced camera system (order %d): %s" % (
-                n_c, "k_chol_persist, one launch" if 4096 <= n_c < 30000 else "k_chol_potrf2 + k_chol_panel + k_chol_update_lds<256,128>, a launch per step with look-ahead"),
+                n_c, "k_chol_persist, one launch" if 4096 <= n_c < 30000 else "k_chol_potrf2 + k_chol_panel + k_chol_update_v, a launch per step with look-ahead"),
             "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
             "algorithmic_flops_per_launch": fac_flops, "avg_launch_ms": avg, "launches": fa["count"] or ch["count"], "measured_ceiling": ceiling,
             "linear_solve_ms_per_trial": solve_ms, "trial_ms": trial_ms,
@@ -940,7 +940,7 @@ def main():
                     rk = prof.get("rank_k_update", dict(count=0, total_ms=0.0))
                     avg = rk["total_ms"] / max(rk["count"], 1)
                     fl = slam_flops(n_c, n_o, 2, st)["rank_k_update"] / world
-                    roof = {"kernel": "k_chol_update_lds<256,128>: rank 0's launches of the separators' rank-K update (one per owned outer panel of T)",
+                    roof = {"kernel": "k_chol_update_v: rank 0's launches of the separators' rank-K update (one per owned outer panel of T)",
                             "bound": "mfma", "achieved": fl / (avg * 1e-3) / 1e12 if avg > 0 else 0.0, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                             "traffic": None, "algorithmic_flops_per_launch": fl, "avg_launch_ms": avg, "launches": rk["count"],
                             "trial_ms": roof.get("trial_ms"), "trial_frac_of_n_gpus_peak": (roof["trial_frac"] / world) if roof.get("trial_frac") else None,

@@ -951,7 +951,10 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
                                                             const long long* __restrict__ boff, const long long* __restrict__ roff,
                                                             const double* __restrict__ P, const double* __restrict__ Prhs,
                                                             const double* __restrict__ Hoo, const double* __restrict__ bo, double lambda,
-                                                            double* __restrict__ T, long ldt, int o2_begin, int o2_end, const int* __restrict__ unrank) {
+                                                            double* __restrict__ T, long ldt, int o2_begin, int o2_end, const int* __restrict__ unrank,
+                                                            int accumulate = 0) {
+  // accumulate (round 6): T already holds -Xs^T Xs, written by the rank-K update in its assign form while the segments' products ran
+  // beside it on a second stream (esl_slam.hip); (D - sum) + (-acc) is the same double as (D - sum) - acc
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t1 = blockIdx.x;                    // block row of T (its order: unrank, null = ellipsoid order); N = the right-hand side (row 9 N of T)
   const int o1 = (t1 == N || !unrank) ? t1 : unrank[t1];
@@ -1005,7 +1008,7 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
       }
     }
     if (rhs) {
-      if (lane < 9) T[n_o + (9L * t2 + lane) * ldt] = bo[(size_t)o2 * 9 + lane] - s0;
+      if (lane < 9) { double* tp = &T[n_o + (9L * t2 + lane) * ldt]; const double v = bo[(size_t)o2 * 9 + lane] - s0; *tp = accumulate ? v + *tp : v; }
     } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1015,7 +1018,9 @@ static __global__ __launch_bounds__(256) void k_cf_T_gather(int N, int nw, const
         if (o1 == o2 && i < j) continue;        // (above the diagonal: never stored, never read)
         double base = 0;
         if (o1 == o2) base = Hoo[(size_t)o1 * 45 + j * 9 - (j * (j - 1)) / 2 + (i - j)] + ((i == j) ? lambda : 0.0);
-        T[(9L * t1 + i) + (9L * t2 + j) * ldt] = base - (h ? s1 : s0);
+        double* tp = &T[(9L * t1 + i) + (9L * t2 + j) * ldt];
+        const double v = base - (h ? s1 : s0);
+        *tp = accumulate ? v + *tp : v;
       }
     }
   }

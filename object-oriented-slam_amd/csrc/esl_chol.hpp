@@ -1048,7 +1048,7 @@ __host__ __device__ inline long chol_v_grid(long ntI, int sb) {
 }
 static __global__ __launch_bounds__(256, 2) void k_chol_update_v(double* __restrict__ M, long lda, long rows, long ncols, int kcol0, int K, long base, int ntJ,
                                                                  int rect, const double* __restrict__ Pext, long ldp,
-                                                                 const int* __restrict__ kfirst = nullptr, int sb = 0) {
+                                                                 const int* __restrict__ kfirst = nullptr, int sb = 0, int assign = 0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const long b = blockIdx.x;
   long ti, tj;
@@ -1083,12 +1083,19 @@ static __global__ __launch_bounds__(256, 2) void k_chol_update_v(double* __restr
     if (((K - ks) & kKC) != 0 && ks >= kKC) ks -= kKC;   // (the tile's unguarded loop takes chunks in pairs: an odd count sent half the tiles down the guarded path)
     P += (long)ks * ldp;
     K -= ks;
-    if (K <= 0) return;
+    if (K <= 0) {
+      if (assign)   // C = -P P^T: a tile the staircase skips altogether still has to leave zeros
+        for (int e = threadIdx.x; e < kVT * kVT; e += 256) {
+          const long row = i0 + e % kVT, col = j0 + e / kVT;
+          if (row < rows && col < ncols && row >= col) M[row + col * lda] = 0.0;
+        }
+      return;
+    }
   }
 #ifdef ESL_V_FORCE_WT
-  chol_update_tile_v<true>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, false);
+  chol_update_tile_v<true>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, assign != 0);
 #else
-  chol_update_tile_v<false>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, false);
+  chol_update_tile_v<false>(sm, M, lda, rows, ncols, P, ldp, K, i0, j0, assign != 0);
 #endif
 }
 
@@ -1475,8 +1482,18 @@ constexpr size_t kCholLdsSmall = (size_t)(2 * kKC * (128 + 16 + 64 + 16)) * size
 constexpr int kCholMaxSplit = 16;
 // kfirst (optional, with Pext): per group of 64 columns the first row of Pext that can be non-zero there (see the kernel); the array
 // covers rows + 256 columns.
+inline bool chol_update_v_enabled() { static const int use_v = [] { const char* e = std::getenv("ESL_UPD_V"); return (e && std::atoi(e) == 0) ? 0 : 1; }(); return use_v != 0; }
+// would chol_launch_update take the k_chol_update_v path for this region?  (The only path that can ASSIGN C = -P P^T instead of updating C.)
+inline bool chol_update_v_applies(long lda, long rows, long base, long col_limit, bool ext, long ldp) {
+  const long nrows = rows - base, nc = col_limit - base;
+  if (nrows <= 0 || nc <= 0) return false;
+  const bool whole = (nc >= nrows - 1);
+  const long big_tiles = ((nrows + 255) / 256) * ((nc + 127) / 128) / (whole ? 2 : 1);
+  static const int waves4 = [] { const char* e = std::getenv("ESL_UPD_WAVES"); return (e && std::atoi(e) == 4) ? 1 : 0; }();
+  return big_tiles >= 1024 && chol_update_v_enabled() && !waves4 && (lda & 1) == 0 && (base & 1) == 0 && (!ext || (ldp & 1) == 0);
+}
 inline void chol_launch_update(double* M, long lda, long rows, hipStream_t stream, int kcol0, int K, long base, long col_limit,
-                               const double* Pext = nullptr, long ldp = 0, double* part = nullptr, const int* kfirst = nullptr) {
+                               const double* Pext = nullptr, long ldp = 0, double* part = nullptr, const int* kfirst = nullptr, bool assign = false) {
   // trailing region: rows [base, rows), cols [base, col_limit)
   const long nrows = rows - base, nc = col_limit - base;
   if (nrows <= 0 || nc <= 0) return;
@@ -1488,12 +1505,11 @@ inline void chol_launch_update(double* M, long lda, long rows, hipStream_t strea
     const long nblk = whole ? ntI * (ntI + 1) : ntI * ntJ;   // triangle: sum over ti of (2 ti + 2) tiles
     static const int waves4 = [] { const char* e = std::getenv("ESL_UPD_WAVES"); return (e && std::atoi(e) == 4) ? 1 : 0; }();
     // round 6: the vendor-shaped 128 x 128 tile, two four-wave workgroups per CU (k_chol_update_v; ESL_UPD_V=0: the 256 x 128 tile).  Same bits.
-    static const int use_v = [] { const char* e = std::getenv("ESL_UPD_V"); return (e && std::atoi(e) == 0) ? 0 : 1; }();
-    if (use_v && !waves4 && (lda & 1) == 0 && (base & 1) == 0 && (!Pext || (ldp & 1) == 0)) {
+    if (chol_update_v_applies(lda, rows, base, col_limit, Pext != nullptr, ldp)) {
       const long vI = (nrows + kVT - 1) / kVT, vJ = (nc + kVT - 1) / kVT;
       const long vblk = whole ? chol_v_grid(vI, 0) : vI * vJ;
       hipLaunchKernelGGL(k_chol_update_v, dim3((unsigned)vblk), dim3(256), kCholLdsV, stream, M, lda, rows, col_limit, kcol0, K, base, (int)vJ, whole ? 0 : 1, Pext, ldp,
-                         Pext ? kfirst : nullptr, 0);
+                         Pext ? kfirst : nullptr, 0, assign ? 1 : 0);
       return;
     }
     if (waves4)   // (experiment, round 6) four waves of 128 x 64, one per SIMD, accumulators in AGPRs
@@ -1997,11 +2013,6 @@ static __global__ __launch_bounds__(kPwThreads) void k_chol_persist(double* __re
 #ifdef ESL_PERSIST_TILE_LDS
           chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * (tk.c & 0xffff), false);
 #else
-#ifdef ESL_PERSIST_MIX
-          if (chol_uniform(tk.type) == 1) {
-            chol_update_tile<256, 128, 4, 2, true>(sm, M, lda, rows, (long)n, M + c0 * lda, lda, K, 256L * tk.b, 128L * (tk.c & 0xffff), false);
-          } else
-#endif
           {
           // round 6: the two halves of the workgroup take the tile's upper and lower 128 rows independently (chol_update_tile_v, HV = 1)
           const int hv = chol_uniform(t >> 8), Ku = chol_uniform(K);
@@ -2063,7 +2074,22 @@ struct CholRuntime {
   // optional event bracket around the FACTORISATION alone (not the back-substitution): mark(user, 1) before, mark(user, 0) after
   void (*prof_mark)(void* user, int begin) = nullptr;
   void* prof_user = nullptr;
+  hipStream_t cf_side = nullptr;                            // camera-first elimination: the segments' products run here beside the rank-K update (esl_slam.hip)
+  hipEvent_t cf_ev_x = nullptr, cf_ev_p = nullptr;
+  hipError_t cf_overlap_init() {
+    if (cf_side) return hipSuccess;
+    // (a plain second stream.  Two full-size grids on two streams do not run side by side -- the second kernel's workgroups are placed
+    //  when the first one's are all dispatched -- and with the side stream confined to every 2nd / 4th / 8th CU of every XCD
+    //  (hipExtStreamCreateWithCUMask) the products simply ran later AND slower: the bracket around T's build 29.3 -> 32.9 / 40.7 / 57.2 ms.
+    //  What the second stream does give: the products fill the update's last, partly empty round of tiles: 30.0 -> 29.3 ms.)
+    hipError_t e = hipStreamCreateWithFlags(&cf_side, hipStreamNonBlocking); if (e != hipSuccess) return e;
+    e = hipEventCreateWithFlags(&cf_ev_x, hipEventDisableTiming); if (e != hipSuccess) return e;
+    return hipEventCreateWithFlags(&cf_ev_p, hipEventDisableTiming);
+  }
   void release() {
+    if (cf_side) { (void)hipStreamDestroy(cf_side); cf_side = nullptr; }
+    if (cf_ev_x) { (void)hipEventDestroy(cf_ev_x); cf_ev_x = nullptr; }
+    if (cf_ev_p) { (void)hipEventDestroy(cf_ev_p); cf_ev_p = nullptr; }
     if (bs_flags) { (void)hipFree(bs_flags); bs_flags = nullptr; bs_flags_cap = 0; }
     if (d_tasks) { (void)hipFree(d_tasks); d_tasks = nullptr; d_tasks_cap = 0; }
     if (d_ns) { (void)hipFree(d_ns); d_ns = nullptr; d_ns_cap = 0; }

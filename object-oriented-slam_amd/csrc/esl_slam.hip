@@ -439,16 +439,18 @@ static int cf_ensure_impl(esl_ctx* c) {
       h_kfirst[col / 64] = std::min(h_kfirst[col / 64], row);
     }
     h_kfirst[n_o / 64] = 0;   // the right-hand side's row
-    // flops the update executes: per 256 x 128 tile of the lower triangle, K from the later of the tile's two earliest rows on
-    const long nti = ((long)n_o + 1 + 255) / 256;
+    // flops the update executes (k_chol_update_v, the default tile of the big launches): per 128 x 128 tile of the lower triangle, K from
+    // the later of the tile's two earliest rows on, rounded down to a chunk pair as the kernel does; a tile on the diagonal counts its
+    // lower triangle.  (The 256 x 128 tile of ESL_UPD_V=0 starts a little earlier: it executes ~1 % more.)
+    const long nti = ((long)n_o + 1 + 127) / 128;
     for (long ti = 0; ti < nti; ++ti) {
-      int ka = Ks;
-      for (long g2 = ti * 4; g2 < ti * 4 + 4; ++g2) ka = std::min(ka, h_kfirst[(size_t)g2]);
-      for (long tj = 0; tj <= 2 * ti + 1 && tj * 128 < (long)n_o; ++tj) {
+      const int ka = std::min(h_kfirst[(size_t)(ti * 2)], h_kfirst[(size_t)(ti * 2 + 1)]);
+      for (long tj = 0; tj <= ti && tj * 128 < (long)n_o; ++tj) {
         const int kb = std::min(h_kfirst[(size_t)(tj * 2)], h_kfirst[(size_t)(tj * 2 + 1)]);
-        const int ks = std::min(std::max(ka, kb), Ks) & ~(kKC - 1);
-        const double rows_t = (double)std::min<long>(256, (long)n_o + 1 - ti * 256), cols_t = (double)std::min<long>(128, (long)n_o - tj * 128);
-        const double in_triangle = tj < 2 * ti ? 1.0 : (tj == 2 * ti ? 0.75 : 0.25);   // the two tiles of a tile row that meet the diagonal
+        int ks = std::min(std::max(ka, kb), Ks) & ~(kKC - 1);
+        if (((Ks - ks) & kKC) != 0 && ks >= kKC) ks -= kKC;
+        const double rows_t = (double)std::min<long>(128, (long)n_o + 1 - ti * 128), cols_t = (double)std::min<long>(128, (long)n_o - tj * 128);
+        const double in_triangle = tj < ti ? 1.0 : 0.5 * (cols_t + 1.0) / cols_t;
         upd_flops += 2.0 * rows_t * cols_t * (double)(Ks - ks) * in_triangle;
       }
     }
@@ -610,30 +612,61 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
     // distributed factorisation below expects them)
     const int Wp = chol_outer_panels(n_o), n_outer = ((n_o + kNB - 1) / kNB + Wp - 1) / Wp;
     const bool dist = cf_dist(c);
-    if (!c->cf_sparse) {   // (T was written whole by the edge-scale launch)
-    } else {   // T = D - (interior rows)^T (interior rows), block by block (every block on and below the diagonal is written)
-      ProfScope pk(c, 8);
-      if (c->cf_sp_form == 1)   // the segments' products (all of them on every rank: 3 % of a trial)
-      {
-        hipLaunchKernelGGL(k_cf_seg_syrk, dim3((unsigned)c->cf_n_twork), dim3(256), 0, c->stream, c->cf_twork, c->cf_seg_start, c->cf_seg_first, c->cf_xoff,
-                           c->cf_xld, c->cf_Xc, c->cf_boff, c->cf_P);
-        hipLaunchKernelGGL(k_cf_seg_rhs, dim3((unsigned)c->cf_n_fwork), dim3(64), 0, c->stream, c->cf_fwork, c->cf_seg_start, c->cf_xoff, c->cf_xld, c->cf_Xc,
-                           c->cf_roff, c->cf_Prhs);
-      }
+    // Round 6: the segments' products (HBM-bound: 16.7 GB written) run on a second stream BESIDE the separators' rank-K update
+    // (MFMA-bound): the update ASSIGNS T = -Xs^T Xs instead of updating what the gather wrote, and the gather, which now comes last,
+    // adds its D - sum to that -- (D - sum) + (-acc) is the same double as (D - sum) - acc, so T has the same bits.  Single rank, X
+    // kept sparse with stored products, the update on its k_chol_update_v path (the one with an assign form); ESL_CF_OVERLAP=0: the
+    // serial order.
+    static const bool overlap_on = !(std::getenv("ESL_CF_OVERLAP") && std::getenv("ESL_CF_OVERLAP")[0] == '0');
+    const int Ks_ = (int)c->cf_kpad_s;
+    const bool overlap = overlap_on && c->cf_sparse && c->cf_sp_form == 1 && !dist && Ks_ > 0 &&
+                         chol_update_v_applies(ldt, (long)n_o + 1, 0, (long)n_o, true, ldx) && rt.cf_overlap_init() == hipSuccess;
+    ESL_HIP_TRY(chol_set_attributes(rt));
+    auto launch_products = [&](hipStream_t st2) {
+      hipLaunchKernelGGL(k_cf_seg_syrk, dim3((unsigned)c->cf_n_twork), dim3(256), 0, st2, c->cf_twork, c->cf_seg_start, c->cf_seg_first, c->cf_xoff,
+                         c->cf_xld, c->cf_Xc, c->cf_boff, c->cf_P);
+      hipLaunchKernelGGL(k_cf_seg_rhs, dim3((unsigned)c->cf_n_fwork), dim3(64), 0, st2, c->cf_fwork, c->cf_seg_start, c->cf_xoff, c->cf_xld, c->cf_Xc,
+                         c->cf_roff, c->cf_Prhs);
+    };
+    auto launch_gather = [&](int accumulate) {
       for (int op = dist ? c->comm_rank : 0; op < (dist ? n_outer : 1); op += dist ? c->comm_ranks : 1) {
         const long c_begin = dist ? (long)op * Wp * kNB : 0, c_end = dist ? std::min<long>((long)(op + 1) * Wp * kNB, (long)n_o) : (long)n_o;
         const int o2b = (int)(c_begin / 9), o2e = (int)((c_end + 8) / 9);   // (a block that straddles a panel boundary: on both sides)
         const dim3 grid((unsigned)(N + 1), (unsigned)((o2e - o2b + kCfTPer - 1) / kCfTPer));
         if (c->cf_sp_form == 1)
           hipLaunchKernelGGL(k_cf_T_gather, grid, dim3(256), 0, c->stream, N, c->cf_sp_nw, c->cf_mask, c->cf_cmap, c->cf_boff, c->cf_roff, c->cf_P, c->cf_Prhs,
-                             c->Hoo, c->bo, lambda, c->cf_T, ldt, o2b, o2e, (const int*)c->cf_unrank);
+                             c->Hoo, c->bo, lambda, c->cf_T, ldt, o2b, o2e, (const int*)c->cf_unrank, accumulate);
         else
           hipLaunchKernelGGL(k_cf_T_sparse, grid, dim3(256), 0, c->stream, N, c->cf_sp_nw, c->cf_mask, c->cf_cmap, c->cf_xoff, c->cf_xld, c->cf_Xc, c->Hoo, c->bo,
                              lambda, c->cf_T, ldt, o2b, o2e, (const int*)c->cf_unrank);
       }
+    };
+    if (overlap) {
+      // (the slabs Xc were complete after k_cf_forward<2>; the event is recorded here, behind the separators' short chain, which the
+      //  products do not need but which costs them 0.3 ms of head start at most)
+      ESL_HIP_TRY(hipEventRecord(rt.cf_ev_x, c->stream));
+      ESL_HIP_TRY(hipStreamWaitEvent(rt.cf_side, rt.cf_ev_x, 0));
+      launch_products(rt.cf_side);
+      ESL_HIP_TRY(hipEventRecord(rt.cf_ev_p, rt.cf_side));
+      {
+        ProfScope pk(c, 7);   // the rank-K update (assign form), with the products running beside it
+        chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, Ks_, 0, (long)n_o, c->cf_Xs, ldx, nullptr, c->cf_kfirst, true);
+      }
+      ESL_HIP_TRY(hipStreamWaitEvent(c->stream, rt.cf_ev_p, 0));
+      {
+        ProfScope pk(c, 8);   // (what is left of the products' path on this stream: the gather)
+        launch_gather(1);
+      }
+      ESL_HIP_TRY(hipGetLastError());
+    } else {
+    if (!c->cf_sparse) {   // (T was written whole by the edge-scale launch)
+    } else {   // T = D - (interior rows)^T (interior rows), block by block (every block on and below the diagonal is written)
+      ProfScope pk(c, 8);
+      if (c->cf_sp_form == 1)   // the segments' products (all of them on every rank: 3 % of a trial)
+        launch_products(c->stream);
+      launch_gather(0);
     }
     ESL_HIP_TRY(hipGetLastError());
-    ESL_HIP_TRY(chol_set_attributes(rt));
     {
       ProfScope pk(c, 7);   // the rank-K update alone (nested in class 2): the MFMA roofline kernel of this form
       const double* Xf = c->cf_sparse ? c->cf_Xs : c->cf_Xt;
@@ -646,6 +679,7 @@ static int slam_try_step_cf(esl_ctx* c, double lambda) {
       } else if (K > 0) {
         chol_launch_update(c->cf_T, ldt, (long)n_o + 1, c->stream, 0, K, 0, (long)n_o, Xf, ldx, c->cf_part, c->cf_sparse ? c->cf_kfirst : nullptr);
       }
+    }
     }
     ESL_HIP_TRY(hipGetLastError());
   }

@@ -14,14 +14,14 @@ __global__ __launch_bounds__(NT * (HALVES ? 2 : 1), HALVES ? 2 : WPS) void k_pro
   const int half = HALVES ? (threadIdx.x >> 8) : 0;
   const int t = threadIdx.x & 255, wave = t >> 6, lane = t & 63, r = lane & 15, kq = lane >> 4;
   int* bar = reinterpret_cast<int*>(sm + (HALVES ? 2 : 1) * 2 * kKC * VLd) + 32 * half;   // one counter per half, in LDS lines of their own
-  if (HALVES) sm += half * 2 * kKC * VLd;
+  if (HALVES && HALVES != 3) sm += half * 2 * kKC * VLd;
   for (int i = t; i < 2 * kKC * VLd; i += NT) sm[i] = 1e-3 * (i % 97);
   if (t == 0) *bar = 0;
   __syncthreads();
   int phase = 0;
   if (HALVES == 2 && blockIdx.x == 0 && lane == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); out[4096 * NT + (threadIdx.x >> 6)] = (double)((hw >> 4) & 3); }
   auto sync_half = [&]() {
-    if (!HALVES) { __syncthreads(); return; }
+    if (!HALVES || HALVES == 3) { __syncthreads(); return; }
     phase += 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(NT * (HALVES ? 2 : 1), HALVES ? 2 : WPS) void k_pro
   auto chunk = [&](double2_t (&a_cur)[4], double2_t (&a_nxt)[4], int kn, int buf) {
     asm volatile("" ::: "memory");
     if (MODE >= 4) {
-      for (int q = 0; q < QB; ++q) rb[q] = *reinterpret_cast<const double2_t*>(pB[q] + (long)(kn % 512) * ldp);
+      for (int q = 0; q < (HALVES == 3 ? QB / 2 : QB); ++q) rb[q] = *reinterpret_cast<const double2_t*>(pB[HALVES == 3 ? 2 * q + half : q] + (long)(kn % 512) * ldp);
       for (int s = 0; s < 4; ++s) a_nxt[s] = *reinterpret_cast<const double2_t*>(pA + (long)(kn % 512 + 4 * s) * ldp);
     }
     const double* Bb = sm + buf * kKC * VLd + r;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT * (HALVES ? 2 : 1), HALVES ? 2 : WPS) void k_pro
     __builtin_amdgcn_sched_barrier(0);
     if (MODE >= 3) {
 #pragma unroll
-      for (int q = 0; q < QB; ++q) { const int e = t + NT * q; *reinterpret_cast<double2_t*>(sm + ((buf ^ 1) * kKC + e / (VT / 2)) * VLd + 2 * (e % (VT / 2))) = rb[q]; }
+      for (int q = 0; q < (HALVES == 3 ? QB / 2 : QB); ++q) { const int e = t + NT * (HALVES == 3 ? 2 * q + half : q); *reinterpret_cast<double2_t*>(sm + ((buf ^ 1) * kKC + e / (VT / 2)) * VLd + 2 * (e % (VT / 2))) = rb[q]; }
     }
     if (MODE >= 2) sync_half();
   };
@@ -104,6 +104,8 @@ int main() {
   run<4, 2, 1>("one 512-thread workgroup per CU, two halves, LDS-counter barrier: whole loop", P, ldp, out, K);
   run<2, 2, 1>("   the same without the staging stores and global loads", P, ldp, out, K);
   run<4, 2, 2>("   (whole loop again; SIMD ids of the eight waves below)", P, ldp, out, K);
+  run<4, 2, 3>("one 512-thread workgroup: ONE shared image of the staged operand, hardware barrier", P, ldp, out, K);
+  run<2, 2, 3>("   the same without the staging stores and global loads", P, ldp, out, K);
   double simd[8]; hipMemcpy(simd, out + (size_t)4096 * NT, sizeof(simd), hipMemcpyDeviceToHost);
   printf("SIMD of waves 0..7 of workgroup 0:"); for (int i = 0; i < 8; ++i) printf(" %d", (int)simd[i]); printf("\n");
   return 0;

@@ -46,9 +46,10 @@ def main():
                              "fetch_bytes_corrected": 2 * f_kib * 1024, "write_bytes": w_kib * 1024,
                              "traffic_bytes_per_launch": 2 * f_kib * 1024 + w_kib * 1024}
     # the launch the bench line's roofline is quoted on: the rank-K update T -= X^T X of the camera-first elimination = the
-    # dispatch of the 256 x 128 update kernel with the LARGEST grid (the whole lower triangle of T; the trailing updates of the
-    # factorisation that follows cover less and less of it)
-    big = [k for k in fetch if "k_chol_update_lds<256" in k and k in write]
+    # dispatch of the big update kernel (round 6: k_chol_update_v; before: k_chol_update_lds<256, 128>) with the LARGEST grid (the whole
+    # lower triangle of T; the trailing updates of the factorisation that follows cover less and less of it)
+    big = [k for k in fetch if ("k_chol_update_v" in k or "k_chol_update_lds<256" in k) and k in write]
+    big.sort(key=lambda k: -max(g for _, g in fetch[k]))
     if big:
         k = big[0]
         gmax = max(g for _, g in fetch[k])

@@ -225,6 +225,27 @@ def test_persistent_dense_cholesky_selftest_residual(pkg, monkeypatch, n):
     assert res < 1e-13 and abs(res2 - res) <= 1e-9 * res
 
 
+def test_launch_path_update_tiles_agree(pkg):
+    """The launch-per-step factorisation (ESL_CHOL_PERSISTENT=0) with the rank-K update in its two tile shapes -- k_chol_update_v (round 6:
+    128 x 128, four waves of 32 x 128, two workgroups per CU, the default) and k_chol_update_lds<256, 128> (ESL_UPD_V=0) -- on the same
+    generated systems: both at round-off, and the same x (the two kernels accumulate every entry in the same order: bit-identical C,
+    scripts/debug/upd_v_probe.hip; the residual's own sum is an atomic reduction, so it is compared to 1e-9 of itself).  The switch is read
+    once per process: one subprocess per setting."""
+    import subprocess, sys, os, json
+    code = ("import importlib, json, sys; sys.path.insert(0, %r); pkg = importlib.import_module('object-oriented-slam_amd'); cx = pkg.Context(0); "
+            "print(json.dumps([cx.selftest_cholesky(n) for n in (9001, 12000)])); cx.close()") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for v in ("1", "0"):
+        env = dict(os.environ, ESL_CHOL_PERSISTENT="0", ESL_UPD_V=v)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[v] = json.loads(r.stdout.strip().splitlines()[-1])
+    print("launch path, update tile v / lds: (ms, residual) per size:", out["1"], out["0"])
+    for (ms1, res1), (ms0, res0) in zip(out["1"], out["0"]):
+        assert res1 < 1e-13 and res0 < 1e-13
+        assert abs(res1 - res0) <= 1e-9 * res0
+
+
 @pytest.mark.parametrize("n", [130, 1153, 4097, 9001])
 def test_persistent_cholesky_without_the_fused_chain(pkg, monkeypatch, n):
     """ESL_CHOL_FUSE=0: the strips under the diagonal block and the next block's update as worker tasks (the first form of round 4,
