@@ -61,6 +61,36 @@ template <bool WT>
 __device__ __forceinline__ void chol_store(double* p, double v) {
   if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
 }
+// Write-through stores in PAIRS (round 6).  An 8-byte sc1 store costs 2.7 x a 16-byte one per byte (the guide's store table), and in the
+// product layouts of this file a lane holds ONE row: 16 lanes = 16 consecutive rows of a column.  Two values of the lane's row that belong
+// to two different columns (x -> column a, y -> column b) are exchanged with the neighbouring lane (lane ^ 1: rows 2 m, 2 m + 1) so that
+// the even lane stores rows {2 m, 2 m + 1} of column a and the odd lane the same rows of column b, 16 bytes each: half the store
+// instructions, all of them wide.  `pa`, `pb`: this lane's own addresses of (row, a) and (row, b); `ok`: the lane's row is inside the
+// matrix; `wide`: 16-byte alignment holds (even leading dimension and even first row).  A pair whose second row is outside falls
+// back to 8-byte stores.  The inline-assembly store carries the wait states of the wide-store data hazard (see chol_update_tile_v).
+#ifdef ESL_NO_WT_PAIRS   // (A/B switch: the 8-byte write-through stores everywhere but the update tile)
+constexpr bool kWtPairs = false;
+#else
+constexpr bool kWtPairs = true;
+#endif
+__device__ __forceinline__ double chol_xchg_lane1(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void chol_store_wt_pair(double* pa, double* pb, double x, double y, bool ok, bool wide) {
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  const bool odd = (threadIdx.x & 1) != 0;
+  const double got = chol_xchg_lane1(odd ? x : y);
+  const bool nb_ok = __builtin_amdgcn_mov_dpp((int)ok, 0xB1, 0xF, 0xF, true) != 0;
+  if (kWtPairs && wide && ok && nb_ok) {
+    double* p = odd ? pb - 1 : pa;
+    const double2_t v = odd ? double2_t{got, y} : double2_t{x, got};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+  } else if (ok) {
+    chol_store<true>(pa, x);
+    chol_store<true>(pb, y);
+  }
+}
 // ---- the triangular inverse of the factored diagonal block, in place in the LDS copy (see chol_potrf2_body) -------------------------------
 // A function of its own, NOT inlined (round 6): inlined into k_chol_persist its register pressure (two tile columns of double4 accumulators)
 // moved the merged kernel's allocation and the chain's fused row solve picked up spills -- 15.5 -> 24.7 us per panel, which ate the
@@ -372,7 +402,17 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
       for (int r = 0; r < 4; ++r) {
         const int i = 4 * bi + r, j = 4 * bj + c;
         if (i >= j) {
-          if (i < nb && j < nb) chol_store<WT>(&M[(long)(k0 + i) + (long)(k0 + j) * lda], a[r][c]);
+          if constexpr (WT) {
+            // write-through: the block's rows (2 p, 2 p + 1) of a column as one 16-byte store where both are stored (see chol_store_wt_pair)
+            const bool pair = !kWtPairs ? false : (r & 1) == 0 ? (i + 1 < nb && j < nb && (lda & 1) == 0) : (i - 1 >= j && i < nb && j < nb && (lda & 1) == 0);
+            if (pair) {
+              if ((r & 1) == 0) {
+                typedef double double2_t __attribute__((ext_vector_type(2)));
+                const double2_t v = double2_t{a[r][c], a[r | 1][c]};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(&M[(long)(k0 + i) + (long)(k0 + j) * lda]), "v"(v) : "memory");
+              }
+            } else if (i < nb && j < nb) chol_store<WT>(&M[(long)(k0 + i) + (long)(k0 + j) * lda], a[r][c]);
+          } else if (i < nb && j < nb) chol_store<WT>(&M[(long)(k0 + i) + (long)(k0 + j) * lda], a[r][c]);
           LL(i, j) = (bi == bj) ? xd[r][c] : a[r][c];
         }
       }
@@ -381,6 +421,14 @@ __device__ __forceinline__ void chol_potrf2_body(double* __restrict__ sm, double
   POTRF_MARK(5); POTRF_MARK(6); POTRF_MARK(7);
   chol_inv_levels<NT>();
   POTRF_MARK(8);
+  if constexpr (WT && kWtPairs) {   // (write-through: 16-byte stores, see chol_store_wt_pair; the workspace is 16-byte aligned, kNB is even)
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    for (int idx = 2 * t; idx < kNB * kNB; idx += 2 * NT) {
+      const int i = idx % kNB, j = idx / kNB;
+      const double2_t v = double2_t{(i < nb && j < nb && i >= j) ? LL(i, j) : 0.0, (i + 1 < nb && j < nb && i + 1 >= j) ? LL(i + 1, j) : 0.0};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(&Linv[idx]), "v"(v) : "memory");
+    }
+  } else
   for (int idx = t; idx < kNB * kNB; idx += NT) {
     const int i = idx % kNB, j = idx / kNB;
     chol_store<WT>(&Linv[idx], (i < nb && j < nb && i >= j) ? LL(i, j) : 0.0);
@@ -533,6 +581,14 @@ __device__ __forceinline__ void chol_panel_body(double* __restrict__ M, long lda
         // store 128 contiguous bytes of a column (row-major-in-lanes stores touched 64 different cache lines per instruction)
         const long row = r0 + mi * 16 + r;
         const int col = cg + nj * 16 + kq + 4 * g;
+        if constexpr (WT) {
+          if (nb == kNB) {   // write-through, full panel: the lane's two column blocks leave as one 16-byte store per lane pair
+            if (nj == 0)
+              chol_store_wt_pair(&M[row + (long)(k0 + col) * lda], &M[row + (long)(k0 + col + 16) * lda], acc[mi][0][g], acc[mi][1][g], row < rows,
+                                 ((lda | (r0 + mi * 16)) & 1) == 0);
+            continue;
+          }
+        }
         if (row < rows && col < nb) chol_store<WT>(&M[row + (long)(k0 + col) * lda], acc[mi][nj][g]);
       }
 }
@@ -723,6 +779,25 @@ __device__ __forceinline__ void chol_update_tile(double* __restrict__ sm, double
     // round trips to a tile another CU wrote last -- ~2 us each, in a task that is visited 216 times per worker at n = 18,000.
     // Launch-path kernels only (n = 32,768: 215.9 -> 213.6 ms): the persistent kernel owns all 256 registers of its two waves per SIMD
     // and the second register set went to scratch there (128 -> 224 B, task bodies 33.6 -> 34.3 ms) -- it keeps the one-set form.
+    if constexpr (WT && kWtPairs && NJ == 2 && MI == 2) {
+      // the persistent kernel's quarter tiles (32 x 32 per wave): both column groups' C values first, then the lane's two columns of a
+      // row leave with its neighbour's as 16-byte write-through stores (chol_store_wt_pair)
+      double c2[2][MI][4];
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) c2[nj][mi][g] = assign ? 0.0 : M[(iw + mi * 16 + r) + (jw + nj * 16 + rq + 4 * g) * lda];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          chol_store_wt_pair(&M[(iw + mi * 16 + r) + (jw + rq + 4 * g) * lda], &M[(iw + mi * 16 + r) + (jw + 16 + rq + 4 * g) * lda], c2[0][mi][g] - acc[0][mi][g],
+                             c2[1][mi][g] - acc[1][mi][g], true, ((lda | iw) & 1) == 0);
+      asm volatile("" :: "v"(c_dummy));
+      return;
+    }
     constexpr int NSET = WT ? 1 : 2;
     double cv[NSET][MI][4];
     auto load_group = [&](int nj, double (&dst)[MI][4]) {
@@ -1779,7 +1854,14 @@ __device__ __forceinline__ void chol_chain_solve_rows(double* __restrict__ sm, d
       }
   }
   // X -> global memory: lane r = row, 16 lanes store 128 contiguous bytes of a column
-  if (rv) {
+  if constexpr (WT) {
+#pragma unroll
+    for (int jb = 0; jb < 8; jb += 2)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        chol_store_wt_pair(&M[row + (long)(k0 + 16 * jb + 4 * g + kq) * lda], &M[row + (long)(k0 + 16 * (jb + 1) + 4 * g + kq) * lda], acc[jb][g], acc[jb + 1][g], rv,
+                           ((lda | (r0 + 16 * wave)) & 1) == 0);
+  } else if (rv) {
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
