@@ -935,7 +935,12 @@ __device__ __forceinline__ void chol_update_tile_v(double* __restrict__ sm, doub
   constexpr int NT = 256, NJ = kVT / 16, QB = kVT * kKC / 2 / NT;   // 8 column blocks; 4 double2 of the shared operand per thread and chunk
   const int t = HV ? (int)(threadIdx.x & 255) : (int)threadIdx.x, wave = t >> 6, lane = t & 63, r = lane & 15, kq = lane >> 4;
   const long iw = i0 + wave * 32;
-  const bool interior = (i0 + kVT <= rows) && (K % (2 * kKC) == 0);
+  // The unguarded loop only needs the tile's 128 rows of P to be READABLE: rows [rows, ldp) of a column-major array are padding inside
+  // the allocation, and what they hold cannot matter -- row r of either operand only enters row / column r of the product, and rows and
+  // columns >= `rows` of C are never stored.  With a leading dimension that is a multiple of 128 (esl_slam.hip pads its own) the
+  // LAST tile row takes the unguarded loop like every other: as the guarded form it ran 2 - 3 x longer, 141 tiles of it at the very
+  // end of the launch -- a fixed ~2 ms on the rank-3,744 update.
+  const bool interior = (i0 + kVT <= ldp) && (K % (2 * kKC) == 0);
   const bool skipw = (j0 > iw + 31) || iw >= rows;   // this wave's rows lie above the diagonal / under the matrix: staging and barriers only
   int phase = 0;
   auto sync = [&]() {

@@ -177,7 +177,7 @@ int slam_alloc(esl_ctx* c) {
   const size_t EU = (size_t)g.n_bbox + g.n_e3d;
   const int64_t n = 6 * (int64_t)nf;
   c->S_n = n;
-  c->S_lda = ((n + 1 + 15) / 16) * 16;
+  c->S_lda = ((n + 1 + 127) / 128) * 128;   // (whole 128-row tiles for the update kernels: chol_update_tile_v reads pad rows instead of guarding the last tile row)
   BlobStage st;
   const int i_ust = st.up(&g.ue_start, start.size()), i_uid = st.up(&g.ue_id, nue), i_usl = st.up(&g.ue_slot, nue);
   const int i_cst = st.up(&g.cu_start, (size_t)nf + 1), i_cob = st.up(&g.cu_obj, nue), i_cid = st.up(&g.cu_id, nue);
@@ -318,7 +318,7 @@ static int cf_ensure_impl(esl_ctx* c) {
   const size_t nf = (size_t)nfi, EU = (size_t)g.n_bbox + g.n_e3d, n_o = (size_t)9 * N;
   const bool timing = std::getenv("ESL_UPLOAD_HOST_TIMING") != nullptr;
   const double t0 = timing ? now_us() : 0;
-  c->cf_ldx = (int64_t)((n_o + 1 + 15) / 16 * 16);
+  c->cf_ldx = (int64_t)((n_o + 1 + 127) / 128 * 128);   // (whole 128-row tiles: the update tiles read the pad rows instead of guarding their last tile row, chol_update_tile_v)
   c->cf_kpad = (int64_t)((6 * nf + kKC - 1) / kKC * kKC);
   c->cf_ldt = c->cf_ldx;
   const std::vector<int>& start = c->h_ue_start;
@@ -1060,7 +1060,7 @@ extern "C" int esl_selftest_cholesky(esl_ctx* c, int32_t n, double* ms_out, doub
   using namespace esl;
   if (!c || n < 1 || !ms_out || !rel_residual_out) return ESL_ERR_INVALID;
   ESL_HIP_TRY(hipSetDevice(c->device));
-  const long lda = (((long)n + 1 + 15) / 16) * 16;
+  const long lda = (((long)n + 1 + 127) / 128) * 128;
   double *M = nullptr, *Linv = nullptr, *z = nullptr, *x = nullptr, *out2 = nullptr;
   int* info = nullptr;
   const size_t np = (size_t)((n + kNB - 1) / kNB);

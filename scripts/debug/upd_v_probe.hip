@@ -9,7 +9,7 @@ using namespace esl;
 int main(int argc, char** argv) {
   const long n = argc > 1 ? atol(argv[1]) : 18000, K = argc > 2 ? atol(argv[2]) : 3744;
   const int stair = argc > 3 ? atoi(argv[3]) : 0, sb = argc > 4 ? atoi(argv[4]) : 0;
-  const long rows = n + 1, lda = (rows + 15) / 16 * 16, ldx = lda;
+  const long rows = n + 1, lda = (rows + 127) / 128 * 128, ldx = lda;
   std::vector<double> hX((size_t)ldx * K), hM((size_t)lda * n);
   unsigned long long s = 12345;
   auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)((s >> 33) & 0xFFFFF) / 1048576.0 - 0.5; };
